@@ -1,0 +1,267 @@
+#!/usr/bin/env python3
+"""Manufacture the golden fixtures under tests/golden/ from the REAL HM 16.0 reference.
+
+TEST INFRASTRUCTURE ONLY.  Runs in the builder container (needs /root/reference + `make -C oracle ref`).
+The reference has no test vectors of its own, so every fixture is produced here by
+running HM itself (oracle/_ref/TAppEncoder to make small bitstreams from seeded synthetic clips,
+oracle/_ref/libhmref.so = HM's TDecTop + TLibCommon to decode them and to answer kernel-level KATs).
+Fixtures are DATA only (inputs + HM's outputs); no reference source text is stored.
+
+  python oracle/make_golden.py streams     # P1/P2: picture-level dumps of small real streams
+  python oracle/make_golden.py kats        # K1/K3/K4: kernel-level known-answer tests
+  python oracle/make_golden.py all
+"""
+import os
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+from oracle import hmref  # noqa: E402
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+HM_CFG = "/root/reference/cfg"
+
+
+# ------------------------------------------------------------------------------------------ synthetic clips
+def synth_clip(w, h, frames, bit_depth, seed):
+    """gradient + checker + moving textured blobs + seeded noise, 4:2:0 planar, returns list of (Y,U,V) uint16"""
+    rng = np.random.RandomState(seed)
+    maxv = (1 << bit_depth) - 1
+    big = 2 * max(w, h) + 128
+    yy, xx = np.mgrid[0:big, 0:big].astype(np.float64)
+    tex = (0.45 + 0.25 * np.sin(xx / 9.0) * np.cos(yy / 13.0) + 0.15 * (((xx // 16) + (yy // 16)) % 2)
+           + 0.1 * np.sin((xx + 2 * yy) / 31.0))
+    tex += 0.06 * rng.randn(big, big)
+    tex2 = 0.5 + 0.3 * np.sin(xx / 5.0 + yy / 7.0) + 0.08 * rng.randn(big, big)
+    out = []
+    for f in range(frames):
+        # global pan with sub-pel motion (bilinear resample) + one object moving the other way
+        dx, dy = 1.75 * f, 0.5 * f
+        x0, y0 = 40 + dx, 40 + dy
+        xi, yi = int(np.floor(x0)), int(np.floor(y0))
+        fx, fy = x0 - xi, y0 - yi
+        a = tex[yi:yi + h + 1, xi:xi + w + 1]
+        img = ((1 - fx) * (1 - fy) * a[:h, :w] + fx * (1 - fy) * a[:h, 1:w + 1]
+               + (1 - fx) * fy * a[1:h + 1, :w] + fx * fy * a[1:h + 1, 1:w + 1])
+        ox, oy = int(w * 0.3 - 3 * f), int(h * 0.35 + 2 * f)
+        bw, bh = w // 4, h // 3
+        x1, y1 = max(ox, 0), max(oy, 0)
+        x2, y2 = min(ox + bw, w), min(oy + bh, h)
+        if x2 > x1 and y2 > y1:
+            img[y1:y2, x1:x2] = tex2[100 + y1 - oy:100 + y2 - oy, 100 + x1 - ox:100 + x2 - ox]
+        img = img + 0.012 * rng.randn(h, w)
+        Y = np.clip(np.round(img * maxv), 0, maxv).astype(np.uint16)
+        U = np.clip(np.round((0.5 + 0.2 * np.sin((xx[:h // 2, :w // 2] + 3 * f) / 11.0)) * maxv), 0, maxv).astype(np.uint16)
+        V = np.clip(np.round((0.5 + 0.2 * np.cos((yy[:h // 2, :w // 2] - 2 * f) / 17.0)
+                              + 0.1 * (Y[::2, ::2].astype(np.float64) / maxv - 0.5)) * maxv), 0, maxv).astype(np.uint16)
+        out.append((Y, U, V))
+    return out
+
+
+def write_yuv(path, clip, bit_depth):
+    with open(path, "wb") as f:
+        for planes in clip:
+            for p in planes:
+                f.write(p.astype(np.uint8 if bit_depth == 8 else "<u2").tobytes())
+
+
+# ------------------------------------------------------------------------------------------ streams
+STREAMS = {
+    # name: (cfg, w, h, frames, input bit depth, internal bit depth, qp, extra encoder args)
+    "ldp_main8_416x240": ("encoder_lowdelay_P_main.cfg", 416, 240, 3, 8, 8, 32, []),
+    "ra_main10_208x120": ("encoder_randomaccess_main10.cfg", 208, 120, 9, 8, 10, 30, ["--IntraPeriod=8"]),
+    "ldp_main10_208x120": ("encoder_lowdelay_P_main10.cfg", 208, 120, 4, 10, 10, 26, []),
+    # NOTE: multi-slice inter streams (--SliceMode=1) are not used: HM 16.0's own TAppDecoder asserts
+    # (TComBitStream.h:191) on the streams its encoder writes for them, at every optimisation level.
+    "intra_main10_208x120": ("encoder_intra_main10.cfg", 208, 120, 1, 10, 10, 30, []),
+}
+
+
+def encode(name, tmp):
+    cfg, w, h, frames, ibd, bd, qp, extra = STREAMS[name]
+    yuv = os.path.join(tmp, name + ".yuv")
+    clip = synth_clip(w, h, frames, ibd, seed=0x484D + sum(map(ord, name)))
+    write_yuv(yuv, clip, ibd)
+    bs = os.path.join(tmp, name + ".bin")
+    rec = os.path.join(tmp, name + "_rec.yuv")
+    cmd = [hmref.ENCODER_PATH, "-c", os.path.join(HM_CFG, cfg), "-i", yuv, "-wdt", str(w), "-hgt", str(h), "-fr", "30",
+           "-f", str(frames), "--InputBitDepth=%d" % ibd, "--InternalBitDepth=%d" % bd, "--OutputBitDepth=%d" % bd,
+           "-q", str(qp), "-b", bs, "-o", rec, "--SEIDecodedPictureHash=1", "--Level=3.1"] + extra
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        print(r.stdout[-3000:])
+        raise RuntimeError("encoder failed for " + name)
+    with open(bs, "rb") as f:
+        data = f.read()
+    recdata = np.fromfile(rec, dtype=np.uint8 if bd == 8 else "<u2")
+    return data, recdata, (w, h, frames, bd)
+
+
+def dump_stream(name, bitstream, enc_rec, geom):
+    w, h, frames, bd = geom
+    dec = hmref.RefDecoder(bitstream, check_hash=True)
+    out = {"bitstream": np.frombuffer(bitstream, dtype=np.uint8)}
+    pics = []
+    final_by_poc = {}
+    while dec.next():
+        info = dec.info()
+        k = "pic%02d_" % len(pics)
+        ns = info["num_slices"]
+        out[k + "info"] = np.array([info[x] for x in ["width", "height", "bd_y", "bd_c", "poc", "slice_type", "num_ctus",
+                                                      "ctus_w", "parts", "ctu_size", "num_slices", "use_sao",
+                                                      "lf_across_tiles", "chroma_format", "tid", "max_depth"]], dtype=np.int32)
+        out[k + "slices"] = dec.slices(ns)
+        meta = dec.meta(info)
+        for n2, a in meta.items():
+            out[k + "meta_" + n2] = a
+        co = dec.coeffs(info)
+        for c in range(3):
+            assert co[c].min() >= -32768 and co[c].max() <= 32767
+            out[k + "coeff%d" % c] = co[c].astype(np.int16)
+        out[k + "sao_raw"] = dec.sao_params(info)
+        for c, p in enumerate(dec.planes(info)):
+            out[k + "pre%d" % c] = p
+        dec.filter_step()
+        for c, p in enumerate(dec.planes(info)):
+            out[k + "dbk%d" % c] = p
+        dec.filter_step()
+        out[k + "sao_rec"] = dec.sao_params(info)
+        fin = dec.planes(info)
+        for c, p in enumerate(fin):
+            out[k + "fin%d" % c] = p
+        ok, md5 = dec.finish()
+        assert ok, "HM hash mismatch in %s pic %d" % (name, len(pics))
+        out[k + "md5"] = md5
+        final_by_poc[info["poc"]] = fin
+        pics.append(info)
+        print("  %s pic %d: POC %d type %d slices %d" % (name, len(pics) - 1, info["poc"], info["slice_type"], ns))
+    dec.close()
+    assert len(pics) == frames
+    # encoder reconstruction == decoder output (HM practice): check in POC order
+    per = w * h * 3 // 2
+    for poc in sorted(final_by_poc):
+        fr = enc_rec[poc * per:(poc + 1) * per].astype(np.int16)
+        y, cb, cr = final_by_poc[poc]
+        assert np.array_equal(fr[:w * h].reshape(h, w), y)
+        assert np.array_equal(fr[w * h:w * h * 5 // 4].reshape(h // 2, w // 2), cb)
+        assert np.array_equal(fr[w * h * 5 // 4:].reshape(h // 2, w // 2), cr)
+    out["num_pics"] = np.array([len(pics)], dtype=np.int32)
+    path = os.path.join(GOLD, "stream_%s.npz" % name)
+    np.savez_compressed(path, **out)
+    print("wrote %s (%.1f KB)" % (path, os.path.getsize(path) / 1024.0))
+
+
+def make_streams(names=None):
+    os.makedirs(GOLD, exist_ok=True)
+    with tempfile.TemporaryDirectory() as tmp:
+        for name in (names or STREAMS):
+            print("encoding", name)
+            bs, rec, geom = encode(name, tmp)
+            dump_stream(name, bs, rec, geom)
+
+
+# ------------------------------------------------------------------------------------------ KATs
+def xorshift_rng(seed):
+    return np.random.RandomState(seed & 0x7FFFFFFF)
+
+
+def make_kats():
+    os.makedirs(GOLD, exist_ok=True)
+    out = {}
+    # K1: inverse transforms through HM xITrMxN ------------------------------------------------
+    for bd in (8, 10):
+        hmref.kat_init(bd, bd)
+        for n in (4, 8, 16, 32):
+            rng = xorshift_rng(0x484D3136 + n * 16 + bd)
+            blocks = []
+            blocks.append(rng.randint(-32768, 32768, size=(6, n, n)))                       # full range stress
+            imp = np.zeros((8, n, n), dtype=np.int64)                                       # single-basis impulses
+            for i, (r, c, v) in enumerate([(0, 0, 32767), (0, 0, -32768), (n - 1, n - 1, 32767), (n - 1, 0, -32768),
+                                           (0, n - 1, 1), (1, 2 % n, -1), (n // 2, n // 2, 32767), (3 % n, 1, 1000)]):
+                imp[i, r, c] = v
+            blocks.append(imp)
+            lowf = np.zeros((6, n, n), dtype=np.int64)                                      # typical low-frequency
+            k = min(n, 8)
+            lowf[:, :k, :k] = np.round(rng.laplace(0, 120, size=(6, k, k))) * (rng.rand(6, k, k) < 0.35)
+            blocks.append(np.clip(lowf, -32768, 32767))
+            coeff = np.concatenate(blocks).astype(np.int32)
+            out["itr_in_n%d_bd%d" % (n, bd)] = coeff.astype(np.int16)
+            out["itr_dct_n%d_bd%d" % (n, bd)] = hmref.kat_itr(bd, coeff, 0).astype(np.int16)
+            if n == 4:
+                out["itr_dst_n4_bd%d" % bd] = hmref.kat_itr(bd, coeff, 1).astype(np.int16)
+    # K3: interpolation through HM TComInterpolationFilter ---------------------------------------
+    for bd in (8, 10):
+        hmref.kat_init(bd, bd)
+        rng = xorshift_rng(0x1234 + bd)
+        plane = rng.randint(0, 1 << bd, size=(96, 96)).astype(np.int16)
+        plane[40:56, 40:56] = (1 << bd) - 1      # saturated patch: exercises the final clip
+        plane[20:30, 60:70] = 0
+        out["interp_plane_bd%d" % bd] = plane
+        cases = []
+        res = []
+        for comp, nfrac in ((0, 4), (1, 8)):
+            sizes = [(8, 8), (16, 4), (4, 16), (32, 32), (12, 16)] if comp == 0 else [(4, 4), (8, 2), (2, 8), (16, 16), (6, 8)]
+            for bi in (0, 1):
+                for yf in range(nfrac):
+                    for xf in range(nfrac):
+                        w, h = sizes[(xf + yf * nfrac + bi) % len(sizes)]
+                        x0 = 8 + int(rng.randint(0, 96 - 16 - w))
+                        y0 = 8 + int(rng.randint(0, 96 - 16 - h))
+                        d = hmref.kat_interp(comp, plane, x0, y0, w, h, xf, yf, bi)
+                        cases.append([comp, bi, xf, yf, x0, y0, w, h])
+                        res.append(d.ravel())
+        out["interp_cases_bd%d" % bd] = np.array(cases, dtype=np.int32)
+        out["interp_out_bd%d" % bd] = np.concatenate(res).astype(np.int16)
+        # addAvg on 14-bit intermediates
+        a = rng.randint(-8192, 8192 + (1 << 13), size=(16, 16)).astype(np.int16)
+        b = rng.randint(-8192, 8192 + (1 << 13), size=(16, 16)).astype(np.int16)
+        out["addavg_a_bd%d" % bd] = a
+        out["addavg_b_bd%d" % bd] = b
+        out["addavg_out_bd%d" % bd] = hmref.kat_addavg(a, b)
+    # K4: SAO offsetBlock -------------------------------------------------------------------------
+    for bd in (8, 10):
+        rng = xorshift_rng(0x5A0 + bd)
+        maxo = 7 if bd == 8 else 31
+        # smooth-ish plane so that all five edge classes occur
+        base = rng.randint(0, 1 << bd, size=(40, 48)).astype(np.int64)
+        base = (base + np.roll(base, 1, 0) + np.roll(base, 1, 1) + np.roll(base, -1, 0)) // 4
+        base[:, :6] = (1 << bd) - 1 - (base[:, :6] % 3)       # near-max: clip at the top
+        base[:5, :] = base[:5, :] % 3                          # near-zero: clip at the bottom
+        plane = base.astype(np.int16)
+        out["sao_plane_bd%d" % bd] = plane
+        cases, res = [], []
+        for comp in (0, 1):
+            for typ in range(5):
+                for av in range(0, 256, 5 if typ in (2, 3) else 37):
+                    avail = [(av >> i) & 1 for i in range(8)]
+                    off = np.zeros(32, dtype=np.int32)
+                    if typ == 4:
+                        start = int(rng.randint(0, 32))
+                        for i in range(4):
+                            off[(start + i) % 32] = int(rng.randint(-maxo, maxo + 1))
+                    else:
+                        off[0], off[1] = int(rng.randint(0, maxo + 1)), int(rng.randint(0, maxo + 1))
+                        off[3], off[4] = -int(rng.randint(0, maxo + 1)), -int(rng.randint(0, maxo + 1))
+                    w, h = (32, 24) if (av & 1) else (17, 9)
+                    x0, y0 = 4, 4
+                    r = hmref.kat_sao_block(comp, bd, bd, typ, off, plane, x0, y0, w, h, avail)
+                    cases.append([comp, typ, av, x0, y0, w, h] + list(off))
+                    res.append(r[y0:y0 + h, x0:x0 + w].ravel())
+        out["sao_cases_bd%d" % bd] = np.array(cases, dtype=np.int32)
+        out["sao_out_bd%d" % bd] = np.concatenate(res).astype(np.int16)
+    path = os.path.join(GOLD, "kats.npz")
+    np.savez_compressed(path, **out)
+    print("wrote %s (%.1f KB)" % (path, os.path.getsize(path) / 1024.0))
+
+
+if __name__ == "__main__":
+    what = sys.argv[1] if len(sys.argv) > 1 else "all"
+    if what in ("kats", "all"):
+        make_kats()
+    if what in ("streams", "all"):
+        make_streams(sys.argv[2:] or None)
