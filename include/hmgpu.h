@@ -1,0 +1,216 @@
+/* hmgpu.h -- C ABI of libhmgpu.so: MI355X-native pixel reconstruction for the HM (HEVC) decoder.
+ *
+ * This is the drop-in boundary for the one hot path of ChristianFeldmann/libHM (HM 16.0) that is
+ * accelerated: everything HM does between the end of CABAC parsing of a slice and the finished,
+ * loop-filtered picture.  HM has no plugin seam there, so the seam sits at the two
+ * calls HM itself isolates and times:
+ *
+ *     TDecGop::decompressSlice()  TLibDecoder/TDecGop.cpp:105   -> hmgpu_decompress_slice()
+ *     TDecGop::filterPicture()    TLibDecoder/TDecGop.cpp:157   -> hmgpu_filter_picture()
+ *
+ * Parsing stays with the (host) caller.  What crosses the boundary is exactly what HM's parser leaves
+ * behind in TComPicSym: per-CTU TComDataCU arrays (4x4-partition granularity, z-scan order,
+ * TComDataCU.h:86-157), coefficient levels (TComDataCU.cpp:165-173), SAOBlkParam per CTU
+ * (TypeDef.h:754-779) and a handful of slice/PPS/SPS constants that HM keeps in globals.  The
+ * reference-side shim is a field-by-field memcpy.  All traversal (CU/TU/PU
+ * quadtrees, boundary strengths, SAO merge resolution ...) happens behind this interface, on the GPU.
+ *
+ * Conventions: plain C, no HIP/torch types; every function returns an hmgpu_status (never aborts,
+ * unlike HM's assert/exit: TComTrQuant.cpp:925); one context per host thread and per GPU; calls on one
+ * context are serialised by the caller; work is enqueued on the context's HIP stream and completes at
+ * hmgpu_sync()/hmgpu_picture_download().  Samples are HM's Pel = int16, levels int16 (HM's TCoeff
+ * int32 narrowed by the shim; exact for bit depth <= 10 because xDeQuant clips its input to 16 bits
+ * first: TComTrQuant.cpp:1284-1287).
+ */
+#ifndef HMGPU_H
+#define HMGPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HMGPU_VERSION 1
+
+typedef enum hmgpu_status {
+  HMGPU_OK = 0,
+  HMGPU_EINVAL = 1,       /* bad argument / inconsistent geometry (HM: assert) */
+  HMGPU_EDEVICE = 2,      /* HIP error; code via hmgpu_last_device_error() */
+  HMGPU_EUNSUPPORTED = 3, /* coding tool outside the supported envelope; nothing was enqueued */
+  HMGPU_ENOMEM = 4
+} hmgpu_status;
+
+#define HMGPU_MAX_REF 16         /* MAX_NUM_REF in HM (CommonDef.h) */
+#define HMGPU_MAX_SLICES 600     /* slices per picture kept on the device */
+#define HMGPU_NO_PIC (-1)
+
+/* HM enums that appear in the metadata (TypeDef.h:374-443) */
+enum { HMGPU_B_SLICE = 0, HMGPU_P_SLICE = 1, HMGPU_I_SLICE = 2 };
+enum { HMGPU_MODE_INTER = 0, HMGPU_MODE_INTRA = 1 };
+enum { HMGPU_SIZE_2Nx2N = 0, HMGPU_SIZE_2NxN = 1, HMGPU_SIZE_Nx2N = 2, HMGPU_SIZE_NxN = 3, HMGPU_SIZE_2NxnU = 4,
+       HMGPU_SIZE_2NxnD = 5, HMGPU_SIZE_nLx2N = 6, HMGPU_SIZE_nRx2N = 7, HMGPU_SIZE_NONE = 8 /* NUMBER_OF_PART_SIZES: not decoded */ };
+enum { HMGPU_SAO_OFF = 0, HMGPU_SAO_NEW = 1, HMGPU_SAO_MERGE = 2 };                   /* SAOMode, TypeDef.h:604 */
+enum { HMGPU_SAO_EO_0 = 0, HMGPU_SAO_EO_90 = 1, HMGPU_SAO_EO_135 = 2, HMGPU_SAO_EO_45 = 3, HMGPU_SAO_BO = 4 }; /* :620 */
+enum { HMGPU_SAO_MERGE_LEFT = 0, HMGPU_SAO_MERGE_ABOVE = 1 };                         /* :612 */
+
+typedef struct hmgpu_ctx hmgpu_ctx;
+typedef int32_t hmgpu_pic;       /* handle of a device-resident picture (TComPic/TComPicYuv counterpart) */
+
+/* What TDecTop::xActivateParameterSets turns into globals (TDecTop.cpp:283-348: g_bitDepth, g_uiMaxCUWidth,
+ * g_uiMaxCUDepth ...).  Fixed for the life of a context. */
+typedef struct hmgpu_seq_params {
+  int32_t width, height;          /* SPS pic_{width,height}_in_luma_samples (multiple of the 8x8 minimum CU) */
+  int32_t bit_depth_luma;         /* g_bitDepth[CHANNEL_TYPE_LUMA]   (8..10) */
+  int32_t bit_depth_chroma;       /* g_bitDepth[CHANNEL_TYPE_CHROMA] (8..10) */
+  int32_t chroma_format;          /* chroma_format_idc; only 1 (4:2:0) */
+  int32_t log2_ctu_size;          /* log2 g_uiMaxCUWidth: 4, 5 or 6.  partitions are 4x4 => (1<<(2*log2_ctu_size-4)) per CTU */
+  int32_t max_pictures;           /* device pictures to pre-allocate (DPB size + pictures in flight) */
+  int32_t pcm_loop_filter_disable;/* SPS pcm_loop_filter_disabled_flag && pcm_enabled_flag */
+  int32_t reserved[8];
+} hmgpu_seq_params;
+
+/* Per-slice constants the hot path reads through pcCU->getSlice() */
+typedef struct hmgpu_slice_params {
+  int32_t slice_type;                   /* HMGPU_{B,P,I}_SLICE */
+  int32_t cb_qp_offset, cr_qp_offset;   /* pps_cb/cr_qp_offset + slice_cb/cr_qp_offset: dequant QpParam (TComTrQuant.cpp:107-112) */
+  int32_t pps_cb_qp_offset, pps_cr_qp_offset; /* PPS part only: chroma deblocking (TComLoopFilter.cpp:759) */
+  int32_t deblocking_disable;           /* getDeblockingFilterDisable() */
+  int32_t beta_offset_div2, tc_offset_div2;
+  int32_t lf_across_slices;             /* getLFCrossSliceBoundaryFlag() */
+  int32_t weighted_pred;                /* PPS weighted_pred_flag / weighted_bipred_flag for this slice type: must be 0 */
+  int32_t num_ref_idx[2];
+  hmgpu_pic ref_pic[2][HMGPU_MAX_REF];  /* getRefPic(list, idx) as device picture handles */
+  int32_t ref_poc[2][HMGPU_MAX_REF];    /* getRefPOC(list, idx) (identical-motion test, TComPrediction.cpp:497-512) */
+  int32_t reserved[6];
+} hmgpu_slice_params;
+
+/* The picture-persistent TComDataCU arrays of TComPicSym (TComPicSym.cpp:93-114).  Every array covers the WHOLE
+ * picture: [num_ctus][parts_per_ctu] in CTU raster order and HM z-scan order inside the CTU; a call only reads the
+ * CTUs it is asked to process.  Optional arrays may be NULL (treated as all zero). */
+typedef struct hmgpu_ctu_meta {
+  const uint8_t* depth;              /* m_puhDepth */
+  const int8_t*  part_size;          /* m_pePartSize (HMGPU_SIZE_*; HMGPU_SIZE_NONE = CTU part never decoded) */
+  const int8_t*  pred_mode;          /* m_pePredMode */
+  const int8_t*  qp;                 /* m_phQP */
+  const uint8_t* tr_idx;             /* m_puhTrIdx */
+  const uint8_t* cbf[3];             /* m_puhCbf[Y,Cb,Cr]: bit d = cbf at transform depth d (TComDataCU.h:310) */
+  const uint8_t* transform_skip[3];  /* m_puhTransformSkip[Y,Cb,Cr]                         (optional) */
+  const int16_t* mv[2];              /* m_acCUMvField[list].m_pcMv as {hor,ver} pairs: [num_ctus][parts][2] */
+  const int8_t*  ref_idx[2];         /* m_acCUMvField[list].m_piRefIdx (-1 = list unused) */
+  const uint8_t* intra_dir[2];       /* m_puhIntraDir[luma,chroma]                          (optional; intra path) */
+  const uint8_t* transquant_bypass;  /* m_CUTransquantBypass                                (optional; must be 0) */
+  const uint8_t* ipcm;               /* m_pbIPCMFlag                                        (optional; must be 0) */
+  const uint16_t* slice_idx;         /* [num_ctus] index into the picture's slice table     (optional: all 0) */
+  const uint16_t* tile_idx;          /* [num_ctus] TComPicSym::getTileIdxMap                (optional: all 0) */
+} hmgpu_ctu_meta;
+
+/* Coefficient levels, HM layout (m_pcTrCoeff: TU blocks contiguous in z-order, raster inside a TU, offset of a TU =
+ * 16 * z-index of its first partition for luma, 4 * ... for chroma; TComTU.cpp:64-76,186): whole-picture arrays
+ * y: [num_ctus][ctu*ctu], cb/cr: [num_ctus][ctu*ctu/4]. */
+typedef struct hmgpu_coeffs {
+  const int16_t* level[3];
+} hmgpu_coeffs;
+
+/* SAOBlkParam as parsed (TDecSbac::parseSAOBlkParam), before reconstructBlkSAOParams: [num_ctus][3] */
+typedef struct hmgpu_sao_param {
+  int32_t mode_idc;       /* HMGPU_SAO_OFF / NEW / MERGE */
+  int32_t type_idc;       /* NEW: HMGPU_SAO_EO_* / BO; MERGE: HMGPU_SAO_MERGE_LEFT / ABOVE */
+  int32_t type_aux_info;  /* BO: first band */
+  int32_t offset[32];     /* coded offsets (EO: classes 0..4; BO: by band) */
+} hmgpu_sao_param;
+
+typedef struct hmgpu_pic_params {
+  int32_t lf_across_tiles;       /* PPS loop_filter_across_tiles_enabled_flag */
+  int32_t sao_enabled;           /* SPS sample_adaptive_offset_enabled_flag (TDecGop.cpp:169) */
+  int32_t sao_offset_shift_luma, sao_offset_shift_chroma;  /* log2_sao_offset_scale_* (0 for Main/Main10) */
+  int32_t reserved[8];
+} hmgpu_pic_params;
+
+/* ------------------------------------------------------------------------------------------------ context */
+hmgpu_status hmgpu_create(const hmgpu_seq_params* seq, int device_ordinal, hmgpu_ctx** out);
+void         hmgpu_destroy(hmgpu_ctx* ctx);
+int32_t      hmgpu_last_device_error(const hmgpu_ctx* ctx);        /* hipError_t of the last HMGPU_EDEVICE */
+const char*  hmgpu_status_string(hmgpu_status s);
+hmgpu_status hmgpu_sync(hmgpu_ctx* ctx);                           /* wait for everything enqueued so far */
+
+/* geometry helpers (TComPicSym::create, TComPicSym.cpp:73-92) */
+int32_t hmgpu_num_ctus(const hmgpu_seq_params* seq);
+int32_t hmgpu_parts_per_ctu(const hmgpu_seq_params* seq);
+
+/* ------------------------------------------------------------------------------------------------ pictures
+ * Counterpart of TDecTop::xGetNewPicBuffer (TDecTop.cpp:134): pictures live in HBM for as long as they are
+ * referenced; planes never leave the device unless downloaded.  Host plane layout at upload/download is HM's
+ * TComPicYuv convention reduced to the visible area: pointer to sample (0,0) + stride in samples. */
+hmgpu_status hmgpu_picture_acquire(hmgpu_ctx* ctx, hmgpu_pic* out);
+hmgpu_status hmgpu_picture_release(hmgpu_ctx* ctx, hmgpu_pic pic);
+hmgpu_status hmgpu_picture_upload(hmgpu_ctx* ctx, hmgpu_pic pic, const int16_t* const planes[3], const int32_t strides[3]);
+hmgpu_status hmgpu_picture_download(hmgpu_ctx* ctx, hmgpu_pic pic, int16_t* const planes[3], const int32_t strides[3]);
+
+/* ------------------------------------------------------------------------------------------------ call 1
+ * Replaces the reconstruction half of TDecGop::decompressSlice -> TDecSlice::decompressSlice ->
+ * TDecCu::decompressCU (TDecSlice.cpp:334, TDecCu.cpp:142,373) for the CTUs [first_ctu, first_ctu+num_ctus) of
+ * slice `slice_idx` of picture `cur`: motion compensation of every inter PU (TComPrediction::motionCompensation),
+ * de-quantisation + inverse transform of every coded TU (TComTrQuant::invRecurTransformNxN) and
+ * recon = ClipBD(pred + resid) into the picture (TComYuv::addClip, TDecCu::xCopyToPic).
+ * Intra CUs: see DESIGN.md (round 1: left untouched, reported through hmgpu_get_stats).
+ * The metadata/coefficients are copied to the device before the call returns to the caller's thread?  No:
+ * they are staged with hipMemcpyAsync from the caller's (ideally pinned) buffers, which must stay valid until
+ * hmgpu_sync() or until a later call on the same context returns HMGPU_OK after a sync. */
+hmgpu_status hmgpu_decompress_slice(hmgpu_ctx* ctx, hmgpu_pic cur, int32_t slice_idx, const hmgpu_slice_params* slice,
+                                    const hmgpu_ctu_meta* meta, const hmgpu_coeffs* coeffs,
+                                    int32_t first_ctu, int32_t num_ctus);
+
+/* ------------------------------------------------------------------------------------------------ call 2
+ * Replaces TDecGop::filterPicture (TDecGop.cpp:157-217): TComLoopFilter::loopFilterPic (all vertical edges, then
+ * all horizontal edges), then reconstructBlkSAOParams + SAOProcess.  Uses the metadata of every CTU handed to
+ * hmgpu_decompress_slice for this picture (HM: pcPic->getCU(addr), TComLoopFilter.cpp:133-135).
+ * `sao` is [num_ctus][3] or NULL when pp->sao_enabled == 0. */
+hmgpu_status hmgpu_filter_picture(hmgpu_ctx* ctx, hmgpu_pic cur, const hmgpu_pic_params* pp, const hmgpu_sao_param* sao);
+
+/* ------------------------------------------------------------------------------------------------ finer seams
+ * The kernel-level seams HM exposes to its own callers (SURVEY.md 8b "finer seams"), used by the parity tests.
+ * All operate on host arrays (copied in and out synchronously). */
+
+/* TComTrQuant::xDeQuant (flat) + xIT/xITransformSkip on `n` TUs of size (1<<log2_size)^2.
+ * levels/resid: [n][size*size].  per TU: qp_per/qp_rem from QpParam, flags bit0 = 4x4 DST (intra luma), bit1 = transform skip.
+ * bit_depth selects transformShift and the second-stage shift (TComTrQuant.cpp:898-899,1233-1236). */
+hmgpu_status hmgpu_inverse_transform_batch(hmgpu_ctx* ctx, int32_t log2_size, int32_t bit_depth, int32_t n,
+                                           const int16_t* levels, const int8_t* qp_per, const int8_t* qp_rem,
+                                           const uint8_t* flags, int16_t* resid);
+
+/* TComPrediction::xPredInterBlk (TComPrediction.cpp:660) for `n` blocks out of one reference plane.
+ * blocks: n x {x, y, w, h, mvx, mvy} in samples of that plane / in 1/4 (luma) or 1/8 (chroma) sample units;
+ * dst: concatenated w*h outputs.  bi != 0 -> 14-bit intermediate (no clip), else final clipped prediction. */
+hmgpu_status hmgpu_mc_batch(hmgpu_ctx* ctx, int32_t is_chroma, int32_t bit_depth, const int16_t* ref_plane, int32_t ref_stride,
+                            int32_t ref_w, int32_t ref_h, int32_t n, const int32_t* blocks, int32_t bi, int16_t* dst);
+
+/* stage control for tests: run only part of hmgpu_filter_picture on `cur`:  1 = vertical edges, 2 = horizontal edges,
+ * 4 = SAO; combine with |.  hmgpu_filter_picture == stages 7. */
+hmgpu_status hmgpu_filter_picture_stages(hmgpu_ctx* ctx, hmgpu_pic cur, const hmgpu_pic_params* pp, const hmgpu_sao_param* sao,
+                                         int32_t stages);
+
+/* ------------------------------------------------------------------------------------------------ measurement
+ * Resident replay: re-run the device work of the last hmgpu_decompress_slice calls / hmgpu_filter_picture of `cur`
+ * from the inputs already staged in HBM (no host->device traffic, no host work), `iters` times.  This is what
+ * bench.py times ("inputs already resident in HBM").  Kernel times are measured with hipEvents on the
+ * context's own stream. */
+hmgpu_status hmgpu_replay(hmgpu_ctx* ctx, hmgpu_pic cur, int32_t stages /* 8 = reconstruct | 1|2|4 filter */, int32_t iters);
+
+#define HMGPU_NUM_KERNELS 12
+typedef struct hmgpu_stats {
+  double   kernel_ms[HMGPU_NUM_KERNELS];      /* accumulated device time per kernel class since the last reset */
+  uint64_t kernel_launches[HMGPU_NUM_KERNELS];
+  uint64_t intra_partitions;                  /* 4x4 partitions of intra CUs seen (not reconstructed in round 1) */
+  uint64_t inter_partitions;
+  uint64_t coded_tus[4][3];                   /* TUs with cbf by log2 size-2 and component */
+} hmgpu_stats;
+const char*  hmgpu_kernel_name(int32_t k);
+hmgpu_status hmgpu_set_profiling(hmgpu_ctx* ctx, int32_t enable);   /* per-kernel hipEvent timing on/off (off by default) */
+hmgpu_status hmgpu_get_stats(hmgpu_ctx* ctx, hmgpu_stats* out, int32_t reset);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HMGPU_H */

@@ -1,0 +1,168 @@
+"""ctypes mirror of include/hmgpu.h (the C ABI of libhmgpu.so) + helpers to fill the structs from numpy arrays.
+
+Pure declarations: no compute here.  Field order and types must match include/hmgpu.h exactly
+(tests/test_abi.py cross-checks sizes against the compiled library).
+"""
+import ctypes as C
+
+import numpy as np
+
+HMGPU_OK, HMGPU_EINVAL, HMGPU_EDEVICE, HMGPU_EUNSUPPORTED, HMGPU_ENOMEM = 0, 1, 2, 3, 4
+MAX_REF = 16
+NO_PIC = -1
+B_SLICE, P_SLICE, I_SLICE = 0, 1, 2
+MODE_INTER, MODE_INTRA = 0, 1
+SIZE_2Nx2N, SIZE_2NxN, SIZE_Nx2N, SIZE_NxN, SIZE_2NxnU, SIZE_2NxnD, SIZE_nLx2N, SIZE_nRx2N, SIZE_NONE = range(9)
+SAO_OFF, SAO_NEW, SAO_MERGE = 0, 1, 2
+SAO_EO_0, SAO_EO_90, SAO_EO_135, SAO_EO_45, SAO_BO = range(5)
+NUM_KERNELS = 12
+
+STAGE_DEBLOCK_VER, STAGE_DEBLOCK_HOR, STAGE_SAO, STAGE_RECON = 1, 2, 4, 8
+
+
+class SeqParams(C.Structure):
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("bit_depth_luma", C.c_int32), ("bit_depth_chroma", C.c_int32),
+                ("chroma_format", C.c_int32), ("log2_ctu_size", C.c_int32), ("max_pictures", C.c_int32),
+                ("pcm_loop_filter_disable", C.c_int32), ("reserved", C.c_int32 * 8)]
+
+
+class SliceParams(C.Structure):
+    _fields_ = [("slice_type", C.c_int32), ("cb_qp_offset", C.c_int32), ("cr_qp_offset", C.c_int32),
+                ("pps_cb_qp_offset", C.c_int32), ("pps_cr_qp_offset", C.c_int32), ("deblocking_disable", C.c_int32),
+                ("beta_offset_div2", C.c_int32), ("tc_offset_div2", C.c_int32), ("lf_across_slices", C.c_int32),
+                ("weighted_pred", C.c_int32), ("num_ref_idx", C.c_int32 * 2),
+                ("ref_pic", (C.c_int32 * MAX_REF) * 2), ("ref_poc", (C.c_int32 * MAX_REF) * 2), ("reserved", C.c_int32 * 6)]
+
+
+class CtuMeta(C.Structure):
+    _fields_ = [("depth", C.c_void_p), ("part_size", C.c_void_p), ("pred_mode", C.c_void_p), ("qp", C.c_void_p),
+                ("tr_idx", C.c_void_p), ("cbf", C.c_void_p * 3), ("transform_skip", C.c_void_p * 3),
+                ("mv", C.c_void_p * 2), ("ref_idx", C.c_void_p * 2), ("intra_dir", C.c_void_p * 2),
+                ("transquant_bypass", C.c_void_p), ("ipcm", C.c_void_p), ("slice_idx", C.c_void_p), ("tile_idx", C.c_void_p)]
+
+
+class Coeffs(C.Structure):
+    _fields_ = [("level", C.c_void_p * 3)]
+
+
+class SaoParam(C.Structure):
+    _fields_ = [("mode_idc", C.c_int32), ("type_idc", C.c_int32), ("type_aux_info", C.c_int32), ("offset", C.c_int32 * 32)]
+
+
+class PicParams(C.Structure):
+    _fields_ = [("lf_across_tiles", C.c_int32), ("sao_enabled", C.c_int32), ("sao_offset_shift_luma", C.c_int32),
+                ("sao_offset_shift_chroma", C.c_int32), ("reserved", C.c_int32 * 8)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("kernel_ms", C.c_double * NUM_KERNELS), ("kernel_launches", C.c_uint64 * NUM_KERNELS),
+                ("intra_partitions", C.c_uint64), ("inter_partitions", C.c_uint64), ("coded_tus", (C.c_uint64 * 3) * 4)]
+
+
+class OraclePicture(C.Structure):           # oracle/hm_oracle.h: hmo_picture
+    _fields_ = [("plane", C.c_void_p * 3)]
+
+
+# ------------------------------------------------------------------------------------------------ helpers
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p).value
+
+
+def make_seq(width, height, bd_luma, bd_chroma=None, log2_ctu=6, max_pictures=8):
+    s = SeqParams()
+    s.width, s.height = width, height
+    s.bit_depth_luma = bd_luma
+    s.bit_depth_chroma = bd_luma if bd_chroma is None else bd_chroma
+    s.chroma_format = 1
+    s.log2_ctu_size = log2_ctu
+    s.max_pictures = max_pictures
+    return s
+
+
+def num_ctus(seq):
+    c = 1 << seq.log2_ctu_size
+    return ((seq.width + c - 1) // c) * ((seq.height + c - 1) // c)
+
+
+def parts_per_ctu(seq):
+    return 1 << (2 * seq.log2_ctu_size - 4)
+
+
+META_ARRAYS = [("depth", np.uint8), ("part_size", np.int8), ("pred_mode", np.int8), ("qp", np.int8), ("tr_idx", np.uint8),
+               ("cbf_y", np.uint8), ("cbf_u", np.uint8), ("cbf_v", np.uint8), ("ts_y", np.uint8), ("ts_u", np.uint8),
+               ("ts_v", np.uint8), ("mv0", np.int16), ("mv1", np.int16), ("ref_idx0", np.int8), ("ref_idx1", np.int8),
+               ("intra_dir_l", np.uint8), ("intra_dir_c", np.uint8), ("bypass", np.uint8), ("ipcm", np.uint8),
+               ("slice_idx", np.uint16), ("tile_idx", np.uint16)]
+
+
+class MetaHolder:
+    """Keeps the numpy arrays alive next to the CtuMeta struct that points into them."""
+
+    def __init__(self, arrays):
+        self.arrays = {}
+        for name, dt in META_ARRAYS:
+            a = arrays.get(name)
+            if a is not None:
+                a = np.ascontiguousarray(a, dtype=dt)
+            self.arrays[name] = a
+        g = self.arrays
+        m = CtuMeta()
+        m.depth, m.part_size, m.pred_mode, m.qp, m.tr_idx = (_ptr(g[k]) for k in ("depth", "part_size", "pred_mode", "qp", "tr_idx"))
+        for i, k in enumerate(("cbf_y", "cbf_u", "cbf_v")):
+            m.cbf[i] = _ptr(g[k])
+        for i, k in enumerate(("ts_y", "ts_u", "ts_v")):
+            m.transform_skip[i] = _ptr(g[k])
+        m.mv[0], m.mv[1] = _ptr(g["mv0"]), _ptr(g["mv1"])
+        m.ref_idx[0], m.ref_idx[1] = _ptr(g["ref_idx0"]), _ptr(g["ref_idx1"])
+        m.intra_dir[0], m.intra_dir[1] = _ptr(g["intra_dir_l"]), _ptr(g["intra_dir_c"])
+        m.transquant_bypass, m.ipcm = _ptr(g["bypass"]), _ptr(g["ipcm"])
+        m.slice_idx, m.tile_idx = _ptr(g["slice_idx"]), _ptr(g["tile_idx"])
+        self.struct = m
+
+
+class CoeffHolder:
+    def __init__(self, y, cb, cr):
+        self.arrays = [np.ascontiguousarray(a, dtype=np.int16) for a in (y, cb, cr)]
+        self.struct = Coeffs()
+        for i in range(3):
+            self.struct.level[i] = _ptr(self.arrays[i])
+
+
+def make_slice(slice_type, ref_pic=((), ()), ref_poc=((), ()), cb_qp_offset=0, cr_qp_offset=0, pps_cb=0, pps_cr=0,
+               deblocking_disable=0, beta_offset_div2=0, tc_offset_div2=0, lf_across_slices=1):
+    s = SliceParams()
+    s.slice_type = slice_type
+    s.cb_qp_offset, s.cr_qp_offset = cb_qp_offset, cr_qp_offset
+    s.pps_cb_qp_offset, s.pps_cr_qp_offset = pps_cb, pps_cr
+    s.deblocking_disable = deblocking_disable
+    s.beta_offset_div2, s.tc_offset_div2 = beta_offset_div2, tc_offset_div2
+    s.lf_across_slices = lf_across_slices
+    for l in range(2):
+        s.num_ref_idx[l] = len(ref_pic[l])
+        for i in range(MAX_REF):
+            s.ref_pic[l][i] = NO_PIC
+        for i, (h, p) in enumerate(zip(ref_pic[l], ref_poc[l])):
+            s.ref_pic[l][i] = int(h)
+            s.ref_poc[l][i] = int(p)
+    return s
+
+
+def make_pic_params(sao_enabled=1, lf_across_tiles=1):
+    p = PicParams()
+    p.sao_enabled, p.lf_across_tiles = sao_enabled, lf_across_tiles
+    return p
+
+
+def sao_array_from_raw(raw):
+    """raw: int32 [num_ctus, 3, 35] (mode, type, aux, offset[32]) -> ctypes array of SaoParam [num_ctus*3]"""
+    raw = np.ascontiguousarray(raw, dtype=np.int32)
+    n = raw.shape[0] * 3
+    arr = (SaoParam * n)()
+    C.memmove(arr, raw.ctypes.data, n * C.sizeof(SaoParam))
+    return arr
+
+
+def sao_array_to_np(arr, n_ctus):
+    out = np.zeros((n_ctus, 3, 35), dtype=np.int32)
+    C.memmove(out.ctypes.data, arr, n_ctus * 3 * C.sizeof(SaoParam))
+    return out

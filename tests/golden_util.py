@@ -1,0 +1,99 @@
+"""Load the golden fixtures (tests/golden/*.npz, made by oracle/make_golden.py from the real HM) into the ABI structs."""
+import hashlib
+import os
+
+import numpy as np
+
+from libhm_amd import abi
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+STREAMS = ["ldp_main8_416x240", "ra_main10_208x120", "ldp_main10_208x120", "intra_main10_208x120"]
+_cache = {}
+
+
+def load(name):
+    if name not in _cache:
+        _cache[name] = np.load(os.path.join(GOLD, name + ".npz"))
+    return _cache[name]
+
+
+class Picture:
+    """One decoded picture of a fixture stream: ABI inputs + HM's planes at the three stages."""
+
+    def __init__(self, z, idx, poc_to_handle):
+        k = "pic%02d_" % idx
+        info = z[k + "info"]
+        (self.width, self.height, self.bd_y, self.bd_c, self.poc, self.slice_type, self.num_ctus, self.ctus_w, self.parts,
+         self.ctu_size, self.num_slices, self.use_sao, self.lf_across_tiles) = (int(v) for v in info[:13])
+        self.index = idx
+        self.seq = abi.make_seq(self.width, self.height, self.bd_y, self.bd_c, log2_ctu=int(np.log2(self.ctu_size)), max_pictures=12)
+        self.slices = []
+        self.ref_pocs = set()
+        for s in z[k + "slices"]:
+            assert s[14] == 0 and s[15] == 0, "weighted prediction not expected in fixtures"
+            refs, pocs = [], []
+            for l in range(2):
+                p = [int(v) for v in s[32 + 16 * l: 32 + 16 * l + int(s[12 + l])]]
+                pocs.append(p)
+                refs.append([poc_to_handle[v] for v in p])
+                self.ref_pocs.update(p)
+            self.slices.append(abi.make_slice(int(s[0]), refs, pocs, cb_qp_offset=int(s[2] + s[4]), cr_qp_offset=int(s[3] + s[5]),
+                                              pps_cb=int(s[2]), pps_cr=int(s[3]), deblocking_disable=int(s[6]),
+                                              beta_offset_div2=int(s[7]), tc_offset_div2=int(s[8]), lf_across_slices=int(s[9])))
+        m = {n: z[k + "meta_" + n] for n in ("depth", "part_size", "pred_mode", "qp", "tr_idx", "cbf_y", "cbf_u", "cbf_v", "ts_y",
+                                             "ts_u", "ts_v", "mv0", "mv1", "ref_idx0", "ref_idx1", "intra_dir_l", "intra_dir_c",
+                                             "bypass", "ipcm")}
+        m["slice_idx"] = z[k + "meta_slice_idx"].astype(np.uint16)
+        self.meta_np = m
+        self.meta = abi.MetaHolder(m)
+        self.coeffs = abi.CoeffHolder(z[k + "coeff0"], z[k + "coeff1"], z[k + "coeff2"])
+        self.sao_raw = z[k + "sao_raw"]
+        self.sao_rec = z[k + "sao_rec"]
+        self.pre = [z[k + "pre%d" % c] for c in range(3)]
+        self.dbk = [z[k + "dbk%d" % c] for c in range(3)]
+        self.fin = [z[k + "fin%d" % c] for c in range(3)]
+        self.md5 = bytes(z[k + "md5"])
+        self.pp = abi.make_pic_params(sao_enabled=self.use_sao, lf_across_tiles=self.lf_across_tiles)
+
+    def inter_mask(self, comp):
+        """boolean mask of the plane: True where the sample belongs to an inter-coded, decoded CU"""
+        cs = 1 if comp else 0
+        mask = np.zeros((self.height >> cs, self.width >> cs), dtype=bool)
+        pm = self.meta_np["pred_mode"]
+        ps = self.meta_np["part_size"]
+        pw = self.ctu_size // 4
+        step = 4 >> cs
+        for a in range(self.num_ctus):
+            cx, cy = (a % self.ctus_w) * self.ctu_size, (a // self.ctus_w) * self.ctu_size
+            for zidx in range(self.parts):
+                x = sum(((zidx >> (2 * b)) & 1) << b for b in range(8))
+                y = sum(((zidx >> (2 * b + 1)) & 1) << b for b in range(8))
+                px, py = cx + 4 * x, cy + 4 * y
+                if px >= self.width or py >= self.height:
+                    continue
+                if pm[a, zidx] == abi.MODE_INTER and ps[a, zidx] != abi.SIZE_NONE:
+                    mask[py >> cs:(py >> cs) + step, px >> cs:(px >> cs) + step] = True
+        return mask
+
+
+def stream_pictures(name):
+    z = load("stream_" + name)
+    n = int(z["num_pics"][0])
+    poc_to_handle = {}
+    pics = []
+    for i in range(n):
+        poc = int(z["pic%02d_info" % i][4])
+        p = Picture(z, i, poc_to_handle)
+        poc_to_handle[poc] = i          # picture handle == decode index
+        pics.append(p)
+    return pics
+
+
+def hm_md5(planes, bit_depths):
+    """MD5 per plane the way TComPicYuvMD5.cpp:44-84,183-205 feeds libmd5: raster order, visible area,
+    1 byte/sample for bit depth <= 8 else 2 bytes little-endian."""
+    out = b""
+    for p, bd in zip(planes, bit_depths):
+        data = p.astype(np.uint8).tobytes() if bd <= 8 else p.astype("<u2").tobytes()
+        out += hashlib.md5(data).digest()
+    return out
