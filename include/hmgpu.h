@@ -80,10 +80,11 @@ typedef struct hmgpu_slice_params {
   int32_t beta_offset_div2, tc_offset_div2;
   int32_t lf_across_slices;             /* getLFCrossSliceBoundaryFlag() */
   int32_t weighted_pred;                /* PPS weighted_pred_flag / weighted_bipred_flag for this slice type: must be 0 */
+  int32_t lf_across_tiles;              /* PPS loop_filter_across_tiles_enabled_flag (TDecGop.cpp:165) */
   int32_t num_ref_idx[2];
   hmgpu_pic ref_pic[2][HMGPU_MAX_REF];  /* getRefPic(list, idx) as device picture handles */
   int32_t ref_poc[2][HMGPU_MAX_REF];    /* getRefPOC(list, idx) (identical-motion test, TComPrediction.cpp:497-512) */
-  int32_t reserved[6];
+  int32_t reserved[5];
 } hmgpu_slice_params;
 
 /* The picture-persistent TComDataCU arrays of TComPicSym (TComPicSym.cpp:93-114).  Every array covers the WHOLE
@@ -197,6 +198,9 @@ hmgpu_status hmgpu_filter_picture_stages(hmgpu_ctx* ctx, hmgpu_pic cur, const hm
  * bench.py times ("inputs already resident in HBM").  Kernel times are measured with hipEvents on the
  * context's own stream. */
 hmgpu_status hmgpu_replay(hmgpu_ctx* ctx, hmgpu_pic cur, int32_t stages /* 8 = reconstruct | 1|2|4 filter */, int32_t iters);
+/* the same for `n` mutually independent pictures at once (<= 16): every kernel is launched once for the whole batch
+ * (one grid z-slice per picture) -- the frame-parallel mode used for throughput measurements */
+hmgpu_status hmgpu_replay_batch(hmgpu_ctx* ctx, const hmgpu_pic* pics, int32_t n, int32_t stages, int32_t iters);
 
 #define HMGPU_NUM_KERNELS 12
 typedef struct hmgpu_stats {

@@ -1,0 +1,176 @@
+"""libhm_amd -- MI355X-native pixel reconstruction for the HM (HEVC) decoder.
+
+The product is libhm_amd/libhmgpu.so: hand-written HIP kernels for gfx950 behind the C ABI of include/hmgpu.h
+(drop-in for HM's TDecGop::decompressSlice / filterPicture).  This package is only the thin ctypes
+binding used by tests and bench.py; it contains no compute and NO fallback: if the shared library or a GPU is missing,
+every entry point raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import abi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libhmgpu.so")
+_lib = None
+
+
+class HmgpuError(RuntimeError):
+    def __init__(self, status, what, device_error=0):
+        self.status = status
+        self.device_error = device_error
+        names = {1: "HMGPU_EINVAL", 2: "HMGPU_EDEVICE", 3: "HMGPU_EUNSUPPORTED", 4: "HMGPU_ENOMEM"}
+        super().__init__("%s failed: %s%s" % (what, names.get(status, status),
+                                              " (hipError %d)" % device_error if status == 2 else ""))
+
+
+def lib():
+    """Load libhmgpu.so.  No fallback: a missing library is an error."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError("libhm_amd/libhmgpu.so is missing: build it with `python libhm_amd/build.py` "
+                               "(or __graft_entry__.build()); there is no CPU fallback")
+        L = C.CDLL(LIB_PATH)
+        L.hmgpu_create.argtypes = [C.POINTER(abi.SeqParams), C.c_int, C.POINTER(C.c_void_p)]
+        L.hmgpu_destroy.argtypes = [C.c_void_p]
+        L.hmgpu_destroy.restype = None
+        L.hmgpu_last_device_error.argtypes = [C.c_void_p]
+        L.hmgpu_sync.argtypes = [C.c_void_p]
+        L.hmgpu_status_string.restype = C.c_char_p
+        L.hmgpu_kernel_name.restype = C.c_char_p
+        L.hmgpu_num_ctus.argtypes = [C.POINTER(abi.SeqParams)]
+        L.hmgpu_parts_per_ctu.argtypes = [C.POINTER(abi.SeqParams)]
+        L.hmgpu_picture_acquire.argtypes = [C.c_void_p, C.POINTER(C.c_int32)]
+        L.hmgpu_picture_release.argtypes = [C.c_void_p, C.c_int32]
+        L.hmgpu_picture_upload.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_int32)]
+        L.hmgpu_picture_download.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_int32)]
+        L.hmgpu_decompress_slice.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(abi.SliceParams), C.POINTER(abi.CtuMeta),
+                                             C.POINTER(abi.Coeffs), C.c_int32, C.c_int32]
+        L.hmgpu_filter_picture.argtypes = [C.c_void_p, C.c_int32, C.POINTER(abi.PicParams), C.c_void_p]
+        L.hmgpu_filter_picture_stages.argtypes = [C.c_void_p, C.c_int32, C.POINTER(abi.PicParams), C.c_void_p, C.c_int32]
+        L.hmgpu_replay.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32]
+        L.hmgpu_replay_batch.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.c_int32, C.c_int32, C.c_int32]
+        L.hmgpu_set_profiling.argtypes = [C.c_void_p, C.c_int32]
+        L.hmgpu_get_stats.argtypes = [C.c_void_p, C.POINTER(abi.Stats), C.c_int32]
+        L.hmgpu_inverse_transform_batch.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32] + [C.c_void_p] * 5
+        L.hmgpu_mc_batch.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                     C.c_void_p, C.c_int32, C.c_void_p]
+        _lib = L
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class Context:
+    """One hmgpu context = one GPU + one HIP stream + a pool of device pictures (HM: one TDecTop)."""
+
+    def __init__(self, seq, device=0):
+        self.seq = seq
+        self._h = C.c_void_p()
+        st = lib().hmgpu_create(C.byref(seq), device, C.byref(self._h))
+        if st != 0:
+            raise HmgpuError(st, "hmgpu_create")
+        self.num_ctus = lib().hmgpu_num_ctus(C.byref(seq))
+        self.parts = lib().hmgpu_parts_per_ctu(C.byref(seq))
+
+    def _chk(self, st, what):
+        if st != 0:
+            raise HmgpuError(st, what, lib().hmgpu_last_device_error(self._h))
+
+    def close(self):
+        if self._h:
+            lib().hmgpu_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def sync(self):
+        self._chk(lib().hmgpu_sync(self._h), "hmgpu_sync")
+
+    # ---- pictures
+    def acquire(self):
+        h = C.c_int32(-1)
+        self._chk(lib().hmgpu_picture_acquire(self._h, C.byref(h)), "hmgpu_picture_acquire")
+        return h.value
+
+    def release(self, pic):
+        self._chk(lib().hmgpu_picture_release(self._h, pic), "hmgpu_picture_release")
+
+    def upload(self, pic, planes):
+        planes = [np.ascontiguousarray(p, dtype=np.int16) for p in planes]
+        ptrs = (C.c_void_p * 3)(*[p.ctypes.data for p in planes])
+        strides = (C.c_int32 * 3)(*[p.shape[1] for p in planes])
+        self._chk(lib().hmgpu_picture_upload(self._h, pic, ptrs, strides), "hmgpu_picture_upload")
+
+    def download(self, pic):
+        w, h = self.seq.width, self.seq.height
+        planes = [np.zeros((h, w), dtype=np.int16), np.zeros((h // 2, w // 2), dtype=np.int16), np.zeros((h // 2, w // 2), dtype=np.int16)]
+        ptrs = (C.c_void_p * 3)(*[p.ctypes.data for p in planes])
+        strides = (C.c_int32 * 3)(*[p.shape[1] for p in planes])
+        self._chk(lib().hmgpu_picture_download(self._h, pic, ptrs, strides), "hmgpu_picture_download")
+        return planes
+
+    # ---- the two calls
+    def decompress_slice(self, pic, slice_idx, slice_params, meta, coeffs, first_ctu=0, num_ctus=None):
+        n = self.num_ctus - first_ctu if num_ctus is None else num_ctus
+        st = lib().hmgpu_decompress_slice(self._h, pic, slice_idx, C.byref(slice_params), C.byref(meta.struct),
+                                          C.byref(coeffs.struct), first_ctu, n)
+        self._chk(st, "hmgpu_decompress_slice")
+
+    def filter_picture(self, pic, pic_params, sao_raw=None, stages=7):
+        arr = abi.sao_array_from_raw(sao_raw) if sao_raw is not None else None
+        st = lib().hmgpu_filter_picture_stages(self._h, pic, C.byref(pic_params), arr, stages)
+        self._chk(st, "hmgpu_filter_picture_stages")
+
+    def replay(self, pics, stages, iters):
+        pics = list(pics) if isinstance(pics, (list, tuple)) else [pics]
+        arr = (C.c_int32 * len(pics))(*pics)
+        self._chk(lib().hmgpu_replay_batch(self._h, arr, len(pics), stages, iters), "hmgpu_replay_batch")
+
+    def set_profiling(self, on):
+        self._chk(lib().hmgpu_set_profiling(self._h, int(on)), "hmgpu_set_profiling")
+
+    def stats(self, reset=False):
+        s = abi.Stats()
+        self._chk(lib().hmgpu_get_stats(self._h, C.byref(s), int(reset)), "hmgpu_get_stats")
+        out = {"intra_partitions": int(s.intra_partitions), "inter_partitions": int(s.inter_partitions), "kernels": {}}
+        for k in range(abi.NUM_KERNELS):
+            out["kernels"][lib().hmgpu_kernel_name(k).decode()] = (float(s.kernel_ms[k]), int(s.kernel_launches[k]))
+        return out
+
+    # ---- finer seams
+    def inverse_transform_batch(self, levels, log2_size, bit_depth, qp_per, qp_rem, flags):
+        levels = np.ascontiguousarray(levels, dtype=np.int16)
+        n = levels.shape[0]
+        per = np.ascontiguousarray(qp_per, dtype=np.int8)
+        rem = np.ascontiguousarray(qp_rem, dtype=np.int8)
+        fl = np.ascontiguousarray(flags, dtype=np.uint8)
+        out = np.zeros_like(levels)
+        st = lib().hmgpu_inverse_transform_batch(self._h, log2_size, bit_depth, n, _p(levels), _p(per), _p(rem), _p(fl), _p(out))
+        self._chk(st, "hmgpu_inverse_transform_batch")
+        return out
+
+    def mc_batch(self, is_chroma, bit_depth, plane, blocks, bi):
+        """blocks: int32 [n, 6] = x, y, w, h, mvx, mvy.  returns list of (h, w) arrays"""
+        plane = np.ascontiguousarray(plane, dtype=np.int16)
+        blocks = np.ascontiguousarray(blocks, dtype=np.int32)
+        total = int((blocks[:, 2] * blocks[:, 3]).sum())
+        dst = np.zeros(total, dtype=np.int16)
+        st = lib().hmgpu_mc_batch(self._h, int(is_chroma), bit_depth, _p(plane), plane.shape[1], plane.shape[1], plane.shape[0],
+                                  blocks.shape[0], _p(blocks), int(bi), _p(dst))
+        self._chk(st, "hmgpu_mc_batch")
+        out, pos = [], 0
+        for b in blocks:
+            w, h = int(b[2]), int(b[3])
+            out.append(dst[pos:pos + w * h].reshape(h, w))
+            pos += w * h
+        return out

@@ -30,8 +30,8 @@ class SliceParams(C.Structure):
     _fields_ = [("slice_type", C.c_int32), ("cb_qp_offset", C.c_int32), ("cr_qp_offset", C.c_int32),
                 ("pps_cb_qp_offset", C.c_int32), ("pps_cr_qp_offset", C.c_int32), ("deblocking_disable", C.c_int32),
                 ("beta_offset_div2", C.c_int32), ("tc_offset_div2", C.c_int32), ("lf_across_slices", C.c_int32),
-                ("weighted_pred", C.c_int32), ("num_ref_idx", C.c_int32 * 2),
-                ("ref_pic", (C.c_int32 * MAX_REF) * 2), ("ref_poc", (C.c_int32 * MAX_REF) * 2), ("reserved", C.c_int32 * 6)]
+                ("weighted_pred", C.c_int32), ("lf_across_tiles", C.c_int32), ("num_ref_idx", C.c_int32 * 2),
+                ("ref_pic", (C.c_int32 * MAX_REF) * 2), ("ref_poc", (C.c_int32 * MAX_REF) * 2), ("reserved", C.c_int32 * 5)]
 
 
 class CtuMeta(C.Structure):
@@ -57,10 +57,6 @@ class PicParams(C.Structure):
 class Stats(C.Structure):
     _fields_ = [("kernel_ms", C.c_double * NUM_KERNELS), ("kernel_launches", C.c_uint64 * NUM_KERNELS),
                 ("intra_partitions", C.c_uint64), ("inter_partitions", C.c_uint64), ("coded_tus", (C.c_uint64 * 3) * 4)]
-
-
-class OraclePicture(C.Structure):           # oracle/hm_oracle.h: hmo_picture
-    _fields_ = [("plane", C.c_void_p * 3)]
 
 
 # ------------------------------------------------------------------------------------------------ helpers
@@ -129,7 +125,7 @@ class CoeffHolder:
 
 
 def make_slice(slice_type, ref_pic=((), ()), ref_poc=((), ()), cb_qp_offset=0, cr_qp_offset=0, pps_cb=0, pps_cr=0,
-               deblocking_disable=0, beta_offset_div2=0, tc_offset_div2=0, lf_across_slices=1):
+               deblocking_disable=0, beta_offset_div2=0, tc_offset_div2=0, lf_across_slices=1, lf_across_tiles=1):
     s = SliceParams()
     s.slice_type = slice_type
     s.cb_qp_offset, s.cr_qp_offset = cb_qp_offset, cr_qp_offset
@@ -137,6 +133,7 @@ def make_slice(slice_type, ref_pic=((), ()), ref_poc=((), ()), cb_qp_offset=0, c
     s.deblocking_disable = deblocking_disable
     s.beta_offset_div2, s.tc_offset_div2 = beta_offset_div2, tc_offset_div2
     s.lf_across_slices = lf_across_slices
+    s.lf_across_tiles = lf_across_tiles
     for l in range(2):
         s.num_ref_idx[l] = len(ref_pic[l])
         for i in range(MAX_REF):

@@ -1,0 +1,653 @@
+// hmgpu_api.hip -- host runtime of libhmgpu.so: context, device pictures (the DPB lives in HBM), staging of HM's
+// per-CTU arrays, kernel sequencing, and the extern "C" surface declared in include/hmgpu.h.
+//
+// Host-side counterpart of TDecGop/TDecSlice/TDecCu's control flow (TDecGop.cpp:105-217), reduced to what is left
+// once every traversal runs on the device: copy arrays, launch kernels, keep per-picture state.  The only serial
+// host computation is reconstructBlkSAOParams' merge resolution (a dependent chain over CTUs, 3 x num_ctus items).
+#include "hmgpu_dev.h"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+using namespace hmgpu;
+
+namespace {
+
+enum { K_PREP = 0, K_MC_LUMA, K_MC_CHROMA, K_ITX4, K_ITX8, K_ITX16, K_ITX32, K_DBK_VER, K_DBK_HOR, K_SAO, K_H2D, K_OTHER };
+const char* const kKernelNames[HMGPU_NUM_KERNELS] = {"prep", "mc_luma", "mc_chroma", "itx4", "itx8", "itx16", "itx32",
+                                                     "deblock_ver", "deblock_hor", "sao", "h2d_stage", "other"};
+
+struct SliceCall { int first_ctu, num_ctus, slice_idx; };
+
+struct Picture {
+  bool in_use = false;
+  bool sao_applied = false;
+  bool filter_ready = false;            // SAO parameters staged
+  bool sao_any = false;
+  std::vector<SliceCall> calls;
+  // device allocations (owned)
+  void* planes = nullptr;               // rec[3] + sao[3]
+  void* meta = nullptr;                 // raw HM arrays
+  void* coef = nullptr;
+  void* derived = nullptr;              // blk, tu lists, counters, sao params, slices
+  PicDev dev;                           // host mirror of the device descriptor
+  std::vector<SliceDev> slices;         // host mirror of the slice table
+  int max_slice = -1;
+};
+
+struct EventPair { hipEvent_t a, b; int kind; };
+
+}  // namespace
+
+struct hmgpu_ctx {
+  hmgpu_seq_params seq;
+  int device = 0;
+  hipStream_t stream = nullptr;
+  int32_t last_err = 0;
+  // geometry
+  int ctu = 64, pw = 16, parts = 256, ctus_w = 0, ctus_h = 0, num_ctus = 0;
+  int pitch[3] = {0, 0, 0}, rows[3] = {0, 0, 0};
+  int grid_w = 0, grid_h = 0;
+  uint32_t tu_cap[4] = {0, 0, 0, 0};
+  size_t coef_elems[3] = {0, 0, 0};
+  std::vector<Picture> pics;
+  PicDev* d_pics = nullptr;
+  PlaneSet* d_finals = nullptr;
+  std::vector<PlaneSet> h_finals;
+  // profiling
+  bool profiling = false;
+  std::vector<EventPair> pending;
+  std::vector<EventPair> free_events;
+  double kernel_ms[HMGPU_NUM_KERNELS] = {0};
+  uint64_t kernel_launches[HMGPU_NUM_KERNELS] = {0};
+};
+
+namespace {
+
+#define HIP_TRY(ctx, expr)                                   \
+  do {                                                       \
+    hipError_t e__ = (expr);                                 \
+    if (e__ != hipSuccess) {                                 \
+      (ctx)->last_err = (int32_t)e__;                        \
+      return HMGPU_EDEVICE;                                  \
+    }                                                        \
+  } while (0)
+
+size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+struct Carver {                       // sub-allocates one device block, 256-byte aligned pieces
+  char* base; size_t off = 0;
+  explicit Carver(void* b) : base((char*)b) {}
+  template <typename T> T* take(size_t n) { T* p = base ? (T*)(base + off) : nullptr; off += align_up(n * sizeof(T), 256); return p; }
+};
+
+// profiling: a pair of events around one launch, resolved lazily
+void prof_begin(hmgpu_ctx* c, int kind, EventPair* ep) {
+  if (!c->profiling) return;
+  if (c->free_events.empty()) {
+    hipEventCreate(&ep->a); hipEventCreate(&ep->b);
+  } else { *ep = c->free_events.back(); c->free_events.pop_back(); }
+  ep->kind = kind;
+  hipEventRecord(ep->a, c->stream);
+}
+void prof_end(hmgpu_ctx* c, EventPair* ep) {
+  if (!c->profiling) return;
+  hipEventRecord(ep->b, c->stream);
+  c->pending.push_back(*ep);
+}
+void prof_drain(hmgpu_ctx* c) {
+  for (EventPair& ep : c->pending) {
+    float ms = 0.f;
+    hipEventSynchronize(ep.b);
+    if (hipEventElapsedTime(&ms, ep.a, ep.b) == hipSuccess) { c->kernel_ms[ep.kind] += ms; c->kernel_launches[ep.kind]++; }
+    c->free_events.push_back(ep);
+  }
+  c->pending.clear();
+}
+struct ProfScope {
+  hmgpu_ctx* c; EventPair ep;
+  ProfScope(hmgpu_ctx* ctx, int kind) : c(ctx) { prof_begin(c, kind, &ep); }
+  ~ProfScope() { prof_end(c, &ep); if (c->pending.size() > 8192) prof_drain(c); }
+};
+
+hmgpu_status alloc_picture(hmgpu_ctx* c, Picture& p) {
+  const hmgpu_seq_params& s = c->seq;
+  size_t plane_bytes = 0;
+  for (int k = 0; k < 3; k++) plane_bytes += align_up((size_t)c->pitch[k] * c->rows[k] * sizeof(int16_t), 256);
+  HIP_TRY(c, hipMalloc(&p.planes, plane_bytes * 2));
+  HIP_TRY(c, hipMemset(p.planes, 0, plane_bytes * 2));
+  const size_t np = (size_t)c->num_ctus * c->parts;
+  // raw metadata: 11 byte arrays + 2 mv arrays (4 B) + 2 ref_idx + slice/tile idx
+  Carver cm(nullptr);
+  for (int pass = 0; pass < 2; pass++) {
+    Carver m(pass ? p.meta : nullptr);
+    PicDev& d = p.dev;
+    d.depth = m.take<uint8_t>(np); d.part_size = m.take<int8_t>(np); d.pred_mode = m.take<int8_t>(np);
+    d.qp = m.take<int8_t>(np); d.tr_idx = m.take<uint8_t>(np);
+    for (int k = 0; k < 3; k++) d.cbf[k] = m.take<uint8_t>(np);
+    for (int k = 0; k < 3; k++) d.tskip[k] = m.take<uint8_t>(np);
+    for (int k = 0; k < 2; k++) d.mv[k] = m.take<int16_t>(np * 2);
+    for (int k = 0; k < 2; k++) d.ref_idx[k] = m.take<int8_t>(np);
+    d.slice_idx = m.take<uint16_t>(c->num_ctus); d.tile_idx = m.take<uint16_t>(c->num_ctus);
+    if (!pass) { HIP_TRY(c, hipMalloc(&p.meta, m.off)); HIP_TRY(c, hipMemset(p.meta, 0, m.off)); }
+  }
+  {
+    size_t bytes = 0;
+    for (int k = 0; k < 3; k++) bytes += align_up(c->coef_elems[k] * sizeof(int16_t), 256);
+    HIP_TRY(c, hipMalloc(&p.coef, bytes));
+    HIP_TRY(c, hipMemset(p.coef, 0, bytes));
+    Carver m(p.coef);
+    for (int k = 0; k < 3; k++) p.dev.coef[k] = m.take<int16_t>(c->coef_elems[k]);
+  }
+  for (int pass = 0; pass < 2; pass++) {
+    Carver m(pass ? p.derived : nullptr);
+    PicDev& d = p.dev;
+    d.blk = m.take<BlkInfo>((size_t)c->grid_w * c->grid_h);
+    for (int k = 0; k < 4; k++) d.tu[k] = m.take<TuRec>((size_t)c->tu_cap[k] * kTuShards);
+    d.tu_count = m.take<uint32_t>(4 * kTuShards);
+    d.stats = m.take<unsigned long long>(2 * kTuShards);
+    d.saoprm = m.take<SaoDev>((size_t)c->num_ctus * 3);
+    d.slices = m.take<SliceDev>(HMGPU_MAX_SLICES);
+    if (!pass) { HIP_TRY(c, hipMalloc(&p.derived, m.off)); HIP_TRY(c, hipMemset(p.derived, 0, m.off)); }
+  }
+  PicDev& d = p.dev;
+  d.width = s.width; d.height = s.height;
+  d.bd[0] = s.bit_depth_luma; d.bd[1] = d.bd[2] = s.bit_depth_chroma;
+  d.log2ctu = s.log2_ctu_size; d.ctus_w = c->ctus_w; d.ctus_h = c->ctus_h; d.num_ctus = c->num_ctus; d.parts = c->parts; d.pw = c->pw;
+  for (int k = 0; k < 3; k++) d.pitch[k] = c->pitch[k];
+  d.grid_w = c->grid_w; d.grid_h = c->grid_h;
+  d.lf_across_tiles = 1; d.sao_applied = 0;
+  for (int k = 0; k < 4; k++) d.tu_cap[k] = c->tu_cap[k];
+  {
+    Carver m(p.planes);
+    for (int k = 0; k < 3; k++) d.rec[k] = m.take<int16_t>((size_t)c->pitch[k] * c->rows[k]);
+    for (int k = 0; k < 3; k++) d.sao[k] = m.take<int16_t>((size_t)c->pitch[k] * c->rows[k]);
+  }
+  p.slices.assign(HMGPU_MAX_SLICES, SliceDev());
+  return HMGPU_OK;
+}
+
+void free_picture(Picture& p) {
+  if (p.planes) hipFree(p.planes);
+  if (p.meta) hipFree(p.meta);
+  if (p.coef) hipFree(p.coef);
+  if (p.derived) hipFree(p.derived);
+  p.planes = p.meta = p.coef = p.derived = nullptr;
+}
+
+hmgpu_status push_picdev(hmgpu_ctx* c, int pic) {
+  HIP_TRY(c, hipMemcpyAsync(c->d_pics + pic, &c->pics[pic].dev, sizeof(PicDev), hipMemcpyHostToDevice, c->stream));
+  return HMGPU_OK;
+}
+hmgpu_status push_final(hmgpu_ctx* c, int pic) {
+  Picture& p = c->pics[pic];
+  for (int k = 0; k < 3; k++) c->h_finals[pic].p[k] = p.sao_applied ? p.dev.sao[k] : p.dev.rec[k];
+  HIP_TRY(c, hipMemcpyAsync(c->d_finals + pic, &c->h_finals[pic], sizeof(PlaneSet), hipMemcpyHostToDevice, c->stream));
+  return HMGPU_OK;
+}
+
+bool valid_pic(const hmgpu_ctx* c, hmgpu_pic pic) { return pic >= 0 && pic < (int)c->pics.size() && c->pics[pic].in_use; }
+
+// device work of one batch of slice calls (one call per picture): counters, prep, MC, inverse transforms
+hmgpu_status run_recon(hmgpu_ctx* c, const Batch& b) {
+  int max_ctus = 0;
+  for (int i = 0; i < b.n; i++) max_ctus = std::max(max_ctus, b.num_ctus[i]);
+  for (int i = 0; i < b.n; i++) {
+    Picture& p = c->pics[b.pic[i]];
+    HIP_TRY(c, hipMemsetAsync(p.dev.tu_count, 0, sizeof(uint32_t) * 4 * kTuShards, c->stream));
+  }
+  { ProfScope ps(c, K_PREP); launch_prep(c->d_pics, b, max_ctus, c->parts, c->stream); }
+  { ProfScope ps(c, K_MC_LUMA); launch_mc_luma(c->d_pics, c->d_finals, b, max_ctus, c->seq.log2_ctu_size, c->stream); }
+  { ProfScope ps(c, K_MC_CHROMA); launch_mc_chroma(c->d_pics, c->d_finals, b, max_ctus, c->seq.log2_ctu_size, c->stream); }
+  // blocks per shard: enough to keep the chip busy on a full picture, few enough that a short list costs nothing
+  const uint32_t bps = (uint32_t)std::max(4, std::min(64, max_ctus / 8 + 1));
+  for (int l2 = 2; l2 <= 5; l2++) { ProfScope ps(c, K_ITX4 + (l2 - 2)); launch_itx(c->d_pics, b, l2, bps, c->stream); }
+  HIP_TRY(c, hipGetLastError());
+  return HMGPU_OK;
+}
+
+hmgpu_status run_filter(hmgpu_ctx* c, const Batch& b, int stages) {
+  if (stages & 1) { ProfScope ps(c, K_DBK_VER); launch_deblock(c->d_pics, b, 0, c->seq.width, c->seq.height, c->stream); }
+  if (stages & 2) { ProfScope ps(c, K_DBK_HOR); launch_deblock(c->d_pics, b, 1, c->seq.width, c->seq.height, c->stream); }
+  if (stages & 4) {
+    bool any = false;
+    for (int i = 0; i < b.n; i++) any |= c->pics[b.pic[i]].sao_any;
+    if (any) { ProfScope ps(c, K_SAO); launch_sao(c->d_pics, b, c->seq.width, c->seq.height, c->stream); }
+  }
+  HIP_TRY(c, hipGetLastError());
+  return HMGPU_OK;
+}
+
+// reconstructBlkSAOParams (TComSampleAdaptiveOffset.cpp:229-372) + deriveLoopFilterBoundaryAvailibility
+// (TComPicSym.cpp:365-471), host side: a dependent chain over CTUs, a few microseconds of work.
+hmgpu_status stage_sao(hmgpu_ctx* c, Picture& p, const hmgpu_pic_params* pp, const hmgpu_sao_param* sao,
+                       const std::vector<uint16_t>& slice_idx, const std::vector<uint16_t>& tile_idx) {
+  const int n = c->num_ctus;
+  std::vector<hmgpu_sao_param> rec(sao, sao + (size_t)n * 3);
+  std::vector<SaoDev> dev((size_t)n * 3);
+  bool any = false;
+  for (int a = 0; a < n; a++) {
+    const int cx = a % c->ctus_w, cy = a / c->ctus_w;
+    const hmgpu_sao_param* merge[2] = {nullptr, nullptr};
+    auto same = [&](int o) { return slice_idx[o] == slice_idx[a] && tile_idx[o] == tile_idx[a]; };
+    if (cx > 0 && same(a - 1)) merge[HMGPU_SAO_MERGE_LEFT] = &rec[(size_t)(a - 1) * 3];
+    if (cy > 0 && same(a - c->ctus_w)) merge[HMGPU_SAO_MERGE_ABOVE] = &rec[(size_t)(a - c->ctus_w) * 3];
+    // neighbour availability, order L,R,A,B,AL,AR,BL,BR
+    static const int dx[8] = {-1, 1, 0, 0, -1, 1, -1, 1}, dy[8] = {0, 0, -1, 1, -1, -1, 1, 1};
+    unsigned avail = 0;
+    for (int k = 0; k < 8; k++) {
+      const int nx = cx + dx[k], ny = cy + dy[k];
+      if (nx < 0 || nx >= c->ctus_w || ny < 0 || ny >= c->ctus_h) continue;
+      const int o = ny * c->ctus_w + nx;
+      bool ok = true;
+      if (slice_idx[o] != slice_idx[a]) {
+        // the slice that comes later in decoding order decides with its own flag (TComPicSym.cpp:403-452)
+        const SliceDev& later = p.slices[std::max(slice_idx[o], slice_idx[a])];
+        ok = later.lf_across_slices != 0;
+      }
+      if (ok && !pp->lf_across_tiles) ok = tile_idx[o] == tile_idx[a];
+      if (ok) avail |= 1u << k;
+    }
+    for (int comp = 0; comp < 3; comp++) {
+      hmgpu_sao_param& r = rec[(size_t)a * 3 + comp];
+      const int shift = comp == 0 ? pp->sao_offset_shift_luma : pp->sao_offset_shift_chroma;
+      if (r.mode_idc == HMGPU_SAO_NEW) {
+        int32_t coded[32];
+        memcpy(coded, r.offset, sizeof(coded));
+        memset(r.offset, 0, sizeof(r.offset));
+        if (r.type_idc == HMGPU_SAO_BO) {
+          for (int i = 0; i < 4; i++) { const int band = (r.type_aux_info + i) & 31; r.offset[band] = coded[band] * (1 << shift); }
+        } else {
+          for (int i = 0; i < 5; i++) r.offset[i] = coded[i] * (1 << shift);
+        }
+      } else if (r.mode_idc == HMGPU_SAO_MERGE) {
+        if (r.type_idc < 0 || r.type_idc > 1 || !merge[r.type_idc]) return HMGPU_EINVAL;     // HM: assert(mergeTarget != NULL)
+        r = merge[r.type_idc][comp];
+      }
+      SaoDev& d = dev[(size_t)a * 3 + comp];
+      d.type = r.mode_idc == HMGPU_SAO_OFF ? -1 : (int8_t)r.type_idc;
+      d.avail = (uint8_t)avail;
+      for (int i = 0; i < 32; i++) d.offset[i] = (int8_t)r.offset[i];
+      d.pad[0] = d.pad[1] = 0;
+      any |= d.type >= 0;
+    }
+  }
+  p.sao_any = any;
+  HIP_TRY(c, hipMemcpyAsync(p.dev.saoprm, dev.data(), dev.size() * sizeof(SaoDev), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));        // `dev` is a local
+  return HMGPU_OK;
+}
+
+}  // namespace
+
+// ======================================================================================================= C ABI
+extern "C" {
+
+const char* hmgpu_status_string(hmgpu_status s) {
+  switch (s) {
+    case HMGPU_OK: return "ok";
+    case HMGPU_EINVAL: return "invalid argument";
+    case HMGPU_EDEVICE: return "device (HIP) error";
+    case HMGPU_EUNSUPPORTED: return "coding tool not supported";
+    case HMGPU_ENOMEM: return "out of memory";
+  }
+  return "?";
+}
+const char* hmgpu_kernel_name(int32_t k) { return (k >= 0 && k < HMGPU_NUM_KERNELS) ? kKernelNames[k] : ""; }
+
+int32_t hmgpu_num_ctus(const hmgpu_seq_params* seq) {
+  const int c = 1 << seq->log2_ctu_size;
+  return ((seq->width + c - 1) / c) * ((seq->height + c - 1) / c);
+}
+int32_t hmgpu_parts_per_ctu(const hmgpu_seq_params* seq) { return 1 << (2 * seq->log2_ctu_size - 4); }
+
+hmgpu_status hmgpu_create(const hmgpu_seq_params* seq, int device_ordinal, hmgpu_ctx** out) {
+  if (!seq || !out) return HMGPU_EINVAL;
+  *out = nullptr;
+  if (seq->width <= 0 || seq->height <= 0 || (seq->width & 7) || (seq->height & 7)) return HMGPU_EINVAL;
+  if (seq->log2_ctu_size < 4 || seq->log2_ctu_size > 6) return HMGPU_EINVAL;
+  if (seq->max_pictures < 1 || seq->max_pictures > kMaxPics) return HMGPU_EINVAL;
+  if (seq->chroma_format != 1) return HMGPU_EUNSUPPORTED;
+  if (seq->bit_depth_luma < 8 || seq->bit_depth_luma > 10 || seq->bit_depth_chroma < 8 || seq->bit_depth_chroma > 10) return HMGPU_EUNSUPPORTED;
+  hmgpu_ctx* c = new (std::nothrow) hmgpu_ctx();
+  if (!c) return HMGPU_ENOMEM;
+  c->seq = *seq;
+  c->device = device_ordinal;
+  hipError_t e = hipSetDevice(device_ordinal);
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+  if (e != hipSuccess) { delete c; return HMGPU_EDEVICE; }
+  c->ctu = 1 << seq->log2_ctu_size; c->pw = c->ctu / 4; c->parts = c->pw * c->pw;
+  c->ctus_w = (seq->width + c->ctu - 1) / c->ctu; c->ctus_h = (seq->height + c->ctu - 1) / c->ctu;
+  c->num_ctus = c->ctus_w * c->ctus_h;
+  c->grid_w = c->ctus_w * c->pw; c->grid_h = c->ctus_h * c->pw;
+  // planes: rows 128-byte aligned (+ one spare 128-byte line so that vector loads may run past the last sample)
+  c->pitch[0] = (int)align_up((size_t)seq->width, 64) + 64;
+  c->pitch[1] = c->pitch[2] = (int)align_up((size_t)seq->width / 2, 64) + 64;
+  c->rows[0] = c->ctus_h * c->ctu + 8; c->rows[1] = c->rows[2] = c->ctus_h * c->ctu / 2 + 8;
+  c->coef_elems[0] = (size_t)c->num_ctus * c->ctu * c->ctu;
+  c->coef_elems[1] = c->coef_elems[2] = c->coef_elems[0] / 4;
+  {
+    // TU list capacity of one shard: blocks of 256 partitions go round-robin to the shards; a block (one 64x64 luma
+    // area) holds at most 256+128 4x4, 64+32 8x8, 16+8 16x16 and 4 32x32 TUs
+    const size_t blocks = ((size_t)c->num_ctus * c->parts + 255) / 256;
+    const size_t per_shard = (blocks + kTuShards - 1) / kTuShards;
+    const uint32_t per_block[4] = {384, 96, 24, 4};
+    for (int k = 0; k < 4; k++) c->tu_cap[k] = (uint32_t)(per_shard * per_block[k]);
+  }
+  c->pics.resize(seq->max_pictures);
+  c->h_finals.resize(seq->max_pictures);
+  hmgpu_status st = HMGPU_OK;
+  for (int i = 0; i < seq->max_pictures && st == HMGPU_OK; i++) st = alloc_picture(c, c->pics[i]);
+  if (st == HMGPU_OK) {
+    if (hipMalloc((void**)&c->d_pics, sizeof(PicDev) * seq->max_pictures) != hipSuccess ||
+        hipMalloc((void**)&c->d_finals, sizeof(PlaneSet) * seq->max_pictures) != hipSuccess) st = HMGPU_EDEVICE;
+  }
+  if (st == HMGPU_OK) {
+    for (int i = 0; i < seq->max_pictures && st == HMGPU_OK; i++) { st = push_picdev(c, i); if (st == HMGPU_OK) st = push_final(c, i); }
+    if (st == HMGPU_OK && hipStreamSynchronize(c->stream) != hipSuccess) st = HMGPU_EDEVICE;
+  }
+  if (st != HMGPU_OK) { hmgpu_destroy(c); return st; }
+  *out = c;
+  return HMGPU_OK;
+}
+
+void hmgpu_destroy(hmgpu_ctx* c) {
+  if (!c) return;
+  hipSetDevice(c->device);
+  if (c->stream) hipStreamSynchronize(c->stream);
+  prof_drain(c);
+  for (EventPair& ep : c->free_events) { hipEventDestroy(ep.a); hipEventDestroy(ep.b); }
+  for (Picture& p : c->pics) free_picture(p);
+  if (c->d_pics) hipFree(c->d_pics);
+  if (c->d_finals) hipFree(c->d_finals);
+  if (c->stream) hipStreamDestroy(c->stream);
+  delete c;
+}
+
+int32_t hmgpu_last_device_error(const hmgpu_ctx* c) { return c ? c->last_err : 0; }
+
+hmgpu_status hmgpu_sync(hmgpu_ctx* c) {
+  if (!c) return HMGPU_EINVAL;
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  prof_drain(c);
+  return HMGPU_OK;
+}
+
+hmgpu_status hmgpu_picture_acquire(hmgpu_ctx* c, hmgpu_pic* out) {
+  if (!c || !out) return HMGPU_EINVAL;
+  for (size_t i = 0; i < c->pics.size(); i++) {
+    Picture& p = c->pics[i];
+    if (!p.in_use) {
+      p.in_use = true; p.sao_applied = false; p.filter_ready = false; p.sao_any = false; p.calls.clear(); p.max_slice = -1;
+      p.dev.sao_applied = 0;
+      *out = (hmgpu_pic)i;
+      hmgpu_status st = push_final(c, (int)i);
+      return st;
+    }
+  }
+  return HMGPU_ENOMEM;
+}
+
+hmgpu_status hmgpu_picture_release(hmgpu_ctx* c, hmgpu_pic pic) {
+  if (!c || !valid_pic(c, pic)) return HMGPU_EINVAL;
+  c->pics[pic].in_use = false;
+  return HMGPU_OK;
+}
+
+hmgpu_status hmgpu_picture_upload(hmgpu_ctx* c, hmgpu_pic pic, const int16_t* const planes[3], const int32_t strides[3]) {
+  if (!c || !valid_pic(c, pic) || !planes || !strides) return HMGPU_EINVAL;
+  Picture& p = c->pics[pic];
+  for (int k = 0; k < 3; k++) {
+    const int w = c->seq.width >> (k ? 1 : 0), h = c->seq.height >> (k ? 1 : 0);
+    int16_t* dst = p.sao_applied ? p.dev.sao[k] : p.dev.rec[k];
+    HIP_TRY(c, hipMemcpy2DAsync(dst, (size_t)c->pitch[k] * 2, planes[k], (size_t)strides[k] * 2, (size_t)w * 2, h,
+                                hipMemcpyHostToDevice, c->stream));
+  }
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return HMGPU_OK;
+}
+
+hmgpu_status hmgpu_picture_download(hmgpu_ctx* c, hmgpu_pic pic, int16_t* const planes[3], const int32_t strides[3]) {
+  if (!c || !valid_pic(c, pic) || !planes || !strides) return HMGPU_EINVAL;
+  Picture& p = c->pics[pic];
+  for (int k = 0; k < 3; k++) {
+    const int w = c->seq.width >> (k ? 1 : 0), h = c->seq.height >> (k ? 1 : 0);
+    const int16_t* src = p.sao_applied ? p.dev.sao[k] : p.dev.rec[k];
+    HIP_TRY(c, hipMemcpy2DAsync(planes[k], (size_t)strides[k] * 2, src, (size_t)c->pitch[k] * 2, (size_t)w * 2, h,
+                                hipMemcpyDeviceToHost, c->stream));
+  }
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  prof_drain(c);
+  return HMGPU_OK;
+}
+
+hmgpu_status hmgpu_decompress_slice(hmgpu_ctx* c, hmgpu_pic cur, int32_t slice_idx, const hmgpu_slice_params* sl,
+                                    const hmgpu_ctu_meta* m, const hmgpu_coeffs* co, int32_t first_ctu, int32_t num_ctus) {
+  if (!c || !valid_pic(c, cur) || !sl || !m || !co) return HMGPU_EINVAL;
+  if (slice_idx < 0 || slice_idx >= HMGPU_MAX_SLICES) return HMGPU_EINVAL;
+  if (first_ctu < 0 || num_ctus <= 0 || first_ctu + num_ctus > c->num_ctus) return HMGPU_EINVAL;
+  if (!m->depth || !m->part_size || !m->pred_mode || !m->qp || !m->tr_idx || !m->cbf[0] || !m->cbf[1] || !m->cbf[2] ||
+      !m->mv[0] || !m->mv[1] || !m->ref_idx[0] || !m->ref_idx[1] || !co->level[0] || !co->level[1] || !co->level[2])
+    return HMGPU_EINVAL;
+  if (sl->weighted_pred) return HMGPU_EUNSUPPORTED;
+  Picture& p = c->pics[cur];
+  const size_t po = (size_t)first_ctu * c->parts, pn = (size_t)num_ctus * c->parts;
+  // tools outside the envelope: lossless / PCM CUs
+  for (const uint8_t* arr : {m->transquant_bypass, m->ipcm})
+    if (arr) for (size_t i = 0; i < pn; i++) if (arr[po + i]) return HMGPU_EUNSUPPORTED;
+  // reference pictures must be live device pictures
+  for (int l = 0; l < 2; l++) {
+    if (sl->num_ref_idx[l] < 0 || sl->num_ref_idx[l] > HMGPU_MAX_REF) return HMGPU_EINVAL;
+    for (int i = 0; i < sl->num_ref_idx[l]; i++) if (!valid_pic(c, sl->ref_pic[l][i]) || sl->ref_pic[l][i] == cur) return HMGPU_EINVAL;
+  }
+  hipSetDevice(c->device);
+  // ---- slice table entry
+  SliceDev sd;
+  memset(&sd, 0, sizeof(sd));
+  sd.slice_type = sl->slice_type; sd.cb_qp_offset = sl->cb_qp_offset; sd.cr_qp_offset = sl->cr_qp_offset;
+  sd.pps_cb_qp_offset = sl->pps_cb_qp_offset; sd.pps_cr_qp_offset = sl->pps_cr_qp_offset;
+  sd.deblocking_disable = sl->deblocking_disable; sd.beta_offset_div2 = sl->beta_offset_div2; sd.tc_offset_div2 = sl->tc_offset_div2;
+  sd.lf_across_slices = sl->lf_across_slices;
+  for (int l = 0; l < 2; l++)
+    for (int i = 0; i < HMGPU_MAX_REF; i++) {
+      sd.ref_poc[l][i] = i < sl->num_ref_idx[l] ? sl->ref_poc[l][i] : 0;
+      sd.ref_pic[l][i] = i < sl->num_ref_idx[l] ? (int8_t)sl->ref_pic[l][i] : (int8_t)-1;
+    }
+  p.slices[slice_idx] = sd;
+  p.max_slice = std::max(p.max_slice, (int)slice_idx);
+  p.dev.lf_across_tiles = sl->lf_across_tiles;
+  {
+    ProfScope ps(c, K_H2D);
+    HIP_TRY(c, hipMemcpyAsync((void*)(p.dev.slices + slice_idx), &p.slices[slice_idx], sizeof(SliceDev), hipMemcpyHostToDevice, c->stream));
+    // ---- HM arrays of the CTU range (field-by-field, exactly the arrays TComDataCU owns)
+#define STAGE(dst, src, elem_bytes)                                                                                       \
+    if (src) HIP_TRY(c, hipMemcpyAsync((char*)(dst) + po * (elem_bytes), (const char*)(src) + po * (elem_bytes), pn * (elem_bytes), \
+                                       hipMemcpyHostToDevice, c->stream));                                                \
+    else HIP_TRY(c, hipMemsetAsync((char*)(dst) + po * (elem_bytes), 0, pn * (elem_bytes), c->stream))
+    STAGE(p.dev.depth, m->depth, 1); STAGE(p.dev.part_size, m->part_size, 1); STAGE(p.dev.pred_mode, m->pred_mode, 1);
+    STAGE(p.dev.qp, m->qp, 1); STAGE(p.dev.tr_idx, m->tr_idx, 1);
+    for (int k = 0; k < 3; k++) { STAGE(p.dev.cbf[k], m->cbf[k], 1); STAGE(p.dev.tskip[k], m->transform_skip[k], 1); }
+    for (int k = 0; k < 2; k++) { STAGE(p.dev.mv[k], m->mv[k], 4); STAGE(p.dev.ref_idx[k], m->ref_idx[k], 1); }
+#undef STAGE
+    // per-CTU slice / tile index (the slice index of this call wins over a missing array)
+    {
+      std::vector<uint16_t> tmp((size_t)num_ctus);
+      for (int i = 0; i < num_ctus; i++) tmp[i] = m->slice_idx ? m->slice_idx[first_ctu + i] : (uint16_t)slice_idx;
+      HIP_TRY(c, hipMemcpy((void*)(p.dev.slice_idx + first_ctu), tmp.data(), tmp.size() * 2, hipMemcpyHostToDevice));
+      for (int i = 0; i < num_ctus; i++) tmp[i] = m->tile_idx ? m->tile_idx[first_ctu + i] : (uint16_t)0;
+      HIP_TRY(c, hipMemcpy((void*)(p.dev.tile_idx + first_ctu), tmp.data(), tmp.size() * 2, hipMemcpyHostToDevice));
+    }
+    for (int k = 0; k < 3; k++) {
+      const size_t per = (size_t)(c->ctu * c->ctu) >> (k ? 2 : 0);
+      HIP_TRY(c, hipMemcpyAsync((void*)(p.dev.coef[k] + first_ctu * per), co->level[k] + first_ctu * per, (size_t)num_ctus * per * 2,
+                                hipMemcpyHostToDevice, c->stream));
+    }
+    hmgpu_status st = push_picdev(c, cur);
+    if (st != HMGPU_OK) return st;
+  }
+  SliceCall call = {first_ctu, num_ctus, slice_idx};
+  p.calls.push_back(call);
+  Batch b; memset(&b, 0, sizeof(b));
+  b.n = 1; b.pic[0] = cur; b.first_ctu[0] = first_ctu; b.num_ctus[0] = num_ctus;
+  return run_recon(c, b);
+}
+
+hmgpu_status hmgpu_filter_picture_stages(hmgpu_ctx* c, hmgpu_pic cur, const hmgpu_pic_params* pp, const hmgpu_sao_param* sao,
+                                         int32_t stages) {
+  if (!c || !valid_pic(c, cur) || !pp) return HMGPU_EINVAL;
+  if ((stages & 4) && pp->sao_enabled && !sao) return HMGPU_EINVAL;
+  hipSetDevice(c->device);
+  Picture& p = c->pics[cur];
+  p.sao_any = false;
+  if ((stages & 4) && pp->sao_enabled) {
+    std::vector<uint16_t> sidx(c->num_ctus), tidx(c->num_ctus);
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipMemcpy(sidx.data(), p.dev.slice_idx, sidx.size() * 2, hipMemcpyDeviceToHost));
+    HIP_TRY(c, hipMemcpy(tidx.data(), p.dev.tile_idx, tidx.size() * 2, hipMemcpyDeviceToHost));
+    hmgpu_status st = stage_sao(c, p, pp, sao, sidx, tidx);
+    if (st != HMGPU_OK) return st;
+  }
+  p.filter_ready = true;
+  Batch b; memset(&b, 0, sizeof(b));
+  b.n = 1; b.pic[0] = cur; b.first_ctu[0] = 0; b.num_ctus[0] = c->num_ctus;
+  hmgpu_status st = run_filter(c, b, stages);
+  if (st != HMGPU_OK) return st;
+  if ((stages & 4) && p.sao_any) {
+    // SAOProcess ran: the SAO planes are the picture now (HM: resYuv written in place after the snapshot copy)
+    p.sao_applied = true; p.dev.sao_applied = 1;
+    st = push_final(c, cur);
+  }
+  return st;
+}
+
+hmgpu_status hmgpu_filter_picture(hmgpu_ctx* c, hmgpu_pic cur, const hmgpu_pic_params* pp, const hmgpu_sao_param* sao) {
+  return hmgpu_filter_picture_stages(c, cur, pp, sao, 7);
+}
+
+hmgpu_status hmgpu_replay_batch(hmgpu_ctx* c, const hmgpu_pic* pics, int32_t n, int32_t stages, int32_t iters) {
+  if (!c || !pics || n < 1 || n > kMaxBatch || iters < 0) return HMGPU_EINVAL;
+  size_t ncalls = 0;
+  for (int i = 0; i < n; i++) {
+    if (!valid_pic(c, pics[i])) return HMGPU_EINVAL;
+    if (i == 0) ncalls = c->pics[pics[i]].calls.size();
+    else if (c->pics[pics[i]].calls.size() != ncalls) return HMGPU_EINVAL;
+  }
+  if ((stages & 8) && ncalls == 0) return HMGPU_EINVAL;
+  hipSetDevice(c->device);
+  for (int it = 0; it < iters; it++) {
+    if (stages & 8) {
+      for (size_t k = 0; k < ncalls; k++) {
+        Batch b; memset(&b, 0, sizeof(b));
+        b.n = n;
+        for (int i = 0; i < n; i++) {
+          const SliceCall& sc = c->pics[pics[i]].calls[k];
+          b.pic[i] = pics[i]; b.first_ctu[i] = sc.first_ctu; b.num_ctus[i] = sc.num_ctus;
+        }
+        hmgpu_status st = run_recon(c, b);
+        if (st != HMGPU_OK) return st;
+      }
+    }
+    if (stages & 7) {
+      Batch b; memset(&b, 0, sizeof(b));
+      b.n = n;
+      for (int i = 0; i < n; i++) { b.pic[i] = pics[i]; b.first_ctu[i] = 0; b.num_ctus[i] = c->num_ctus; }
+      hmgpu_status st = run_filter(c, b, stages & 7);
+      if (st != HMGPU_OK) return st;
+    }
+  }
+  return HMGPU_OK;
+}
+
+hmgpu_status hmgpu_replay(hmgpu_ctx* c, hmgpu_pic cur, int32_t stages, int32_t iters) { return hmgpu_replay_batch(c, &cur, 1, stages, iters); }
+
+hmgpu_status hmgpu_set_profiling(hmgpu_ctx* c, int32_t enable) {
+  if (!c) return HMGPU_EINVAL;
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  prof_drain(c);
+  c->profiling = enable != 0;
+  return HMGPU_OK;
+}
+
+hmgpu_status hmgpu_get_stats(hmgpu_ctx* c, hmgpu_stats* out, int32_t reset) {
+  if (!c || !out) return HMGPU_EINVAL;
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  prof_drain(c);
+  memset(out, 0, sizeof(*out));
+  for (int k = 0; k < HMGPU_NUM_KERNELS; k++) { out->kernel_ms[k] = c->kernel_ms[k]; out->kernel_launches[k] = c->kernel_launches[k]; }
+  for (Picture& p : c->pics) {
+    if (!p.in_use) continue;
+    unsigned long long st[2 * kTuShards];
+    HIP_TRY(c, hipMemcpy(st, p.dev.stats, sizeof(st), hipMemcpyDeviceToHost));
+    for (int s = 0; s < kTuShards; s++) { out->intra_partitions += st[s]; out->inter_partitions += st[kTuShards + s]; }
+    if (reset) HIP_TRY(c, hipMemset(p.dev.stats, 0, sizeof(st)));
+  }
+  if (reset) for (int k = 0; k < HMGPU_NUM_KERNELS; k++) { c->kernel_ms[k] = 0; c->kernel_launches[k] = 0; }
+  return HMGPU_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- finer seams
+hmgpu_status hmgpu_inverse_transform_batch(hmgpu_ctx* c, int32_t log2_size, int32_t bit_depth, int32_t n, const int16_t* levels,
+                                           const int8_t* qp_per, const int8_t* qp_rem, const uint8_t* flags, int16_t* resid) {
+  if (!c || log2_size < 2 || log2_size > 5 || n < 1 || !levels || !qp_per || !qp_rem || !flags || !resid) return HMGPU_EINVAL;
+  if (bit_depth < 8 || bit_depth > 10) return HMGPU_EUNSUPPORTED;
+  hipSetDevice(c->device);
+  const size_t elems = (size_t)n << (2 * log2_size);
+  int16_t *d_lev = nullptr, *d_res = nullptr; int8_t *d_per = nullptr, *d_rem = nullptr; uint8_t* d_fl = nullptr;
+  hmgpu_status st = HMGPU_OK;
+  auto fail = [&](hipError_t e) { if (e != hipSuccess && st == HMGPU_OK) { c->last_err = (int32_t)e; st = HMGPU_EDEVICE; } };
+  fail(hipMalloc((void**)&d_lev, elems * 2)); fail(hipMalloc((void**)&d_res, elems * 2));
+  fail(hipMalloc((void**)&d_per, n)); fail(hipMalloc((void**)&d_rem, n)); fail(hipMalloc((void**)&d_fl, n));
+  if (st == HMGPU_OK) {
+    fail(hipMemcpy(d_lev, levels, elems * 2, hipMemcpyHostToDevice));
+    fail(hipMemcpy(d_per, qp_per, n, hipMemcpyHostToDevice)); fail(hipMemcpy(d_rem, qp_rem, n, hipMemcpyHostToDevice));
+    fail(hipMemcpy(d_fl, flags, n, hipMemcpyHostToDevice));
+  }
+  if (st == HMGPU_OK) {
+    launch_itx_flat(log2_size, bit_depth, n, d_lev, d_per, d_rem, d_fl, d_res, c->stream);
+    fail(hipGetLastError());
+    fail(hipStreamSynchronize(c->stream));
+    fail(hipMemcpy(resid, d_res, elems * 2, hipMemcpyDeviceToHost));
+  }
+  hipFree(d_lev); hipFree(d_res); hipFree(d_per); hipFree(d_rem); hipFree(d_fl);
+  return st;
+}
+
+hmgpu_status hmgpu_mc_batch(hmgpu_ctx* c, int32_t is_chroma, int32_t bit_depth, const int16_t* ref_plane, int32_t ref_stride,
+                            int32_t ref_w, int32_t ref_h, int32_t n, const int32_t* blocks, int32_t bi, int16_t* dst) {
+  if (!c || !ref_plane || !blocks || !dst || n < 1 || ref_w < 1 || ref_h < 1 || ref_stride < ref_w) return HMGPU_EINVAL;
+  if (bit_depth < 8 || bit_depth > 10) return HMGPU_EUNSUPPORTED;
+  hipSetDevice(c->device);
+  std::vector<int32_t> off(n);
+  size_t total = 0;
+  for (int i = 0; i < n; i++) {
+    const int w = blocks[i * 6 + 2], h = blocks[i * 6 + 3];
+    if (w < 2 || h < 2 || (w & 1) || (h & 1) || w > 64 || h > 64) return HMGPU_EINVAL;
+    off[i] = (int32_t)total; total += (size_t)w * h;
+  }
+  // device copy of the plane with the runtime's own pitch rule (even, >= width + 64 so vector loads may overrun)
+  const int pitch = (int)align_up((size_t)ref_w, 64) + 64;
+  int16_t *d_ref = nullptr, *d_dst = nullptr; int32_t *d_blk = nullptr, *d_off = nullptr;
+  hmgpu_status st = HMGPU_OK;
+  auto fail = [&](hipError_t e) { if (e != hipSuccess && st == HMGPU_OK) { c->last_err = (int32_t)e; st = HMGPU_EDEVICE; } };
+  fail(hipMalloc((void**)&d_ref, (size_t)pitch * (ref_h + 1) * 2)); fail(hipMalloc((void**)&d_dst, total * 2));
+  fail(hipMalloc((void**)&d_blk, (size_t)n * 24)); fail(hipMalloc((void**)&d_off, (size_t)n * 4));
+  if (st == HMGPU_OK) {
+    fail(hipMemset(d_ref, 0, (size_t)pitch * (ref_h + 1) * 2));
+    fail(hipMemcpy2D(d_ref, (size_t)pitch * 2, ref_plane, (size_t)ref_stride * 2, (size_t)ref_w * 2, ref_h, hipMemcpyHostToDevice));
+    fail(hipMemcpy(d_blk, blocks, (size_t)n * 24, hipMemcpyHostToDevice));
+    fail(hipMemcpy(d_off, off.data(), (size_t)n * 4, hipMemcpyHostToDevice));
+  }
+  if (st == HMGPU_OK) {
+    launch_mc_flat(is_chroma, bit_depth, d_ref, pitch, ref_w, ref_h, n, d_blk, d_off, bi, d_dst, c->stream);
+    fail(hipGetLastError());
+    fail(hipStreamSynchronize(c->stream));
+    fail(hipMemcpy(dst, d_dst, total * 2, hipMemcpyDeviceToHost));
+  }
+  hipFree(d_ref); hipFree(d_dst); hipFree(d_blk); hipFree(d_off);
+  return st;
+}
+
+}  // extern "C"

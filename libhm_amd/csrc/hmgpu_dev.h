@@ -1,0 +1,131 @@
+// hmgpu_dev.h -- device-side data model shared by the HIP kernels and the host runtime of libhmgpu.so.
+//
+// Design: the host hands over HM's per-CTU TComDataCU arrays untouched (z-scan SoA).  A
+// "prep" kernel turns them, one thread per 4x4 partition, into
+//   * a picture-wide raster grid of 16-byte BlkInfo records (motion, QP, intra/cbf flags, deblocking edge
+//     flags) that the motion-compensation, deblocking and SAO kernels index by sample position, and
+//   * per-size lists of coded transform units (TuRec) appended with wave-aggregated atomics.
+// No quadtree is ever walked serially; every kernel is a flat grid over partitions, tiles, TUs or edges.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/hmgpu.h"
+
+namespace hmgpu {
+
+constexpr int kMaxBatch = 16;       // pictures per batched launch (blockIdx.z)
+constexpr int kMaxPics = 64;        // device pictures per context
+constexpr int kTuShards = 8;        // TU lists are sharded by (prep block index % 8) so that list appends do not pile on one word
+
+// ---- per-4x4-block record (raster grid over the CTU-padded picture) -------------------------------------------
+struct __attribute__((aligned(16))) BlkInfo {
+  int16_t mv[2][2];   // HM TComMv per list {hor, ver} in quarter luma samples, UNclipped (deblocking compares these); 0 if unused
+  int8_t  ref[2];     // device picture handle per list (slice ref_pic[list][ref_idx]); -1 = list unused
+  int8_t  qp;         // TComDataCU::getQP(partition)
+  uint8_t flags;      // BF_*
+  uint8_t edge;       // BE_*
+  uint8_t log2cu;     // log2 CU size (3..6): clipMv needs the CU origin
+  uint16_t slice;     // index into the picture's slice table
+};
+static_assert(sizeof(BlkInfo) == 16, "BlkInfo must be 16 bytes");
+
+enum : uint8_t {
+  BF_VALID = 1,    // partition decoded (part_size != NUMBER_OF_PART_SIZES) and inside the picture
+  BF_INTRA = 2,
+  BF_CBFY = 4,     // luma cbf at the partition's transform depth (Bs = 1 rule)
+  BF_MC_L0 = 8,    // prediction uses list 0  (after the identical-motion collapse of xCheckIdenticalMotion)
+  BF_MC_L1 = 16,   // prediction uses list 1
+};
+enum : uint8_t {
+  BE_VER_FILTER = 1,     // left edge of this block is a deblocking edge (m_aapbEdgeFilter[EDGE_VER]) on the 8x8 grid
+  BE_VER_TRANSFORM = 2,  // ... and it is a TU/CU edge (the m_aapucBS marker xGetBoundaryStrengthSingle reads)
+  BE_HOR_FILTER = 4,
+  BE_HOR_TRANSFORM = 8,
+};
+
+// ---- coded transform unit ---------------------------------------------------------------------------------------
+struct TuRec {
+  uint16_t x4, y4;        // origin in 4-luma-sample units (picture coordinates)
+  uint8_t  comp_flags;    // bits 0-1 component, bit 2 DST (4x4 intra luma), bit 3 transform skip
+  int8_t   per, rem;      // QpParam per / rem
+  uint8_t  pad;
+  uint32_t coef_off;      // element offset into the component's coefficient array
+};
+static_assert(sizeof(TuRec) == 12, "TuRec must be 12 bytes");
+
+// ---- slice constants on the device --------------------------------------------------------------------------------
+struct SliceDev {
+  int32_t slice_type;
+  int32_t cb_qp_offset, cr_qp_offset;
+  int32_t pps_cb_qp_offset, pps_cr_qp_offset;
+  int32_t deblocking_disable, beta_offset_div2, tc_offset_div2, lf_across_slices;
+  int32_t ref_poc[2][HMGPU_MAX_REF];
+  int8_t  ref_pic[2][HMGPU_MAX_REF];
+};
+
+struct SaoDev {                 // reconstructed SAO parameters of one CTU component
+  int8_t  type;                 // -1 off, else HMGPU_SAO_EO_0..BO
+  uint8_t avail;                // bit k = neighbour CTU k available (L,R,A,B,AL,AR,BL,BR)
+  int8_t  offset[32];           // EO: [0..4] by class (class 2 == 0); BO: by band
+  int8_t  pad[2];
+};
+static_assert(sizeof(SaoDev) == 36, "SaoDev layout");
+
+struct PlaneSet { int16_t* p[3]; };
+
+// ---- everything the kernels need to know about one picture; one slot per device picture, resident in HBM ----------
+struct PicDev {
+  int32_t width, height;           // luma samples
+  int32_t bd[3];                   // bit depth per component
+  int32_t log2ctu, ctus_w, ctus_h, num_ctus, parts, pw;   // pw = partitions per CTU row
+  int32_t pitch[3];                // samples
+  int32_t grid_w, grid_h;          // BlkInfo grid (CTU padded)
+  int32_t lf_across_tiles;
+  int32_t sao_applied;             // final planes are sao[] (else rec[])
+  int16_t* rec[3];                 // reconstruction / deblocked in place
+  int16_t* sao[3];                 // SAO output
+  // raw HM arrays (device copies, whole picture)
+  const uint8_t* depth; const int8_t* part_size; const int8_t* pred_mode; const int8_t* qp; const uint8_t* tr_idx;
+  const uint8_t* cbf[3]; const uint8_t* tskip[3];
+  const int16_t* mv[2]; const int8_t* ref_idx[2];
+  const uint16_t* slice_idx; const uint16_t* tile_idx;
+  const int16_t* coef[3];
+  const SliceDev* slices;
+  // derived
+  BlkInfo* blk;
+  TuRec* tu[4];                    // by log2 size - 2: kTuShards shards of tu_cap[] records each
+  uint32_t* tu_count;              // [4][kTuShards]
+  uint32_t tu_cap[4];              // capacity of ONE shard
+  SaoDev* saoprm;                  // [num_ctus][3]
+  unsigned long long* stats;       // [2][kTuShards]: intra / inter partitions seen by the prep kernel
+};
+
+// batched launch descriptor, passed by value
+struct Batch {
+  int32_t n;
+  int32_t pic[kMaxBatch];          // index into the PicDev table
+  int32_t first_ctu[kMaxBatch];
+  int32_t num_ctus[kMaxBatch];
+};
+
+// ---- small device helpers ------------------------------------------------------------------------------------------
+__host__ __device__ inline int zscan_x(int z) {   // HM g_auiZscanToRaster column: even bits of z
+  int x = z & 0x5555; x = (x | (x >> 1)) & 0x3333; x = (x | (x >> 2)) & 0x0f0f; x = (x | (x >> 4)) & 0x00ff; return x;
+}
+__host__ __device__ inline int zscan_y(int z) { return zscan_x(z >> 1); }
+__device__ inline int clip3(int lo, int hi, int v) { return min(hi, max(lo, v)); }
+
+// ---- launchers (one per kernel family; defined in the .hip files) ---------------------------------------------------
+void launch_prep(const PicDev* pics, const Batch& b, int max_ctus, int parts, hipStream_t s);
+void launch_mc_luma(const PicDev* pics, const PlaneSet* finals, const Batch& b, int max_ctus, int log2ctu, hipStream_t s);
+void launch_mc_chroma(const PicDev* pics, const PlaneSet* finals, const Batch& b, int max_ctus, int log2ctu, hipStream_t s);
+void launch_itx(const PicDev* pics, const Batch& b, int log2size, uint32_t blocks_per_shard, hipStream_t s);
+void launch_deblock(const PicDev* pics, const Batch& b, int dir, int width, int height, hipStream_t s);
+void launch_sao(const PicDev* pics, const Batch& b, int width, int height, hipStream_t s);
+// kernel-level seams for tests
+void launch_itx_flat(int log2size, int bit_depth, int n, const int16_t* levels, const int8_t* per, const int8_t* rem,
+                     const uint8_t* flags, int16_t* resid, hipStream_t s);
+void launch_mc_flat(int is_chroma, int bit_depth, const int16_t* ref, int ref_stride, int ref_w, int ref_h, int n,
+                    const int32_t* blocks, const int32_t* out_off, int bi, int16_t* dst, hipStream_t s);
+
+}  // namespace hmgpu

@@ -1,0 +1,223 @@
+// k_itx.hip -- de-quantisation + inverse transform + reconstruction add for coded TUs.
+//   TComTrQuant::invTransformNxN -> xDeQuant (flat) -> xIT -> xITrMxN / xITransformSkip   TComTrQuant.cpp:1423,1203,1836,894,1920
+//   TComYuv::addClip (recon = ClipBD(pred + resid))                                      TComYuv.cpp:264
+//
+// One N-lane group per N x N TU (N = 4, 8, 16, 32; a wave holds 64/N TUs).  Stage 1: lane n owns coefficient column
+// n (coalesced 2-byte reads along the row), de-quantises it and runs the N-point 1-D inverse transform in registers
+// with the even/odd decomposition (full-rate 24-bit integer multiply-adds, all matrix entries are immediates).  The
+// 16-bit-clipped intermediates cross to the row owners through a padded LDS tile (conflict-free b32 writes / b128
+// reads).  Stage 2: lane y owns row y, transforms it, adds it to the prediction already sitting in the picture
+// (written by the MC kernels) and writes the clipped reconstruction back: the residual never touches HBM.
+// TUs come from the per-class lists built by k_prep; blocks stride over a list whose length only the device knows.
+#include "hmgpu_dev.h"
+#include <algorithm>
+
+namespace hmgpu {
+
+// HM g_aiT<N>[TRANSFORM_INVERSE][k][n] (TComRom.cpp:335-417): the 32-point basis sampled at odd multiples of pi/64.
+__host__ __device__ constexpr int cos64(int a) {
+  constexpr int t[33] = {64, 90, 90, 90, 89, 88, 87, 85, 83, 82, 80, 78, 75, 73, 70, 67, 64,
+                         61, 57, 54, 50, 46, 43, 38, 36, 31, 25, 22, 18, 13, 9,  4,  0};
+  return t[a];
+}
+__host__ __device__ constexpr int tmat(int n_size, int k, int n) {
+  const int a = ((2 * n + 1) * k * (32 / n_size)) & 127;
+  return a <= 32 ? cos64(a) : (a <= 64 ? -cos64(64 - a) : (a <= 96 ? -cos64(a - 64) : cos64(128 - a)));
+}
+__host__ __device__ constexpr int dst4(int m, int k) {       // g_as_DST_MAT_4[TRANSFORM_INVERSE] (TComRom.cpp:456-484)
+  constexpr int t[4][4] = {{29, 55, 74, 84}, {74, 74, 0, -74}, {84, -29, -74, 55}, {55, -84, 74, -29}};
+  return t[m][k];
+}
+
+// N-point inverse DCT, unrounded: out[k] = sum_m T_N[m][k] * in[m]; partialButterflyInverseN's even/odd structure
+// (TComTrQuant.cpp:468-828).  Inputs are 17-bit signed, so v_mad_i32_i24 is exact.
+template <int N>
+__device__ inline void idct_1d(const int (&in)[N], int (&out)[N]) {
+  if constexpr (N == 2) {
+    out[0] = __mul24(64, in[0]) + __mul24(64, in[1]);
+    out[1] = __mul24(64, in[0]) - __mul24(64, in[1]);
+  } else {
+    int ev[N / 2], e[N / 2];
+#pragma unroll
+    for (int i = 0; i < N / 2; i++) ev[i] = in[2 * i];
+    idct_1d<N / 2>(ev, e);
+#pragma unroll
+    for (int k = 0; k < N / 2; k++) {
+      int o = 0;
+#pragma unroll
+      for (int m = 1; m < N; m += 2) o += __mul24(tmat(N, m, k), in[m]);
+      out[k] = e[k] + o;
+      out[N - 1 - k] = e[k] - o;
+    }
+  }
+}
+
+__device__ inline void idst_4(const int (&in)[4], int (&out)[4]) {     // fastInverseDst, TComTrQuant.cpp:437
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    int s = 0;
+#pragma unroll
+    for (int m = 0; m < 4; m++) s += __mul24(dst4(m, k), in[m]);
+    out[k] = s;
+  }
+}
+
+template <int LOG2N> struct ItxCfg {
+  static constexpr int N = 1 << LOG2N;
+  static constexpr int STRIDE = N == 4 ? 4 : N + 4;       // dwords per LDS row (conflict-free ds_read_b128)
+  static constexpr int TPB = 256 / N;                     // TUs per 256-thread block
+};
+
+// Both stages for the TU of this N-lane group.  lev: the TU's N*N levels (row-major).  tile: the group's LDS tile.
+// Returns row `n` of the residual in res[].  flags: bit0 DST, bit1 transform skip.
+template <int LOG2N>
+__device__ inline void itx_tu(const int16_t* __restrict__ lev, bool active, int n, int per, int rem, int flags, int bd,
+                              int* __restrict__ tile, int (&res)[1 << LOG2N]) {
+  constexpr int N = 1 << LOG2N, S = ItxCfg<LOG2N>::STRIDE;
+  // ---- xDeQuant, flat scaling (TComTrQuant.cpp:1276-1311) on column n
+  const int tshift = 15 - bd - LOG2N;                     // getTransformShift
+  const int rshift = 6 - (tshift + per);                  // IQUANT_SHIFT - (transformShift + per)
+  const int scale = rem == 0 ? 40 : rem == 1 ? 45 : rem == 2 ? 51 : rem == 3 ? 57 : rem == 4 ? 64 : 72;
+  int c[N];
+#pragma unroll
+  for (int m = 0; m < N; m++) {
+    const int q = active ? (int)lev[m * N + n] : 0;
+    int v;
+    if (rshift > 0) v = (__mul24(q, scale) + (1 << (rshift - 1))) >> rshift;
+    else v = (int)((unsigned)__mul24(q, scale) << (-rshift));
+    c[m] = clip3(-32768, 32767, v);
+  }
+  int o[N];
+  if (flags & 2) {
+    // xITransformSkip (TComTrQuant.cpp:1920-1959): stage 1 does the rounding shift, stage 2 passes the row through
+#pragma unroll
+    for (int m = 0; m < N; m++) o[m] = tshift > 0 ? (c[m] + (1 << (tshift - 1))) >> tshift : (tshift == 0 ? c[m] : c[m] << (-tshift));
+  } else {
+    if (LOG2N == 2 && (flags & 1)) { int t4[4] = {c[0], c[1], c[2], c[3]}, r4[4]; idst_4(t4, r4);
+#pragma unroll
+      for (int k = 0; k < 4; k++) o[k] = r4[k]; }
+    else idct_1d<N>(c, o);
+#pragma unroll
+    for (int k = 0; k < N; k++) o[k] = clip3(-32768, 32767, (o[k] + 64) >> 7);          // shift_1st = 7, clip to 16 bit
+  }
+#pragma unroll
+  for (int k = 0; k < N; k++) tile[k * S + n] = o[k];     // T1[row k][column n]
+  __syncthreads();
+  int r[N];
+#pragma unroll
+  for (int i = 0; i < N; i += 4) {
+    const int4 v = *reinterpret_cast<const int4*>(&tile[n * S + i]);
+    r[i] = v.x; r[i + 1] = v.y; r[i + 2] = v.z; r[i + 3] = v.w;
+  }
+  __syncthreads();                                         // tile is reused by the next TU of this group
+  if (flags & 2) {
+#pragma unroll
+    for (int x = 0; x < N; x++) res[x] = (int)(int16_t)r[x];
+  } else {
+    const int shift2 = 20 - bd;                            // TRANSFORM_MATRIX_SHIFT + maxTrDynamicRange - 1 - bitDepth
+    if (LOG2N == 2 && (flags & 1)) { int t4[4] = {r[0], r[1], r[2], r[3]}, r4[4]; idst_4(t4, r4);
+#pragma unroll
+      for (int k = 0; k < 4; k++) res[k] = r4[k]; }
+    else idct_1d<N>(r, res);
+#pragma unroll
+    for (int x = 0; x < N; x++) res[x] = clip3(-32768, 32767, (res[x] + (1 << (shift2 - 1))) >> shift2);
+  }
+}
+
+template <int LOG2N>
+__global__ void __launch_bounds__(256) k_itx(const PicDev* __restrict__ pics, Batch b) {
+  constexpr int N = 1 << LOG2N, S = ItxCfg<LOG2N>::STRIDE, TPB = ItxCfg<LOG2N>::TPB;
+  __shared__ __attribute__((aligned(16))) int lds[TPB * N * S];
+  const PicDev& P = pics[b.pic[blockIdx.z]];
+  const int cls = LOG2N - 2, shard = blockIdx.y;
+  const uint32_t count = min(P.tu_count[cls * kTuShards + shard], P.tu_cap[cls]);
+  const TuRec* __restrict__ list = P.tu[cls] + (size_t)shard * P.tu_cap[cls];
+  const int j = threadIdx.x / N, n = threadIdx.x % N;
+  int* tile = lds + j * N * S;
+  for (uint32_t base = blockIdx.x * TPB; base < count; base += gridDim.x * TPB) {
+    const uint32_t t = base + j;
+    const bool active = t < count;
+    TuRec rec; rec.x4 = rec.y4 = 0; rec.comp_flags = 0; rec.per = 0; rec.rem = 0; rec.coef_off = 0;
+    if (active) rec = list[t];
+    const int comp = rec.comp_flags & 3, flags = rec.comp_flags >> 2;
+    const int bd = P.bd[comp];
+    int res[N];
+    itx_tu<LOG2N>(P.coef[comp] + rec.coef_off, active, n, rec.per, rec.rem, flags, bd, tile, res);
+    if (!active) continue;
+    // recon row n: ClipBD(pred + resid) in place
+    const int cs = comp ? 1 : 0;
+    const int maxv = (1 << bd) - 1;
+    int16_t* row = P.rec[comp] + (size_t)(((int)rec.y4 * 4 >> cs) + n) * P.pitch[comp] + ((int)rec.x4 * 4 >> cs);
+    if constexpr (N == 4) {
+      uint2 v = *reinterpret_cast<const uint2*>(row);
+      uint32_t w[2] = {v.x, v.y};
+#pragma unroll
+      for (int i = 0; i < 2; i++) {
+        const int a = clip3(0, maxv, (int)(w[i] & 0xffff) + res[2 * i]), c = clip3(0, maxv, (int)(w[i] >> 16) + res[2 * i + 1]);
+        w[i] = (uint32_t)a | ((uint32_t)c << 16);
+      }
+      *reinterpret_cast<uint2*>(row) = make_uint2(w[0], w[1]);
+    } else {
+#pragma unroll
+      for (int seg = 0; seg < N / 8; seg++) {
+        uint4 v = *reinterpret_cast<const uint4*>(row + seg * 8);
+        uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+          const int a = clip3(0, maxv, (int)(w[i] & 0xffff) + res[seg * 8 + 2 * i]);
+          const int c = clip3(0, maxv, (int)(w[i] >> 16) + res[seg * 8 + 2 * i + 1]);
+          w[i] = (uint32_t)a | ((uint32_t)c << 16);
+        }
+        *reinterpret_cast<uint4*>(row + seg * 8) = make_uint4(w[0], w[1], w[2], w[3]);
+      }
+    }
+  }
+}
+
+void launch_itx(const PicDev* pics, const Batch& b, int log2size, uint32_t blocks_per_shard, hipStream_t s) {
+  dim3 grid(blocks_per_shard, kTuShards, (unsigned)b.n);
+  switch (log2size) {
+    case 2: hipLaunchKernelGGL(k_itx<2>, grid, dim3(256), 0, s, pics, b); break;
+    case 3: hipLaunchKernelGGL(k_itx<3>, grid, dim3(256), 0, s, pics, b); break;
+    case 4: hipLaunchKernelGGL(k_itx<4>, grid, dim3(256), 0, s, pics, b); break;
+    case 5: hipLaunchKernelGGL(k_itx<5>, grid, dim3(256), 0, s, pics, b); break;
+    default: break;
+  }
+}
+
+// ---- kernel-level seam: residual of n TUs from flat arrays (tests; hmgpu_inverse_transform_batch) ----------------------
+template <int LOG2N>
+__global__ void __launch_bounds__(256) k_itx_flat(int bit_depth, int n_tus, const int16_t* __restrict__ levels,
+                                                  const int8_t* __restrict__ per, const int8_t* __restrict__ rem,
+                                                  const uint8_t* __restrict__ flags, int16_t* __restrict__ resid) {
+  constexpr int N = 1 << LOG2N, S = ItxCfg<LOG2N>::STRIDE, TPB = ItxCfg<LOG2N>::TPB;
+  __shared__ __attribute__((aligned(16))) int lds[TPB * N * S];
+  const int j = threadIdx.x / N, n = threadIdx.x % N;
+  int* tile = lds + j * N * S;
+  for (int base = blockIdx.x * TPB; base < n_tus; base += gridDim.x * TPB) {
+    const int t = base + j;
+    const bool active = t < n_tus;
+    int res[N];
+    itx_tu<LOG2N>(levels + (size_t)(active ? t : 0) * N * N, active, n, active ? per[t] : 0, active ? rem[t] : 0,
+                  active ? flags[t] : 0, bit_depth, tile, res);
+    if (!active) continue;
+    int16_t* row = resid + (size_t)t * N * N + n * N;
+#pragma unroll
+    for (int x = 0; x < N; x++) row[x] = (int16_t)res[x];
+  }
+}
+
+void launch_itx_flat(int log2size, int bit_depth, int n, const int16_t* levels, const int8_t* per, const int8_t* rem,
+                     const uint8_t* flags, int16_t* resid, hipStream_t s) {
+  const int tpb = 256 >> log2size;
+  dim3 grid((unsigned)std::min(4096, (n + tpb - 1) / tpb));
+  switch (log2size) {
+    case 2: hipLaunchKernelGGL(k_itx_flat<2>, grid, dim3(256), 0, s, bit_depth, n, levels, per, rem, flags, resid); break;
+    case 3: hipLaunchKernelGGL(k_itx_flat<3>, grid, dim3(256), 0, s, bit_depth, n, levels, per, rem, flags, resid); break;
+    case 4: hipLaunchKernelGGL(k_itx_flat<4>, grid, dim3(256), 0, s, bit_depth, n, levels, per, rem, flags, resid); break;
+    case 5: hipLaunchKernelGGL(k_itx_flat<5>, grid, dim3(256), 0, s, bit_depth, n, levels, per, rem, flags, resid); break;
+    default: break;
+  }
+}
+
+}  // namespace hmgpu

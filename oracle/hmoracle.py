@@ -11,6 +11,10 @@ import numpy as np
 
 from libhm_amd import abi
 
+class OraclePicture(C.Structure):           # hm_oracle.h: hmo_picture
+    _fields_ = [("plane", C.c_void_p * 3)]
+
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libhmoracle.so")
 _lib = None
@@ -36,7 +40,7 @@ def _p(a):
 
 
 def _pic(planes):
-    p = abi.OraclePicture()
+    p = OraclePicture()
     for i in range(3):
         p.plane[i] = planes[i].ctypes.data_as(C.c_void_p).value
     return p
@@ -103,7 +107,7 @@ def decompress_ctus(seq, slices, meta, coeffs, cur_planes, ref_planes_list, firs
     """cur_planes: list of 3 int16 arrays (modified in place).  ref_planes_list: list indexed by picture handle."""
     n = abi.num_ctus(seq) if num_ctus is None else num_ctus
     cur = _pic(cur_planes)
-    refs = (abi.OraclePicture * max(1, len(ref_planes_list)))()
+    refs = (OraclePicture * max(1, len(ref_planes_list)))()
     for i, rp in enumerate(ref_planes_list):
         if rp is not None:
             refs[i] = _pic(rp)
