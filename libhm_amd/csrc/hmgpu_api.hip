@@ -400,9 +400,15 @@ hmgpu_status hmgpu_picture_release(hmgpu_ctx* c, hmgpu_pic pic) {
 hmgpu_status hmgpu_picture_upload(hmgpu_ctx* c, hmgpu_pic pic, const int16_t* const planes[3], const int32_t strides[3]) {
   if (!c || !valid_pic(c, pic) || !planes || !strides) return HMGPU_EINVAL;
   Picture& p = c->pics[pic];
+  if (p.sao_applied) {                 // uploaded samples ARE the picture: back to the reconstruction planes
+    p.sao_applied = false; p.dev.sao_applied = 0;
+    hmgpu_status st = push_final(c, pic);
+    if (st == HMGPU_OK) st = push_picdev(c, pic);
+    if (st != HMGPU_OK) return st;
+  }
   for (int k = 0; k < 3; k++) {
     const int w = c->seq.width >> (k ? 1 : 0), h = c->seq.height >> (k ? 1 : 0);
-    int16_t* dst = p.sao_applied ? p.dev.sao[k] : p.dev.rec[k];
+    int16_t* dst = p.dev.rec[k];
     HIP_TRY(c, hipMemcpy2DAsync(dst, (size_t)c->pitch[k] * 2, planes[k], (size_t)strides[k] * 2, (size_t)w * 2, h,
                                 hipMemcpyHostToDevice, c->stream));
   }
@@ -434,6 +440,11 @@ hmgpu_status hmgpu_decompress_slice(hmgpu_ctx* c, hmgpu_pic cur, int32_t slice_i
     return HMGPU_EINVAL;
   if (sl->weighted_pred) return HMGPU_EUNSUPPORTED;
   Picture& p = c->pics[cur];
+  if (p.sao_applied) {                 // picture buffer decoded again without release/acquire: reconstruction planes again
+    p.sao_applied = false; p.dev.sao_applied = 0;
+    hmgpu_status st = push_final(c, cur);
+    if (st != HMGPU_OK) return st;
+  }
   const size_t po = (size_t)first_ctu * c->parts, pn = (size_t)num_ctus * c->parts;
   // tools outside the envelope: lossless / PCM CUs
   for (const uint8_t* arr : {m->transquant_bypass, m->ipcm})
@@ -488,8 +499,12 @@ hmgpu_status hmgpu_decompress_slice(hmgpu_ctx* c, hmgpu_pic cur, int32_t slice_i
     hmgpu_status st = push_picdev(c, cur);
     if (st != HMGPU_OK) return st;
   }
+  // a range decoded again (picture buffer reused without release/acquire) replaces the earlier record
+  p.calls.erase(std::remove_if(p.calls.begin(), p.calls.end(), [&](const SliceCall& o) {
+                  return o.first_ctu < first_ctu + num_ctus && first_ctu < o.first_ctu + o.num_ctus; }), p.calls.end());
   SliceCall call = {first_ctu, num_ctus, slice_idx};
   p.calls.push_back(call);
+
   Batch b; memset(&b, 0, sizeof(b));
   b.n = 1; b.pic[0] = cur; b.first_ctu[0] = first_ctu; b.num_ctus[0] = num_ctus;
   return run_recon(c, b);

@@ -1,0 +1,134 @@
+"""GPU parity at BASELINE.json's full sizes on synthetic HM-shaped pictures (tests/synth.py): bit-exact against the C
+oracle (which finishes a 2160p picture in well under a second), plus size-independent properties of the path."""
+import numpy as np
+import pytest
+
+from libhm_amd import abi
+from tests import golden_util as gu
+from tests import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle_chain(oracle, p, cur, refs):
+    rec = [a.copy() for a in cur]
+    oracle.decompress_ctus(p.seq, [p.slice], p.meta, p.coeffs, rec, refs)
+    dbk = [a.copy() for a in rec]
+    oracle.loop_filter_pic(p.seq, [p.slice], p.meta, p.pp, dbk, 3)
+    prm = oracle.sao_reconstruct_params(p.seq, p.pp, p.meta, p.sao_raw)
+    fin = oracle.sao_process(p.seq, [p.slice], p.pp, p.meta, prm, dbk)
+    return rec, dbk, fin
+
+
+@pytest.mark.parametrize("width,height,bd,bi,intra", [(3840, 2160, 10, False, 0.1), (3840, 2160, 10, True, 0.0),
+                                                      (1920, 1080, 10, False, 0.05), (416, 240, 8, True, 0.1)])
+def test_synthetic_picture_matches_oracle(oracle, width, height, bd, bi, intra):
+    import libhm_amd
+    p = synth.make_picture(width, height, bd, seed=width + bd + int(bi), bi=bi, intra_frac=intra, ref_handles=([0], [1]))
+    ref0 = synth.noise_planes(width, height, bd, 11)
+    ref1 = synth.blocky_planes(width, height, bd, 12)
+    cur = synth.blocky_planes(width, height, bd, 13)          # supplies the samples of intra CUs
+    want_rec, want_dbk, want_fin = _oracle_chain(oracle, p, cur, [ref0, ref1])
+    with libhm_amd.Context(p.seq) as ctx:
+        h0, h1, hc = ctx.acquire(), ctx.acquire(), ctx.acquire()
+        ctx.upload(h0, ref0)
+        ctx.upload(h1, ref1)
+        ctx.upload(hc, cur)
+        ctx.decompress_slice(hc, 0, p.slice, p.meta, p.coeffs)
+        got = ctx.download(hc)
+        for c in range(3):
+            assert np.array_equal(got[c], want_rec[c]), "reconstruction comp %d" % c
+        ctx.filter_picture(hc, p.pp, p.sao_raw, stages=3)
+        got = ctx.download(hc)
+        for c in range(3):
+            assert np.array_equal(got[c], want_dbk[c]), "deblocking comp %d" % c
+        ctx.filter_picture(hc, p.pp, p.sao_raw, stages=4)
+        got = ctx.download(hc)
+        for c in range(3):
+            assert np.array_equal(got[c], want_fin[c]), "SAO comp %d" % c
+        st = ctx.stats()
+        assert st["intra_partitions"] == int(p.intra.sum())
+        assert st["inter_partitions"] == int((p.inside & ~p.intra).sum())
+
+
+def test_identical_motion_collapses_to_uni(oracle):
+    """B slice, both lists point at the same POC with the same MV: xCheckIdenticalMotion -> uni-prediction rounding"""
+    import libhm_amd
+    w, h, bd = 256, 128, 10
+    p = synth.make_picture(w, h, bd, seed=5, bi=True, ref_handles=([0], [0]))
+    p.slice.ref_poc[1][0] = p.slice.ref_poc[0][0]
+    m = dict(p.meta_np)
+    m["mv1"] = np.where((m["ref_idx1"] >= 0)[:, :, None], m["mv0"], 0)            # same MV wherever both lists are used
+    both = (m["ref_idx0"] >= 0) & (m["ref_idx1"] >= 0)
+    m["mv1"] = np.where(both[:, :, None], m["mv0"], m["mv1"])
+    p.meta = abi.MetaHolder(m)
+    ref = synth.noise_planes(w, h, bd, 3)
+    cur = synth.noise_planes(w, h, bd, 4)
+    want = [a.copy() for a in cur]
+    oracle.decompress_ctus(p.seq, [p.slice], p.meta, p.coeffs, want, [ref])
+    with libhm_amd.Context(p.seq) as ctx:
+        h0, hc = ctx.acquire(), ctx.acquire()
+        ctx.upload(h0, ref)
+        ctx.upload(hc, cur)
+        ctx.decompress_slice(hc, 0, p.slice, p.meta, p.coeffs)
+        got = ctx.download(hc)
+    for c in range(3):
+        assert np.array_equal(got[c], want[c])
+
+
+def test_properties_at_2160p():
+    """size-independent properties: (1) zero motion + no residual reproduces the reference picture; (2) SAO with all
+    offsets zero and deblocking disabled leave the picture untouched; (3) a batched replay of independent pictures gives
+    the same samples (checksum of checksums) as picture-by-picture calls."""
+    import libhm_amd
+    w, h, bd = 3840, 2160, 10
+    p = synth.make_picture(w, h, bd, seed=21, cbf_prob=0.0, mv_range=0, ref_handles=([0], [0]))
+    m = dict(p.meta_np)
+    m["mv0"] = np.zeros_like(m["mv0"])
+    p.meta = abi.MetaHolder(m)
+    p.sao_raw[:, :, 3:] = 0
+    p.slice.deblocking_disable = 1
+    ref = synth.noise_planes(w, h, bd, 31)
+    with libhm_amd.Context(p.seq) as ctx:
+        h0, hc, hd = ctx.acquire(), ctx.acquire(), ctx.acquire()
+        ctx.upload(h0, ref)
+        ctx.upload(hc, synth.noise_planes(w, h, bd, 32))
+        ctx.decompress_slice(hc, 0, p.slice, p.meta, p.coeffs)
+        ctx.filter_picture(hc, p.pp, p.sao_raw)
+        got = ctx.download(hc)
+        for c in range(3):
+            assert np.array_equal(got[c], ref[c])
+        # (3) two independent pictures with real work, replayed as one batch
+        q = synth.make_picture(w, h, bd, seed=22, ref_handles=([0], [0]))
+        for pic in (hc, hd):
+            ctx.upload(pic, synth.noise_planes(w, h, bd, 33))
+            ctx.decompress_slice(pic, 0, q.slice, q.meta, q.coeffs)
+            ctx.filter_picture(pic, q.pp, q.sao_raw)
+        single = ctx.download(hc)
+        digest_single = gu.hm_md5(single, [bd] * 3)
+        ctx.replay([hc, hd], 15, 2)
+        a, b = ctx.download(hc), ctx.download(hd)
+        assert gu.hm_md5(a, [bd] * 3) == digest_single
+        assert gu.hm_md5(b, [bd] * 3) == digest_single
+
+
+def test_unsupported_tools_are_refused():
+    import libhm_amd
+    p = synth.make_picture(128, 64, 8, seed=2, ref_handles=([0], [0]))
+    with libhm_amd.Context(p.seq) as ctx:
+        h0, hc = ctx.acquire(), ctx.acquire()
+        p.slice.weighted_pred = 1
+        with pytest.raises(libhm_amd.HmgpuError) as e:
+            ctx.decompress_slice(hc, 0, p.slice, p.meta, p.coeffs)
+        assert e.value.status == abi.HMGPU_EUNSUPPORTED
+        p.slice.weighted_pred = 0
+        m = dict(p.meta_np)
+        m["ipcm"] = np.ones_like(m["depth"])
+        with pytest.raises(libhm_amd.HmgpuError) as e:
+            ctx.decompress_slice(hc, 0, p.slice, abi.MetaHolder(m), p.coeffs)
+        assert e.value.status == abi.HMGPU_EUNSUPPORTED
+        with pytest.raises(libhm_amd.HmgpuError) as e:                     # reference handle that is not a live picture
+            p.slice.ref_pic[0][0] = 7
+            ctx.decompress_slice(hc, 0, p.slice, p.meta, p.coeffs)
+        assert e.value.status == abi.HMGPU_EINVAL
+        assert h0 == 0
