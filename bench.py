@@ -1,0 +1,205 @@
+#!/usr/bin/env python3
+"""bench.py -- throughput of the HM pixel-reconstruction hot path on MI355X.
+
+Workload (BASELINE.json: "decoded Mpixels/s + achieved HBM GB/s, 2160p Main10"): synthetic 3840x2160 Main10
+lowdelay_P-shaped pictures (SURVEY.md 8d configs #3 + #4 in one: random CTU partitioning, one random quarter-sample MV
+per PU, "typical" coefficients with cbf probability 0.5, QP 22..37, SAO parameters per CTU), pre-parsed, i.e. exactly
+what HM's CABAC stage leaves behind.  One "step" = the whole device path -- prep (flattening) + luma/chroma motion
+compensation + de-quantisation/inverse transform/reconstruction + deblocking (both edge directions) + SAO -- over one
+batch of `--batch` independent pictures (frame-parallel, one launch per kernel for the batch), replayed from inputs that
+are already resident in HBM (hmgpu_replay_batch).  The pictures use distinct device buffers (~110 MB each), so the
+working set is far beyond the 256 MiB Infinity Cache.
+
+Output: ONE JSON line (rank 0), see README/DESIGN.md.  `roofline` is for the dominant kernel (largest share of device
+time); `kernels` lists every kernel.  `cpu_baseline` times the oracle (oracle/hm_oracle.c, the C restatement pinned
+against HM) on this box's host cores on a bounded sample of the same workload -- a reported baseline, not a target.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
+
+
+def algorithmic_bytes(p):
+    """algorithmic HBM bytes per picture and kernel (DESIGN.md 'Algorithmic bytes'): int16 samples/levels, each counted once"""
+    m = p.meta_np
+    decoded = p.inside & (m["part_size"] != 8)
+    inter = decoded & (m["pred_mode"] == 0)
+    lists = (m["ref_idx0"] >= 0).astype(np.int64) + (m["ref_idx1"] >= 0).astype(np.int64)
+    luma_inter = int(inter.sum()) * 16
+    ref_reads = int((lists * inter).sum()) * 16            # luma samples read from reference pictures (one per list used)
+    out = {}
+    out["mc_luma"] = 2 * ref_reads + 2 * luma_inter
+    out["mc_chroma"] = (2 * ref_reads + 2 * luma_inter) // 2
+    # coded TU samples per size class: 2 (level) + 2 (prediction read) + 2 (reconstruction write)
+    tr = m["tr_idx"]
+    log2tu = 6 - m["depth"] - tr
+    chain = (1 << (tr + 1)) - 1
+    per_cls = {2: 0, 3: 0, 4: 0, 5: 0}
+    for comp, key in enumerate(("cbf_y", "cbf_u", "cbf_v")):
+        has = inter & ((m[key] & chain) == chain)
+        for l2 in (2, 3, 4, 5):
+            n_part = int((has & (log2tu == l2)).sum())     # partitions covered by coded TUs whose luma node is 2^l2
+            if comp == 0:
+                per_cls[l2] += n_part * 16
+            else:
+                cls = max(l2 - 1, 2)
+                per_cls[cls] += n_part * 4
+    for l2 in (2, 3, 4, 5):
+        out["itx%d" % (1 << l2)] = 6 * per_cls[l2]
+    samples = p.width * p.height * 3 // 2
+    out["deblock_ver"] = 2 * samples                       # each pass = half of the 4 B/sample two-pass budget
+    out["deblock_hor"] = 2 * samples
+    out["sao"] = 4 * samples
+    out["prep"] = int(decoded.sum()) * (21 + 16)           # HM arrays read + BlkInfo written per partition
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=8, help="independent pictures per step (<= 16)")
+    ap.add_argument("--width", type=int, default=3840)
+    ap.add_argument("--height", type=int, default=2160)
+    ap.add_argument("--bi", type=int, default=0, help="1: B pictures (bi-prediction) instead of P")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--profile-steps", type=int, default=5)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist_mod
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist_mod.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        dist = dist_mod
+
+    import libhm_amd
+    from libhm_amd import abi
+    from tests import synth
+
+    w, h, bd = args.width, args.height, 10
+    nb = args.batch
+    # two distinct parsed pictures, staged alternately into nb device pictures with their own buffers
+    metas = [synth.make_picture(w, h, bd, seed=0x484D3136 + 7 * rank + i, bi=bool(args.bi), ref_handles=([0], [1])) for i in range(2)]
+    seq = abi.make_seq(w, h, bd, bd, log2_ctu=6, max_pictures=nb + 2)
+    ctx = libhm_amd.Context(seq, device=local_rank)
+    refs = [ctx.acquire(), ctx.acquire()]
+    ctx.upload(refs[0], synth.noise_planes(w, h, bd, 100 + rank))
+    ctx.upload(refs[1], synth.blocky_planes(w, h, bd, 200 + rank))
+    pics = []
+    t_stage = time.time()
+    for i in range(nb):
+        hc = ctx.acquire()
+        p = metas[i % 2]
+        ctx.decompress_slice(hc, 0, p.slice, p.meta, p.coeffs)      # stages the inputs in HBM (and runs once)
+        ctx.filter_picture(hc, p.pp, p.sao_raw)
+        pics.append(hc)
+    ctx.sync()
+    t_stage = time.time() - t_stage
+
+    def barrier():
+        ctx.sync()
+        if dist is not None:
+            dist.barrier()
+
+    ALL = 15
+    for _ in range(args.warmup):
+        ctx.replay(pics, ALL, 1)
+    barrier()
+    t0 = time.perf_counter()
+    ctx.replay(pics, ALL, args.steps)
+    ctx.sync()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        import torch
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        dist.barrier()
+
+    # ---- per-kernel device times: hipEvents on the context's own stream, around every launch of extra steps
+    ctx.set_profiling(True)
+    ctx.stats(reset=True)
+    ctx.replay(pics, ALL, args.profile_steps)
+    st = ctx.stats(reset=True)
+    ctx.set_profiling(False)
+
+    if rank == 0:
+        luma_px = w * h
+        total_px = world * nb * args.steps * luma_px
+        value = total_px / elapsed / 1e6
+        bytes_pp = [algorithmic_bytes(m) for m in metas]
+        kernels = {}
+        dom, dom_t = None, -1.0
+        for name, (ms, launches) in st["kernels"].items():
+            if launches == 0 or name in ("h2d_stage", "other"):
+                continue
+            avg_ms = ms / launches
+            per_launch = sum(bytes_pp[i % 2][name] for i in range(nb))
+            gbs = per_launch / (avg_ms * 1e-3) / 1e9
+            kernels[name] = {"avg_ms": round(avg_ms, 5), "alg_MB": round(per_launch / 1e6, 2), "GBps": round(gbs, 1),
+                             "frac": round(gbs / HBM_PEAK_GBS, 4)}
+            if ms > dom_t:
+                dom, dom_t = name, ms
+        roof = {"kernel": dom, "bound": "hbm", "achieved": kernels[dom]["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": kernels[dom]["frac"], "traffic": None}
+        dev_ms = sum(k["avg_ms"] for k in kernels.values())
+        out = {
+            "metric": "decoded Mpixels/s (luma), 2160p Main10 reconstruction + loop filters", "value": round(value, 1),
+            "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "int16 samples / int32 accumulate", "data": "synthetic",
+            "config": {"workload": "%dx%d Main10 %s pictures, pre-parsed CTU metadata: prep+MC+dequant/IT/recon+deblock+SAO, "
+                                   "batch of %d independent pictures per step, inputs resident in HBM" %
+                                   (w, h, "B (bi-pred)" if args.bi else "lowdelay_P", nb),
+                       "pictures_per_step": nb, "parallelism": "frame-parallel, 1 process per GPU, no data-path collective"},
+            "roofline": roof, "kernels": kernels, "device_ms_per_step_sum_of_kernels": round(dev_ms, 4),
+            "hbm_GBps_whole_step_algorithmic": round(sum(sum(b[k] for k in kernels) for b in [bytes_pp[i % 2] for i in range(nb)])
+                                                    / (elapsed / args.steps) / 1e9, 1),
+            "staging_s_for_batch_incl_first_run": round(t_stage, 3),
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(metas[0], w, h, bd)
+        print(json.dumps(out), flush=True)
+    ctx.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(p, w, h, bd):
+    """the oracle (C restatement of HM, pinned against HM goldens) on this box's host: single thread, whole pictures"""
+    from oracle import hmoracle
+    from tests import synth
+    hmoracle.lib()
+    refs = [synth.noise_planes(w, h, bd, 100), synth.blocky_planes(w, h, bd, 200)]
+    n, t_total = 0, 0.0
+    while t_total < 10.0 and n < 40:
+        cur = [np.zeros_like(r) for r in refs[0]]
+        t0 = time.perf_counter()
+        hmoracle.decompress_ctus(p.seq, [p.slice], p.meta, p.coeffs, cur, refs)
+        hmoracle.loop_filter_pic(p.seq, [p.slice], p.meta, p.pp, cur, 3)
+        prm = hmoracle.sao_reconstruct_params(p.seq, p.pp, p.meta, p.sao_raw)
+        hmoracle.sao_process(p.seq, [p.slice], p.pp, p.meta, prm, cur)
+        t_total += time.perf_counter() - t0
+        n += 1
+    return {"value": round(n * w * h / t_total / 1e6, 2), "unit": "Mpixels/s", "cores": 1, "kind": "port",
+            "sample": "%d whole %dx%d pictures of the same synthetic workload through oracle/hm_oracle.c (recon+deblock+SAO), %.1f s" % (n, w, h, t_total)}
+
+
+if __name__ == "__main__":
+    main()
