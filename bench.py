@@ -95,17 +95,22 @@ def main():
     w, h, bd = args.width, args.height, 10
     nb = args.batch
     # two distinct parsed pictures, staged alternately into nb device pictures with their own buffers
+    # every picture of the batch predicts from its OWN reference pictures (no flattering reuse of one reference in cache)
     metas = [synth.make_picture(w, h, bd, seed=0x484D3136 + 7 * rank + i, bi=bool(args.bi), ref_handles=([0], [1])) for i in range(2)]
-    seq = abi.make_seq(w, h, bd, bd, log2_ctu=6, max_pictures=nb + 2)
+    seq = abi.make_seq(w, h, bd, bd, log2_ctu=6, max_pictures=3 * nb)
     ctx = libhm_amd.Context(seq, device=local_rank)
-    refs = [ctx.acquire(), ctx.acquire()]
-    ctx.upload(refs[0], synth.noise_planes(w, h, bd, 100 + rank))
-    ctx.upload(refs[1], synth.blocky_planes(w, h, bd, 200 + rank))
+    ref_planes = [synth.noise_planes(w, h, bd, 100 + rank), synth.blocky_planes(w, h, bd, 200 + rank)]
     pics = []
     t_stage = time.time()
     for i in range(nb):
+        r0, r1 = ctx.acquire(), ctx.acquire()
+        ctx.upload(r0, ref_planes[0])
+        ctx.upload(r1, ref_planes[1])
         hc = ctx.acquire()
         p = metas[i % 2]
+        for l, r in ((0, r0), (1, r1)):
+            if p.slice.num_ref_idx[l] > 0:
+                p.slice.ref_pic[l][0] = r
         ctx.decompress_slice(hc, 0, p.slice, p.meta, p.coeffs)      # stages the inputs in HBM (and runs once)
         ctx.filter_picture(hc, p.pp, p.sao_raw)
         pics.append(hc)

@@ -195,10 +195,6 @@ bool valid_pic(const hmgpu_ctx* c, hmgpu_pic pic) { return pic >= 0 && pic < (in
 hmgpu_status run_recon(hmgpu_ctx* c, const Batch& b) {
   int max_ctus = 0;
   for (int i = 0; i < b.n; i++) max_ctus = std::max(max_ctus, b.num_ctus[i]);
-  for (int i = 0; i < b.n; i++) {
-    Picture& p = c->pics[b.pic[i]];
-    HIP_TRY(c, hipMemsetAsync(p.dev.tu_count, 0, sizeof(uint32_t) * 4 * kTuShards, c->stream));
-  }
   { ProfScope ps(c, K_PREP); launch_prep(c->d_pics, b, max_ctus, c->parts, c->stream); }
   { ProfScope ps(c, K_MC_LUMA); launch_mc_luma(c->d_pics, c->d_finals, b, max_ctus, c->seq.log2_ctu_size, c->stream); }
   { ProfScope ps(c, K_MC_CHROMA); launch_mc_chroma(c->d_pics, c->d_finals, b, max_ctus, c->seq.log2_ctu_size, c->stream); }
@@ -268,10 +264,15 @@ hmgpu_status stage_sao(hmgpu_ctx* c, Picture& p, const hmgpu_pic_params* pp, con
         r = merge[r.type_idc][comp];
       }
       SaoDev& d = dev[(size_t)a * 3 + comp];
+      memset(&d, 0, sizeof(d));
       d.type = r.mode_idc == HMGPU_SAO_OFF ? -1 : (int8_t)r.type_idc;
       d.avail = (uint8_t)avail;
-      for (int i = 0; i < 32; i++) d.offset[i] = (int8_t)r.offset[i];
-      d.pad[0] = d.pad[1] = 0;
+      if (d.type == HMGPU_SAO_BO) {
+        d.band = (uint8_t)(r.type_aux_info & 31);
+        for (int i = 0; i < 4; i++) d.off[i] = (int8_t)r.offset[(r.type_aux_info + i) & 31];
+      } else if (d.type >= 0) {
+        for (int i = 0; i < 5; i++) d.off[i] = (int8_t)r.offset[i];
+      }
       any |= d.type >= 0;
     }
   }

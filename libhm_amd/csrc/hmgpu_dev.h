@@ -63,13 +63,14 @@ struct SliceDev {
   int8_t  ref_pic[2][HMGPU_MAX_REF];
 };
 
-struct SaoDev {                 // reconstructed SAO parameters of one CTU component
+struct SaoDev {                 // reconstructed SAO parameters of one CTU component, 12 bytes
   int8_t  type;                 // -1 off, else HMGPU_SAO_EO_0..BO
   uint8_t avail;                // bit k = neighbour CTU k available (L,R,A,B,AL,AR,BL,BR)
-  int8_t  offset[32];           // EO: [0..4] by class (class 2 == 0); BO: by band
-  int8_t  pad[2];
+  uint8_t band;                 // BO: first band
+  uint8_t pad;
+  int8_t  off[8];               // EO: [0..4] by edge class (class 2 == 0); BO: [0..3] = offsets of bands band+0..3 (mod 32)
 };
-static_assert(sizeof(SaoDev) == 36, "SaoDev layout");
+static_assert(sizeof(SaoDev) == 12, "SaoDev layout");
 
 struct PlaneSet { int16_t* p[3]; };
 
@@ -114,6 +115,29 @@ __host__ __device__ inline int zscan_x(int z) {   // HM g_auiZscanToRaster colum
 }
 __host__ __device__ inline int zscan_y(int z) { return zscan_x(z >> 1); }
 __device__ inline int clip3(int lo, int hi, int v) { return min(hi, max(lo, v)); }
+
+// XCD-aware work distribution (speed only, never correctness): workgroups are dealt round-robin to the 8 XCDs, each
+// with its own L2.  For a batch of n pictures with nb workgroups each, picture p is served by the XCDs x with
+// x % n == p and each of those XCDs walks one contiguous band of the picture in raster order, so that neighbouring
+// tiles (which share reference-picture rows) hit in the same L2.  Returns false for padding workgroups.
+__device__ inline bool xcd_remap(int bid, int n, int nb, int& slot, int& lb) {
+  if (n < 0) { n = -n; slot = bid % n; lb = bid / n; return lb < nb; }     // tuning knob: plain interleave
+  if (n <= 8 && (8 % n) == 0) {
+    const int m = 8 / n;                       // XCDs per picture
+    const int per = (nb + m - 1) / m;          // workgroups per band
+    const int x = bid & 7, t = bid >> 3;
+    slot = x % n;
+    const int r = x / n;
+    lb = r * per + t;
+    return t < per && lb < nb;
+  }
+  slot = bid % n; lb = bid / n;
+  return lb < nb;
+}
+__host__ inline int xcd_grid(int n, int nb) {
+  if (n <= 8 && (8 % n) == 0) { const int m = 8 / n; return 8 * ((nb + m - 1) / m); }
+  return n * nb;
+}
 
 // ---- launchers (one per kernel family; defined in the .hip files) ---------------------------------------------------
 void launch_prep(const PicDev* pics, const Batch& b, int max_ctus, int parts, hipStream_t s);

@@ -15,6 +15,7 @@
 // from the wave.
 #include "hmgpu_dev.h"
 #include <algorithm>
+#include <cstdlib>
 
 namespace hmgpu {
 
@@ -160,17 +161,26 @@ __device__ inline bool same_motion(const BlkInfo& a, const BlkInfo& b) {
 }
 __device__ inline bool is_inter(const BlkInfo& b) { return (b.flags & BF_VALID) && (b.flags & (BF_MC_L0 | BF_MC_L1)); }
 
-// ---- luma: one thread per 8x4 tile; a wave covers 8x8 tiles = 64x32 samples; block = 4 waves stacked = 64x128 ---------
-__global__ void __launch_bounds__(256) k_mc_luma(const PicDev* __restrict__ pics, const PlaneSet* __restrict__ finals, Batch b) {
-  const PicDev& P = pics[b.pic[blockIdx.z]];
+// one 4x4 luma cell on its own (only where the two cells of an 8x4 tile do not share their motion); kept out of line so
+// that the common path's register budget is not the sum of three instantiations
+__device__ __attribute__((noinline)) void luma_cell(const PicDev& P, const PlaneSet* __restrict__ finals, const BlkInfo& c, int x, int y) {
+  const int cs = 1 << c.log2cu;
+  predict_tile<8, 4, 4>(P, finals, 0, x, y, c, x & ~(cs - 1), y & ~(cs - 1), P.rec[0]);
+}
+
+// ---- luma: one thread per 8x4 tile; a wave covers 8x8 tiles = 64x32 samples; block = 4 consecutive strips ---------------
+__global__ void __launch_bounds__(256) k_mc_luma(const PicDev* __restrict__ pics, const PlaneSet* __restrict__ finals, Batch b, int nblocks) {
+  int slot, lb;
+  if (!xcd_remap(blockIdx.x, b.n, nblocks, slot, lb)) return;
+  const PicDev& P = pics[b.pic[slot]];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int ctu_sz = 1 << P.log2ctu;
   // each wave handles one 64x32 strip; strips are enumerated over the call's CTU range as (ctu, strip inside the ctu)
   const int strips_x = max(1, ctu_sz / 64), strips_y = max(1, ctu_sz / 32);
   const int strips_per_ctu = strips_x * strips_y;
-  const int sid = blockIdx.x * 4 + wave;
-  if (sid >= b.num_ctus[blockIdx.z] * strips_per_ctu) return;
-  const int ctu = b.first_ctu[blockIdx.z] + sid / strips_per_ctu;
+  const int sid = lb * 4 + wave;
+  if (sid >= b.num_ctus[slot] * strips_per_ctu) return;
+  const int ctu = b.first_ctu[slot] + sid / strips_per_ctu;
   const int s_in = sid % strips_per_ctu;
   const int cx = (ctu % P.ctus_w) * ctu_sz, cy = (ctu / P.ctus_w) * ctu_sz;
   const int x0 = cx + (s_in % strips_x) * 64 + (lane & 7) * 8;
@@ -182,8 +192,8 @@ __global__ void __launch_bounds__(256) k_mc_luma(const PicDev* __restrict__ pics
     const int cs = 1 << c0.log2cu;
     predict_tile<8, 8, 4>(P, finals, 0, x0, y0, c0, x0 & ~(cs - 1), y0 & ~(cs - 1), P.rec[0]);
   } else {
-    if (is_inter(c0)) { const int cs = 1 << c0.log2cu; predict_tile<8, 4, 4>(P, finals, 0, x0, y0, c0, x0 & ~(cs - 1), y0 & ~(cs - 1), P.rec[0]); }
-    if (is_inter(c1)) { const int cs = 1 << c1.log2cu; predict_tile<8, 4, 4>(P, finals, 0, x0 + 4, y0, c1, (x0 + 4) & ~(cs - 1), y0 & ~(cs - 1), P.rec[0]); }
+    if (is_inter(c0)) luma_cell(P, finals, c0, x0, y0);
+    if (is_inter(c1)) luma_cell(P, finals, c1, x0 + 4, y0);
   }
 }
 
@@ -196,16 +206,18 @@ __device__ inline void chroma_cell(const PicDev& P, const PlaneSet* __restrict__
 }
 
 // ---- chroma: one thread per 4x4 chroma tile (8x8 luma area, four cells) of BOTH planes ----------------------------------
-__global__ void __launch_bounds__(256) k_mc_chroma(const PicDev* __restrict__ pics, const PlaneSet* __restrict__ finals, Batch b) {
-  const PicDev& P = pics[b.pic[blockIdx.z]];
+__global__ void __launch_bounds__(256) k_mc_chroma(const PicDev* __restrict__ pics, const PlaneSet* __restrict__ finals, Batch b, int nblocks) {
+  int slot, lb;
+  if (!xcd_remap(blockIdx.x, b.n, nblocks, slot, lb)) return;
+  const PicDev& P = pics[b.pic[slot]];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int ctu_sz = 1 << P.log2ctu;
   // a wave covers 8x8 tiles = 64x64 luma samples
   const int strips_x = max(1, ctu_sz / 64), strips_y = max(1, ctu_sz / 64);
   const int strips_per_ctu = strips_x * strips_y;
-  const int sid = blockIdx.x * 4 + wave;
-  if (sid >= b.num_ctus[blockIdx.z] * strips_per_ctu) return;
-  const int ctu = b.first_ctu[blockIdx.z] + sid / strips_per_ctu;
+  const int sid = lb * 4 + wave;
+  if (sid >= b.num_ctus[slot] * strips_per_ctu) return;
+  const int ctu = b.first_ctu[slot] + sid / strips_per_ctu;
   const int s_in = sid % strips_per_ctu;
   const int cx = (ctu % P.ctus_w) * ctu_sz, cy = (ctu / P.ctus_w) * ctu_sz;
   const int x0 = cx + (s_in % strips_x) * 64 + (lane & 7) * 8;     // luma coordinates of the 8x8 area
@@ -229,12 +241,16 @@ __global__ void __launch_bounds__(256) k_mc_chroma(const PicDev* __restrict__ pi
 void launch_mc_luma(const PicDev* pics, const PlaneSet* finals, const Batch& b, int max_ctus, int log2ctu, hipStream_t s) {
   const int ctu_sz = 1 << log2ctu;
   const int strips = max_ctus * std::max(1, ctu_sz / 64) * std::max(1, ctu_sz / 32);
-  hipLaunchKernelGGL(k_mc_luma, dim3((unsigned)((strips + 3) / 4), 1, (unsigned)b.n), dim3(256), 0, s, pics, finals, b);
+  const int nb = (strips + 3) / 4;
+  static const bool plain = getenv("HMGPU_NO_XCD_REMAP") != nullptr;
+  if (plain) { Batch bb = b; bb.n = -b.n; hipLaunchKernelGGL(k_mc_luma, dim3((unsigned)(b.n * nb)), dim3(256), 0, s, pics, finals, bb, nb); return; }
+  hipLaunchKernelGGL(k_mc_luma, dim3((unsigned)xcd_grid(b.n, nb)), dim3(256), 0, s, pics, finals, b, nb);
 }
 void launch_mc_chroma(const PicDev* pics, const PlaneSet* finals, const Batch& b, int max_ctus, int log2ctu, hipStream_t s) {
   const int ctu_sz = 1 << log2ctu;
   const int strips = max_ctus * std::max(1, ctu_sz / 64) * std::max(1, ctu_sz / 64);
-  hipLaunchKernelGGL(k_mc_chroma, dim3((unsigned)((strips + 3) / 4), 1, (unsigned)b.n), dim3(256), 0, s, pics, finals, b);
+  const int nb = (strips + 3) / 4;
+  hipLaunchKernelGGL(k_mc_chroma, dim3((unsigned)xcd_grid(b.n, nb)), dim3(256), 0, s, pics, finals, b, nb);
 }
 
 // ---- kernel-level seam: xPredInterBlk on a list of blocks of one plane (tests) ------------------------------------------

@@ -224,7 +224,14 @@ __global__ void __launch_bounds__(256) k_prep(const PicDev* __restrict__ pics, B
   }
 }
 
+// resets the TU list lengths of every picture of the batch (one launch instead of one memset per picture)
+__global__ void k_zero_counts(const PicDev* __restrict__ pics, Batch b) {
+  const PicDev& P = pics[b.pic[blockIdx.x]];
+  if (threadIdx.x < 4 * kTuShards) P.tu_count[threadIdx.x] = 0;
+}
+
 void launch_prep(const PicDev* pics, const Batch& b, int max_ctus, int parts, hipStream_t s) {
+  hipLaunchKernelGGL(k_zero_counts, dim3((unsigned)b.n), dim3(64), 0, s, pics, b);
   dim3 grid((unsigned)(((size_t)max_ctus * parts + 255) / 256), 1, (unsigned)b.n);
   hipLaunchKernelGGL(k_prep, grid, dim3(256), 0, s, pics, b);
 }

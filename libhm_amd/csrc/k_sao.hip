@@ -4,14 +4,38 @@
 // HM copies the whole deblocked picture to a temporary and filters CTU by CTU from that snapshot.  Here the
 // deblocked planes (PicDev::rec) ARE the snapshot: the kernel reads them and writes the SAO planes (PicDev::sao),
 // which become the picture's final planes; no copy pass exists.  One thread per 8 horizontally adjacent samples of one
-// component.  HM's per-CTU loop bounds (first/last row and column skipped when a neighbouring CTU is unavailable) are
-// equivalent to one per-sample rule: a sample is modified iff both samples it is compared with lie in the current CTU
-// or in a neighbouring CTU whose availability bit is set (derivation in DESIGN.md "SAO bounds").
+// component: 16-byte loads of the current row and of the two neighbour rows, one 16-byte store.  HM's per-CTU loop
+// bounds (first/last row and column skipped when a neighbouring CTU is unavailable) are equivalent to one per-sample
+// rule: a sample is modified iff both samples it is compared with lie in the current CTU or in a neighbouring CTU
+// whose availability bit is set (derivation in DESIGN.md "SAO bounds"); only the first and last sample of a thread's
+// group can face another CTU horizontally, so the rule costs a handful of scalar-like operations per thread.
 #include "hmgpu_dev.h"
 
 namespace hmgpu {
 
-__device__ inline int sgn3(int v) { return (v > 0) - (v < 0); }
+__device__ inline void unpack8u(const uint4 v, int (&s)[8]) {
+  s[0] = v.x & 0xffff; s[1] = v.x >> 16; s[2] = v.y & 0xffff; s[3] = v.y >> 16;
+  s[4] = v.z & 0xffff; s[5] = v.z >> 16; s[6] = v.w & 0xffff; s[7] = v.w >> 16;
+}
+
+// the 8 samples at x+dx .. x+7+dx of row `r` (dx in {-1,0,1}); columns are clamped into the picture (the clamped
+// values are only ever used for samples that the availability rule leaves untouched)
+__device__ inline void row_shifted(const int16_t* __restrict__ r, int x, int w, int dx, int (&s)[8]) {
+  int v[8];
+  unpack8u(*reinterpret_cast<const uint4*>(r + x), v);
+  const int l = (uint16_t)r[max(x - 1, 0)], rr = (uint16_t)r[min(x + 8, w - 1)];
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    const int left = i == 0 ? l : v[i - 1], right = i == 7 ? rr : v[i + 1];
+    s[i] = dx == 0 ? v[i] : (dx < 0 ? left : right);
+  }
+}
+
+// availability bit (SaoDev::avail order L,R,A,B,AL,AR,BL,BR; 8 = inside the CTB) of the CTU that holds a position with
+// vertical class v (0 above, 1 inside, 2 below) and horizontal class hcls (0 left, 1 inside, 2 right)
+__device__ inline int region_bit(int v, int hcls) {
+  return v == 1 ? (hcls == 0 ? 0 : (hcls == 2 ? 1 : 8)) : (v == 0 ? (hcls == 0 ? 4 : (hcls == 2 ? 5 : 2)) : (hcls == 0 ? 6 : (hcls == 2 ? 7 : 3)));
+}
 
 __global__ void __launch_bounds__(256) k_sao(const PicDev* __restrict__ pics, Batch b) {
   const PicDev& P = pics[b.pic[blockIdx.z]];
@@ -25,46 +49,65 @@ __global__ void __launch_bounds__(256) k_sao(const PicDev* __restrict__ pics, Ba
   const int pitch = P.pitch[comp];
   const int16_t* __restrict__ src = P.rec[comp];
   int16_t* __restrict__ dst = P.sao[comp];
-  const int ctb = (1 << P.log2ctu) >> cs;                       // CTB size in this component
-  const int cx = x / ctb, cy = row / ctb;
-  const SaoDev* __restrict__ pp = &P.saoprm[((size_t)cy * P.ctus_w + cx) * 3 + comp];
-  struct { int type; unsigned avail; } prm = {pp->type, pp->avail};   // offsets are indexed per sample: read through L1
+  const int log2ctb = P.log2ctu - cs;
+  const int cx = x >> log2ctb, cy = row >> log2ctb;
+  const uint32_t* pw = reinterpret_cast<const uint32_t*>(&P.saoprm[((size_t)cy * P.ctus_w + cx) * 3 + comp]);
+  const uint32_t w0 = pw[0];
+  const int type = (int)(int8_t)(w0 & 0xff);
   const uint4 cur = *reinterpret_cast<const uint4*>(src + (size_t)row * pitch + x);
-  if (prm.type < 0) { *reinterpret_cast<uint4*>(dst + (size_t)row * pitch + x) = cur; return; }
-  int c[8] = {(int)(cur.x & 0xffff), (int)(cur.x >> 16), (int)(cur.y & 0xffff), (int)(cur.y >> 16),
-              (int)(cur.z & 0xffff), (int)(cur.z >> 16), (int)(cur.w & 0xffff), (int)(cur.w >> 16)};
+  if (type < 0) { *reinterpret_cast<uint4*>(dst + (size_t)row * pitch + x) = cur; return; }
+  const uint32_t off_lo = pw[1], off_hi = pw[2];            // off[0..3], off[4..7]
+  int c[8], o[8];
+  unpack8u(cur, c);
   const int bd = P.bd[comp];
   const int maxv = (1 << bd) - 1;
-  int o[8];
-  if (prm.type == HMGPU_SAO_BO) {
-    const int shift = bd - 5;
-#pragma unroll
-    for (int i = 0; i < 8; i++) o[i] = clip3(0, maxv, c[i] + pp->offset[c[i] >> shift]);
-  } else {
-    // neighbour direction a = (dx, dy), b = (-dx, -dy)
-    const int dx = prm.type == HMGPU_SAO_EO_90 ? 0 : (prm.type == HMGPU_SAO_EO_45 ? 1 : -1);
-    const int dy = prm.type == HMGPU_SAO_EO_0 ? 0 : -1;
-    // CTB bounds in component samples (clipped to the picture, as offsetCTU does: :679-682)
-    const int x0 = cx * ctb, y0 = cy * ctb;
-    const int x1 = min(x0 + ctb, w) - 1, y1 = min(y0 + ctb, h) - 1;
-    const int ya = row + dy, yb = row - dy;
-    const int16_t* ra = src + (size_t)clip3(0, h - 1, ya) * pitch;
-    const int16_t* rb = src + (size_t)clip3(0, h - 1, yb) * pitch;
-    // vertical class of the two neighbour rows: 0 above the CTB, 1 inside, 2 below
-    const int va = ya < y0 ? 0 : (ya > y1 ? 2 : 1), vb = yb < y0 ? 0 : (yb > y1 ? 2 : 1);
+  if (type == HMGPU_SAO_BO) {
+    const int shift = bd - 5, band0 = (w0 >> 16) & 0xff;
 #pragma unroll
     for (int i = 0; i < 8; i++) {
-      const int xa = x + i + dx, xb = x + i - dx;
-      const int ha = xa < x0 ? 0 : (xa > x1 ? 2 : 1), hb = xb < x0 ? 0 : (xb > x1 ? 2 : 1);
-      // availability bit of the CTU a position falls into: order L,R,A,B,AL,AR,BL,BR (SaoDev::avail); inside = always
-      // index by (v,h): (0,0) AL=4 (0,1) A=2 (0,2) AR=5 (1,0) L=0 (1,1) inside (1,2) R=1 (2,0) BL=6 (2,1) B=3 (2,2) BR=7
-      const int bit_a = va == 1 ? (ha == 0 ? 0 : (ha == 2 ? 1 : 8)) : (va == 0 ? (ha == 0 ? 4 : (ha == 2 ? 5 : 2)) : (ha == 0 ? 6 : (ha == 2 ? 7 : 3)));
-      const int bit_b = vb == 1 ? (hb == 0 ? 0 : (hb == 2 ? 1 : 8)) : (vb == 0 ? (hb == 0 ? 4 : (hb == 2 ? 5 : 2)) : (hb == 0 ? 6 : (hb == 2 ? 7 : 3)));
-      const unsigned av = (unsigned)prm.avail | 0x100u;
-      const bool ok = ((av >> bit_a) & 1) && ((av >> bit_b) & 1);
-      const int sa = (uint16_t)ra[clip3(0, w - 1, xa)], sb = (uint16_t)rb[clip3(0, w - 1, xb)];
-      const int et = sgn3(c[i] - sa) + sgn3(c[i] - sb);
-      o[i] = ok ? clip3(0, maxv, c[i] + pp->offset[2 + et]) : c[i];
+      const unsigned k = ((c[i] >> shift) - band0) & 31;
+      const int off = k < 4 ? (int)(int8_t)(off_lo >> (8 * k)) : 0;
+      o[i] = clip3(0, maxv, c[i] + off);
+    }
+  } else {
+    // neighbour a = (dx, dy), neighbour b = (-dx, -dy)
+    const int dx = type == HMGPU_SAO_EO_90 ? 0 : (type == HMGPU_SAO_EO_45 ? 1 : -1);
+    const int dy = type == HMGPU_SAO_EO_0 ? 0 : -1;
+    const int ctb = 1 << log2ctb;
+    const int x0 = cx << log2ctb, y0 = cy << log2ctb;
+    const int x1 = min(x0 + ctb, w) - 1, y1 = min(y0 + ctb, h) - 1;        // CTB clipped to the picture (offsetCTU :679-682)
+    const int ya = row + dy, yb = row - dy;
+    int sa[8], sb[8];
+    row_shifted(src + (size_t)clip3(0, h - 1, ya) * pitch, x, w, dx, sa);
+    row_shifted(src + (size_t)clip3(0, h - 1, yb) * pitch, x, w, -dx, sb);
+    const int va = ya < y0 ? 0 : (ya > y1 ? 2 : 1), vb = yb < y0 ? 0 : (yb > y1 ? 2 : 1);
+    const unsigned av = ((w0 >> 8) & 0xff) | 0x100u;
+    // interior samples of the group compare with positions in the CTB's own columns
+    const bool mid_ok = ((av >> region_bit(va, 1)) & 1) && ((av >> region_bit(vb, 1)) & 1);
+    // sample 0 may face the left CTU column, the last sample the right one
+    const int ha0 = (x + dx) < x0 ? 0 : 1, hb0 = (x - dx) < x0 ? 0 : 1;
+    const int ha7 = (x + 7 + dx) > x1 ? 2 : 1, hb7 = (x + 7 - dx) > x1 ? 2 : 1;
+    const bool ok0 = ((av >> region_bit(va, ha0)) & 1) && ((av >> region_bit(vb, hb0)) & 1);
+    const bool ok7 = ((av >> region_bit(va, ha7)) & 1) && ((av >> region_bit(vb, hb7)) & 1);
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      const int et = ((c[i] > sa[i]) - (c[i] < sa[i])) + ((c[i] > sb[i]) - (c[i] < sb[i])) + 2;       // 0..4
+      const int off = et < 4 ? (int)(int8_t)(off_lo >> (8 * et)) : (int)(int8_t)(off_hi & 0xff);
+      const bool ok = i == 0 ? ok0 : (i == 7 ? ok7 : mid_ok);
+      o[i] = ok ? clip3(0, maxv, c[i] + off) : c[i];
+    }
+    // a picture narrower than the group (chroma width not a multiple of 8): the "last" sample is x1, not x+7
+    if (x + 7 > x1) {
+#pragma unroll
+      for (int i = 1; i < 7; i++) {
+        if (x + i == x1) {
+          const int ha = (x + i + dx) > x1 ? 2 : 1, hb = (x + i - dx) > x1 ? 2 : 1;
+          const bool ok = ((av >> region_bit(va, ha)) & 1) && ((av >> region_bit(vb, hb)) & 1);
+          const int et = ((c[i] > sa[i]) - (c[i] < sa[i])) + ((c[i] > sb[i]) - (c[i] < sb[i])) + 2;
+          const int off = et < 4 ? (int)(int8_t)(off_lo >> (8 * et)) : (int)(int8_t)(off_hi & 0xff);
+          o[i] = ok ? clip3(0, maxv, c[i] + off) : c[i];
+        }
+      }
     }
   }
   *reinterpret_cast<uint4*>(dst + (size_t)row * pitch + x) =
