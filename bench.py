@@ -60,6 +60,8 @@ def algorithmic_bytes(p):
     out["deblock_hor"] = 2 * samples
     out["sao"] = 4 * samples
     out["prep"] = int(decoded.sum()) * (21 + 16)           # HM arrays read + BlkInfo written per partition
+    # replicated margins written around the three final planes (128/64 samples left+right, 80/40 rows above+below)
+    out["extend_border"] = 2 * ((2 * 128 * (p.height + 160) + 160 * p.width) + 2 * (2 * 64 * (p.height // 2 + 80) + 80 * (p.width // 2)))
     return out
 
 

@@ -16,9 +16,9 @@ using namespace hmgpu;
 
 namespace {
 
-enum { K_PREP = 0, K_MC_LUMA, K_MC_CHROMA, K_ITX4, K_ITX8, K_ITX16, K_ITX32, K_DBK_VER, K_DBK_HOR, K_SAO, K_H2D, K_OTHER };
+enum { K_PREP = 0, K_MC_LUMA, K_MC_CHROMA, K_ITX4, K_ITX8, K_ITX16, K_ITX32, K_DBK_VER, K_DBK_HOR, K_SAO, K_H2D, K_EXTEND };
 const char* const kKernelNames[HMGPU_NUM_KERNELS] = {"prep", "mc_luma", "mc_chroma", "itx4", "itx8", "itx16", "itx32",
-                                                     "deblock_ver", "deblock_hor", "sao", "h2d_stage", "other"};
+                                                     "deblock_ver", "deblock_hor", "sao", "h2d_stage", "extend_border"};
 
 struct SliceCall { int first_ctu, num_ctus, slice_idx; };
 
@@ -27,6 +27,7 @@ struct Picture {
   bool sao_applied = false;
   bool filter_ready = false;            // SAO parameters staged
   bool sao_any = false;
+  bool extended = false;                // margins of the final planes hold the replicated border
   std::vector<SliceCall> calls;
   // device allocations (owned)
   void* planes = nullptr;               // rec[3] + sao[3]
@@ -50,6 +51,7 @@ struct hmgpu_ctx {
   // geometry
   int ctu = 64, pw = 16, parts = 256, ctus_w = 0, ctus_h = 0, num_ctus = 0;
   int pitch[3] = {0, 0, 0}, rows[3] = {0, 0, 0};
+  int mx[3] = {0, 0, 0}, my[3] = {0, 0, 0};
   int grid_w = 0, grid_h = 0;
   uint32_t tu_cap[4] = {0, 0, 0, 0};
   size_t coef_elems[3] = {0, 0, 0};
@@ -162,9 +164,11 @@ hmgpu_status alloc_picture(hmgpu_ctx* c, Picture& p) {
   d.lf_across_tiles = 1; d.sao_applied = 0;
   for (int k = 0; k < 4; k++) d.tu_cap[k] = c->tu_cap[k];
   {
+    // plane pointers address sample (0,0); the margins lie at negative coordinates
     Carver m(p.planes);
-    for (int k = 0; k < 3; k++) d.rec[k] = m.take<int16_t>((size_t)c->pitch[k] * c->rows[k]);
-    for (int k = 0; k < 3; k++) d.sao[k] = m.take<int16_t>((size_t)c->pitch[k] * c->rows[k]);
+    for (int k = 0; k < 3; k++) { d.mx[k] = c->mx[k]; d.my[k] = c->my[k]; }
+    for (int k = 0; k < 3; k++) d.rec[k] = m.take<int16_t>((size_t)c->pitch[k] * c->rows[k]) + (size_t)c->my[k] * c->pitch[k] + c->mx[k];
+    for (int k = 0; k < 3; k++) d.sao[k] = m.take<int16_t>((size_t)c->pitch[k] * c->rows[k]) + (size_t)c->my[k] * c->pitch[k] + c->mx[k];
   }
   p.slices.assign(HMGPU_MAX_SLICES, SliceDev());
   return HMGPU_OK;
@@ -190,6 +194,29 @@ hmgpu_status push_final(hmgpu_ctx* c, int pic) {
 }
 
 bool valid_pic(const hmgpu_ctx* c, hmgpu_pic pic) { return pic >= 0 && pic < (int)c->pics.size() && c->pics[pic].in_use; }
+
+// lazy border extension, as HM does when a picture first enters a reference list (TComSlice.cpp:350: extendPicBorder)
+hmgpu_status ensure_extended(hmgpu_ctx* c, int pic) {
+  Picture& p = c->pics[pic];
+  if (p.extended) return HMGPU_OK;
+  Batch b; memset(&b, 0, sizeof(b));
+  b.n = 1; b.pic[0] = pic;
+  { ProfScope ps(c, K_EXTEND); launch_extend(c->d_pics, b, c->seq.width, c->seq.height, c->mx[0], c->my[0], c->stream); }
+  HIP_TRY(c, hipGetLastError());
+  p.extended = true;
+  return HMGPU_OK;
+}
+hmgpu_status ensure_refs_extended(hmgpu_ctx* c, const Batch& b, size_t call_idx) {
+  for (int i = 0; i < b.n; i++) {
+    const Picture& p = c->pics[b.pic[i]];
+    if (call_idx >= p.calls.size()) continue;
+    const SliceDev& sd = p.slices[p.calls[call_idx].slice_idx];
+    for (int l = 0; l < 2; l++)
+      for (int r = 0; r < HMGPU_MAX_REF; r++)
+        if (sd.ref_pic[l][r] >= 0) { hmgpu_status st = ensure_extended(c, sd.ref_pic[l][r]); if (st != HMGPU_OK) return st; }
+  }
+  return HMGPU_OK;
+}
 
 // device work of one batch of slice calls (one call per picture): counters, prep, MC, inverse transforms
 hmgpu_status run_recon(hmgpu_ctx* c, const Batch& b) {
@@ -324,10 +351,15 @@ hmgpu_status hmgpu_create(const hmgpu_seq_params* seq, int device_ordinal, hmgpu
   c->ctus_w = (seq->width + c->ctu - 1) / c->ctu; c->ctus_h = (seq->height + c->ctu - 1) / c->ctu;
   c->num_ctus = c->ctus_w * c->ctus_h;
   c->grid_w = c->ctus_w * c->pw; c->grid_h = c->ctus_h * c->pw;
-  // planes: rows 128-byte aligned (+ one spare 128-byte line so that vector loads may run past the last sample)
-  c->pitch[0] = (int)align_up((size_t)seq->width, 64) + 64;
-  c->pitch[1] = c->pitch[2] = (int)align_up((size_t)seq->width / 2, 64) + 64;
-  c->rows[0] = c->ctus_h * c->ctu + 8; c->rows[1] = c->rows[2] = c->ctus_h * c->ctu / 2 + 8;
+  // planes: HM's picture-buffer shape (TComPicYuv.cpp:89-100: margins of maxCU + 16 luma samples all around, extended by
+  // replication) with device-friendly numbers: 128-sample (256-byte) horizontal margins keep sample (0,y) cache-line
+  // aligned, rows are a multiple of 128 bytes plus one spare line (vector loads may run past the margin; the pitch is
+  // never a power of two)
+  c->mx[0] = 128; c->mx[1] = c->mx[2] = 64;
+  c->my[0] = 80; c->my[1] = c->my[2] = 40;
+  c->pitch[0] = (int)align_up((size_t)seq->width, 64) + 2 * c->mx[0] + 64;
+  c->pitch[1] = c->pitch[2] = (int)align_up((size_t)seq->width / 2, 64) + 2 * c->mx[1] + 64;
+  c->rows[0] = c->ctus_h * c->ctu + 2 * c->my[0] + 8; c->rows[1] = c->rows[2] = c->ctus_h * c->ctu / 2 + 2 * c->my[1] + 8;
   c->coef_elems[0] = (size_t)c->num_ctus * c->ctu * c->ctu;
   c->coef_elems[1] = c->coef_elems[2] = c->coef_elems[0] / 4;
   {
@@ -383,6 +415,7 @@ hmgpu_status hmgpu_picture_acquire(hmgpu_ctx* c, hmgpu_pic* out) {
     Picture& p = c->pics[i];
     if (!p.in_use) {
       p.in_use = true; p.sao_applied = false; p.filter_ready = false; p.sao_any = false; p.calls.clear(); p.max_slice = -1;
+      p.extended = false;
       p.dev.sao_applied = 0;
       *out = (hmgpu_pic)i;
       hmgpu_status st = push_final(c, (int)i);
@@ -414,6 +447,7 @@ hmgpu_status hmgpu_picture_upload(hmgpu_ctx* c, hmgpu_pic pic, const int16_t* co
                                 hipMemcpyHostToDevice, c->stream));
   }
   HIP_TRY(c, hipStreamSynchronize(c->stream));
+  p.extended = false;
   return HMGPU_OK;
 }
 
@@ -508,6 +542,9 @@ hmgpu_status hmgpu_decompress_slice(hmgpu_ctx* c, hmgpu_pic cur, int32_t slice_i
 
   Batch b; memset(&b, 0, sizeof(b));
   b.n = 1; b.pic[0] = cur; b.first_ctu[0] = first_ctu; b.num_ctus[0] = num_ctus;
+  p.extended = false;
+  hmgpu_status st = ensure_refs_extended(c, b, p.calls.size() - 1);
+  if (st != HMGPU_OK) return st;
   return run_recon(c, b);
 }
 
@@ -535,8 +572,11 @@ hmgpu_status hmgpu_filter_picture_stages(hmgpu_ctx* c, hmgpu_pic cur, const hmgp
     // SAOProcess ran: the SAO planes are the picture now (HM: resYuv written in place after the snapshot copy)
     p.sao_applied = true; p.dev.sao_applied = 1;
     st = push_final(c, cur);
+    if (st == HMGPU_OK) st = push_picdev(c, cur);
+    if (st != HMGPU_OK) return st;
   }
-  return st;
+  p.extended = false;
+  return ensure_extended(c, cur);        // the finished picture is ready to be referenced
 }
 
 hmgpu_status hmgpu_filter_picture(hmgpu_ctx* c, hmgpu_pic cur, const hmgpu_pic_params* pp, const hmgpu_sao_param* sao) {
@@ -562,7 +602,8 @@ hmgpu_status hmgpu_replay_batch(hmgpu_ctx* c, const hmgpu_pic* pics, int32_t n, 
           const SliceCall& sc = c->pics[pics[i]].calls[k];
           b.pic[i] = pics[i]; b.first_ctu[i] = sc.first_ctu; b.num_ctus[i] = sc.num_ctus;
         }
-        hmgpu_status st = run_recon(c, b);
+        hmgpu_status st = ensure_refs_extended(c, b, k);
+        if (st == HMGPU_OK) st = run_recon(c, b);
         if (st != HMGPU_OK) return st;
       }
     }
@@ -572,6 +613,8 @@ hmgpu_status hmgpu_replay_batch(hmgpu_ctx* c, const hmgpu_pic* pics, int32_t n, 
       for (int i = 0; i < n; i++) { b.pic[i] = pics[i]; b.first_ctu[i] = 0; b.num_ctus[i] = c->num_ctus; }
       hmgpu_status st = run_filter(c, b, stages & 7);
       if (st != HMGPU_OK) return st;
+      { ProfScope ps(c, K_EXTEND); launch_extend(c->d_pics, b, c->seq.width, c->seq.height, c->mx[0], c->my[0], c->stream); }
+      HIP_TRY(c, hipGetLastError());
     }
   }
   return HMGPU_OK;
@@ -643,21 +686,34 @@ hmgpu_status hmgpu_mc_batch(hmgpu_ctx* c, int32_t is_chroma, int32_t bit_depth, 
     if (w < 2 || h < 2 || (w & 1) || (h & 1) || w > 64 || h > 64) return HMGPU_EINVAL;
     off[i] = (int32_t)total; total += (size_t)w * h;
   }
-  // device copy of the plane with the runtime's own pitch rule (even, >= width + 64 so vector loads may overrun)
-  const int pitch = (int)align_up((size_t)ref_w, 64) + 64;
+  // device copy of the plane with replicated margins (what extendPicBorder gives HM's xPredInterBlk); blocks and MVs must
+  // keep the filter window within 96 samples of the plane
+  const int M = 96;
+  for (int i = 0; i < n; i++) {
+    const int sh = is_chroma ? 3 : 2;
+    const int bx = blocks[i * 6 + 0] + (blocks[i * 6 + 4] >> sh), by = blocks[i * 6 + 1] + (blocks[i * 6 + 5] >> sh);
+    if (bx < -(M - 8) || by < -(M - 8) || bx + blocks[i * 6 + 2] > ref_w + M - 8 || by + blocks[i * 6 + 3] > ref_h + M - 8) return HMGPU_EINVAL;
+  }
+  const int pitch = (int)align_up((size_t)ref_w + 2 * M, 64) + 64;
+  const int prow = ref_h + 2 * M;
+  std::vector<int16_t> padded((size_t)pitch * prow, 0);
+  for (int y = 0; y < prow; y++) {
+    const int16_t* src = ref_plane + (size_t)std::min(std::max(y - M, 0), ref_h - 1) * ref_stride;
+    int16_t* dstrow = padded.data() + (size_t)y * pitch;
+    for (int x = 0; x < ref_w + 2 * M; x++) dstrow[x] = src[std::min(std::max(x - M, 0), ref_w - 1)];
+  }
   int16_t *d_ref = nullptr, *d_dst = nullptr; int32_t *d_blk = nullptr, *d_off = nullptr;
   hmgpu_status st = HMGPU_OK;
   auto fail = [&](hipError_t e) { if (e != hipSuccess && st == HMGPU_OK) { c->last_err = (int32_t)e; st = HMGPU_EDEVICE; } };
-  fail(hipMalloc((void**)&d_ref, (size_t)pitch * (ref_h + 1) * 2)); fail(hipMalloc((void**)&d_dst, total * 2));
+  fail(hipMalloc((void**)&d_ref, padded.size() * 2)); fail(hipMalloc((void**)&d_dst, total * 2));
   fail(hipMalloc((void**)&d_blk, (size_t)n * 24)); fail(hipMalloc((void**)&d_off, (size_t)n * 4));
   if (st == HMGPU_OK) {
-    fail(hipMemset(d_ref, 0, (size_t)pitch * (ref_h + 1) * 2));
-    fail(hipMemcpy2D(d_ref, (size_t)pitch * 2, ref_plane, (size_t)ref_stride * 2, (size_t)ref_w * 2, ref_h, hipMemcpyHostToDevice));
+    fail(hipMemcpy(d_ref, padded.data(), padded.size() * 2, hipMemcpyHostToDevice));
     fail(hipMemcpy(d_blk, blocks, (size_t)n * 24, hipMemcpyHostToDevice));
     fail(hipMemcpy(d_off, off.data(), (size_t)n * 4, hipMemcpyHostToDevice));
   }
   if (st == HMGPU_OK) {
-    launch_mc_flat(is_chroma, bit_depth, d_ref, pitch, ref_w, ref_h, n, d_blk, d_off, bi, d_dst, c->stream);
+    launch_mc_flat(is_chroma, bit_depth, d_ref + (size_t)M * pitch + M, pitch, ref_w, ref_h, n, d_blk, d_off, bi, d_dst, c->stream);
     fail(hipGetLastError());
     fail(hipStreamSynchronize(c->stream));
     fail(hipMemcpy(dst, d_dst, total * 2, hipMemcpyDeviceToHost));

@@ -80,6 +80,7 @@ struct PicDev {
   int32_t bd[3];                   // bit depth per component
   int32_t log2ctu, ctus_w, ctus_h, num_ctus, parts, pw;   // pw = partitions per CTU row
   int32_t pitch[3];                // samples
+  int32_t mx[3], my[3];            // margins (samples / rows) around every plane, border-extended like TComPicYuv::extendPicBorder
   int32_t grid_w, grid_h;          // BlkInfo grid (CTU padded)
   int32_t lf_across_tiles;
   int32_t sao_applied;             // final planes are sao[] (else rec[])
@@ -109,12 +110,29 @@ struct Batch {
   int32_t num_ctus[kMaxBatch];
 };
 
+// Pointers stored inside PicDev / PlaneSet reach the kernels through memory, so the compiler only knows them as generic
+// ("flat") pointers: flat loads cannot be counted separately from LDS traffic and force a full s_waitcnt after every
+// batch.  Every hot pointer is therefore re-typed as a global-address-space pointer before use.
+#define HMGPU_AS1 __attribute__((address_space(1)))
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef u32x4 u32x4_a8 __attribute__((aligned(8)));
+template <typename T> __device__ inline T ldg(const T* p) { return *(const T HMGPU_AS1*)p; }          // scalar types
+template <typename T> __device__ inline void stg(T* p, T v) { *(T HMGPU_AS1*)p = v; }
+__device__ inline u32x4 ldg4(const void* p) { return *(const u32x4 HMGPU_AS1*)p; }
+__device__ inline u32x4 ldg4_a8(const void* p) { return *(const u32x4_a8 HMGPU_AS1*)p; }
+__device__ inline u32x2 ldg2(const void* p) { return *(const u32x2 HMGPU_AS1*)p; }
+__device__ inline void stg4(void* p, u32x4 v) { *(u32x4 HMGPU_AS1*)p = v; }
+__device__ inline void stg4_a8(void* p, u32x4 v) { *(u32x4_a8 HMGPU_AS1*)p = v; }
+__device__ inline void stg2(void* p, u32x2 v) { *(u32x2 HMGPU_AS1*)p = v; }
+
 // ---- small device helpers ------------------------------------------------------------------------------------------
 __host__ __device__ inline int zscan_x(int z) {   // HM g_auiZscanToRaster column: even bits of z
   int x = z & 0x5555; x = (x | (x >> 1)) & 0x3333; x = (x | (x >> 2)) & 0x0f0f; x = (x | (x >> 4)) & 0x00ff; return x;
 }
 __host__ __device__ inline int zscan_y(int z) { return zscan_x(z >> 1); }
 __device__ inline int clip3(int lo, int hi, int v) { return min(hi, max(lo, v)); }
+__device__ inline BlkInfo ld_blk(const BlkInfo* p) { return __builtin_bit_cast(BlkInfo, ldg4(p)); }
 
 // XCD-aware work distribution (speed only, never correctness): workgroups are dealt round-robin to the 8 XCDs, each
 // with its own L2.  For a batch of n pictures with nb workgroups each, picture p is served by the XCDs x with
@@ -146,6 +164,7 @@ void launch_mc_chroma(const PicDev* pics, const PlaneSet* finals, const Batch& b
 void launch_itx(const PicDev* pics, const Batch& b, int log2size, uint32_t blocks_per_shard, hipStream_t s);
 void launch_deblock(const PicDev* pics, const Batch& b, int dir, int width, int height, hipStream_t s);
 void launch_sao(const PicDev* pics, const Batch& b, int width, int height, hipStream_t s);
+void launch_extend(const PicDev* pics, const Batch& b, int width, int height, int mx, int my, hipStream_t s);
 // kernel-level seams for tests
 void launch_itx_flat(int log2size, int bit_depth, int n, const int16_t* levels, const int8_t* per, const int8_t* rem,
                      const uint8_t* flags, int16_t* resid, hipStream_t s);

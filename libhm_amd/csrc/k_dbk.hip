@@ -73,10 +73,10 @@ __device__ inline uint4 pack8(const int (&s)[8]) {
 struct __attribute__((aligned(8))) U4a8 { uint32_t x, y, z, w; };    // 16 bytes at 8-byte alignment
 
 // luma decisions for one 4-line unit (xEdgeFilterLuma :587-650); l[i] = line i, 8 samples across the edge
-__device__ inline void filter_luma_unit(int (&l)[4][8], int bs, int qp, const SliceDev& sl, int bd) {
+__device__ inline void filter_luma_unit(int (&l)[4][8], int bs, int qp, int tc_offset_div2, int beta_offset_div2, int bd) {
   const int scale = 1 << (bd - 8);
-  const int tc = c_tc_table[clip3(0, 53, qp + 2 * (bs - 1) + (sl.tc_offset_div2 << 1))] * scale;
-  const int beta = c_beta_table[clip3(0, 51, qp + (sl.beta_offset_div2 << 1))] * scale;
+  const int tc = c_tc_table[clip3(0, 53, qp + 2 * (bs - 1) + (tc_offset_div2 << 1))] * scale;
+  const int beta = c_beta_table[clip3(0, 51, qp + (beta_offset_div2 << 1))] * scale;
   const int side = (beta + (beta >> 1)) >> 3;
   const int dp0 = abs(l[0][1] - 2 * l[0][2] + l[0][3]), dq0 = abs(l[0][4] - 2 * l[0][5] + l[0][6]);
   const int dp3 = abs(l[3][1] - 2 * l[3][2] + l[3][3]), dq3 = abs(l[3][4] - 2 * l[3][5] + l[3][6]);
@@ -111,12 +111,13 @@ __global__ void __launch_bounds__(256) k_deblock(const PicDev* __restrict__ pics
   const int x = gx * 4, y = gy * 4;
   if (x >= P.width || y >= P.height) return;
   if (DIR == 0 ? gx == 0 : gy == 0) return;
-  const BlkInfo q = P.blk[(size_t)gy * P.grid_w + gx];
+  const BlkInfo q = ld_blk(P.blk + (size_t)gy * P.grid_w + gx);
   if (!(q.edge & (DIR == 0 ? BE_VER_FILTER : BE_HOR_FILTER))) return;
-  const BlkInfo p = DIR == 0 ? P.blk[(size_t)gy * P.grid_w + gx - 1] : P.blk[(size_t)(gy - 1) * P.grid_w + gx];
+  const BlkInfo p = ld_blk(DIR == 0 ? P.blk + (size_t)gy * P.grid_w + gx - 1 : P.blk + (size_t)(gy - 1) * P.grid_w + gx);
   const int bs = boundary_strength(p, q, (q.edge & (DIR == 0 ? BE_VER_TRANSFORM : BE_HOR_TRANSFORM)) != 0);
   if (bs == 0) return;
-  const SliceDev& sl = P.slices[q.slice];            // offsets come from the Q side's slice (:565-566)
+  const SliceDev* slp = P.slices + q.slice;                         // offsets come from the Q side's slice (:565-566)
+  const int tc_off = ldg(&slp->tc_offset_div2), beta_off = ldg(&slp->beta_offset_div2);
   const int qp = ((int)p.qp + (int)q.qp + 1) >> 1;
   const int pitch = P.pitch[0];
   int16_t* base = P.rec[0] + (size_t)y * pitch + x;
@@ -124,29 +125,31 @@ __global__ void __launch_bounds__(256) k_deblock(const PicDev* __restrict__ pics
   if (DIR == 0) {
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-      const U4a8 v = *reinterpret_cast<const U4a8*>(base + (size_t)i * pitch - 4);
+      const u32x4 v = ldg4_a8(base + (size_t)i * pitch - 4);
       unpack8(make_uint4(v.x, v.y, v.z, v.w), l[i]);
     }
   } else {
 #pragma unroll
     for (int r = 0; r < 8; r++) {
-      const uint2 v = *reinterpret_cast<const uint2*>(base + (ptrdiff_t)(r - 4) * pitch);
+      const u32x2 v = ldg2(base + (ptrdiff_t)(r - 4) * pitch);
       l[0][r] = v.x & 0xffff; l[1][r] = v.x >> 16; l[2][r] = v.y & 0xffff; l[3][r] = v.y >> 16;
     }
   }
-  filter_luma_unit(l, bs, qp, sl, P.bd[0]);
+  filter_luma_unit(l, bs, qp, tc_off, beta_off, P.bd[0]);
   if (DIR == 0) {
 #pragma unroll
     for (int i = 0; i < 4; i++) {
       const uint4 v = pack8(l[i]);
-      U4a8 o; o.x = v.x; o.y = v.y; o.z = v.z; o.w = v.w;
-      *reinterpret_cast<U4a8*>(base + (size_t)i * pitch - 4) = o;
+      u32x4 o = {v.x, v.y, v.z, v.w};
+      stg4_a8(base + (size_t)i * pitch - 4, o);
     }
   } else {
 #pragma unroll
     for (int r = 1; r < 7; r++)
-      *reinterpret_cast<uint2*>(base + (ptrdiff_t)(r - 4) * pitch) =
-          make_uint2((uint32_t)l[0][r] | ((uint32_t)l[1][r] << 16), (uint32_t)l[2][r] | ((uint32_t)l[3][r] << 16));
+    {
+      u32x2 o = {(uint32_t)l[0][r] | ((uint32_t)l[1][r] << 16), (uint32_t)l[2][r] | ((uint32_t)l[3][r] << 16)};
+      stg2(base + (ptrdiff_t)(r - 4) * pitch, o);
+    }
   }
   // chroma: Bs 2 only, edges on the 8-sample chroma grid = 16-sample luma grid (:225-229, :684-692, :727)
   if (bs == 2 && ((DIR == 0 ? x : y) & 15) == 0) {
@@ -154,17 +157,17 @@ __global__ void __launch_bounds__(256) k_deblock(const PicDev* __restrict__ pics
     const int maxc = (1 << P.bd[1]) - 1;
 #pragma unroll
     for (int comp = 1; comp < 3; comp++) {
-      const int tc = chroma_tc(qp, comp == 1 ? sl.pps_cb_qp_offset : sl.pps_cr_qp_offset, sl.tc_offset_div2, P.bd[comp]);
+      const int tc = chroma_tc(qp, ldg(comp == 1 ? &slp->pps_cb_qp_offset : &slp->pps_cr_qp_offset), tc_off, P.bd[comp]);
       int16_t* cb = P.rec[comp] + (size_t)(y >> 1) * cp + (x >> 1);
 #pragma unroll
       for (int i = 0; i < 2; i++) {
         // xPelFilterChroma (:870-891): two lines per unit
         int16_t* s = DIR == 0 ? cb + (size_t)i * cp : cb + i;
         const ptrdiff_t o = DIR == 0 ? 1 : cp;
-        const int m2 = (uint16_t)s[-2 * o], m3 = (uint16_t)s[-o], m4 = (uint16_t)s[0], m5 = (uint16_t)s[o];
+        const int m2 = (uint16_t)ldg(s - 2 * o), m3 = (uint16_t)ldg(s - o), m4 = (uint16_t)ldg(s), m5 = (uint16_t)ldg(s + o);
         const int delta = clip3(-tc, tc, ((((m4 - m3) << 2) + m2 - m5 + 4) >> 3));
-        s[-o] = (int16_t)clip3(0, maxc, m3 + delta);
-        s[0] = (int16_t)clip3(0, maxc, m4 - delta);
+        stg(s - o, (int16_t)clip3(0, maxc, m3 + delta));
+        stg(s, (int16_t)clip3(0, maxc, m4 - delta));
       }
     }
   }

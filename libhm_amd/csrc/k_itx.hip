@@ -81,7 +81,7 @@ __device__ inline void itx_tu(const int16_t* __restrict__ lev, bool active, int 
   int c[N];
 #pragma unroll
   for (int m = 0; m < N; m++) {
-    const int q = active ? (int)lev[m * N + n] : 0;
+    const int q = active ? (int)ldg(lev + m * N + n) : 0;
     int v;
     if (rshift > 0) v = (__mul24(q, scale) + (1 << (rshift - 1))) >> rshift;
     else v = (int)((unsigned)__mul24(q, scale) << (-rshift));
@@ -130,7 +130,7 @@ __global__ void __launch_bounds__(256) k_itx(const PicDev* __restrict__ pics, Ba
   __shared__ __attribute__((aligned(16))) int lds[TPB * N * S];
   const PicDev& P = pics[b.pic[blockIdx.z]];
   const int cls = LOG2N - 2, shard = blockIdx.y;
-  const uint32_t count = min(P.tu_count[cls * kTuShards + shard], P.tu_cap[cls]);
+  const uint32_t count = min(ldg(P.tu_count + cls * kTuShards + shard), P.tu_cap[cls]);
   const TuRec* __restrict__ list = P.tu[cls] + (size_t)shard * P.tu_cap[cls];
   const int j = threadIdx.x / N, n = threadIdx.x % N;
   int* tile = lds + j * N * S;
@@ -138,7 +138,13 @@ __global__ void __launch_bounds__(256) k_itx(const PicDev* __restrict__ pics, Ba
     const uint32_t t = base + j;
     const bool active = t < count;
     TuRec rec; rec.x4 = rec.y4 = 0; rec.comp_flags = 0; rec.per = 0; rec.rem = 0; rec.coef_off = 0;
-    if (active) rec = list[t];
+    if (active) {
+      const uint32_t* rp = reinterpret_cast<const uint32_t*>(list + t);
+      const uint32_t w0 = ldg(rp), w1 = ldg(rp + 1);
+      rec.x4 = (uint16_t)(w0 & 0xffff); rec.y4 = (uint16_t)(w0 >> 16);
+      rec.comp_flags = (uint8_t)(w1 & 0xff); rec.per = (int8_t)((w1 >> 8) & 0xff); rec.rem = (int8_t)((w1 >> 16) & 0xff);
+      rec.coef_off = ldg(rp + 2);
+    }
     const int comp = rec.comp_flags & 3, flags = rec.comp_flags >> 2;
     const int bd = P.bd[comp];
     int res[N];
@@ -149,18 +155,18 @@ __global__ void __launch_bounds__(256) k_itx(const PicDev* __restrict__ pics, Ba
     const int maxv = (1 << bd) - 1;
     int16_t* row = P.rec[comp] + (size_t)(((int)rec.y4 * 4 >> cs) + n) * P.pitch[comp] + ((int)rec.x4 * 4 >> cs);
     if constexpr (N == 4) {
-      uint2 v = *reinterpret_cast<const uint2*>(row);
+      const u32x2 v = ldg2(row);
       uint32_t w[2] = {v.x, v.y};
 #pragma unroll
       for (int i = 0; i < 2; i++) {
         const int a = clip3(0, maxv, (int)(w[i] & 0xffff) + res[2 * i]), c = clip3(0, maxv, (int)(w[i] >> 16) + res[2 * i + 1]);
         w[i] = (uint32_t)a | ((uint32_t)c << 16);
       }
-      *reinterpret_cast<uint2*>(row) = make_uint2(w[0], w[1]);
+      { u32x2 o = {w[0], w[1]}; stg2(row, o); }
     } else {
 #pragma unroll
       for (int seg = 0; seg < N / 8; seg++) {
-        uint4 v = *reinterpret_cast<const uint4*>(row + seg * 8);
+        const u32x4 v = ldg4(row + seg * 8);
         uint32_t w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
         for (int i = 0; i < 4; i++) {
@@ -168,7 +174,7 @@ __global__ void __launch_bounds__(256) k_itx(const PicDev* __restrict__ pics, Ba
           const int c = clip3(0, maxv, (int)(w[i] >> 16) + res[seg * 8 + 2 * i + 1]);
           w[i] = (uint32_t)a | ((uint32_t)c << 16);
         }
-        *reinterpret_cast<uint4*>(row + seg * 8) = make_uint4(w[0], w[1], w[2], w[3]);
+        { u32x4 o = {w[0], w[1], w[2], w[3]}; stg4(row + seg * 8, o); }
       }
     }
   }

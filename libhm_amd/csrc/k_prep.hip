@@ -37,11 +37,11 @@ __device__ inline void qp_param(int qp_y, int comp, int bd, int chroma_off, int8
 struct TuStage { TuRec r[3]; int cls[3]; int loc[3]; int n; };
 
 __device__ inline void stage_tu(const PicDev& P, TuStage& st, uint32_t* lds_cnt, int log2size, int x4, int y4, int comp,
-                                int flags, int qp_y, const SliceDev& sl, uint32_t coef_off) {
+                                int flags, int qp_y, const SliceDev* sl, uint32_t coef_off) {
   TuRec r;
   r.x4 = (uint16_t)x4; r.y4 = (uint16_t)y4;
   r.comp_flags = (uint8_t)(comp | (flags << 2));
-  const int coff = comp == 1 ? sl.cb_qp_offset : (comp == 2 ? sl.cr_qp_offset : 0);
+  const int coff = comp == 1 ? ldg(&sl->cb_qp_offset) : (comp == 2 ? ldg(&sl->cr_qp_offset) : 0);
   qp_param(qp_y, comp, P.bd[comp], coff, r.per, r.rem);
   r.pad = 0;
   r.coef_off = coef_off;
@@ -52,10 +52,10 @@ __device__ inline void stage_tu(const PicDev& P, TuStage& st, uint32_t* lds_cnt,
 }
 
 // one partition: BlkInfo + staged TU records + counts of intra/inter partitions
-__device__ inline void prep_partition(const PicDev& P, const Batch& b, int gp, TuStage& st, uint32_t* lds_cnt, uint32_t* lds_stat) {
+__device__ inline void prep_partition(const PicDev& P, const Batch& b, int gpart, TuStage& st, uint32_t* lds_cnt, uint32_t* lds_stat) {
   const int parts = P.parts;
-  const int ctu = b.first_ctu[blockIdx.z] + gp / parts;
-  const int z = gp % parts;
+  const int ctu = b.first_ctu[blockIdx.z] + gpart / parts;
+  const int z = gpart % parts;
   const size_t idx = (size_t)ctu * parts + z;
   const int cx = ctu % P.ctus_w, cy = ctu / P.ctus_w;
   const int x4 = zscan_x(z), y4 = zscan_y(z);              // inside the CTU, partition units
@@ -68,35 +68,35 @@ __device__ inline void prep_partition(const PicDev& P, const Batch& b, int gp, T
   bi.qp = 0; bi.flags = 0; bi.edge = 0; bi.log2cu = 3; bi.slice = 0;
   BlkInfo* out = &P.blk[(size_t)gy * P.grid_w + gx];
 
-  const int part_size = P.part_size[idx];
-  if (px >= P.width || py >= P.height || part_size == HMGPU_SIZE_NONE) { *out = bi; return; }
+  const int part_size = ldg(P.part_size + (idx));
+  if (px >= P.width || py >= P.height || part_size == HMGPU_SIZE_NONE) { stg4(out, __builtin_bit_cast(u32x4, bi)); return; }
 
-  const int sidx = P.slice_idx ? P.slice_idx[ctu] : 0;
-  const SliceDev& sl = P.slices[sidx];
-  const int depth = P.depth[idx];
-  const int tr = P.tr_idx[idx];
+  const int sidx = P.slice_idx ? ldg(P.slice_idx + (ctu)) : 0;
+  const SliceDev* sl = P.slices + sidx;
+  const int depth = ldg(P.depth + (idx));
+  const int tr = ldg(P.tr_idx + (idx));
   const int log2cu = P.log2ctu - depth;
   const int log2tu = log2cu - tr;
   const int cu_parts = 1 << (log2cu - 2);                  // CU width in partitions
   const int tu_parts = log2tu > 2 ? 1 << (log2tu - 2) : 1;
   const int cux = x4 & ~(cu_parts - 1), cuy = y4 & ~(cu_parts - 1);
   const int rx = x4 - cux, ry = y4 - cuy;                  // inside the CU
-  const bool intra = P.pred_mode[idx] == HMGPU_MODE_INTRA;
-  const int cbf_y = P.cbf[0][idx];
+  const bool intra = ldg(P.pred_mode + (idx)) == HMGPU_MODE_INTRA;
+  const int cbf_y = ldg(P.cbf[0] + (idx));
 
   bi.flags = BF_VALID | (intra ? BF_INTRA : 0) | (((cbf_y >> tr) & 1) ? BF_CBFY : 0);
-  bi.qp = P.qp[idx];
+  bi.qp = ldg(P.qp + (idx));
   bi.log2cu = (uint8_t)log2cu;
   bi.slice = (uint16_t)sidx;
 
   // ---- motion ---------------------------------------------------------------------------------------------------
   if (!intra) {
-    const int r0 = P.ref_idx[0][idx], r1 = P.ref_idx[1][idx];
+    const int r0 = ldg(P.ref_idx[0] + (idx)), r1 = ldg(P.ref_idx[1] + (idx));
     int use0 = r0 >= 0, use1 = r1 >= 0;
-    if (use0) { bi.mv[0][0] = P.mv[0][idx * 2]; bi.mv[0][1] = P.mv[0][idx * 2 + 1]; bi.ref[0] = sl.ref_pic[0][r0]; }
-    if (use1) { bi.mv[1][0] = P.mv[1][idx * 2]; bi.mv[1][1] = P.mv[1][idx * 2 + 1]; bi.ref[1] = sl.ref_pic[1][r1]; }
+    if (use0) { bi.mv[0][0] = ldg(P.mv[0] + (idx * 2)); bi.mv[0][1] = ldg(P.mv[0] + (idx * 2 + 1)); bi.ref[0] = ldg(&sl->ref_pic[0][r0]); }
+    if (use1) { bi.mv[1][0] = ldg(P.mv[1] + (idx * 2)); bi.mv[1][1] = ldg(P.mv[1] + (idx * 2 + 1)); bi.ref[1] = ldg(&sl->ref_pic[1][r1]); }
     // xCheckIdenticalMotion (TComPrediction.cpp:497-512): B slice, both lists, same POC and same MV -> list 0 only
-    if (sl.slice_type == HMGPU_B_SLICE && use0 && use1 && sl.ref_poc[0][r0] == sl.ref_poc[1][r1] &&
+    if (ldg(&sl->slice_type) == HMGPU_B_SLICE && use0 && use1 && ldg(&sl->ref_poc[0][r0]) == ldg(&sl->ref_poc[1][r1]) &&
         bi.mv[0][0] == bi.mv[1][0] && bi.mv[0][1] == bi.mv[1][1])
       use1 = 0;
     bi.flags |= (use0 ? BF_MC_L0 : 0) | (use1 ? BF_MC_L1 : 0);
@@ -106,7 +106,8 @@ __device__ inline void prep_partition(const PicDev& P, const Batch& b, int gp, T
   }
 
   // ---- deblocking edge flags (TComLoopFilter.cpp:269-409) ----------------------------------------------------------
-  if (!sl.deblocking_disable) {
+  const int lf_across_slices = ldg(&sl->lf_across_slices);
+  if (!ldg(&sl->deblocking_disable)) {
     const int tux = x4 & ~(tu_parts - 1), tuy = y4 & ~(tu_parts - 1);
     // vertical edge at the left border of this partition
     if ((px & 7) == 0) {
@@ -115,8 +116,8 @@ __device__ inline void prep_partition(const PicDev& P, const Batch& b, int gp, T
         bool avail = px != 0;
         if (avail && x4 == 0) {          // crosses into the left CTU: getPULeft slice/tile restrictions
           const int n = ctu - 1;
-          if (!sl.lf_across_slices && P.slice_idx && P.slice_idx[n] != sidx) avail = false;
-          if (!P.lf_across_tiles && P.tile_idx && P.tile_idx[n] != P.tile_idx[ctu]) avail = false;
+          if (!lf_across_slices && P.slice_idx && ldg(P.slice_idx + (n)) != sidx) avail = false;
+          if (!P.lf_across_tiles && P.tile_idx && ldg(P.tile_idx + (n)) != ldg(P.tile_idx + (ctu))) avail = false;
         }
         filt = trans = avail;
       } else {
@@ -138,8 +139,8 @@ __device__ inline void prep_partition(const PicDev& P, const Batch& b, int gp, T
         bool avail = py != 0;
         if (avail && y4 == 0) {
           const int n = ctu - P.ctus_w;
-          if (!sl.lf_across_slices && P.slice_idx && P.slice_idx[n] != sidx) avail = false;
-          if (!P.lf_across_tiles && P.tile_idx && P.tile_idx[n] != P.tile_idx[ctu]) avail = false;
+          if (!lf_across_slices && P.slice_idx && ldg(P.slice_idx + (n)) != sidx) avail = false;
+          if (!P.lf_across_tiles && P.tile_idx && ldg(P.tile_idx + (n)) != ldg(P.tile_idx + (ctu))) avail = false;
         }
         filt = trans = avail;
       } else {
@@ -156,13 +157,13 @@ __device__ inline void prep_partition(const PicDev& P, const Batch& b, int gp, T
       bi.edge |= (filt ? BE_HOR_FILTER : 0) | (trans ? BE_HOR_TRANSFORM : 0);
     }
   }
-  *out = bi;
+  stg4(out, __builtin_bit_cast(u32x4, bi));
 
   // ---- transform units -------------------------------------------------------------------------------------------
   // cbf bit d of a partition = cbf of its ancestor TU node at transform depth d (TComDataCU.h:310); HM descends
   // only while every node on the way has its bit set (TComTrQuant.cpp:1558-1564)
   const unsigned chain = (1u << (tr + 1)) - 1;
-  const int qp_cu = P.qp[(size_t)ctu * parts + (z & ~(cu_parts * cu_parts - 1))];   // cu.getQP(0): first partition of the CU
+  const int qp_cu = ldg(P.qp + ((size_t)ctu * parts + (z & ~(cu_parts * cu_parts - 1))));   // cu.getQP(0): first partition of the CU
   const int ctu_luma = 1 << (2 * P.log2ctu);
   if (log2tu > 5) return;                                   // not a legal HEVC TU size; nothing to transform
   if (intra) return;                                        // intra CUs are not reconstructed on the device yet: their
@@ -170,12 +171,12 @@ __device__ inline void prep_partition(const PicDev& P, const Batch& b, int gp, T
   if (log2tu > 2) {
     if (x4 == (x4 & ~(tu_parts - 1)) && y4 == (y4 & ~(tu_parts - 1))) {
       if ((cbf_y & chain) == chain) {
-        const int ts = P.tskip[0] ? P.tskip[0][idx] : 0;
+        const int ts = P.tskip[0] ? ldg(P.tskip[0] + (idx)) : 0;
         stage_tu(P, st, lds_cnt, log2tu, gx, gy, 0, (ts ? 2 : 0), qp_cu, sl, (uint32_t)ctu * ctu_luma + 16u * z);
       }
       for (int comp = 1; comp < 3; comp++) {
-        if ((P.cbf[comp][idx] & chain) == chain) {
-          const int ts = P.tskip[comp] ? P.tskip[comp][idx] : 0;
+        if ((ldg(P.cbf[comp] + (idx)) & chain) == chain) {
+          const int ts = P.tskip[comp] ? ldg(P.tskip[comp] + (idx)) : 0;
           stage_tu(P, st, lds_cnt, log2tu - 1, gx, gy, comp, (ts ? 2 : 0), qp_cu, sl, (uint32_t)ctu * (ctu_luma >> 2) + 4u * z);
         }
       }
@@ -183,14 +184,14 @@ __device__ inline void prep_partition(const PicDev& P, const Batch& b, int gp, T
   } else {
     // 4x4 luma TU: every partition is an origin
     if ((cbf_y & chain) == chain) {
-      const int ts = P.tskip[0] ? P.tskip[0][idx] : 0;
+      const int ts = P.tskip[0] ? ldg(P.tskip[0] + (idx)) : 0;
       stage_tu(P, st, lds_cnt, 2, gx, gy, 0, (intra ? 1 : 0) | (ts ? 2 : 0), qp_cu, sl, (uint32_t)ctu * ctu_luma + 16u * z);
     }
     // the one 4x4 chroma TU of the parent 8x8 node rides with the first child (z multiple of 4)
     if ((z & 3) == 0) {
       for (int comp = 1; comp < 3; comp++) {
-        if ((P.cbf[comp][idx] & chain) == chain) {
-          const int ts = P.tskip[comp] ? P.tskip[comp][idx] : 0;
+        if ((ldg(P.cbf[comp] + (idx)) & chain) == chain) {
+          const int ts = P.tskip[comp] ? ldg(P.tskip[comp] + (idx)) : 0;
           stage_tu(P, st, lds_cnt, 2, gx, gy, comp, (ts ? 2 : 0), qp_cu, sl, (uint32_t)ctu * (ctu_luma >> 2) + 4u * z);
         }
       }
@@ -205,8 +206,8 @@ __global__ void __launch_bounds__(256) k_prep(const PicDev* __restrict__ pics, B
   if (threadIdx.x < 2) lds_stat[threadIdx.x] = 0;
   __syncthreads();
   TuStage st; st.n = 0;
-  const int gp = blockIdx.x * 256 + threadIdx.x;
-  if (gp < b.num_ctus[blockIdx.z] * P.parts) prep_partition(P, b, gp, st, lds_cnt, lds_stat);
+  const int gpart = blockIdx.x * 256 + threadIdx.x;
+  if (gpart < b.num_ctus[blockIdx.z] * P.parts) prep_partition(P, b, gpart, st, lds_cnt, lds_stat);
   __syncthreads();
   const int shard = blockIdx.x & (kTuShards - 1);
   if (threadIdx.x < 4) {
@@ -220,14 +221,18 @@ __global__ void __launch_bounds__(256) k_prep(const PicDev* __restrict__ pics, B
   for (int k = 0; k < st.n; k++) {
     const int c = st.cls[k];
     const uint32_t i = lds_base[c] + (uint32_t)st.loc[k];
-    if (i < P.tu_cap[c]) P.tu[c][(size_t)shard * P.tu_cap[c] + i] = st.r[k];
+    if (i < P.tu_cap[c]) {
+      uint32_t* dst = reinterpret_cast<uint32_t*>(P.tu[c] + (size_t)shard * P.tu_cap[c] + i);
+      const uint32_t* src = reinterpret_cast<const uint32_t*>(&st.r[k]);
+      stg(dst, src[0]); stg(dst + 1, src[1]); stg(dst + 2, src[2]);
+    }
   }
 }
 
 // resets the TU list lengths of every picture of the batch (one launch instead of one memset per picture)
 __global__ void k_zero_counts(const PicDev* __restrict__ pics, Batch b) {
   const PicDev& P = pics[b.pic[blockIdx.x]];
-  if (threadIdx.x < 4 * kTuShards) P.tu_count[threadIdx.x] = 0;
+  if (threadIdx.x < 4 * kTuShards) stg(P.tu_count + threadIdx.x, 0u);
 }
 
 void launch_prep(const PicDev* pics, const Batch& b, int max_ctus, int parts, hipStream_t s) {

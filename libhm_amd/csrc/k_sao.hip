@@ -13,7 +13,7 @@
 
 namespace hmgpu {
 
-__device__ inline void unpack8u(const uint4 v, int (&s)[8]) {
+__device__ inline void unpack8u(const u32x4 v, int (&s)[8]) {
   s[0] = v.x & 0xffff; s[1] = v.x >> 16; s[2] = v.y & 0xffff; s[3] = v.y >> 16;
   s[4] = v.z & 0xffff; s[5] = v.z >> 16; s[6] = v.w & 0xffff; s[7] = v.w >> 16;
 }
@@ -22,8 +22,8 @@ __device__ inline void unpack8u(const uint4 v, int (&s)[8]) {
 // values are only ever used for samples that the availability rule leaves untouched)
 __device__ inline void row_shifted(const int16_t* __restrict__ r, int x, int w, int dx, int (&s)[8]) {
   int v[8];
-  unpack8u(*reinterpret_cast<const uint4*>(r + x), v);
-  const int l = (uint16_t)r[max(x - 1, 0)], rr = (uint16_t)r[min(x + 8, w - 1)];
+  unpack8u(ldg4(r + x), v);
+  const int l = (uint16_t)ldg(r + max(x - 1, 0)), rr = (uint16_t)ldg(r + min(x + 8, w - 1));
 #pragma unroll
   for (int i = 0; i < 8; i++) {
     const int left = i == 0 ? l : v[i - 1], right = i == 7 ? rr : v[i + 1];
@@ -51,12 +51,12 @@ __global__ void __launch_bounds__(256) k_sao(const PicDev* __restrict__ pics, Ba
   int16_t* __restrict__ dst = P.sao[comp];
   const int log2ctb = P.log2ctu - cs;
   const int cx = x >> log2ctb, cy = row >> log2ctb;
-  const uint32_t* pw = reinterpret_cast<const uint32_t*>(&P.saoprm[((size_t)cy * P.ctus_w + cx) * 3 + comp]);
-  const uint32_t w0 = pw[0];
+  const uint32_t* pw = reinterpret_cast<const uint32_t*>(P.saoprm + ((size_t)cy * P.ctus_w + cx) * 3 + comp);
+  const uint32_t w0 = ldg(pw);
   const int type = (int)(int8_t)(w0 & 0xff);
-  const uint4 cur = *reinterpret_cast<const uint4*>(src + (size_t)row * pitch + x);
-  if (type < 0) { *reinterpret_cast<uint4*>(dst + (size_t)row * pitch + x) = cur; return; }
-  const uint32_t off_lo = pw[1], off_hi = pw[2];            // off[0..3], off[4..7]
+  const u32x4 cur = ldg4(src + (size_t)row * pitch + x);
+  if (type < 0) { stg4(dst + (size_t)row * pitch + x, cur); return; }
+  const uint32_t off_lo = ldg(pw + 1), off_hi = ldg(pw + 2);            // off[0..3], off[4..7]
   int c[8], o[8];
   unpack8u(cur, c);
   const int bd = P.bd[comp];
@@ -110,9 +110,51 @@ __global__ void __launch_bounds__(256) k_sao(const PicDev* __restrict__ pics, Ba
       }
     }
   }
-  *reinterpret_cast<uint4*>(dst + (size_t)row * pitch + x) =
-      make_uint4((uint32_t)o[0] | ((uint32_t)o[1] << 16), (uint32_t)o[2] | ((uint32_t)o[3] << 16),
-                 (uint32_t)o[4] | ((uint32_t)o[5] << 16), (uint32_t)o[6] | ((uint32_t)o[7] << 16));
+  u32x4 res = {(uint32_t)o[0] | ((uint32_t)o[1] << 16), (uint32_t)o[2] | ((uint32_t)o[3] << 16),
+               (uint32_t)o[4] | ((uint32_t)o[5] << 16), (uint32_t)o[6] | ((uint32_t)o[7] << 16)};
+  stg4(dst + (size_t)row * pitch + x, res);
+}
+
+// TComPicYuv::extendPicBorder (TComPicYuv.cpp:173-217): replicate the edge samples of the picture's FINAL planes into the
+// margins so that motion compensation of later pictures never has to clamp coordinates.  One thread per margin sample
+// pair; every thread reads only samples of the visible picture, so there is no ordering between margin writes.
+__global__ void __launch_bounds__(256) k_extend(const PicDev* __restrict__ pics, Batch b, int total_luma_pairs, int total_chroma_pairs) {
+  const PicDev& P = pics[b.pic[blockIdx.z]];
+  int idx = blockIdx.x * 256 + threadIdx.x;
+  int comp = 0;
+  if (idx >= total_luma_pairs) { idx -= total_luma_pairs; comp = 1; if (idx >= total_chroma_pairs) { idx -= total_chroma_pairs; comp = 2; if (idx >= total_chroma_pairs) return; } }
+  const int cs = comp ? 1 : 0;
+  const int w = P.width >> cs, h = P.height >> cs, mx = P.mx[comp], my = P.my[comp], pitch = P.pitch[comp];
+  int16_t* pl = P.sao_applied ? P.sao[comp] : P.rec[comp];
+  // margin region in pairs of samples: first the left+right bands of the rows [-my, h+my), then the top+bottom bands over [0, w)
+  const int side_pairs_per_row = mx;                         // (mx left + mx right) / 2
+  const int rows = h + 2 * my;
+  int x, y;
+  if (idx < side_pairs_per_row * rows) {
+    y = idx / side_pairs_per_row - my;
+    const int k = (idx % side_pairs_per_row) * 2;            // 0 .. 2*mx-2
+    x = k < mx ? k - mx : w + (k - mx);
+  } else {
+    idx -= side_pairs_per_row * rows;
+    const int pairs_per_row = w >> 1;
+    const int r = idx / pairs_per_row;                       // 0 .. 2*my-1
+    if (r >= 2 * my) return;
+    y = r < my ? r - my : h + (r - my);
+    x = (idx % pairs_per_row) * 2;
+  }
+  const int sy = clip3(0, h - 1, y);
+  const uint32_t a = (uint16_t)ldg(pl + (ptrdiff_t)sy * pitch + clip3(0, w - 1, x));
+  const uint32_t c = (uint16_t)ldg(pl + (ptrdiff_t)sy * pitch + clip3(0, w - 1, x + 1));
+  stg(reinterpret_cast<uint32_t*>(pl + (ptrdiff_t)y * pitch + x), a | (c << 16));
+}
+
+void launch_extend(const PicDev* pics, const Batch& b, int width, int height, int mx, int my, hipStream_t s) {
+  // luma margins (mx, my); chroma margins are half of them
+  const int luma = mx * (height + 2 * my) + (width / 2) * 2 * my;
+  const int cw = width / 2, chh = height / 2, cmx = mx / 2, cmy = my / 2;
+  const int chroma = cmx * (chh + 2 * cmy) + (cw / 2) * 2 * cmy;
+  dim3 grid((unsigned)((luma + 2 * chroma + 255) / 256), 1, (unsigned)b.n);
+  hipLaunchKernelGGL(k_extend, grid, dim3(256), 0, s, pics, b, luma, chroma);
 }
 
 void launch_sao(const PicDev* pics, const Batch& b, int width, int height, hipStream_t s) {

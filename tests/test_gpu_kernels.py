@@ -93,6 +93,10 @@ def test_interpolation_with_border_clamp_matches_oracle(ctx, oracle, bd):
             x0 -= x0 % 2
             y0 -= y0 % 2
             mvx, mvy = int(rng.randint(-80 * 4, 80 * 4)), int(rng.randint(-80 * 4, 80 * 4))
+            # what TComDataCU::clipMv guarantees the decoder (CU origin = block origin, luma units; chroma: half of it)
+            sc = 2 if is_chroma else 1
+            mvx = min(((88 * sc + 8 - x0 * sc - 1) << 2) // 1, max((-64 - 8 - x0 * sc + 1) * 4, mvx))
+            mvy = min(((72 * sc + 8 - y0 * sc - 1) << 2) // 1, max((-64 - 8 - y0 * sc + 1) * 4, mvy))
             blocks.append([x0, y0, w, h, mvx, mvy])
         blocks = np.array(blocks, dtype=np.int32)
         for bi in (0, 1):
