@@ -13,23 +13,10 @@
 
 namespace hmgpu {
 
-__device__ inline void unpack8u(const u32x4 v, int (&s)[8]) {
-  s[0] = v.x & 0xffff; s[1] = v.x >> 16; s[2] = v.y & 0xffff; s[3] = v.y >> 16;
-  s[4] = v.z & 0xffff; s[5] = v.z >> 16; s[6] = v.w & 0xffff; s[7] = v.w >> 16;
-}
-
-// the 8 samples at x+dx .. x+7+dx of row `r` (dx in {-1,0,1}); columns are clamped into the picture (the clamped
-// values are only ever used for samples that the availability rule leaves untouched)
-__device__ inline void row_shifted(const int16_t* __restrict__ r, int x, int w, int dx, int (&s)[8]) {
-  int v[8];
-  unpack8u(ldg4(r + x), v);
-  const int l = (uint16_t)ldg(r + max(x - 1, 0)), rr = (uint16_t)ldg(r + min(x + 8, w - 1));
-#pragma unroll
-  for (int i = 0; i < 8; i++) {
-    const int left = i == 0 ? l : v[i - 1], right = i == 7 ? rr : v[i + 1];
-    s[i] = dx == 0 ? v[i] : (dx < 0 ? left : right);
-  }
-}
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+__device__ inline s16x2 as_s16x2(uint32_t v) { return __builtin_bit_cast(s16x2, v); }
+__device__ inline uint32_t as_u32(s16x2 v) { return __builtin_bit_cast(uint32_t, v); }
+__device__ inline s16x2 splat(int v) { return (s16x2){(short)v, (short)v}; }
 
 // availability bit (SaoDev::avail order L,R,A,B,AL,AR,BL,BR; 8 = inside the CTB) of the CTU that holds a position with
 // vertical class v (0 above, 1 inside, 2 below) and horizontal class hcls (0 left, 1 inside, 2 right)
@@ -37,14 +24,86 @@ __device__ inline int region_bit(int v, int hcls) {
   return v == 1 ? (hcls == 0 ? 0 : (hcls == 2 ? 1 : 8)) : (v == 0 ? (hcls == 0 ? 4 : (hcls == 2 ? 5 : 2)) : (hcls == 0 ? 6 : (hcls == 2 ? 7 : 3)));
 }
 
-__global__ void __launch_bounds__(256) k_sao(const PicDev* __restrict__ pics, Batch b) {
+// neighbour samples x+DX .. x+7+DX of a row as four packed pairs; `e` = the row's 8 samples, l / r = samples x-1 / x+8
+template <int DX>
+__device__ inline void shifted(const u32x4 e, uint32_t l, uint32_t r, uint32_t (&n)[4]) {
+  if constexpr (DX == 0) { n[0] = e.x; n[1] = e.y; n[2] = e.z; n[3] = e.w; }
+  else if constexpr (DX < 0) {
+    n[0] = (e.x << 16) | l; n[1] = __builtin_amdgcn_alignbit(e.y, e.x, 16);
+    n[2] = __builtin_amdgcn_alignbit(e.z, e.y, 16); n[3] = __builtin_amdgcn_alignbit(e.w, e.z, 16);
+  } else {
+    n[0] = __builtin_amdgcn_alignbit(e.y, e.x, 16); n[1] = __builtin_amdgcn_alignbit(e.z, e.y, 16);
+    n[2] = __builtin_amdgcn_alignbit(e.w, e.z, 16); n[3] = (e.w >> 16) | (r << 16);
+  }
+}
+
+// offsets by table index (two indices 0..7 packed as 16-bit halves) -> two sign-extended 16-bit offsets.  v_perm_b32 does
+// the 8-entry byte-table lookup for both halves at once: indices are moved to the odd bytes so that the second v_perm can
+// replicate the sign bits (selector codes 8 / 9 = sign of byte 1 / 3).
+__device__ inline s16x2 lut_offsets(uint32_t idx_pk, uint32_t tab_lo, uint32_t tab_hi) {
+  const uint32_t looked = __builtin_amdgcn_perm(tab_hi, tab_lo, idx_pk << 8);   // bytes 1,3 = table[idx]; bytes 0,2 = table[0] (unused)
+  return as_s16x2(__builtin_amdgcn_perm(0u, looked, 0x09030801u));
+}
+
+// edge offset of one row of 8 samples, compile-time direction (DX, DY in {-1,0,1}); everything stays packed (2 samples / register)
+template <int DX, int DY>
+__device__ inline void sao_eo_row(const int16_t* __restrict__ src, int pitch, int w, int h, int x, int row, const u32x4 cur, uint32_t off_lo,
+                                  uint32_t off_hi, unsigned av, int x0, int y0, int x1, int y1, int maxv, uint32_t (&out)[4]) {
+  const int ya = row + DY, yb = row - DY;
+  const int16_t* ra = src + (size_t)clip3(0, h - 1, ya) * pitch;
+  const int16_t* rb = src + (size_t)clip3(0, h - 1, yb) * pitch;
+  uint32_t na[4], nb[4];
+  {
+    const u32x4 ea = DY == 0 ? cur : ldg4(ra + x), eb = DY == 0 ? cur : ldg4(rb + x);
+    uint32_t la = 0, raa = 0, lb = 0, rbb = 0;
+    if constexpr (DX < 0) { la = (uint16_t)ldg(ra + max(x - 1, 0)); rbb = (uint16_t)ldg(rb + min(x + 8, w - 1)); }
+    if constexpr (DX > 0) { raa = (uint16_t)ldg(ra + min(x + 8, w - 1)); lb = (uint16_t)ldg(rb + max(x - 1, 0)); }
+    shifted<DX>(ea, la, raa, na);
+    shifted<-DX>(eb, lb, rbb, nb);
+  }
+  // availability: interior samples face positions in the CTB's own columns; sample 0 / the last sample may face the
+  // left / right CTU column
+  const int va = ya < y0 ? 0 : (ya > y1 ? 2 : 1), vb = yb < y0 ? 0 : (yb > y1 ? 2 : 1);
+  const bool mid_ok = ((av >> region_bit(va, 1)) & 1) && ((av >> region_bit(vb, 1)) & 1);
+  const int last = min(7, x1 - x);                          // last sample of the group that lies inside the CTB / picture
+  const int ha0 = (x + DX) < x0 ? 0 : 1, hb0 = (x - DX) < x0 ? 0 : 1;
+  const int hal = (x + last + DX) > x1 ? 2 : 1, hbl = (x + last - DX) > x1 ? 2 : 1;
+  const bool ok0 = ((av >> region_bit(va, ha0)) & 1) && ((av >> region_bit(vb, hb0)) & 1);
+  const bool okl = ((av >> region_bit(va, hal)) & 1) && ((av >> region_bit(vb, hbl)) & 1);
+  const uint32_t c[4] = {cur.x, cur.y, cur.z, cur.w};
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const s16x2 cc = as_s16x2(c[j]);
+    const s16x2 one = splat(1), mone = splat(-1);
+    const s16x2 sa = __builtin_elementwise_max(__builtin_elementwise_min(cc - as_s16x2(na[j]), one), mone);
+    const s16x2 sb = __builtin_elementwise_max(__builtin_elementwise_min(cc - as_s16x2(nb[j]), one), mone);
+    const uint32_t et = as_u32(sa + sb + splat(2));         // edge class 0..4 in each half
+    const s16x2 off = lut_offsets(et, off_lo, off_hi);
+    const s16x2 res = __builtin_elementwise_min(__builtin_elementwise_max(cc + off, splat(0)), splat(maxv));
+    // per-half enable mask
+    const bool ok_lo = (2 * j == 0) ? ok0 : ((2 * j == last) ? okl : mid_ok);
+    const bool ok_hi = (2 * j + 1 == last) ? okl : mid_ok;
+    const uint32_t m = (ok_lo ? 0xffffu : 0u) | (ok_hi ? 0xffff0000u : 0u);
+    out[j] = (as_u32(res) & m) | (c[j] & ~m);
+  }
+}
+
+// One wave = one 64x8 luma block (8 lanes across, 8 rows) or one 32x16 chroma block (4 lanes across, 16 rows): always
+// inside ONE CTB, so the SAO type is wave-uniform and the type switch below costs no divergence.
+__global__ void __launch_bounds__(256) k_sao(const PicDev* __restrict__ pics, Batch b, int luma_waves, int chroma_waves) {
   const PicDev& P = pics[b.pic[blockIdx.z]];
-  const int x = (blockIdx.x * 64 + (threadIdx.x & 63)) * 8;
-  int row = blockIdx.y * 4 + (threadIdx.x >> 6);
+  int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
   int comp = 0;
-  if (row >= P.height) { row -= P.height; comp = 1; if (row >= (P.height >> 1)) { row -= P.height >> 1; comp = 2; } }
+  if (wid >= luma_waves) { wid -= luma_waves; comp = 1; if (wid >= chroma_waves) { wid -= chroma_waves; comp = 2; if (wid >= chroma_waves) return; } }
   const int cs = comp ? 1 : 0;
   const int w = P.width >> cs, h = P.height >> cs;
+  const int bw = comp ? 32 : 64, bh = comp ? 16 : 8;        // block covered by the wave (samples)
+  const int blocks_x = (w + bw - 1) / bw;
+  const int bx = wid % blocks_x, by = wid / blocks_x;
+  const int lanes_x = bw / 8;
+  const int x = bx * bw + (lane % lanes_x) * 8;
+  const int row = by * bh + lane / lanes_x;
   if (x >= w || row >= h) return;
   const int pitch = P.pitch[comp];
   const int16_t* __restrict__ src = P.rec[comp];
@@ -57,61 +116,33 @@ __global__ void __launch_bounds__(256) k_sao(const PicDev* __restrict__ pics, Ba
   const u32x4 cur = ldg4(src + (size_t)row * pitch + x);
   if (type < 0) { stg4(dst + (size_t)row * pitch + x, cur); return; }
   const uint32_t off_lo = ldg(pw + 1), off_hi = ldg(pw + 2);            // off[0..3], off[4..7]
-  int c[8], o[8];
-  unpack8u(cur, c);
   const int bd = P.bd[comp];
   const int maxv = (1 << bd) - 1;
+  uint32_t out[4];
   if (type == HMGPU_SAO_BO) {
+    // band k = (sample >> (bd-5)) - first band (mod 32); bands 0..3 carry offsets, every other band maps to table entry 4 (= 0)
     const int shift = bd - 5, band0 = (w0 >> 16) & 0xff;
+    const uint32_t c[4] = {cur.x, cur.y, cur.z, cur.w};
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
-      const unsigned k = ((c[i] >> shift) - band0) & 31;
-      const int off = k < 4 ? (int)(int8_t)(off_lo >> (8 * k)) : 0;
-      o[i] = clip3(0, maxv, c[i] + off);
+    for (int j = 0; j < 4; j++) {
+      const uint32_t lo = c[j] & 0xffffu, hi = c[j] >> 16;
+      const uint32_t k0 = min(((lo >> shift) - band0) & 31u, 4u), k1 = min(((hi >> shift) - band0) & 31u, 4u);
+      const s16x2 off = lut_offsets(k0 | (k1 << 16), off_lo, 0u);
+      out[j] = as_u32(__builtin_elementwise_min(__builtin_elementwise_max(as_s16x2(c[j]) + off, splat(0)), splat(maxv)));
     }
   } else {
-    // neighbour a = (dx, dy), neighbour b = (-dx, -dy)
-    const int dx = type == HMGPU_SAO_EO_90 ? 0 : (type == HMGPU_SAO_EO_45 ? 1 : -1);
-    const int dy = type == HMGPU_SAO_EO_0 ? 0 : -1;
     const int ctb = 1 << log2ctb;
     const int x0 = cx << log2ctb, y0 = cy << log2ctb;
-    const int x1 = min(x0 + ctb, w) - 1, y1 = min(y0 + ctb, h) - 1;        // CTB clipped to the picture (offsetCTU :679-682)
-    const int ya = row + dy, yb = row - dy;
-    int sa[8], sb[8];
-    row_shifted(src + (size_t)clip3(0, h - 1, ya) * pitch, x, w, dx, sa);
-    row_shifted(src + (size_t)clip3(0, h - 1, yb) * pitch, x, w, -dx, sb);
-    const int va = ya < y0 ? 0 : (ya > y1 ? 2 : 1), vb = yb < y0 ? 0 : (yb > y1 ? 2 : 1);
+    const int x1 = min(x0 + ctb, w) - 1, y1 = min(y0 + ctb, h) - 1;     // CTB clipped to the picture (offsetCTU :679-682)
     const unsigned av = ((w0 >> 8) & 0xff) | 0x100u;
-    // interior samples of the group compare with positions in the CTB's own columns
-    const bool mid_ok = ((av >> region_bit(va, 1)) & 1) && ((av >> region_bit(vb, 1)) & 1);
-    // sample 0 may face the left CTU column, the last sample the right one
-    const int ha0 = (x + dx) < x0 ? 0 : 1, hb0 = (x - dx) < x0 ? 0 : 1;
-    const int ha7 = (x + 7 + dx) > x1 ? 2 : 1, hb7 = (x + 7 - dx) > x1 ? 2 : 1;
-    const bool ok0 = ((av >> region_bit(va, ha0)) & 1) && ((av >> region_bit(vb, hb0)) & 1);
-    const bool ok7 = ((av >> region_bit(va, ha7)) & 1) && ((av >> region_bit(vb, hb7)) & 1);
-#pragma unroll
-    for (int i = 0; i < 8; i++) {
-      const int et = ((c[i] > sa[i]) - (c[i] < sa[i])) + ((c[i] > sb[i]) - (c[i] < sb[i])) + 2;       // 0..4
-      const int off = et < 4 ? (int)(int8_t)(off_lo >> (8 * et)) : (int)(int8_t)(off_hi & 0xff);
-      const bool ok = i == 0 ? ok0 : (i == 7 ? ok7 : mid_ok);
-      o[i] = ok ? clip3(0, maxv, c[i] + off) : c[i];
-    }
-    // a picture narrower than the group (chroma width not a multiple of 8): the "last" sample is x1, not x+7
-    if (x + 7 > x1) {
-#pragma unroll
-      for (int i = 1; i < 7; i++) {
-        if (x + i == x1) {
-          const int ha = (x + i + dx) > x1 ? 2 : 1, hb = (x + i - dx) > x1 ? 2 : 1;
-          const bool ok = ((av >> region_bit(va, ha)) & 1) && ((av >> region_bit(vb, hb)) & 1);
-          const int et = ((c[i] > sa[i]) - (c[i] < sa[i])) + ((c[i] > sb[i]) - (c[i] < sb[i])) + 2;
-          const int off = et < 4 ? (int)(int8_t)(off_lo >> (8 * et)) : (int)(int8_t)(off_hi & 0xff);
-          o[i] = ok ? clip3(0, maxv, c[i] + off) : c[i];
-        }
-      }
+    switch (type) {                                                      // a = (x+DX, y+DY), b = (x-DX, y-DY)
+      case HMGPU_SAO_EO_0:   sao_eo_row<-1, 0>(src, pitch, w, h, x, row, cur, off_lo, off_hi, av, x0, y0, x1, y1, maxv, out); break;
+      case HMGPU_SAO_EO_90:  sao_eo_row<0, -1>(src, pitch, w, h, x, row, cur, off_lo, off_hi, av, x0, y0, x1, y1, maxv, out); break;
+      case HMGPU_SAO_EO_135: sao_eo_row<-1, -1>(src, pitch, w, h, x, row, cur, off_lo, off_hi, av, x0, y0, x1, y1, maxv, out); break;
+      default:               sao_eo_row<1, -1>(src, pitch, w, h, x, row, cur, off_lo, off_hi, av, x0, y0, x1, y1, maxv, out); break;
     }
   }
-  u32x4 res = {(uint32_t)o[0] | ((uint32_t)o[1] << 16), (uint32_t)o[2] | ((uint32_t)o[3] << 16),
-               (uint32_t)o[4] | ((uint32_t)o[5] << 16), (uint32_t)o[6] | ((uint32_t)o[7] << 16)};
+  u32x4 res = {out[0], out[1], out[2], out[3]};
   stg4(dst + (size_t)row * pitch + x, res);
 }
 
@@ -158,8 +189,10 @@ void launch_extend(const PicDev* pics, const Batch& b, int width, int height, in
 }
 
 void launch_sao(const PicDev* pics, const Batch& b, int width, int height, hipStream_t s) {
-  dim3 grid((unsigned)((width / 8 + 63) / 64), (unsigned)((2 * height + 3) / 4), (unsigned)b.n);
-  hipLaunchKernelGGL(k_sao, grid, dim3(256), 0, s, pics, b);
+  const int luma = ((width + 63) / 64) * ((height + 7) / 8);
+  const int chroma = ((width / 2 + 31) / 32) * ((height / 2 + 15) / 16);
+  dim3 grid((unsigned)((luma + 2 * chroma + 3) / 4), 1, (unsigned)b.n);
+  hipLaunchKernelGGL(k_sao, grid, dim3(256), 0, s, pics, b, luma, chroma);
 }
 
 }  // namespace hmgpu
