@@ -363,11 +363,11 @@ hmgpu_status hmgpu_create(const hmgpu_seq_params* seq, int device_ordinal, hmgpu
   c->coef_elems[0] = (size_t)c->num_ctus * c->ctu * c->ctu;
   c->coef_elems[1] = c->coef_elems[2] = c->coef_elems[0] / 4;
   {
-    // TU list capacity of one shard: blocks of 256 partitions go round-robin to the shards; a block (one 64x64 luma
-    // area) holds at most 256+128 4x4, 64+32 8x8, 16+8 16x16 and 4 32x32 TUs
-    const size_t blocks = ((size_t)c->num_ctus * c->parts + 255) / 256;
+    // TU list capacity of one shard: prep blocks (256 threads x 4 partitions = 1024 partitions) go round-robin to the
+    // shards; 256 partitions (one 64x64 luma area) hold at most 256+128 4x4, 64+32 8x8, 16+8 16x16 and 4 32x32 TUs
+    const size_t blocks = ((size_t)c->num_ctus * (c->parts / 4) + 255) / 256;
     const size_t per_shard = (blocks + kTuShards - 1) / kTuShards;
-    const uint32_t per_block[4] = {384, 96, 24, 4};
+    const uint32_t per_block[4] = {4 * 384, 4 * 96, 4 * 24, 4 * 4};
     for (int k = 0; k < 4; k++) c->tu_cap[k] = (uint32_t)(per_shard * per_block[k]);
   }
   c->pics.resize(seq->max_pictures);
@@ -644,6 +644,31 @@ hmgpu_status hmgpu_get_stats(hmgpu_ctx* c, hmgpu_stats* out, int32_t reset) {
     if (reset) HIP_TRY(c, hipMemset(p.dev.stats, 0, sizeof(st)));
   }
   if (reset) for (int k = 0; k < HMGPU_NUM_KERNELS; k++) { c->kernel_ms[k] = 0; c->kernel_launches[k] = 0; }
+  return HMGPU_OK;
+}
+
+// diagnostic (not part of the product surface): per-wave phase times of the luma MC kernel for picture `cur`, in shader
+// cycles: out[0] = entry -> BlkInfo arrived, out[1] = BlkInfo -> tile stored, out[2] = waves measured, out[3] = span of the launch
+hmgpu_status hmgpu_debug_mc_stamps(hmgpu_ctx* c, hmgpu_pic cur, double* out) {
+  if (!c || !valid_pic(c, cur) || !out || c->pics[cur].calls.empty()) return HMGPU_EINVAL;
+  Batch b; memset(&b, 0, sizeof(b));
+  b.n = 1; b.pic[0] = cur; b.first_ctu[0] = 0; b.num_ctus[0] = c->num_ctus;
+  const int nw = launch_mc_luma_stamped(c->d_pics, c->d_finals, b, c->num_ctus, c->seq.log2_ctu_size, nullptr, c->stream);
+  unsigned long long* d = nullptr;
+  HIP_TRY(c, hipMalloc((void**)&d, (size_t)nw * 24));
+  HIP_TRY(c, hipMemset(d, 0, (size_t)nw * 24));
+  launch_mc_luma_stamped(c->d_pics, c->d_finals, b, c->num_ctus, c->seq.log2_ctu_size, d, c->stream);
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  std::vector<unsigned long long> h((size_t)nw * 3);
+  HIP_TRY(c, hipMemcpy(h.data(), d, h.size() * 8, hipMemcpyDeviceToHost));
+  hipFree(d);
+  double s0 = 0, s1 = 0, n = 0; unsigned long long lo = ~0ull, hi = 0;
+  for (int w = 0; w < nw; w++) {
+    if (!h[w * 3 + 2]) continue;
+    s0 += (double)(h[w * 3 + 1] - h[w * 3]); s1 += (double)(h[w * 3 + 2] - h[w * 3 + 1]); n += 1;
+    lo = std::min(lo, h[w * 3]); hi = std::max(hi, h[w * 3 + 2]);
+  }
+  out[0] = n ? s0 / n : 0; out[1] = n ? s1 / n : 0; out[2] = n; out[3] = n ? (double)(hi - lo) : 0;
   return HMGPU_OK;
 }
 

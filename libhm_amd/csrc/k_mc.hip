@@ -68,13 +68,23 @@ __device__ inline void predict14(const int16_t* __restrict__ ref, int pitch, int
     for (int x = 0; x < W; x++) out[y][x] = 0;
   const int sh_odd = (xs & 1) * 16;
   const int16_t* base = ref + (ptrdiff_t)ys * pitch + (xs & ~1);
-  int prev[W];
+  // every row of the window is requested before any arithmetic starts: one memory latency per tile instead of one per
+  // row (left to itself the compiler issues each row's loads ~100 instructions before their use and then waits for them).
+  // Loads return in order, so the counted waits let row r be filtered while rows r+1.. are still in flight.
+  uint32_t raw[ROWS][ND];
 #pragma unroll
   for (int r = 0; r < ROWS; r++) {
     const uint32_t* q = reinterpret_cast<const uint32_t*>(base + (ptrdiff_t)r * pitch);
+#pragma unroll
+    for (int i = 0; i < ND; i++) raw[r][i] = ldg(q + i);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  int prev[W];
+#pragma unroll
+  for (int r = 0; r < ROWS; r++) {
     uint32_t a[ND + 1];
 #pragma unroll
-    for (int i = 0; i < ND; i++) a[i] = ldg(q + i);
+    for (int i = 0; i < ND; i++) a[i] = raw[r][i];
     a[ND] = 0;
     // a[j] = (s[2j], s[2j+1]) relative to xs: drop one sample when the start is odd
 #pragma unroll
@@ -96,7 +106,7 @@ __device__ inline void predict14(const int16_t* __restrict__ ref, int pitch, int
       // pair (row r-1, row r) feeds output rows y with r-1-y in {0, 2, .., TAPS-2}
 #pragma unroll
       for (int x = 0; x < W; x++) {
-        const uint32_t pv = ((uint32_t)prev[x] & 0xffffu) | ((uint32_t)t[x] << 16);
+        const uint32_t pv = __builtin_amdgcn_perm((uint32_t)t[x], (uint32_t)prev[x], 0x05040100u);   // (prev.lo16, t.lo16)
 #pragma unroll
         for (int k = 0; k < HT; k++) {
           const int y = r - 1 - 2 * k;
@@ -107,14 +117,12 @@ __device__ inline void predict14(const int16_t* __restrict__ ref, int pitch, int
 #pragma unroll
     for (int x = 0; x < W; x++) prev[x] = t[x];
   }
-#pragma unroll
-  for (int y = 0; y < H; y++)
-#pragma unroll
-    for (int x = 0; x < W; x++) out[y][x] >>= 6;          // filter<N,true,false,false>
+  // out[][] still carries the 6 fractional bits of the vertical pass: HM's value is out >> 6 (filter<N,true,false,false>)
 }
 
-// uni-prediction final rounding of a 14-bit intermediate: clip((v + 8192 + 2^(head-1)) >> head)   [= HM filter isLast]
-__device__ inline int finish_uni(int v, int head, int maxv) { return clip3(0, maxv, (v + 8192 + (1 << (head - 1))) >> head); }
+// uni-prediction final rounding, v6 = vertical sum with its 6 fractional bits: HM computes ((v6 >> 6) + 8192 + 2^(head-1)) >> head
+// [filter isLast]; the constants are multiples of 64, so both shifts merge exactly into one
+__device__ inline int finish_uni(int v6, int head, int maxv) { return clip3(0, maxv, (v6 + (8192 << 6) + (32 << head)) >> (6 + head)); }
 // TComYuv::addAvg: clip((a + b + 2^head + 2*8192) >> (head+1))
 __device__ inline int finish_bi(int a, int b, int head, int maxv) { return clip3(0, maxv, (a + b + (1 << head) + 16384) >> (head + 1)); }
 
@@ -139,8 +147,8 @@ __device__ inline void predict_tile(const PicDev& P, const PlaneSet* __restrict_
 #pragma unroll
       for (int x = 0; x < W; x += 2) {
         // bi: park the 14-bit intermediates (they fit 16 bits) while the second list is computed
-        const int v0 = both ? a[y][x] : finish_uni(a[y][x], head, maxv), v1 = both ? a[y][x + 1] : finish_uni(a[y][x + 1], head, maxv);
-        res[y][x / 2] = ((uint32_t)v0 & 0xffffu) | ((uint32_t)v1 << 16);
+        const int v0 = both ? (a[y][x] >> 6) : finish_uni(a[y][x], head, maxv), v1 = both ? (a[y][x + 1] >> 6) : finish_uni(a[y][x + 1], head, maxv);
+        res[y][x / 2] = __builtin_amdgcn_perm((uint32_t)v1, (uint32_t)v0, 0x05040100u);
       }
   }
   if (both) {
@@ -153,8 +161,8 @@ __device__ inline void predict_tile(const PicDev& P, const PlaneSet* __restrict_
 #pragma unroll
       for (int x = 0; x < W; x += 2) {
         const int a0 = (int)(int16_t)(res[y][x / 2] & 0xffffu), a1 = (int)(int16_t)(res[y][x / 2] >> 16);
-        const int v0 = finish_bi(a0, b[y][x], head, maxv), v1 = finish_bi(a1, b[y][x + 1], head, maxv);
-        res[y][x / 2] = (uint32_t)v0 | ((uint32_t)v1 << 16);
+        const int v0 = finish_bi(a0, b[y][x] >> 6, head, maxv), v1 = finish_bi(a1, b[y][x + 1] >> 6, head, maxv);
+        res[y][x / 2] = __builtin_amdgcn_perm((uint32_t)v1, (uint32_t)v0, 0x05040100u);
       }
   }
 #pragma unroll
@@ -203,16 +211,31 @@ __device__ inline bool tile_origin(const PicDev& P, const Batch& b, int slot, in
   return x0 < cx + ctu_sz && y0 < cy + ctu_sz && x0 < P.width && y0 < P.height;
 }
 
-__global__ void __launch_bounds__(256) k_mc_luma(const PicDev* __restrict__ pics, const PlaneSet* __restrict__ finals, Batch b, int nblocks) {
+// STAMP: diagnostic build only (hmgpu_debug_mc_stamps): lane 0 of every wave records s_memtime at entry, after the
+// BlkInfo records arrived, and at exit, into a buffer nothing else reads.
+template <bool STAMP>
+__global__ void __launch_bounds__(256) k_mc_luma(const PicDev* __restrict__ pics, const PlaneSet* __restrict__ finals, Batch b, int nblocks,
+                                                 unsigned long long* __restrict__ stamps) {
+  unsigned long long t0 = 0, t1 = 0;
+  if (STAMP) t0 = __builtin_amdgcn_s_memtime();
   int slot, lb, x0, y0;
   if (!xcd_remap(blockIdx.x, b.n, nblocks, slot, lb)) return;
   const PicDev& P = pics[b.pic[slot]];
   if (!tile_origin(P, b, slot, lb, x0, y0)) return;
   const BlkInfo* g = P.blk + (size_t)(y0 >> 2) * P.grid_w + (x0 >> 2);
   const BlkInfo c00 = ld_blk(g), c01 = ld_blk(g + 1), c10 = ld_blk(g + P.grid_w), c11 = ld_blk(g + P.grid_w + 1);
+  if (STAMP) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); t1 = __builtin_amdgcn_s_memtime(); }
   if (is_inter(c00) && same_motion(c00, c01) && same_motion(c00, c10) && same_motion(c00, c11)) {
     const int cs = 1 << c00.log2cu;
     predict_tile<8, 8, 8>(P, finals, 0, x0, y0, c00, x0 & ~(cs - 1), y0 & ~(cs - 1), P.rec[0]);
+    if (STAMP) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const unsigned long long t2 = __builtin_amdgcn_s_memtime();
+      if ((threadIdx.x & 63) == 0) {
+        const size_t w = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+        stamps[w * 3] = t0; stamps[w * 3 + 1] = t1; stamps[w * 3 + 2] = t2;
+      }
+    }
   } else {
     if (is_inter(c00)) luma_cell(P, finals, c00, x0, y0);
     if (is_inter(c01)) luma_cell(P, finals, c01, x0 + 4, y0);
@@ -248,7 +271,13 @@ static int mc_blocks(int max_ctus, int log2ctu) {
 }
 void launch_mc_luma(const PicDev* pics, const PlaneSet* finals, const Batch& b, int max_ctus, int log2ctu, hipStream_t s) {
   const int nb = mc_blocks(max_ctus, log2ctu);
-  hipLaunchKernelGGL(k_mc_luma, dim3((unsigned)xcd_grid(b.n, nb)), dim3(256), 0, s, pics, finals, b, nb);
+  hipLaunchKernelGGL(k_mc_luma<false>, dim3((unsigned)xcd_grid(b.n, nb)), dim3(256), 0, s, pics, finals, b, nb, (unsigned long long*)nullptr);
+}
+int launch_mc_luma_stamped(const PicDev* pics, const PlaneSet* finals, const Batch& b, int max_ctus, int log2ctu, unsigned long long* stamps, hipStream_t s) {
+  const int nb = mc_blocks(max_ctus, log2ctu);
+  const int grid = xcd_grid(b.n, nb);
+  if (stamps) hipLaunchKernelGGL(k_mc_luma<true>, dim3((unsigned)grid), dim3(256), 0, s, pics, finals, b, nb, stamps);
+  return grid * 4;
 }
 void launch_mc_chroma(const PicDev* pics, const PlaneSet* finals, const Batch& b, int max_ctus, int log2ctu, hipStream_t s) {
   const int nb = mc_blocks(max_ctus, log2ctu);
@@ -273,7 +302,7 @@ __global__ void k_mc_flat(int bit_depth, const int16_t* __restrict__ ref, int re
     int a[T][T];
     predict14<TAPS, T, T>(ref, ref_stride, x0 + px, y0 + py, mvx, mvy, bit_depth, a);
     for (int y = 0; y < T; y++)
-      for (int x = 0; x < T; x++) out[(py + y) * w + px + x] = (int16_t)(bi ? a[y][x] : finish_uni(a[y][x], head, maxv));
+      for (int x = 0; x < T; x++) out[(py + y) * w + px + x] = (int16_t)(bi ? (a[y][x] >> 6) : finish_uni(a[y][x], head, maxv));
   }
   // remainder columns / rows in 2x2 patches
   const int rw = w / 2, rh = h / 2;
@@ -283,7 +312,7 @@ __global__ void k_mc_flat(int bit_depth, const int16_t* __restrict__ ref, int re
     int a[2][2];
     predict14<TAPS, 2, 2>(ref, ref_stride, x0 + px, y0 + py, mvx, mvy, bit_depth, a);
     for (int y = 0; y < 2; y++)
-      for (int x = 0; x < 2; x++) out[(py + y) * w + px + x] = (int16_t)(bi ? a[y][x] : finish_uni(a[y][x], head, maxv));
+      for (int x = 0; x < 2; x++) out[(py + y) * w + px + x] = (int16_t)(bi ? (a[y][x] >> 6) : finish_uni(a[y][x], head, maxv));
   }
 }
 

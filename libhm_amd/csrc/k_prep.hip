@@ -31,172 +31,29 @@ __device__ inline void qp_param(int qp_y, int comp, int bd, int chroma_off, int8
   rem = (int8_t)(base % 6);
 }
 
-// A thread stages at most three TU records (Y, Cb, Cr); the block then reserves one contiguous range per size class
-// in its shard of the picture's TU lists with ONE global atomic per class (atomics on a single word cost ~11 ns each on
-// MI355X: per-thread or per-wave appends would serialise the whole kernel) and writes the records there.
-struct TuStage { TuRec r[3]; int cls[3]; int loc[3]; int n; };
+// One thread handles the four partitions of one 8x8 luma area (z = 4q .. 4q+3: consecutive in HM's z-scan), so every
+// byte array is read as one dword per thread and both MV fields as one 16-byte vector.  8x8 is the minimum CU size,
+// hence depth, part_size, pred_mode, qp and tr_idx are shared by the four partitions; cbf, transform-skip and motion are
+// per partition.  Each thread can emit up to six TU records in fixed slots (four 4x4 luma TUs or one larger luma TU,
+// Cb, Cr).  The block reserves one contiguous range per size class in its shard of the picture's TU lists with ONE
+// global atomic per class (atomics on a single word cost ~11 ns each on MI355X: per-thread or per-wave appends would
+// serialise the kernel); positions inside the range come from LDS atomics.
+struct Quad {
+  int ctu, z0, gx0, gy0;           // CTU address, z index of partition 0, picture coordinates (partition units) of partition 0
+  int log2cu, log2tu, tr, part_size, qp_cu, sidx;
+  bool valid, intra;
+  uint32_t cbf[3], ts[3];          // four bytes each, partition j in byte j
+};
 
-__device__ inline void stage_tu(const PicDev& P, TuStage& st, uint32_t* lds_cnt, int log2size, int x4, int y4, int comp,
-                                int flags, int qp_y, const SliceDev* sl, uint32_t coef_off) {
+__device__ inline TuRec make_tu(const PicDev& P, const Quad& q, const SliceDev* sl, int gx, int gy, int comp, int flags, uint32_t coef_off) {
   TuRec r;
-  r.x4 = (uint16_t)x4; r.y4 = (uint16_t)y4;
+  r.x4 = (uint16_t)gx; r.y4 = (uint16_t)gy;
   r.comp_flags = (uint8_t)(comp | (flags << 2));
   const int coff = comp == 1 ? ldg(&sl->cb_qp_offset) : (comp == 2 ? ldg(&sl->cr_qp_offset) : 0);
-  qp_param(qp_y, comp, P.bd[comp], coff, r.per, r.rem);
+  qp_param(q.qp_cu, comp, P.bd[comp], coff, r.per, r.rem);
   r.pad = 0;
   r.coef_off = coef_off;
-  const int k = st.n++;
-  st.r[k] = r;
-  st.cls[k] = log2size - 2;
-  st.loc[k] = (int)atomicAdd(&lds_cnt[log2size - 2], 1u);      // LDS atomic: position inside the block's range
-}
-
-// one partition: BlkInfo + staged TU records + counts of intra/inter partitions
-__device__ inline void prep_partition(const PicDev& P, const Batch& b, int gpart, TuStage& st, uint32_t* lds_cnt, uint32_t* lds_stat) {
-  const int parts = P.parts;
-  const int ctu = b.first_ctu[blockIdx.z] + gpart / parts;
-  const int z = gpart % parts;
-  const size_t idx = (size_t)ctu * parts + z;
-  const int cx = ctu % P.ctus_w, cy = ctu / P.ctus_w;
-  const int x4 = zscan_x(z), y4 = zscan_y(z);              // inside the CTU, partition units
-  const int gx = cx * P.pw + x4, gy = cy * P.pw + y4;      // picture, partition units
-  const int px = gx * 4, py = gy * 4;
-
-  BlkInfo bi;
-  bi.mv[0][0] = bi.mv[0][1] = bi.mv[1][0] = bi.mv[1][1] = 0;
-  bi.ref[0] = bi.ref[1] = -1;
-  bi.qp = 0; bi.flags = 0; bi.edge = 0; bi.log2cu = 3; bi.slice = 0;
-  BlkInfo* out = &P.blk[(size_t)gy * P.grid_w + gx];
-
-  const int part_size = ldg(P.part_size + (idx));
-  if (px >= P.width || py >= P.height || part_size == HMGPU_SIZE_NONE) { stg4(out, __builtin_bit_cast(u32x4, bi)); return; }
-
-  const int sidx = P.slice_idx ? ldg(P.slice_idx + (ctu)) : 0;
-  const SliceDev* sl = P.slices + sidx;
-  const int depth = ldg(P.depth + (idx));
-  const int tr = ldg(P.tr_idx + (idx));
-  const int log2cu = P.log2ctu - depth;
-  const int log2tu = log2cu - tr;
-  const int cu_parts = 1 << (log2cu - 2);                  // CU width in partitions
-  const int tu_parts = log2tu > 2 ? 1 << (log2tu - 2) : 1;
-  const int cux = x4 & ~(cu_parts - 1), cuy = y4 & ~(cu_parts - 1);
-  const int rx = x4 - cux, ry = y4 - cuy;                  // inside the CU
-  const bool intra = ldg(P.pred_mode + (idx)) == HMGPU_MODE_INTRA;
-  const int cbf_y = ldg(P.cbf[0] + (idx));
-
-  bi.flags = BF_VALID | (intra ? BF_INTRA : 0) | (((cbf_y >> tr) & 1) ? BF_CBFY : 0);
-  bi.qp = ldg(P.qp + (idx));
-  bi.log2cu = (uint8_t)log2cu;
-  bi.slice = (uint16_t)sidx;
-
-  // ---- motion ---------------------------------------------------------------------------------------------------
-  if (!intra) {
-    const int r0 = ldg(P.ref_idx[0] + (idx)), r1 = ldg(P.ref_idx[1] + (idx));
-    int use0 = r0 >= 0, use1 = r1 >= 0;
-    if (use0) { bi.mv[0][0] = ldg(P.mv[0] + (idx * 2)); bi.mv[0][1] = ldg(P.mv[0] + (idx * 2 + 1)); bi.ref[0] = ldg(&sl->ref_pic[0][r0]); }
-    if (use1) { bi.mv[1][0] = ldg(P.mv[1] + (idx * 2)); bi.mv[1][1] = ldg(P.mv[1] + (idx * 2 + 1)); bi.ref[1] = ldg(&sl->ref_pic[1][r1]); }
-    // xCheckIdenticalMotion (TComPrediction.cpp:497-512): B slice, both lists, same POC and same MV -> list 0 only
-    if (ldg(&sl->slice_type) == HMGPU_B_SLICE && use0 && use1 && ldg(&sl->ref_poc[0][r0]) == ldg(&sl->ref_poc[1][r1]) &&
-        bi.mv[0][0] == bi.mv[1][0] && bi.mv[0][1] == bi.mv[1][1])
-      use1 = 0;
-    bi.flags |= (use0 ? BF_MC_L0 : 0) | (use1 ? BF_MC_L1 : 0);
-    atomicAdd(&lds_stat[1], 1u);
-  } else {
-    atomicAdd(&lds_stat[0], 1u);
-  }
-
-  // ---- deblocking edge flags (TComLoopFilter.cpp:269-409) ----------------------------------------------------------
-  const int lf_across_slices = ldg(&sl->lf_across_slices);
-  if (!ldg(&sl->deblocking_disable)) {
-    const int tux = x4 & ~(tu_parts - 1), tuy = y4 & ~(tu_parts - 1);
-    // vertical edge at the left border of this partition
-    if ((px & 7) == 0) {
-      bool filt, trans;
-      if (rx == 0) {                     // CU border: m_stLFCUParam.bLeftEdge
-        bool avail = px != 0;
-        if (avail && x4 == 0) {          // crosses into the left CTU: getPULeft slice/tile restrictions
-          const int n = ctu - 1;
-          if (!lf_across_slices && P.slice_idx && ldg(P.slice_idx + (n)) != sidx) avail = false;
-          if (!P.lf_across_tiles && P.tile_idx && ldg(P.tile_idx + (n)) != ldg(P.tile_idx + (ctu))) avail = false;
-        }
-        filt = trans = avail;
-      } else {
-        trans = x4 == tux;               // TU border inside the CU
-        bool pu = false;                 // PU border inside the CU (xSetEdgefilterPU)
-        switch (part_size) {
-          case HMGPU_SIZE_Nx2N: case HMGPU_SIZE_NxN: pu = rx == (cu_parts >> 1); break;
-          case HMGPU_SIZE_nLx2N: pu = rx == (cu_parts >> 2); break;
-          case HMGPU_SIZE_nRx2N: pu = rx == cu_parts - (cu_parts >> 2); break;
-          default: break;
-        }
-        filt = trans || pu;
-      }
-      bi.edge |= (filt ? BE_VER_FILTER : 0) | (trans ? BE_VER_TRANSFORM : 0);
-    }
-    if ((py & 7) == 0) {
-      bool filt, trans;
-      if (ry == 0) {
-        bool avail = py != 0;
-        if (avail && y4 == 0) {
-          const int n = ctu - P.ctus_w;
-          if (!lf_across_slices && P.slice_idx && ldg(P.slice_idx + (n)) != sidx) avail = false;
-          if (!P.lf_across_tiles && P.tile_idx && ldg(P.tile_idx + (n)) != ldg(P.tile_idx + (ctu))) avail = false;
-        }
-        filt = trans = avail;
-      } else {
-        trans = y4 == tuy;
-        bool pu = false;
-        switch (part_size) {
-          case HMGPU_SIZE_2NxN: case HMGPU_SIZE_NxN: pu = ry == (cu_parts >> 1); break;
-          case HMGPU_SIZE_2NxnU: pu = ry == (cu_parts >> 2); break;
-          case HMGPU_SIZE_2NxnD: pu = ry == cu_parts - (cu_parts >> 2); break;
-          default: break;
-        }
-        filt = trans || pu;
-      }
-      bi.edge |= (filt ? BE_HOR_FILTER : 0) | (trans ? BE_HOR_TRANSFORM : 0);
-    }
-  }
-  stg4(out, __builtin_bit_cast(u32x4, bi));
-
-  // ---- transform units -------------------------------------------------------------------------------------------
-  // cbf bit d of a partition = cbf of its ancestor TU node at transform depth d (TComDataCU.h:310); HM descends
-  // only while every node on the way has its bit set (TComTrQuant.cpp:1558-1564)
-  const unsigned chain = (1u << (tr + 1)) - 1;
-  const int qp_cu = ldg(P.qp + ((size_t)ctu * parts + (z & ~(cu_parts * cu_parts - 1))));   // cu.getQP(0): first partition of the CU
-  const int ctu_luma = 1 << (2 * P.log2ctu);
-  if (log2tu > 5) return;                                   // not a legal HEVC TU size; nothing to transform
-  if (intra) return;                                        // intra CUs are not reconstructed on the device yet: their
-                                                            // residual must not be added to samples the caller supplied
-  if (log2tu > 2) {
-    if (x4 == (x4 & ~(tu_parts - 1)) && y4 == (y4 & ~(tu_parts - 1))) {
-      if ((cbf_y & chain) == chain) {
-        const int ts = P.tskip[0] ? ldg(P.tskip[0] + (idx)) : 0;
-        stage_tu(P, st, lds_cnt, log2tu, gx, gy, 0, (ts ? 2 : 0), qp_cu, sl, (uint32_t)ctu * ctu_luma + 16u * z);
-      }
-      for (int comp = 1; comp < 3; comp++) {
-        if ((ldg(P.cbf[comp] + (idx)) & chain) == chain) {
-          const int ts = P.tskip[comp] ? ldg(P.tskip[comp] + (idx)) : 0;
-          stage_tu(P, st, lds_cnt, log2tu - 1, gx, gy, comp, (ts ? 2 : 0), qp_cu, sl, (uint32_t)ctu * (ctu_luma >> 2) + 4u * z);
-        }
-      }
-    }
-  } else {
-    // 4x4 luma TU: every partition is an origin
-    if ((cbf_y & chain) == chain) {
-      const int ts = P.tskip[0] ? ldg(P.tskip[0] + (idx)) : 0;
-      stage_tu(P, st, lds_cnt, 2, gx, gy, 0, (intra ? 1 : 0) | (ts ? 2 : 0), qp_cu, sl, (uint32_t)ctu * ctu_luma + 16u * z);
-    }
-    // the one 4x4 chroma TU of the parent 8x8 node rides with the first child (z multiple of 4)
-    if ((z & 3) == 0) {
-      for (int comp = 1; comp < 3; comp++) {
-        if ((ldg(P.cbf[comp] + (idx)) & chain) == chain) {
-          const int ts = P.tskip[comp] ? ldg(P.tskip[comp] + (idx)) : 0;
-          stage_tu(P, st, lds_cnt, 2, gx, gy, comp, (ts ? 2 : 0), qp_cu, sl, (uint32_t)ctu * (ctu_luma >> 2) + 4u * z);
-        }
-      }
-    }
-  }
+  return r;
 }
 
 __global__ void __launch_bounds__(256) k_prep(const PicDev* __restrict__ pics, Batch b) {
@@ -205,9 +62,154 @@ __global__ void __launch_bounds__(256) k_prep(const PicDev* __restrict__ pics, B
   if (threadIdx.x < 4) lds_cnt[threadIdx.x] = 0;
   if (threadIdx.x < 2) lds_stat[threadIdx.x] = 0;
   __syncthreads();
-  TuStage st; st.n = 0;
-  const int gpart = blockIdx.x * 256 + threadIdx.x;
-  if (gpart < b.num_ctus[blockIdx.z] * P.parts) prep_partition(P, b, gpart, st, lds_cnt, lds_stat);
+  const int parts = P.parts;
+  const int gq = blockIdx.x * 256 + threadIdx.x;                 // quad index inside the call's CTU range
+  const bool active = gq < b.num_ctus[blockIdx.z] * (parts >> 2);
+  Quad q; q.valid = false; q.intra = false; q.log2tu = 3; q.tr = 0; q.ctu = 0; q.z0 = 0; q.gx0 = q.gy0 = 0;
+  q.log2cu = 3; q.part_size = 0; q.qp_cu = 0; q.sidx = 0;
+  bool has[6] = {false, false, false, false, false, false};      // slots: luma TU of partition 0..3 (or one larger TU in slot 0), Cb, Cr
+  int cls[6] = {0, 0, 0, 0, 0, 0};
+  uint32_t loc[6] = {0, 0, 0, 0, 0, 0};
+  const SliceDev* sl = P.slices;
+  if (active) {
+    q.ctu = b.first_ctu[blockIdx.z] + gq / (parts >> 2);
+    q.z0 = (gq % (parts >> 2)) * 4;
+    const size_t idx = (size_t)q.ctu * parts + q.z0;
+    const int cx = q.ctu % P.ctus_w, cy = q.ctu / P.ctus_w;
+    const int x4 = zscan_x(q.z0), y4 = zscan_y(q.z0);            // partition 0 inside the CTU; partitions 1..3 are (+1,0),(0,+1),(+1,+1)
+    q.gx0 = cx * P.pw + x4; q.gy0 = cy * P.pw + y4;
+    // ---- the quad's share of HM's arrays
+    const uint32_t part4 = ldg(reinterpret_cast<const uint32_t*>(P.part_size + idx));
+    const uint32_t depth4 = ldg(reinterpret_cast<const uint32_t*>(P.depth + idx));
+    const uint32_t pred4 = ldg(reinterpret_cast<const uint32_t*>(P.pred_mode + idx));
+    const uint32_t qp4 = ldg(reinterpret_cast<const uint32_t*>(P.qp + idx));
+    const uint32_t tr4 = ldg(reinterpret_cast<const uint32_t*>(P.tr_idx + idx));
+    const uint32_t r04 = ldg(reinterpret_cast<const uint32_t*>(P.ref_idx[0] + idx)), r14 = ldg(reinterpret_cast<const uint32_t*>(P.ref_idx[1] + idx));
+    const u32x4 mv0 = ldg4(P.mv[0] + idx * 2), mv1 = ldg4(P.mv[1] + idx * 2);
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+      q.cbf[c] = ldg(reinterpret_cast<const uint32_t*>(P.cbf[c] + idx));
+      q.ts[c] = P.tskip[c] ? ldg(reinterpret_cast<const uint32_t*>(P.tskip[c] + idx)) : 0u;
+    }
+    q.sidx = P.slice_idx ? ldg(P.slice_idx + q.ctu) : 0;
+    sl = P.slices + q.sidx;
+    q.part_size = (int)(int8_t)(part4 & 0xff);
+    const int px0 = q.gx0 * 4, py0 = q.gy0 * 4;
+    q.valid = px0 < P.width && py0 < P.height && q.part_size != HMGPU_SIZE_NONE;   // width/height are multiples of 8
+    const int depth = depth4 & 0xff;
+    q.tr = tr4 & 0xff;
+    q.log2cu = P.log2ctu - depth;
+    q.log2tu = q.log2cu - q.tr;
+    q.intra = (pred4 & 0xff) == HMGPU_MODE_INTRA;
+    const int cu_parts = 1 << (q.log2cu - 2);
+    q.qp_cu = (int)ldg(P.qp + (size_t)q.ctu * parts + (q.z0 & ~(cu_parts * cu_parts - 1)));   // cu.getQP(0): first partition of the CU
+    const int tu_parts = q.log2tu > 2 ? 1 << (q.log2tu - 2) : 1;
+    const bool deblock = q.valid && !ldg(&sl->deblocking_disable);
+    const int lf_across_slices = ldg(&sl->lf_across_slices);
+    const int slice_type = ldg(&sl->slice_type);
+    const uint32_t mvw0[4] = {mv0.x, mv0.y, mv0.z, mv0.w}, mvw1[4] = {mv1.x, mv1.y, mv1.z, mv1.w};
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const int xj = x4 + (j & 1), yj = y4 + (j >> 1);
+      const int gx = q.gx0 + (j & 1), gy = q.gy0 + (j >> 1);
+      BlkInfo bi;
+      bi.mv[0][0] = bi.mv[0][1] = bi.mv[1][0] = bi.mv[1][1] = 0;
+      bi.ref[0] = bi.ref[1] = -1;
+      bi.qp = 0; bi.flags = 0; bi.edge = 0; bi.log2cu = 3; bi.slice = 0;
+      if (q.valid) {
+        const int cbf_y = (q.cbf[0] >> (8 * j)) & 0xff;
+        bi.flags = BF_VALID | (q.intra ? BF_INTRA : 0) | (((cbf_y >> q.tr) & 1) ? BF_CBFY : 0);
+        bi.qp = (int8_t)((qp4 >> (8 * j)) & 0xff);
+        bi.log2cu = (uint8_t)q.log2cu;
+        bi.slice = (uint16_t)q.sidx;
+        if (!q.intra) {
+          const int r0 = (int)(int8_t)((r04 >> (8 * j)) & 0xff), r1 = (int)(int8_t)((r14 >> (8 * j)) & 0xff);
+          int use0 = r0 >= 0, use1 = r1 >= 0;
+          if (use0) { bi.mv[0][0] = (int16_t)(mvw0[j] & 0xffff); bi.mv[0][1] = (int16_t)(mvw0[j] >> 16); bi.ref[0] = ldg(&sl->ref_pic[0][r0]); }
+          if (use1) { bi.mv[1][0] = (int16_t)(mvw1[j] & 0xffff); bi.mv[1][1] = (int16_t)(mvw1[j] >> 16); bi.ref[1] = ldg(&sl->ref_pic[1][r1]); }
+          // xCheckIdenticalMotion (TComPrediction.cpp:497-512): B slice, both lists, same POC and same MV -> list 0 only
+          if (slice_type == HMGPU_B_SLICE && use0 && use1 && ldg(&sl->ref_poc[0][r0]) == ldg(&sl->ref_poc[1][r1]) && mvw0[j] == mvw1[j]) use1 = 0;
+          bi.flags |= (use0 ? BF_MC_L0 : 0) | (use1 ? BF_MC_L1 : 0);
+        }
+        // ---- deblocking edge flags (TComLoopFilter.cpp:269-409); only partitions on the 8x8 grid carry an edge
+        if (deblock) {
+          const int cux = xj & ~(cu_parts - 1), cuy = yj & ~(cu_parts - 1);
+          const int rx = xj - cux, ry = yj - cuy;
+          if ((j & 1) == 0) {                       // vertical edge at the left border (x multiple of 8)
+            bool filt, trans;
+            if (rx == 0) {                          // CU border: m_stLFCUParam.bLeftEdge
+              bool avail = gx != 0;
+              if (avail && xj == 0) {               // crosses into the left CTU: getPULeft slice/tile restrictions
+                const int n = q.ctu - 1;
+                if (!lf_across_slices && P.slice_idx && ldg(P.slice_idx + n) != q.sidx) avail = false;
+                if (!P.lf_across_tiles && P.tile_idx && ldg(P.tile_idx + n) != ldg(P.tile_idx + q.ctu)) avail = false;
+              }
+              filt = trans = avail;
+            } else {
+              trans = xj == (xj & ~(tu_parts - 1));
+              bool pu = false;                      // PU border inside the CU (xSetEdgefilterPU)
+              switch (q.part_size) {
+                case HMGPU_SIZE_Nx2N: case HMGPU_SIZE_NxN: pu = rx == (cu_parts >> 1); break;
+                case HMGPU_SIZE_nLx2N: pu = rx == (cu_parts >> 2); break;
+                case HMGPU_SIZE_nRx2N: pu = rx == cu_parts - (cu_parts >> 2); break;
+                default: break;
+              }
+              filt = trans || pu;
+            }
+            bi.edge |= (filt ? BE_VER_FILTER : 0) | (trans ? BE_VER_TRANSFORM : 0);
+          }
+          if ((j >> 1) == 0) {                      // horizontal edge at the top border (y multiple of 8)
+            bool filt, trans;
+            if (ry == 0) {
+              bool avail = gy != 0;
+              if (avail && yj == 0) {
+                const int n = q.ctu - P.ctus_w;
+                if (!lf_across_slices && P.slice_idx && ldg(P.slice_idx + n) != q.sidx) avail = false;
+                if (!P.lf_across_tiles && P.tile_idx && ldg(P.tile_idx + n) != ldg(P.tile_idx + q.ctu)) avail = false;
+              }
+              filt = trans = avail;
+            } else {
+              trans = yj == (yj & ~(tu_parts - 1));
+              bool pu = false;
+              switch (q.part_size) {
+                case HMGPU_SIZE_2NxN: case HMGPU_SIZE_NxN: pu = ry == (cu_parts >> 1); break;
+                case HMGPU_SIZE_2NxnU: pu = ry == (cu_parts >> 2); break;
+                case HMGPU_SIZE_2NxnD: pu = ry == cu_parts - (cu_parts >> 2); break;
+                default: break;
+              }
+              filt = trans || pu;
+            }
+            bi.edge |= (filt ? BE_HOR_FILTER : 0) | (trans ? BE_HOR_TRANSFORM : 0);
+          }
+        }
+      }
+      stg4(&P.blk[(size_t)gy * P.grid_w + gx], __builtin_bit_cast(u32x4, bi));
+    }
+    if (q.valid) atomicAdd(&lds_stat[q.intra ? 0 : 1], 4u);
+    // ---- which transform units originate in this 8x8 area (intra CUs: not on the device yet)
+    // cbf bit d of a partition = cbf of its ancestor TU node at transform depth d (TComDataCU.h:310); HM descends only
+    // while every node on the way has its bit set (TComTrQuant.cpp:1558-1564)
+    if (q.valid && !q.intra && q.log2tu <= 5) {
+      const uint32_t chain = (1u << (q.tr + 1)) - 1;
+      if (q.log2tu > 2) {
+        // at most one luma TU (and its chroma TUs, half the size) starts here: when partition 0 is aligned to the TU
+        const int tu_parts = 1 << (q.log2tu - 2);
+        if ((x4 & (tu_parts - 1)) == 0 && (y4 & (tu_parts - 1)) == 0) {
+          has[0] = ((q.cbf[0] & 0xff) & chain) == chain; cls[0] = q.log2tu - 2;
+          has[4] = ((q.cbf[1] & 0xff) & chain) == chain; cls[4] = q.log2tu - 3;
+          has[5] = ((q.cbf[2] & 0xff) & chain) == chain; cls[5] = q.log2tu - 3;
+        }
+      } else {
+        // four 4x4 luma TUs; the one 4x4 chroma TU of the 8x8 node rides with the first of them (TComTU.cpp:141-151)
+#pragma unroll
+        for (int j = 0; j < 4; j++) { has[j] = (((q.cbf[0] >> (8 * j)) & 0xff) & chain) == chain; cls[j] = 0; }
+        has[4] = ((q.cbf[1] & 0xff) & chain) == chain; cls[4] = 0;
+        has[5] = ((q.cbf[2] & 0xff) & chain) == chain; cls[5] = 0;
+      }
+#pragma unroll
+      for (int k = 0; k < 6; k++) if (has[k]) loc[k] = atomicAdd(&lds_cnt[cls[k]], 1u);
+    }
+  }
   __syncthreads();
   const int shard = blockIdx.x & (kTuShards - 1);
   if (threadIdx.x < 4) {
@@ -218,12 +220,21 @@ __global__ void __launch_bounds__(256) k_prep(const PicDev* __restrict__ pics, B
     if (n) atomicAdd(&P.stats[(threadIdx.x - 4) * kTuShards + shard], (unsigned long long)n);
   }
   __syncthreads();
-  for (int k = 0; k < st.n; k++) {
-    const int c = st.cls[k];
-    const uint32_t i = lds_base[c] + (uint32_t)st.loc[k];
+  const int ctu_luma = 1 << (2 * P.log2ctu);
+#pragma unroll
+  for (int k = 0; k < 6; k++) {
+    if (!has[k]) continue;
+    const int comp = k < 4 ? 0 : k - 3;
+    const int j = k < 4 ? k : 0;                          // partition the TU starts at
+    const int ts = (q.ts[comp] >> (8 * j)) & 0xff;
+    const int flags = ((comp == 0 && q.log2tu == 2 && q.intra) ? 1 : 0) | (ts ? 2 : 0);
+    const uint32_t off = comp == 0 ? (uint32_t)q.ctu * ctu_luma + 16u * (q.z0 + j) : (uint32_t)q.ctu * (ctu_luma >> 2) + 4u * q.z0;
+    const TuRec r = make_tu(P, q, sl, q.gx0 + (j & 1), q.gy0 + (j >> 1), comp, flags, off);
+    const int c = cls[k];
+    const uint32_t i = lds_base[c] + loc[k];
     if (i < P.tu_cap[c]) {
       uint32_t* dst = reinterpret_cast<uint32_t*>(P.tu[c] + (size_t)shard * P.tu_cap[c] + i);
-      const uint32_t* src = reinterpret_cast<const uint32_t*>(&st.r[k]);
+      const uint32_t* src = reinterpret_cast<const uint32_t*>(&r);
       stg(dst, src[0]); stg(dst + 1, src[1]); stg(dst + 2, src[2]);
     }
   }
@@ -237,7 +248,7 @@ __global__ void k_zero_counts(const PicDev* __restrict__ pics, Batch b) {
 
 void launch_prep(const PicDev* pics, const Batch& b, int max_ctus, int parts, hipStream_t s) {
   hipLaunchKernelGGL(k_zero_counts, dim3((unsigned)b.n), dim3(64), 0, s, pics, b);
-  dim3 grid((unsigned)(((size_t)max_ctus * parts + 255) / 256), 1, (unsigned)b.n);
+  dim3 grid((unsigned)(((size_t)max_ctus * (parts / 4) + 255) / 256), 1, (unsigned)b.n);
   hipLaunchKernelGGL(k_prep, grid, dim3(256), 0, s, pics, b);
 }
 
