@@ -53,8 +53,7 @@ def algorithmic_bytes(p):
             else:
                 cls = max(l2 - 1, 2)
                 per_cls[cls] += n_part * 4
-    for l2 in (2, 3, 4, 5):
-        out["itx%d" % (1 << l2)] = 6 * per_cls[l2]
+    out["itx"] = 6 * sum(per_cls.values())                # all four TU sizes run in one launch
     samples = p.width * p.height * 3 // 2
     out["deblock_ver"] = 2 * samples                       # each pass = half of the 4 B/sample two-pass budget
     out["deblock_hor"] = 2 * samples
@@ -154,7 +153,7 @@ def main():
         kernels = {}
         dom, dom_t = None, -1.0
         for name, (ms, launches) in st["kernels"].items():
-            if launches == 0 or name in ("h2d_stage", "other"):
+            if launches == 0 or name in ("h2d_stage", "other", ""):
                 continue
             avg_ms = ms / launches
             per_launch = sum(bytes_pp[i % 2][name] for i in range(nb))

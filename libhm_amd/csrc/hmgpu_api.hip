@@ -16,9 +16,9 @@ using namespace hmgpu;
 
 namespace {
 
-enum { K_PREP = 0, K_MC_LUMA, K_MC_CHROMA, K_ITX4, K_ITX8, K_ITX16, K_ITX32, K_DBK_VER, K_DBK_HOR, K_SAO, K_H2D, K_EXTEND };
-const char* const kKernelNames[HMGPU_NUM_KERNELS] = {"prep", "mc_luma", "mc_chroma", "itx4", "itx8", "itx16", "itx32",
-                                                     "deblock_ver", "deblock_hor", "sao", "h2d_stage", "extend_border"};
+enum { K_PREP = 0, K_MC_LUMA, K_MC_CHROMA, K_ITX, K_DBK_VER, K_DBK_HOR, K_SAO, K_EXTEND, K_H2D, K_RES9, K_RES10, K_RES11 };
+const char* const kKernelNames[HMGPU_NUM_KERNELS] = {"prep", "mc_luma", "mc_chroma", "itx", "deblock_ver", "deblock_hor", "sao",
+                                                     "extend_border", "h2d_stage", "", "", ""};
 
 struct SliceCall { int first_ctu, num_ctus, slice_idx; };
 
@@ -227,7 +227,7 @@ hmgpu_status run_recon(hmgpu_ctx* c, const Batch& b) {
   { ProfScope ps(c, K_MC_CHROMA); launch_mc_chroma(c->d_pics, c->d_finals, b, max_ctus, c->seq.log2_ctu_size, c->stream); }
   // blocks per shard: enough to keep the chip busy on a full picture, few enough that a short list costs nothing
   const uint32_t bps = (uint32_t)std::max(4, std::min(64, max_ctus / 8 + 1));
-  for (int l2 = 2; l2 <= 5; l2++) { ProfScope ps(c, K_ITX4 + (l2 - 2)); launch_itx(c->d_pics, b, l2, bps, c->stream); }
+  { ProfScope ps(c, K_ITX); launch_itx(c->d_pics, b, 0, bps, c->stream); }
   HIP_TRY(c, hipGetLastError());
   return HMGPU_OK;
 }

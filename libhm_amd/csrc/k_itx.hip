@@ -68,12 +68,27 @@ template <int LOG2N> struct ItxCfg {
   static constexpr int TPB = 256 / N;                     // TUs per 256-thread block
 };
 
-// Both stages for the TU of this N-lane group.  lev: the TU's N*N levels (row-major).  tile: the group's LDS tile.
-// Returns row `n` of the residual in res[].  flags: bit0 DST, bit1 transform skip.
+// Both stages for the TU of this N-lane group.  lev: the TU's N*N levels (row-major, contiguous).  tile: the group's
+// 32-bit LDS tile for the intermediates, ctile: its 16-bit tile for the levels.  Returns row `n` of the residual in res[].
+// flags: bit0 DST, bit1 transform skip.
 template <int LOG2N>
 __device__ inline void itx_tu(const int16_t* __restrict__ lev, bool active, int n, int per, int rem, int flags, int bd,
-                              int* __restrict__ tile, int (&res)[1 << LOG2N]) {
+                              int* __restrict__ tile, int16_t* __restrict__ ctile, int (&res)[1 << LOG2N]) {
   constexpr int N = 1 << LOG2N, S = ItxCfg<LOG2N>::STRIDE;
+  // ---- the level block comes in with 16-byte loads (lane n fetches row n) and is re-read by columns from LDS
+  if constexpr (N == 4) {
+    u32x2 v = {0u, 0u};
+    if (active) v = ldg2(lev + n * 4);
+    *reinterpret_cast<u32x2*>(ctile + n * 4) = v;
+  } else {
+#pragma unroll
+    for (int i = 0; i < N / 8; i++) {
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (active) v = ldg4(lev + n * N + i * 8);
+      *reinterpret_cast<u32x4*>(ctile + n * N + i * 8) = v;
+    }
+  }
+  __syncthreads();
   // ---- xDeQuant, flat scaling (TComTrQuant.cpp:1276-1311) on column n
   const int tshift = 15 - bd - LOG2N;                     // getTransformShift
   const int rshift = 6 - (tshift + per);                  // IQUANT_SHIFT - (transformShift + per)
@@ -81,7 +96,7 @@ __device__ inline void itx_tu(const int16_t* __restrict__ lev, bool active, int 
   int c[N];
 #pragma unroll
   for (int m = 0; m < N; m++) {
-    const int q = active ? (int)ldg(lev + m * N + n) : 0;
+    const int q = (int)ctile[m * N + n];
     int v;
     if (rshift > 0) v = (__mul24(q, scale) + (1 << (rshift - 1))) >> rshift;
     else v = (int)((unsigned)__mul24(q, scale) << (-rshift));
@@ -124,17 +139,27 @@ __device__ inline void itx_tu(const int16_t* __restrict__ lev, bool active, int 
   }
 }
 
+template <int LOG2N> struct ItxLds {
+  static constexpr int N = 1 << LOG2N;
+  static constexpr int TILE = ItxCfg<LOG2N>::TPB * N * ItxCfg<LOG2N>::STRIDE;      // ints
+  static constexpr int CTILE = ItxCfg<LOG2N>::TPB * N * N;                         // int16
+  static constexpr int BYTES = TILE * 4 + CTILE * 2;
+};
+constexpr int kItxLdsBytes = ItxLds<5>::BYTES > ItxLds<4>::BYTES ? ItxLds<5>::BYTES : ItxLds<4>::BYTES;
+
+// all coded TUs of one size class and shard; blocks stride over a list whose length only the device knows
 template <int LOG2N>
-__global__ void __launch_bounds__(256) k_itx(const PicDev* __restrict__ pics, Batch b) {
+__device__ inline void itx_class(const PicDev& P, int shard, int bx, int nbx, char* __restrict__ lds_raw) {
   constexpr int N = 1 << LOG2N, S = ItxCfg<LOG2N>::STRIDE, TPB = ItxCfg<LOG2N>::TPB;
-  __shared__ __attribute__((aligned(16))) int lds[TPB * N * S];
-  const PicDev& P = pics[b.pic[blockIdx.z]];
-  const int cls = LOG2N - 2, shard = blockIdx.y;
+  int* lds = reinterpret_cast<int*>(lds_raw);
+  int16_t* clds = reinterpret_cast<int16_t*>(lds_raw + ItxLds<LOG2N>::TILE * 4);
+  const int cls = LOG2N - 2;
   const uint32_t count = min(ldg(P.tu_count + cls * kTuShards + shard), P.tu_cap[cls]);
   const TuRec* __restrict__ list = P.tu[cls] + (size_t)shard * P.tu_cap[cls];
   const int j = threadIdx.x / N, n = threadIdx.x % N;
   int* tile = lds + j * N * S;
-  for (uint32_t base = blockIdx.x * TPB; base < count; base += gridDim.x * TPB) {
+  int16_t* ctile = clds + j * N * N;
+  for (uint32_t base = bx * TPB; base < count; base += nbx * TPB) {
     const uint32_t t = base + j;
     const bool active = t < count;
     TuRec rec; rec.x4 = rec.y4 = 0; rec.comp_flags = 0; rec.per = 0; rec.rem = 0; rec.coef_off = 0;
@@ -147,48 +172,53 @@ __global__ void __launch_bounds__(256) k_itx(const PicDev* __restrict__ pics, Ba
     }
     const int comp = rec.comp_flags & 3, flags = rec.comp_flags >> 2;
     const int bd = P.bd[comp];
+    const int cs = comp ? 1 : 0;
+    int16_t* row = P.rec[comp] + (size_t)(((int)rec.y4 * 4 >> cs) + n) * P.pitch[comp] + ((int)rec.x4 * 4 >> cs);
+    // the prediction row is requested before the transform starts: its latency hides behind the arithmetic
+    uint32_t pw[N / 2];
+    if (active) {
+      if constexpr (N == 4) { const u32x2 v = ldg2(row); pw[0] = v.x; pw[1] = v.y; }
+      else {
+#pragma unroll
+        for (int seg = 0; seg < N / 8; seg++) { const u32x4 v = ldg4(row + seg * 8); pw[seg * 4] = v.x; pw[seg * 4 + 1] = v.y; pw[seg * 4 + 2] = v.z; pw[seg * 4 + 3] = v.w; }
+      }
+    }
     int res[N];
-    itx_tu<LOG2N>(P.coef[comp] + rec.coef_off, active, n, rec.per, rec.rem, flags, bd, tile, res);
+    itx_tu<LOG2N>(P.coef[comp] + rec.coef_off, active, n, rec.per, rec.rem, flags, bd, tile, ctile, res);
     if (!active) continue;
     // recon row n: ClipBD(pred + resid) in place
-    const int cs = comp ? 1 : 0;
     const int maxv = (1 << bd) - 1;
-    int16_t* row = P.rec[comp] + (size_t)(((int)rec.y4 * 4 >> cs) + n) * P.pitch[comp] + ((int)rec.x4 * 4 >> cs);
-    if constexpr (N == 4) {
-      const u32x2 v = ldg2(row);
-      uint32_t w[2] = {v.x, v.y};
 #pragma unroll
-      for (int i = 0; i < 2; i++) {
-        const int a = clip3(0, maxv, (int)(w[i] & 0xffff) + res[2 * i]), c = clip3(0, maxv, (int)(w[i] >> 16) + res[2 * i + 1]);
-        w[i] = (uint32_t)a | ((uint32_t)c << 16);
-      }
-      { u32x2 o = {w[0], w[1]}; stg2(row, o); }
-    } else {
+    for (int i = 0; i < N / 2; i++) {
+      const int a = clip3(0, maxv, (int)(pw[i] & 0xffff) + res[2 * i]), c = clip3(0, maxv, (int)(pw[i] >> 16) + res[2 * i + 1]);
+      pw[i] = (uint32_t)a | ((uint32_t)c << 16);
+    }
+    if constexpr (N == 4) { u32x2 o = {pw[0], pw[1]}; stg2(row, o); }
+    else {
 #pragma unroll
-      for (int seg = 0; seg < N / 8; seg++) {
-        const u32x4 v = ldg4(row + seg * 8);
-        uint32_t w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-          const int a = clip3(0, maxv, (int)(w[i] & 0xffff) + res[seg * 8 + 2 * i]);
-          const int c = clip3(0, maxv, (int)(w[i] >> 16) + res[seg * 8 + 2 * i + 1]);
-          w[i] = (uint32_t)a | ((uint32_t)c << 16);
-        }
-        { u32x4 o = {w[0], w[1], w[2], w[3]}; stg4(row + seg * 8, o); }
-      }
+      for (int seg = 0; seg < N / 8; seg++) { u32x4 o = {pw[seg * 4], pw[seg * 4 + 1], pw[seg * 4 + 2], pw[seg * 4 + 3]}; stg4(row + seg * 8, o); }
     }
   }
 }
 
-void launch_itx(const PicDev* pics, const Batch& b, int log2size, uint32_t blocks_per_shard, hipStream_t s) {
-  dim3 grid(blocks_per_shard, kTuShards, (unsigned)b.n);
-  switch (log2size) {
-    case 2: hipLaunchKernelGGL(k_itx<2>, grid, dim3(256), 0, s, pics, b); break;
-    case 3: hipLaunchKernelGGL(k_itx<3>, grid, dim3(256), 0, s, pics, b); break;
-    case 4: hipLaunchKernelGGL(k_itx<4>, grid, dim3(256), 0, s, pics, b); break;
-    case 5: hipLaunchKernelGGL(k_itx<5>, grid, dim3(256), 0, s, pics, b); break;
-    default: break;
+// one launch for all four size classes: blockIdx.y = class * kTuShards + shard, so short lists of one class share the
+// chip with the long lists of another instead of each class paying its own latency-bound launch
+__global__ void __launch_bounds__(256) k_itx(const PicDev* __restrict__ pics, Batch b) {
+  __shared__ __attribute__((aligned(16))) char lds[kItxLdsBytes];
+  const PicDev& P = pics[b.pic[blockIdx.z]];
+  const int cls = blockIdx.y / kTuShards, shard = blockIdx.y % kTuShards;
+  switch (cls) {
+    case 0: itx_class<2>(P, shard, blockIdx.x, gridDim.x, lds); break;
+    case 1: itx_class<3>(P, shard, blockIdx.x, gridDim.x, lds); break;
+    case 2: itx_class<4>(P, shard, blockIdx.x, gridDim.x, lds); break;
+    default: itx_class<5>(P, shard, blockIdx.x, gridDim.x, lds); break;
   }
+}
+
+void launch_itx(const PicDev* pics, const Batch& b, int log2size, uint32_t blocks_per_shard, hipStream_t s) {
+  (void)log2size;
+  dim3 grid(blocks_per_shard, 4 * kTuShards, (unsigned)b.n);
+  hipLaunchKernelGGL(k_itx, grid, dim3(256), 0, s, pics, b);
 }
 
 // ---- kernel-level seam: residual of n TUs from flat arrays (tests; hmgpu_inverse_transform_batch) ----------------------
@@ -198,14 +228,16 @@ __global__ void __launch_bounds__(256) k_itx_flat(int bit_depth, int n_tus, cons
                                                   const uint8_t* __restrict__ flags, int16_t* __restrict__ resid) {
   constexpr int N = 1 << LOG2N, S = ItxCfg<LOG2N>::STRIDE, TPB = ItxCfg<LOG2N>::TPB;
   __shared__ __attribute__((aligned(16))) int lds[TPB * N * S];
+  __shared__ __attribute__((aligned(16))) int16_t clds[TPB * N * N];
   const int j = threadIdx.x / N, n = threadIdx.x % N;
   int* tile = lds + j * N * S;
+  int16_t* ctile = clds + j * N * N;
   for (int base = blockIdx.x * TPB; base < n_tus; base += gridDim.x * TPB) {
     const int t = base + j;
     const bool active = t < n_tus;
     int res[N];
     itx_tu<LOG2N>(levels + (size_t)(active ? t : 0) * N * N, active, n, active ? per[t] : 0, active ? rem[t] : 0,
-                  active ? flags[t] : 0, bit_depth, tile, res);
+                  active ? flags[t] : 0, bit_depth, tile, ctile, res);
     if (!active) continue;
     int16_t* row = resid + (size_t)t * N * N + n * N;
 #pragma unroll
