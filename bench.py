@@ -77,17 +77,8 @@ def main():
     ap.add_argument("--profile-steps", type=int, default=5)
     args = ap.parse_args()
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    dist = None
-    if world > 1:
-        import torch
-        import torch.distributed as dist_mod
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist_mod.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-        dist = dist_mod
+    from libhm_amd import dist as hdist
+    dist, rank, world, local_rank = hdist.init_from_env()
 
     import libhm_amd
     from libhm_amd import abi
@@ -118,25 +109,12 @@ def main():
     ctx.sync()
     t_stage = time.time() - t_stage
 
-    def barrier():
-        ctx.sync()
-        if dist is not None:
-            dist.barrier()
-
     ALL = 15
     for _ in range(args.warmup):
         ctx.replay(pics, ALL, 1)
-    barrier()
-    t0 = time.perf_counter()
-    ctx.replay(pics, ALL, args.steps)
-    ctx.sync()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        import torch
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        dist.barrier()
+    # barrier + sync on both sides, MAX over ranks (libhm_amd/dist.py)
+    elapsed = hdist.timed_region(dist, lambda: ctx.replay(pics, ALL, args.steps), ctx.sync,
+                                 device=("cuda:%d" % local_rank) if dist is not None else None)
 
     # ---- per-kernel device times: hipEvents on the context's own stream, around every launch of extra steps
     ctx.set_profiling(True)

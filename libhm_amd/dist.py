@@ -1,0 +1,54 @@
+"""Multi-GPU plumbing: one process per GPU, torch.distributed (backend "nccl" = RCCL on ROCm; "gloo" on CPU for tests).
+
+The hot path shards over PICTURES: pictures that do not reference each other -- all pictures of an
+intra-only stream, separate closed GOPs, the pictures of one temporal level of a hierarchical GOP -- are reconstructed by
+different ranks with no collective in the data path.  The one exchange the path can need is the delivery of a finished
+reference picture to the ranks that predict from it: a broadcast from its owner (frame_parallel.py)."""
+import os
+import time
+
+
+def init_from_env(backend=None):
+    """returns (dist module or None, rank, world, local_rank); rendezvous over 127.0.0.1 by default"""
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world == 1:
+        return None, 0, 1, local_rank
+    import torch
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29511")
+    if backend is None:
+        backend = "nccl" if torch.cuda.is_available() else "gloo"
+    kw = {}
+    if backend == "nccl":
+        torch.cuda.set_device(local_rank)
+        kw["device_id"] = torch.device("cuda", local_rank)
+    dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
+    return dist, rank, world, local_rank
+
+
+def shard(num_units, world, rank):
+    """contiguous share of `num_units` independent units (pictures / GOPs) for `rank`: [begin, end)"""
+    base, rem = divmod(num_units, world)
+    begin = rank * base + min(rank, rem)
+    return begin, begin + base + (1 if rank < rem else 0)
+
+
+def timed_region(dist, run, sync, device=None):
+    """barrier + sync, run(), sync + barrier; returns the MAX elapsed seconds over all ranks (the contract of bench.py)"""
+    sync()
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    run()
+    sync()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        import torch
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device if device is not None else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        dist.barrier()
+    return elapsed

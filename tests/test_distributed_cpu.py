@@ -1,0 +1,92 @@
+"""The N > 1 path on CPU: two ranks over gloo (127.0.0.1) exercise the sharding, the barrier / MAX-over-ranks timing contract
+of bench.py, and the frame-parallel GOP plan with its broadcast of finished reference pictures."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from libhm_amd import dist as hdist
+from libhm_amd import frame_parallel as fp
+
+# random-access GOP-8 of cfg/encoder_randomaccess_main10.cfg: POC 8 <- 0; 4 <- 0,8; 2 <- 0,4; 6 <- 4,8; odd <- neighbours
+RA_GOP8 = {0: [], 8: [0], 4: [0, 8], 2: [0, 4], 6: [4, 8], 1: [0, 2], 3: [2, 4], 5: [4, 6], 7: [6, 8]}
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _fake_reconstruct(poc, refs):
+    out = torch.full((4, 6), float(poc + 1))
+    for r in sorted(refs):
+        out = out * 1.0 + refs[r] * 0.5
+    return out
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist, r, w, _ = hdist.init_from_env(backend="gloo")
+    assert (r, w) == (rank, world)
+    # 1. sharding of independent units
+    b, e = hdist.shard(11, w, r)
+    # 2. timing contract: rank 1 is slower, every rank must see its time
+    import time
+    el = hdist.timed_region(dist, lambda: time.sleep(0.05 * (r + 1)), lambda: None)
+    # 3. frame-parallel GOP with broadcasts of reference pictures
+    have = fp.run_gop(RA_GOP8, r, w, _fake_reconstruct, lambda poc: torch.zeros(4, 6),
+                      lambda buf, src: dist.broadcast(buf, src=src))
+    owner, _, _ = fp.plan_gop(RA_GOP8, w)
+    mine = {p: have[p].numpy().copy() for p in RA_GOP8 if owner[p] == r}
+    q.put((r, (b, e), el, mine))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_over_gloo():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    res.sort(key=lambda t: t[0])
+    # shards tile [0, 11) exactly
+    assert res[0][1] == (0, 6) and res[1][1] == (6, 11)
+    # MAX over ranks: both ranks report (about) the slow rank's time
+    assert abs(res[0][2] - res[1][2]) < 1e-6 and res[0][2] >= 0.1
+    # the distributed GOP equals the serial one
+    serial = {}
+    for poc, refs in RA_GOP8.items():
+        serial[poc] = _fake_reconstruct(poc, {r: serial[r] for r in refs})
+    got = {}
+    for r in res:
+        got.update(r[3])
+    assert sorted(got) == sorted(RA_GOP8)
+    for poc in RA_GOP8:
+        assert np.array_equal(got[poc], serial[poc].numpy())
+
+
+def test_gop_plan_properties():
+    owner, level, sends = fp.plan_gop(RA_GOP8, 8)
+    assert fp.critical_path(RA_GOP8) == 5                  # 0 | 8 | 4 | 2,6 | 1,3,5,7
+    assert level == {0: 0, 8: 1, 4: 2, 2: 3, 6: 3, 1: 4, 3: 4, 5: 4, 7: 4}
+    assert len({owner[p] for p in (1, 3, 5, 7)}) == 4      # one temporal level spreads over ranks
+    sent = {p for p, _, _ in sends}
+    assert sent <= {0, 8, 4, 2, 6} and not sent & {1, 3, 5, 7}   # only referenced pictures travel
+    for poc, src, dst in sends:
+        assert src == owner[poc] and src not in dst
+    with pytest.raises(ValueError):
+        fp.plan_gop({4: [0], 0: []}, 2)
+    # one rank: nothing to send
+    assert fp.plan_gop(RA_GOP8, 1)[2] == []
