@@ -169,16 +169,21 @@ def cpu_baseline(p, w, h, bd):
     """the oracle (C restatement of HM, pinned against HM goldens) on this box's host: single thread, whole pictures"""
     from oracle import hmoracle
     from tests import synth
+    import copy
     hmoracle.lib()
     refs = [synth.noise_planes(w, h, bd, 100), synth.blocky_planes(w, h, bd, 200)]
+    sl = copy.copy(p.slice)             # the device run re-pointed the reference handles at its own pictures
+    for l in range(2):
+        if sl.num_ref_idx[l] > 0:
+            sl.ref_pic[l][0] = l
     n, t_total = 0, 0.0
     while t_total < 10.0 and n < 40:
         cur = [np.zeros_like(r) for r in refs[0]]
         t0 = time.perf_counter()
-        hmoracle.decompress_ctus(p.seq, [p.slice], p.meta, p.coeffs, cur, refs)
-        hmoracle.loop_filter_pic(p.seq, [p.slice], p.meta, p.pp, cur, 3)
+        hmoracle.decompress_ctus(p.seq, [sl], p.meta, p.coeffs, cur, refs)
+        hmoracle.loop_filter_pic(p.seq, [sl], p.meta, p.pp, cur, 3)
         prm = hmoracle.sao_reconstruct_params(p.seq, p.pp, p.meta, p.sao_raw)
-        hmoracle.sao_process(p.seq, [p.slice], p.pp, p.meta, prm, cur)
+        hmoracle.sao_process(p.seq, [sl], p.pp, p.meta, prm, cur)
         t_total += time.perf_counter() - t0
         n += 1
     return {"value": round(n * w * h / t_total / 1e6, 2), "unit": "Mpixels/s", "cores": 1, "kind": "port",

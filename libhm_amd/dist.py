@@ -13,19 +13,32 @@ def init_from_env(backend=None):
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world == 1:
+    if world == 1 and not os.environ.get("HMGPU_FORCE_DIST"):
         return None, 0, 1, local_rank
     import torch
     import torch.distributed as dist
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29511")
+    os.environ.setdefault("NCCL_DEBUG", "WARN")          # keep RCCL's version banner off stdout (bench.py prints ONE JSON line)
     if backend is None:
         backend = "nccl" if torch.cuda.is_available() else "gloo"
     kw = {}
     if backend == "nccl":
         torch.cuda.set_device(local_rank)
         kw["device_id"] = torch.device("cuda", local_rank)
-    dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
+    # RCCL prints a version banner on stdout when the communicator comes up; bench.py owns stdout (ONE JSON line), so the
+    # banner is sent to stderr: fd 1 is pointed at fd 2 while the group and its first collective are created
+    import sys
+    sys.stdout.flush()
+    saved = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
+        dist.barrier()
+    finally:
+        sys.stdout.flush()
+        os.dup2(saved, 1)
+        os.close(saved)
     return dist, rank, world, local_rank
 
 
