@@ -9,6 +9,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 #include <new>
 #include <vector>
 
@@ -226,8 +227,11 @@ hmgpu_status run_recon(hmgpu_ctx* c, const Batch& b) {
   { ProfScope ps(c, K_MC_LUMA); launch_mc_luma(c->d_pics, c->d_finals, b, max_ctus, c->seq.log2_ctu_size, c->stream); }
   { ProfScope ps(c, K_MC_CHROMA); launch_mc_chroma(c->d_pics, c->d_finals, b, max_ctus, c->seq.log2_ctu_size, c->stream); }
   // blocks per shard: enough to keep the chip busy on a full picture, few enough that a short list costs nothing
-  const uint32_t bps = (uint32_t)std::max(4, std::min(64, max_ctus / 8 + 1));
-  { ProfScope ps(c, K_ITX); launch_itx(c->d_pics, b, 0, bps, c->stream); }
+  uint32_t bps = (uint32_t)std::max(4, std::min(16, max_ctus / 8 + 1));   // blocks per shard; 16 measured best at 2160p
+  if (const char* e = getenv("HMGPU_ITX_BPS")) bps = (uint32_t)std::max(1, atoi(e));   // tuning knob
+  int cmask = 0;
+  if (const char* e = getenv("HMGPU_ITX_CLASSES")) cmask = atoi(e);              // tuning aid (wrong output unless 15)
+  { ProfScope ps(c, K_ITX); launch_itx(c->d_pics, b, cmask, bps, c->stream); }
   HIP_TRY(c, hipGetLastError());
   return HMGPU_OK;
 }

@@ -62,6 +62,14 @@ __device__ inline void idst_4(const int (&in)[4], int (&out)[4]) {     // fastIn
   }
 }
 
+// LDS hand-off between the lanes of ONE wave (a TU never spans waves): DS instructions of a wave execute in order, so all
+// that is needed is to stop the compiler from moving LDS accesses across this point and to wait for outstanding DS writes.
+__device__ inline void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 template <int LOG2N> struct ItxCfg {
   static constexpr int N = 1 << LOG2N;
   static constexpr int STRIDE = N == 4 ? 4 : N + 4;       // dwords per LDS row (conflict-free ds_read_b128)
@@ -72,23 +80,21 @@ template <int LOG2N> struct ItxCfg {
 // 32-bit LDS tile for the intermediates, ctile: its 16-bit tile for the levels.  Returns row `n` of the residual in res[].
 // flags: bit0 DST, bit1 transform skip.
 template <int LOG2N>
-__device__ inline void itx_tu(const int16_t* __restrict__ lev, bool active, int n, int per, int rem, int flags, int bd,
+__device__ inline void itx_tu(const uint32_t (&lv)[(1 << LOG2N) / 2], int n, int per, int rem, int flags, int bd,
                               int* __restrict__ tile, int16_t* __restrict__ ctile, int (&res)[1 << LOG2N]) {
   constexpr int N = 1 << LOG2N, S = ItxCfg<LOG2N>::STRIDE;
-  // ---- the level block comes in with 16-byte loads (lane n fetches row n) and is re-read by columns from LDS
+  // ---- the level block came in with 16-byte loads (lane n holds row n) and is re-read by columns from LDS
   if constexpr (N == 4) {
-    u32x2 v = {0u, 0u};
-    if (active) v = ldg2(lev + n * 4);
+    u32x2 v = {lv[0], lv[1]};
     *reinterpret_cast<u32x2*>(ctile + n * 4) = v;
   } else {
 #pragma unroll
     for (int i = 0; i < N / 8; i++) {
-      u32x4 v = {0u, 0u, 0u, 0u};
-      if (active) v = ldg4(lev + n * N + i * 8);
+      u32x4 v = {lv[4 * i], lv[4 * i + 1], lv[4 * i + 2], lv[4 * i + 3]};
       *reinterpret_cast<u32x4*>(ctile + n * N + i * 8) = v;
     }
   }
-  __syncthreads();
+  wave_lds_sync();
   // ---- xDeQuant, flat scaling (TComTrQuant.cpp:1276-1311) on column n
   const int tshift = 15 - bd - LOG2N;                     // getTransformShift
   const int rshift = 6 - (tshift + per);                  // IQUANT_SHIFT - (transformShift + per)
@@ -117,14 +123,14 @@ __device__ inline void itx_tu(const int16_t* __restrict__ lev, bool active, int 
   }
 #pragma unroll
   for (int k = 0; k < N; k++) tile[k * S + n] = o[k];     // T1[row k][column n]
-  __syncthreads();
+  wave_lds_sync();
   int r[N];
 #pragma unroll
   for (int i = 0; i < N; i += 4) {
     const int4 v = *reinterpret_cast<const int4*>(&tile[n * S + i]);
     r[i] = v.x; r[i + 1] = v.y; r[i + 2] = v.z; r[i + 3] = v.w;
   }
-  __syncthreads();                                         // tile is reused by the next TU of this group
+  wave_lds_sync();                                         // tile is reused by the next TU of this group
   if (flags & 2) {
 #pragma unroll
     for (int x = 0; x < N; x++) res[x] = (int)(int16_t)r[x];
@@ -159,54 +165,99 @@ __device__ inline void itx_class(const PicDev& P, int shard, int bx, int nbx, ch
   const int j = threadIdx.x / N, n = threadIdx.x % N;
   int* tile = lds + j * N * S;
   int16_t* ctile = clds + j * N * N;
-  for (uint32_t base = bx * TPB; base < count; base += nbx * TPB) {
-    const uint32_t t = base + j;
-    const bool active = t < count;
-    TuRec rec; rec.x4 = rec.y4 = 0; rec.comp_flags = 0; rec.per = 0; rec.rem = 0; rec.coef_off = 0;
-    if (active) {
-      const uint32_t* rp = reinterpret_cast<const uint32_t*>(list + t);
-      const uint32_t w0 = ldg(rp), w1 = ldg(rp + 1);
-      rec.x4 = (uint16_t)(w0 & 0xffff); rec.y4 = (uint16_t)(w0 >> 16);
-      rec.comp_flags = (uint8_t)(w1 & 0xff); rec.per = (int8_t)((w1 >> 8) & 0xff); rec.rem = (int8_t)((w1 >> 16) & 0xff);
-      rec.coef_off = ldg(rp + 2);
-    }
-    const int comp = rec.comp_flags & 3, flags = rec.comp_flags >> 2;
-    const int bd = P.bd[comp];
-    const int cs = comp ? 1 : 0;
-    int16_t* row = P.rec[comp] + (size_t)(((int)rec.y4 * 4 >> cs) + n) * P.pitch[comp] + ((int)rec.x4 * 4 >> cs);
-    // the prediction row is requested before the transform starts: its latency hides behind the arithmetic
-    uint32_t pw[N / 2];
-    if (active) {
-      if constexpr (N == 4) { const u32x2 v = ldg2(row); pw[0] = v.x; pw[1] = v.y; }
-      else {
+  // Waves run independently.  One loop iteration of a wave covers a group of U*TPW consecutive TUs (lane slot jw takes
+  // TUs base + u*TPW + jw, u < U, one after the other through the same LDS tile), and the loop is a software pipeline:
+  // while group g is transformed the levels and prediction rows of group g+1 are in flight and the records of group g+2
+  // are being fetched.  Measured at 2160p: U > 1 does not pay (the kernel is bound by VALU issue, not by bytes in flight).
+  constexpr int TPW = 64 / N;
+  constexpr int U = 1;
+  const int jw = (threadIdx.x & 63) / N;                          // TU slot inside the wave
+  const uint32_t stride = (uint32_t)nbx * 4 * TPW * U;
+  uint32_t t = ((uint32_t)bx * 4 + (threadIdx.x >> 6)) * TPW * U + jw;
+  struct Rec { uint32_t w0, w1, w2; };
+  auto load_rec = [&](uint32_t ti, Rec& r) {
+    r.w0 = r.w1 = r.w2 = 0;
+    if (ti < count) { const uint32_t* rp = reinterpret_cast<const uint32_t*>(list + ti); r.w0 = ldg(rp); r.w1 = ldg(rp + 1); r.w2 = ldg(rp + 2); }
+  };
+  auto row_ptr = [&](const Rec& r) {
+    const int comp = r.w1 & 3, cs = comp ? 1 : 0;
+    return P.rec[comp] + (size_t)((((int)(r.w0 >> 16) * 4) >> cs) + n) * P.pitch[comp] + (((int)(r.w0 & 0xffff) * 4) >> cs);
+  };
+  auto load_data = [&](uint32_t ti, const Rec& r, uint32_t (&lv)[N / 2], uint32_t (&pw)[N / 2]) {
 #pragma unroll
-        for (int seg = 0; seg < N / 8; seg++) { const u32x4 v = ldg4(row + seg * 8); pw[seg * 4] = v.x; pw[seg * 4 + 1] = v.y; pw[seg * 4 + 2] = v.z; pw[seg * 4 + 3] = v.w; }
+    for (int i = 0; i < N / 2; i++) { lv[i] = 0; pw[i] = 0; }
+    if (ti < count) {
+      const int16_t* lev = P.coef[r.w1 & 3] + r.w2 + n * N;       // lane n: row n of the level block
+      const int16_t* row = row_ptr(r);                            // lane n: row n of the prediction
+      if constexpr (N == 4) {
+        const u32x2 a = ldg2(lev), c = ldg2(row);
+        lv[0] = a.x; lv[1] = a.y; pw[0] = c.x; pw[1] = c.y;
+      } else {
+#pragma unroll
+        for (int i = 0; i < N / 8; i++) { const u32x4 a = ldg4(lev + i * 8); lv[4 * i] = a.x; lv[4 * i + 1] = a.y; lv[4 * i + 2] = a.z; lv[4 * i + 3] = a.w; }
+#pragma unroll
+        for (int i = 0; i < N / 8; i++) { const u32x4 c = ldg4(row + i * 8); pw[4 * i] = c.x; pw[4 * i + 1] = c.y; pw[4 * i + 2] = c.z; pw[4 * i + 3] = c.w; }
       }
     }
-    int res[N];
-    itx_tu<LOG2N>(P.coef[comp] + rec.coef_off, active, n, rec.per, rec.rem, flags, bd, tile, ctile, res);
-    if (!active) continue;
-    // recon row n: ClipBD(pred + resid) in place
-    const int maxv = (1 << bd) - 1;
+  };
+  Rec rc[U], rn[U];
+  uint32_t lv_c[U][N / 2], pw_c[U][N / 2];
 #pragma unroll
-    for (int i = 0; i < N / 2; i++) {
-      const int a = clip3(0, maxv, (int)(pw[i] & 0xffff) + res[2 * i]), c = clip3(0, maxv, (int)(pw[i] >> 16) + res[2 * i + 1]);
-      pw[i] = (uint32_t)a | ((uint32_t)c << 16);
+  for (int u = 0; u < U; u++) load_rec(t + u * TPW, rc[u]);
+#pragma unroll
+  for (int u = 0; u < U; u++) load_rec(t + stride + u * TPW, rn[u]);
+#pragma unroll
+  for (int u = 0; u < U; u++) load_data(t + u * TPW, rc[u], lv_c[u], pw_c[u]);
+  for (uint32_t tw = t - jw; tw < count; tw += stride, t += stride) {   // tw: wave-uniform loop variable
+    uint32_t lv_n[U][N / 2], pw_n[U][N / 2];
+    Rec rnn[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) load_data(t + stride + u * TPW, rn[u], lv_n[u], pw_n[u]);
+#pragma unroll
+    for (int u = 0; u < U; u++) load_rec(t + 2 * stride + u * TPW, rnn[u]);
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      if (tw + u * TPW >= count) break;                           // wave-uniform: the rest of the group is past the end
+      const bool active = t + u * TPW < count;
+      const Rec r = rc[u];
+      const int comp = r.w1 & 3, flags = (r.w1 & 0xff) >> 2;
+      const int per = (int)(int8_t)((r.w1 >> 8) & 0xff), rem = (int)(int8_t)((r.w1 >> 16) & 0xff);
+      const int bd = P.bd[comp];
+      int res[N];
+      itx_tu<LOG2N>(lv_c[u], n, per, rem, flags, bd, tile, ctile, res);
+      if (active) {
+        // recon row n: ClipBD(pred + resid) in place
+        const int maxv = (1 << bd) - 1;
+        int16_t* row = row_ptr(r);
+        uint32_t o[N / 2];
+#pragma unroll
+        for (int i = 0; i < N / 2; i++) {
+          const int a = clip3(0, maxv, (int)(pw_c[u][i] & 0xffff) + res[2 * i]), c = clip3(0, maxv, (int)(pw_c[u][i] >> 16) + res[2 * i + 1]);
+          o[i] = (uint32_t)a | ((uint32_t)c << 16);
+        }
+        if constexpr (N == 4) { u32x2 v = {o[0], o[1]}; stg2(row, v); }
+        else {
+#pragma unroll
+          for (int seg = 0; seg < N / 8; seg++) { u32x4 v = {o[seg * 4], o[seg * 4 + 1], o[seg * 4 + 2], o[seg * 4 + 3]}; stg4(row + seg * 8, v); }
+        }
+      }
     }
-    if constexpr (N == 4) { u32x2 o = {pw[0], pw[1]}; stg2(row, o); }
-    else {
 #pragma unroll
-      for (int seg = 0; seg < N / 8; seg++) { u32x4 o = {pw[seg * 4], pw[seg * 4 + 1], pw[seg * 4 + 2], pw[seg * 4 + 3]}; stg4(row + seg * 8, o); }
+    for (int u = 0; u < U; u++) {
+      rc[u] = rn[u]; rn[u] = rnn[u];
+#pragma unroll
+      for (int i = 0; i < N / 2; i++) { lv_c[u][i] = lv_n[u][i]; pw_c[u][i] = pw_n[u][i]; }
     }
   }
 }
 
 // one launch for all four size classes: blockIdx.y = class * kTuShards + shard, so short lists of one class share the
 // chip with the long lists of another instead of each class paying its own latency-bound launch
-__global__ void __launch_bounds__(256) k_itx(const PicDev* __restrict__ pics, Batch b) {
+__global__ void __launch_bounds__(256) k_itx(const PicDev* __restrict__ pics, Batch b, uint32_t class_mask) {
   __shared__ __attribute__((aligned(16))) char lds[kItxLdsBytes];
   const PicDev& P = pics[b.pic[blockIdx.z]];
   const int cls = blockIdx.y / kTuShards, shard = blockIdx.y % kTuShards;
+  if (!((class_mask >> cls) & 1)) return;                         // tuning aid: time one size class alone
   switch (cls) {
     case 0: itx_class<2>(P, shard, blockIdx.x, gridDim.x, lds); break;
     case 1: itx_class<3>(P, shard, blockIdx.x, gridDim.x, lds); break;
@@ -216,9 +267,8 @@ __global__ void __launch_bounds__(256) k_itx(const PicDev* __restrict__ pics, Ba
 }
 
 void launch_itx(const PicDev* pics, const Batch& b, int log2size, uint32_t blocks_per_shard, hipStream_t s) {
-  (void)log2size;
   dim3 grid(blocks_per_shard, 4 * kTuShards, (unsigned)b.n);
-  hipLaunchKernelGGL(k_itx, grid, dim3(256), 0, s, pics, b);
+  hipLaunchKernelGGL(k_itx, grid, dim3(256), 0, s, pics, b, log2size ? (uint32_t)log2size : 0xfu);
 }
 
 // ---- kernel-level seam: residual of n TUs from flat arrays (tests; hmgpu_inverse_transform_batch) ----------------------
@@ -236,8 +286,10 @@ __global__ void __launch_bounds__(256) k_itx_flat(int bit_depth, int n_tus, cons
     const int t = base + j;
     const bool active = t < n_tus;
     int res[N];
-    itx_tu<LOG2N>(levels + (size_t)(active ? t : 0) * N * N, active, n, active ? per[t] : 0, active ? rem[t] : 0,
-                  active ? flags[t] : 0, bit_depth, tile, ctile, res);
+    uint32_t lv[N / 2];
+#pragma unroll
+    for (int i = 0; i < N / 2; i++) lv[i] = active ? ldg(reinterpret_cast<const uint32_t*>(levels + (size_t)t * N * N + n * N) + i) : 0u;
+    itx_tu<LOG2N>(lv, n, active ? per[t] : 0, active ? rem[t] : 0, active ? flags[t] : 0, bit_depth, tile, ctile, res);
     if (!active) continue;
     int16_t* row = resid + (size_t)t * N * N + n * N;
 #pragma unroll
