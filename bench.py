@@ -10,6 +10,11 @@ batch of `--batch` independent pictures (frame-parallel, one launch per kernel f
 are already resident in HBM (hmgpu_replay_batch).  The pictures use distinct device buffers (~110 MB each), so the
 working set is far beyond the 256 MiB Infinity Cache.
 
+`--workload` selects the SURVEY.md 8(d) sub-benchmarks instead (each prints the same JSON shape, `roofline` then names
+that configuration's kernel):  idct = config #2 (1920x1080, every CTU four 32x32 luma + 16x16 chroma TUs, "stress" levels),
+mc / mc_bi = config #3 (prep + MC + residual add only), filter = config #4 (25 % intra CUs for Bs = 2 edges; the
+reconstruction stages run as well because they regenerate the pre-filter picture the in-place deblocking consumes).
+
 Output: ONE JSON line (rank 0), see README/DESIGN.md.  `roofline` is for the dominant kernel (largest share of device
 time); `kernels` lists every kernel.  `cpu_baseline` times the oracle (oracle/hm_oracle.c, the C restatement pinned
 against HM) on this box's host cores on a bounded sample of the same workload -- a reported baseline, not a target.
@@ -73,12 +78,15 @@ def main():
     ap.add_argument("--width", type=int, default=3840)
     ap.add_argument("--height", type=int, default=2160)
     ap.add_argument("--bi", type=int, default=0, help="1: B pictures (bi-prediction) instead of P")
+    ap.add_argument("--workload", default="full", choices=("full", "idct", "mc", "mc_bi", "filter"))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-steps", type=int, default=5)
     args = ap.parse_args()
 
+    import torch  # noqa: F401  -- first, so that libhmgpu.so binds to the HIP runtime torch ships (one runtime per process)
     from libhm_amd import dist as hdist
     dist, rank, world, local_rank = hdist.init_from_env()
+    copy_gbps = measured_copy_bandwidth(local_rank) if world == 1 else None
 
     import libhm_amd
     from libhm_amd import abi
@@ -86,9 +94,23 @@ def main():
 
     w, h, bd = args.width, args.height, 10
     nb = args.batch
+    wl = args.workload
+    RECON, FILTER = 8, 7
+    stages, roof_kernel, kw = RECON | FILTER, None, {}
+    if wl == "idct":
+        w, h = 1920, 1080
+        stages, roof_kernel = RECON, "itx"
+        kw = dict(mode_probs=(1.0, 0, 0, 0, 0), cbf_prob=1.0, coef_dist="stress", sao=False)
+    elif wl in ("mc", "mc_bi"):
+        stages, roof_kernel = RECON, "mc_luma"
+        args.bi = 1 if wl == "mc_bi" else 0
+    elif wl == "filter":
+        # the reconstruction stages run too: they regenerate the pre-filter picture that the in-place deblocking consumed
+        roof_kernel = "sao"
+        kw = dict(intra_frac=0.25)
     # two distinct parsed pictures, staged alternately into nb device pictures with their own buffers
     # every picture of the batch predicts from its OWN reference pictures (no flattering reuse of one reference in cache)
-    metas = [synth.make_picture(w, h, bd, seed=0x484D3136 + 7 * rank + i, bi=bool(args.bi), ref_handles=([0], [1])) for i in range(2)]
+    metas = [synth.make_picture(w, h, bd, seed=0x484D3136 + 7 * rank + i, bi=bool(args.bi), ref_handles=([0], [1]), **kw) for i in range(2)]
     seq = abi.make_seq(w, h, bd, bd, log2_ctu=6, max_pictures=3 * nb)
     ctx = libhm_amd.Context(seq, device=local_rank)
     ref_planes = [synth.noise_planes(w, h, bd, 100 + rank), synth.blocky_planes(w, h, bd, 200 + rank)]
@@ -109,7 +131,7 @@ def main():
     ctx.sync()
     t_stage = time.time() - t_stage
 
-    ALL = 15
+    ALL = stages
     for _ in range(args.warmup):
         ctx.replay(pics, ALL, 1)
     # barrier + sync on both sides, MAX over ranks (libhm_amd/dist.py)
@@ -140,29 +162,65 @@ def main():
                              "frac": round(gbs / HBM_PEAK_GBS, 4)}
             if ms > dom_t:
                 dom, dom_t = name, ms
+        if roof_kernel is not None:
+            dom = roof_kernel
+        # HBM traffic per launch from the committed PMC passes of this same command (tools/round_profile.sh + pmc_summary.py):
+        # counters cannot be read from inside the process, so the figure is only reported for the workload it was taken on
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+        if wl == "full" and nb == 8 and not args.bi and (w, h) == (3840, 2160) and os.path.exists(tpath):
+            traffic = json.load(open(tpath))["kernels"].get(dom, {}).get("traffic_bytes")
         roof = {"kernel": dom, "bound": "hbm", "achieved": kernels[dom]["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": kernels[dom]["frac"], "traffic": None}
+                "frac": kernels[dom]["frac"], "traffic": traffic,
+                "algorithmic_bytes_per_launch": int(kernels[dom]["alg_MB"] * 1e6)}
         dev_ms = sum(k["avg_ms"] for k in kernels.values())
         out = {
-            "metric": "decoded Mpixels/s (luma), 2160p Main10 reconstruction + loop filters", "value": round(value, 1),
+            "metric": "decoded Mpixels/s (luma), 2160p Main10 reconstruction + loop filters" if wl == "full" else
+                      "Mpixels/s (luma) through the '%s' stage set (SURVEY 8d sub-benchmark)" % wl, "value": round(value, 1),
             "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "int16 samples / int32 accumulate", "data": "synthetic",
-            "config": {"workload": "%dx%d Main10 %s pictures, pre-parsed CTU metadata: prep+MC+dequant/IT/recon+deblock+SAO, "
+            "config": {"workload": "%dx%d Main10 %s pictures, pre-parsed CTU metadata: %s, "
                                    "batch of %d independent pictures per step, inputs resident in HBM" %
-                                   (w, h, "B (bi-pred)" if args.bi else "lowdelay_P", nb),
+                                   (w, h, "B (bi-pred)" if args.bi else "lowdelay_P",
+                                    {"full": "prep+MC+dequant/IT/recon+deblock+SAO", "idct": "prep+MC+dequant/IT/recon, 32x32 luma / 16x16 chroma TUs, stress levels",
+                                     "mc": "prep+MC+dequant/IT/recon", "mc_bi": "prep+MC+dequant/IT/recon", "filter": "prep+MC+dequant/IT/recon+deblock+SAO, 25% intra CUs (Bs 2 edges)"}[wl], nb),
+                       "sub_benchmark": wl,
                        "pictures_per_step": nb, "parallelism": "frame-parallel, 1 process per GPU, no data-path collective"},
             "roofline": roof, "kernels": kernels, "device_ms_per_step_sum_of_kernels": round(dev_ms, 4),
             "hbm_GBps_whole_step_algorithmic": round(sum(sum(b[k] for k in kernels) for b in [bytes_pp[i % 2] for i in range(nb)])
                                                     / (elapsed / args.steps) / 1e9, 1),
             "staging_s_for_batch_incl_first_run": round(t_stage, 3),
         }
-        if not args.no_cpu_baseline:
+        if copy_gbps is not None:
+            out["hbm_copy_GBps_measured"] = copy_gbps
+        if not args.no_cpu_baseline and world == 1 and wl == "full":
             out["cpu_baseline"] = cpu_baseline(metas[0], w, h, bd)
         print(json.dumps(out), flush=True)
     ctx.close()
     if dist is not None:
         dist.destroy_process_group()
+
+
+def measured_copy_bandwidth(device):
+    """device-to-device copy of 1 GiB (read + write counted), the practical HBM ceiling on this box"""
+    import torch
+    dev = "cuda:%d" % device
+    a = torch.empty(1 << 30, dtype=torch.uint8, device=dev)
+    b = torch.empty_like(a)
+    for _ in range(2):
+        b.copy_(a)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize(dev)
+    e0.record()
+    for _ in range(10):
+        b.copy_(a)
+    e1.record()
+    torch.cuda.synchronize(dev)
+    gbps = round(10 * 2 * a.numel() / (e0.elapsed_time(e1) * 1e-3) / 1e9, 1)
+    del a, b
+    torch.cuda.empty_cache()
+    return gbps
 
 
 def cpu_baseline(p, w, h, bd):

@@ -30,9 +30,11 @@ class SynthPicture:
 
 
 def make_picture(width, height, bit_depth=10, seed=1, bi=False, intra_frac=0.0, num_refs=1, slice_qp_range=(22, 37),
-                 cbf_prob=0.5, sao=True, mode_probs=(0.1, 0.3, 0.3, 0.2, 0.1), ref_handles=None, mv_range=64):
+                 cbf_prob=0.5, sao=True, mode_probs=(0.1, 0.3, 0.3, 0.2, 0.1), ref_handles=None, mv_range=64,
+                 coef_dist="typical", tr_split_prob=0.35):
     """Returns a SynthPicture with .seq, .slice (abi.SliceParams), .meta (MetaHolder), .coeffs (CoeffHolder),
-    .sao_raw [num_ctus,3,35], .pp, .meta_np.  ref_handles: device picture handles of list-0 / list-1 references."""
+    .sao_raw [num_ctus,3,35], .pp, .meta_np.  ref_handles: device picture handles of list-0 / list-1 references.
+    coef_dist: "typical" (see above) or "stress" (every level of a coded TU uniform over the full int16 range, SURVEY 8d #2)."""
     rng = np.random.RandomState(seed)
     ctu, pw, parts = 64, 16, 256
     cw, ch = (width + 63) // 64, (height + 63) // 64
@@ -107,7 +109,7 @@ def make_picture(width, height, bit_depth=10, seed=1, bi=False, intra_frac=0.0, 
     mv1 = np.where((ref_idx1 < 0)[:, :, None], 0, mv1)
 
     # ---- transform tree: tr_idx in {0,1} per CU (64x64 CUs and AMP CUs always split once)
-    tr_cu = (rng.rand(n, n_cu_max) < 0.35).astype(np.int64)
+    tr_cu = (rng.rand(n, n_cu_max) < tr_split_prob).astype(np.int64)
     tr_idx = np.take_along_axis(tr_cu, cu_idx, axis=1)
     tr_idx = np.where(((mode == 0) | (mode == 4))[:, None], 1, tr_idx)
     # cbf: per CU one flag for the unsplit TU and four for the children, per component
@@ -162,9 +164,13 @@ def make_picture(width, height, bit_depth=10, seed=1, bi=False, intra_frac=0.0, 
             a_idx, z_idx = np.nonzero(origin)
             if a_idx.size == 0:
                 continue
-            k = min(size, 8)
-            lev = np.round(rng.laplace(0, 12, size=(a_idx.size, k, k))) * (rng.rand(a_idx.size, k, k) < 0.35)
-            lev = np.clip(lev, -32768, 32767).astype(np.int16)
+            if coef_dist == "stress":
+                k = size
+                lev = rng.randint(-32768, 32768, size=(a_idx.size, k, k)).astype(np.int16)
+            else:
+                k = min(size, 8)
+                lev = np.round(rng.laplace(0, 12, size=(a_idx.size, k, k))) * (rng.rand(a_idx.size, k, k) < 0.35)
+                lev = np.clip(lev, -32768, 32767).astype(np.int16)
             off = (16 if comp == 0 else 4) * z_idx
             rr, cc = np.meshgrid(np.arange(k), np.arange(k), indexing="ij")
             flat_idx = off[:, None, None] + rr[None] * size + cc[None]

@@ -1,0 +1,17 @@
+#!/bin/bash
+# usage (on the GPU box, repo root): bash tools/round_profile.sh <tag>   -- bench JSONs, rocprofv3 kernel stats and HBM-byte
+# PMC passes of the default bench command, written under gpurun_out/<tag>/ (copy what is to be kept into profiles/)
+set -e
+tag=$1
+out=$GRAFT_REPO_ROOT/gpurun_out/$tag
+mkdir -p $out
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+python3 bench.py > $out/bench_full.json 2> $out/bench_full.err
+for wl in idct mc mc_bi filter; do
+  python3 bench.py --workload $wl --steps 10 --no-cpu-baseline > $out/bench_$wl.json 2> $out/bench_$wl.err
+done
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline > $out/stats.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -- python3 bench.py --steps 2 --warmup 1 --profile-steps 1 --no-cpu-baseline > $out/pmc_fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/pmc_write -- python3 bench.py --steps 2 --warmup 1 --profile-steps 1 --no-cpu-baseline > $out/pmc_write.log 2>&1
+find $out -name "*.csv" -size +3M -delete      # per-dispatch traces are large; the stats summaries stay
+ls -R $out | head -40
