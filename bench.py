@@ -78,7 +78,7 @@ def main():
     ap.add_argument("--width", type=int, default=3840)
     ap.add_argument("--height", type=int, default=2160)
     ap.add_argument("--bi", type=int, default=0, help="1: B pictures (bi-prediction) instead of P")
-    ap.add_argument("--workload", default="full", choices=("full", "idct", "mc", "mc_bi", "filter"))
+    ap.add_argument("--workload", default="full", choices=("full", "idct", "mc", "mc_bi", "filter", "gop"))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-steps", type=int, default=5)
     args = ap.parse_args()
@@ -92,6 +92,8 @@ def main():
     from libhm_amd import abi
     from tests import synth
 
+    if args.workload == "gop":
+        return gop_main(args, hdist, dist, rank, world, local_rank, copy_gbps)
     w, h, bd = args.width, args.height, 10
     nb = args.batch
     wl = args.workload
@@ -196,6 +198,57 @@ def main():
             out["hbm_copy_GBps_measured"] = copy_gbps
         if not args.no_cpu_baseline and world == 1 and wl == "full":
             out["cpu_baseline"] = cpu_baseline(metas[0], w, h, bd)
+        print(json.dumps(out), flush=True)
+    ctx.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def gop_main(args, hdist, dist, rank, world, local_rank, copy_gbps):
+    """BASELINE config #5: random-access GOPs of 8 B pictures, frame-parallel over the ranks, `world` GOPs in flight; finished
+    reference pictures travel rank-to-rank over RCCL send/recv.  value = pictures of all ranks per second (8 per rank, step)."""
+    import libhm_amd
+    from libhm_amd import abi, frame_parallel as fp
+    from tests import synth
+    w, h, bd = args.width, args.height, 10
+    gops = world
+    metas = [synth.make_picture(w, h, bd, seed=0x484D3136 + 5 + i, bi=True, ref_handles=([0], [0])) for i in range(2)]
+    ctx = libhm_amd.Context(abi.make_seq(w, h, bd, bd, log2_ctu=6, max_pictures=9 * gops), device=local_rank)
+    anchors = [synth.noise_planes(w, h, bd, 100), synth.blocky_planes(w, h, bd, 200)]
+    t0 = time.time()
+    run = fp.DeviceGops(ctx, dist, rank, world, gops, lambda g, poc: metas[(g + poc) % 2], lambda g: anchors[g % 2])
+    t_stage = time.time() - t0
+    for _ in range(args.warmup):
+        run.step()
+
+    def steps():
+        for _ in range(args.steps):
+            run.step()
+    elapsed = hdist.timed_region(dist, steps, ctx.sync, device=("cuda:%d" % local_rank) if dist is not None else None)
+    ctx.set_profiling(True)
+    ctx.stats(reset=True)
+    run.step()
+    st = ctx.stats(reset=True)
+    ctx.set_profiling(False)
+    if rank == 0:
+        plan = run.plan
+        sends = sum(len(s[3]) for lvl in plan for s in lvl["sends"])
+        region = ctx.device_region(run.handle_of[(0, 0)])[1]
+        out = {
+            "metric": "decoded Mpixels/s (luma), 2160p Main10 random-access GOPs, frame-parallel", "unit": "Mpixels/s",
+            "value": round(world * 8 * args.steps * w * h / elapsed / 1e6, 1), "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "int16 samples / int32 accumulate", "data": "synthetic",
+            "config": {"workload": "%dx%d Main10 random-access GOP of 8 B pictures (POC 8<-0; 4<-0,8; 2<-0,4; 6<-4,8; odd<-neighbours), "
+                                   "%d GOPs in flight, pictures of one dependency level batched per rank, inputs resident in HBM" % (w, h, gops),
+                       "sub_benchmark": "gop", "pictures_per_step": 8 * world, "dependency_levels": len(plan),
+                       "parallelism": "frame-parallel, 1 process per GPU, RCCL send/recv of finished reference pictures",
+                       "transfers_per_step": sends, "bytes_per_transfer": region},
+            "kernels_rank0_ms_per_step": {k: round(ms, 4) for k, (ms, n) in st["kernels"].items() if n},
+            "staging_s": round(t_stage, 3),
+        }
+        if copy_gbps is not None:
+            out["hbm_copy_GBps_measured"] = copy_gbps
         print(json.dumps(out), flush=True)
     ctx.close()
     if dist is not None:

@@ -149,6 +149,20 @@ hmgpu_status hmgpu_picture_release(hmgpu_ctx* ctx, hmgpu_pic pic);
 hmgpu_status hmgpu_picture_upload(hmgpu_ctx* ctx, hmgpu_pic pic, const int16_t* const planes[3], const int32_t strides[3]);
 hmgpu_status hmgpu_picture_download(hmgpu_ctx* ctx, hmgpu_pic pic, int16_t* const planes[3], const int32_t strides[3]);
 
+/* Frame-parallel exchange (BASELINE config #5): a finished picture is ONE contiguous device region (three
+ * planes, replicated margins included -- HM's TComPicYuv after extendPicBorder, TComPicYuv.cpp:89-100) that another GPU
+ * needs before it can predict from the picture (TComPrediction.cpp:593).  The collective itself (RCCL broadcast /
+ * send-recv between the owner's region and the receivers' regions) is issued by the caller on hmgpu_stream():
+ *   sender:    hmgpu_picture_device_region(ctx, pic, HMGPU_REGION_FINISHED, &base, &bytes)   (extends the border if needed)
+ *   receiver:  hmgpu_picture_device_region(ctx, pic, HMGPU_REGION_RECEIVE, &base, &bytes); <collective>;
+ *              hmgpu_picture_commit_received(ctx, pic)        (the picture can now be named in ref_pic[][])
+ * Regions of two contexts with equal hmgpu_seq_params have equal size and layout. */
+typedef enum { HMGPU_REGION_FINISHED = 0, HMGPU_REGION_RECEIVE = 1 } hmgpu_region;
+hmgpu_status hmgpu_picture_device_region(hmgpu_ctx* ctx, hmgpu_pic pic, int32_t which, void** base, int64_t* bytes);
+hmgpu_status hmgpu_picture_commit_received(hmgpu_ctx* ctx, hmgpu_pic pic);
+/* the context's HIP stream (a hipStream_t), for callers that order their own device work against the library's */
+void* hmgpu_stream(hmgpu_ctx* ctx);
+
 /* ------------------------------------------------------------------------------------------------ call 1
  * Replaces the reconstruction half of TDecGop::decompressSlice -> TDecSlice::decompressSlice ->
  * TDecCu::decompressCU (TDecSlice.cpp:334, TDecCu.cpp:142,373) for the CTUs [first_ctu, first_ctu+num_ctus) of

@@ -26,6 +26,28 @@ class HmgpuError(RuntimeError):
                                               " (hipError %d)" % device_error if status == 2 else ""))
 
 
+def _share_torch_hip_runtime():
+    """One HIP runtime per process: PyTorch ships its own libamdhip64 and a process that has already initialised the
+    system copy (through libhmgpu.so) can no longer bring up torch's ("No HIP GPUs are available").  The frame-parallel
+    path needs both (RCCL through torch.distributed on this library's stream), so when torch is installed its runtime is
+    loaded first and libhmgpu.so's NEEDED libamdhip64 resolves to it (same soname)."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        return
+    spec = importlib.util.find_spec("torch")
+    if spec is None or not spec.origin:
+        return
+    for name in ("libamdhip64.so", "libamdhip64.so.7", "libamdhip64.so.6"):
+        path = os.path.join(os.path.dirname(spec.origin), "lib", name)
+        if os.path.exists(path):
+            try:
+                C.CDLL(path, mode=C.RTLD_GLOBAL)
+            except OSError:
+                pass
+            return
+
+
 def lib():
     """Load libhmgpu.so.  No fallback: a missing library is an error."""
     global _lib
@@ -33,6 +55,7 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise RuntimeError("libhm_amd/libhmgpu.so is missing: build it with `python libhm_amd/build.py` "
                                "(or __graft_entry__.build()); there is no CPU fallback")
+        _share_torch_hip_runtime()
         L = C.CDLL(LIB_PATH)
         L.hmgpu_create.argtypes = [C.POINTER(abi.SeqParams), C.c_int, C.POINTER(C.c_void_p)]
         L.hmgpu_destroy.argtypes = [C.c_void_p]
@@ -47,6 +70,10 @@ def lib():
         L.hmgpu_picture_release.argtypes = [C.c_void_p, C.c_int32]
         L.hmgpu_picture_upload.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_int32)]
         L.hmgpu_picture_download.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_int32)]
+        L.hmgpu_picture_device_region.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]
+        L.hmgpu_picture_commit_received.argtypes = [C.c_void_p, C.c_int32]
+        L.hmgpu_stream.argtypes = [C.c_void_p]
+        L.hmgpu_stream.restype = C.c_void_p
         L.hmgpu_decompress_slice.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(abi.SliceParams), C.POINTER(abi.CtuMeta),
                                              C.POINTER(abi.Coeffs), C.c_int32, C.c_int32]
         L.hmgpu_filter_picture.argtypes = [C.c_void_p, C.c_int32, C.POINTER(abi.PicParams), C.c_void_p]
@@ -71,6 +98,7 @@ class Context:
 
     def __init__(self, seq, device=0):
         self.seq = seq
+        self.device = device
         self._h = C.c_void_p()
         st = lib().hmgpu_create(C.byref(seq), device, C.byref(self._h))
         if st != 0:
@@ -118,6 +146,20 @@ class Context:
         strides = (C.c_int32 * 3)(*[p.shape[1] for p in planes])
         self._chk(lib().hmgpu_picture_download(self._h, pic, ptrs, strides), "hmgpu_picture_download")
         return planes
+
+    # ---- frame-parallel exchange (hmgpu.h: hmgpu_picture_device_region)
+    def device_region(self, pic, receive=False):
+        """(device address, bytes) of the contiguous plane region of `pic`: the finished picture, or where to receive one"""
+        base, nbytes = C.c_void_p(), C.c_int64()
+        self._chk(lib().hmgpu_picture_device_region(self._h, pic, 1 if receive else 0, C.byref(base), C.byref(nbytes)),
+                  "hmgpu_picture_device_region")
+        return int(base.value), int(nbytes.value)
+
+    def commit_received(self, pic):
+        self._chk(lib().hmgpu_picture_commit_received(self._h, pic), "hmgpu_picture_commit_received")
+
+    def stream_handle(self):
+        return int(lib().hmgpu_stream(self._h) or 0)
 
     # ---- the two calls
     def decompress_slice(self, pic, slice_idx, slice_params, meta, coeffs, first_ctu=0, num_ctus=None):

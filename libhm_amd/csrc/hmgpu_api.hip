@@ -469,6 +469,40 @@ hmgpu_status hmgpu_picture_download(hmgpu_ctx* c, hmgpu_pic pic, int16_t* const 
   return HMGPU_OK;
 }
 
+hmgpu_status hmgpu_picture_device_region(hmgpu_ctx* c, hmgpu_pic pic, int32_t which, void** base, int64_t* bytes) {
+  if (!c || !valid_pic(c, pic) || !base || !bytes || (which != HMGPU_REGION_FINISHED && which != HMGPU_REGION_RECEIVE)) return HMGPU_EINVAL;
+  hipSetDevice(c->device);
+  Picture& p = c->pics[pic];
+  size_t plane_bytes = 0;
+  for (int k = 0; k < 3; k++) plane_bytes += align_up((size_t)c->pitch[k] * c->rows[k] * sizeof(int16_t), 256);
+  if (which == HMGPU_REGION_FINISHED) {
+    hmgpu_status st = ensure_extended(c, pic);
+    if (st != HMGPU_OK) return st;
+    *base = (char*)p.planes + (p.sao_applied ? plane_bytes : 0);     // rec planes first, SAO planes behind (alloc_picture)
+  } else {
+    if (p.sao_applied) {               // a received picture lives in the reconstruction planes, like an uploaded one
+      p.sao_applied = false; p.dev.sao_applied = 0;
+      hmgpu_status st = push_final(c, pic);
+      if (st == HMGPU_OK) st = push_picdev(c, pic);
+      if (st != HMGPU_OK) return st;
+    }
+    p.extended = false;
+    *base = p.planes;
+  }
+  *bytes = (int64_t)plane_bytes;
+  return HMGPU_OK;
+}
+
+hmgpu_status hmgpu_picture_commit_received(hmgpu_ctx* c, hmgpu_pic pic) {
+  if (!c || !valid_pic(c, pic)) return HMGPU_EINVAL;
+  Picture& p = c->pics[pic];
+  if (p.sao_applied) return HMGPU_EINVAL;          // hmgpu_picture_device_region(RECEIVE) was not called
+  p.extended = true;                               // the margins travelled with the planes
+  return HMGPU_OK;
+}
+
+void* hmgpu_stream(hmgpu_ctx* c) { return c ? (void*)c->stream : nullptr; }
+
 hmgpu_status hmgpu_decompress_slice(hmgpu_ctx* c, hmgpu_pic cur, int32_t slice_idx, const hmgpu_slice_params* sl,
                                     const hmgpu_ctu_meta* m, const hmgpu_coeffs* co, int32_t first_ctu, int32_t num_ctus) {
   if (!c || !valid_pic(c, cur) || !sl || !m || !co) return HMGPU_EINVAL;

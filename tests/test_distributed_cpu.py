@@ -77,6 +77,80 @@ def test_two_ranks_over_gloo():
         assert np.array_equal(got[poc], serial[poc].numpy())
 
 
+def _fake_recon2(g, poc, r0, r1):
+    return torch.full((4, 6), float(10 * g + poc + 1)) + 0.5 * r0 + 0.25 * r1
+
+
+def _pipelined_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist, r, w, _ = hdist.init_from_env(backend="gloo")
+    gops = w
+    plan = fp.plan_pipelined(fp.RA_GOP8, w, gops)
+    have = {(g, 0): torch.full((4, 6), float(g)) for g in range(gops)}       # the anchors are everywhere
+
+    def reconstruct_batch(items):
+        for g, poc in items:
+            a, b = fp.RA_GOP8[poc]
+            have[(g, poc)] = _fake_recon2(g, poc, have[(g, a)], have[(g, b)])
+
+    def exchange(transfers):
+        ops = []
+        for g, poc, src, dst in transfers:
+            if r == src:
+                ops += [dist.P2POp(dist.isend, have[(g, poc)], d) for d in dst]
+            else:
+                have[(g, poc)] = torch.zeros(4, 6)
+                ops.append(dist.P2POp(dist.irecv, have[(g, poc)], src))
+        for wk in dist.batch_isend_irecv(ops):
+            wk.wait()
+
+    fp.run_pipelined(plan, r, reconstruct_batch, exchange)
+    mine = {k: have[k].numpy().copy() for lvl in plan for k in lvl["compute"].get(r, [])}
+    q.put((r, mine))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_pipelined_gops_over_gloo(world):
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_pipelined_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    got = {}
+    for _, mine in res:
+        got.update(mine)
+    assert len(got) == 8 * world
+    for g in range(world):
+        serial = {0: torch.full((4, 6), float(g))}
+        for poc, (a, b) in fp.RA_GOP8.items():
+            serial[poc] = _fake_recon2(g, poc, serial[a], serial[b])
+            assert np.array_equal(got[(g, poc)], serial[poc].numpy())
+
+
+def test_pipelined_plan_properties():
+    for world in (1, 2, 4, 8):
+        plan = fp.plan_pipelined(fp.RA_GOP8, world, world)
+        assert len(plan) == 4                                    # critical path of the random-access GOP of 8
+        per_rank = {}
+        for lvl in plan:
+            for r, items in lvl["compute"].items():
+                per_rank[r] = per_rank.get(r, 0) + len(items)
+            for g, poc, src, dst in lvl["sends"]:
+                assert src not in dst and all(0 <= d < world for d in dst)
+        assert per_rank == {r: 8 for r in range(world)}         # weak scaling: 8 pictures per rank and step
+        if world == 1:
+            assert all(not lvl["sends"] for lvl in plan)
+        if world == 8:
+            assert [len(lvl["compute"][0]) for lvl in plan] == [1, 1, 2, 4]
+
+
 def test_gop_plan_properties():
     owner, level, sends = fp.plan_gop(RA_GOP8, 8)
     assert fp.critical_path(RA_GOP8) == 5                  # 0 | 8 | 4 | 2,6 | 1,3,5,7

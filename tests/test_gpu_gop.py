@@ -1,0 +1,76 @@
+"""Frame-parallel GOP path on the device (BASELINE config #5) with one rank: the level-batched replay of a
+random-access GOP of 8 B pictures must give, picture by picture, the oracle's samples when the oracle decodes the same
+pictures one after the other; and a finished picture moved through hmgpu_picture_device_region (the region an RCCL
+send/recv would carry) must serve as a reference exactly like the original."""
+import copy
+
+import numpy as np
+import pytest
+
+from libhm_amd import frame_parallel as fp
+from tests import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle_picture(oracle, p, sl, refs):
+    cur = [np.zeros_like(a) for a in refs[0]]
+    oracle.decompress_ctus(p.seq, [sl], p.meta, p.coeffs, cur, refs)
+    oracle.loop_filter_pic(p.seq, [sl], p.meta, p.pp, cur, 3)
+    prm = oracle.sao_reconstruct_params(p.seq, p.pp, p.meta, p.sao_raw)
+    return oracle.sao_process(p.seq, [sl], p.pp, p.meta, prm, cur)
+
+
+def test_gop_of_8_matches_oracle(oracle):
+    import libhm_amd
+    from libhm_amd import abi
+    w, h, bd = 416, 240, 10
+    pics = {poc: synth.make_picture(w, h, bd, seed=40 + poc, bi=True, ref_handles=([0], [0])) for poc in fp.RA_GOP8}
+    anchor = synth.noise_planes(w, h, bd, 7)
+    # oracle: decode order, every picture from the finished planes of its two references
+    want = {0: anchor}
+    for poc, (a, b) in fp.RA_GOP8.items():
+        sl = copy.copy(pics[poc].slice)
+        sl.ref_pic[0][0], sl.ref_pic[1][0] = 0, 1
+        want[poc] = _oracle_picture(oracle, pics[poc], sl, [want[a], want[b]])
+    with libhm_amd.Context(abi.make_seq(w, h, bd, bd, log2_ctu=6, max_pictures=9)) as ctx:
+        run = fp.DeviceGops(ctx, None, 0, 1, 1, lambda g, poc: pics[poc], lambda g: anchor)
+        assert [len(lvl["compute"][0]) for lvl in run.plan] == [1, 1, 2, 4]
+        for _ in range(2):                        # the replayed step must reproduce the staged run
+            run.step()
+        for poc in fp.RA_GOP8:
+            got = ctx.download(run.handle_of[(0, poc)])
+            for c in range(3):
+                assert np.array_equal(got[c], want[poc][c]), "POC %d comp %d" % (poc, c)
+
+
+def test_received_picture_is_a_reference_like_the_original():
+    import torch
+    import libhm_amd
+    w, h, bd = 416, 240, 10
+    a = synth.make_picture(w, h, bd, seed=3, ref_handles=([0], [0]))
+    b = synth.make_picture(w, h, bd, seed=4, ref_handles=([0], [0]), mv_range=64)
+    from libhm_amd import abi
+    with libhm_amd.Context(abi.make_seq(w, h, bd, bd, log2_ctu=6, max_pictures=5)) as ctx:
+        h0, ha, hb, hr, hc = (ctx.acquire() for _ in range(5))
+        ctx.upload(h0, synth.noise_planes(w, h, bd, 1))
+        ctx.decompress_slice(ha, 0, a.slice, a.meta, a.coeffs)
+        ctx.filter_picture(ha, a.pp, a.sao_raw)
+        # picture B predicted from the original A
+        b.slice.ref_pic[0][0] = ha
+        ctx.decompress_slice(hb, 0, b.slice, b.meta, b.coeffs)
+        want = ctx.download(hb)
+        # ... and from a copy of A that travelled region-to-region on the context's stream
+        with torch.cuda.stream(torch.cuda.ExternalStream(ctx.stream_handle())):
+            src = fp.region_tensor(ctx, ha)
+            dst = fp.region_tensor(ctx, hr, receive=True)
+            assert src.numel() == dst.numel() and src.data_ptr() != dst.data_ptr()
+            dst.copy_(src)
+        ctx.commit_received(hr)
+        for x, y in zip(ctx.download(hr), ctx.download(ha)):
+            assert np.array_equal(x, y)
+        b.slice.ref_pic[0][0] = hr
+        ctx.decompress_slice(hc, 0, b.slice, b.meta, b.coeffs)
+        got = ctx.download(hc)
+        for x, y in zip(got, want):
+            assert np.array_equal(x, y)
