@@ -79,6 +79,7 @@ def main():
     ap.add_argument("--height", type=int, default=2160)
     ap.add_argument("--bi", type=int, default=0, help="1: B pictures (bi-prediction) instead of P")
     ap.add_argument("--workload", default="full", choices=("full", "idct", "mc", "mc_bi", "filter", "gop"))
+    ap.add_argument("--mode-probs", default=None, help="experiment: CTU partition probabilities 64x64,32x32,16x16,8x8,AMP (comma separated)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-steps", type=int, default=5)
     args = ap.parse_args()
@@ -103,13 +104,15 @@ def main():
         w, h = 1920, 1080
         stages, roof_kernel = RECON, "itx"
         kw = dict(mode_probs=(1.0, 0, 0, 0, 0), cbf_prob=1.0, coef_dist="stress", sao=False)
-    elif wl in ("mc", "mc_bi"):
+    if wl in ("mc", "mc_bi"):
         stages, roof_kernel = RECON, "mc_luma"
         args.bi = 1 if wl == "mc_bi" else 0
-    elif wl == "filter":
+    if wl == "filter":
         # the reconstruction stages run too: they regenerate the pre-filter picture that the in-place deblocking consumed
         roof_kernel = "sao"
         kw = dict(intra_frac=0.25)
+    if args.mode_probs:
+        kw["mode_probs"] = tuple(float(v) for v in args.mode_probs.split(","))
     # two distinct parsed pictures, staged alternately into nb device pictures with their own buffers
     # every picture of the batch predicts from its OWN reference pictures (no flattering reuse of one reference in cache)
     metas = [synth.make_picture(w, h, bd, seed=0x484D3136 + 7 * rank + i, bi=bool(args.bi), ref_handles=([0], [1]), **kw) for i in range(2)]
