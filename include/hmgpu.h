@@ -68,7 +68,8 @@ typedef struct hmgpu_seq_params {
   int32_t log2_ctu_size;          /* log2 g_uiMaxCUWidth: 4, 5 or 6.  partitions are 4x4 => (1<<(2*log2_ctu_size-4)) per CTU */
   int32_t max_pictures;           /* device pictures to pre-allocate (DPB size + pictures in flight) */
   int32_t pcm_loop_filter_disable;/* SPS pcm_loop_filter_disabled_flag && pcm_enabled_flag */
-  int32_t reserved[8];
+  int32_t strong_intra_smoothing; /* SPS strong_intra_smoothing_enabled_flag (TComPattern.cpp:201-216) */
+  int32_t reserved[7];
 } hmgpu_seq_params;
 
 /* Per-slice constants the hot path reads through pcCU->getSlice() */
@@ -84,7 +85,8 @@ typedef struct hmgpu_slice_params {
   int32_t num_ref_idx[2];
   hmgpu_pic ref_pic[2][HMGPU_MAX_REF];  /* getRefPic(list, idx) as device picture handles */
   int32_t ref_poc[2][HMGPU_MAX_REF];    /* getRefPOC(list, idx) (identical-motion test, TComPrediction.cpp:497-512) */
-  int32_t reserved[5];
+  int32_t constrained_intra_pred;       /* PPS constrained_intra_pred_flag (TComPattern.cpp:558-572) */
+  int32_t reserved[4];
 } hmgpu_slice_params;
 
 /* The picture-persistent TComDataCU arrays of TComPicSym (TComPicSym.cpp:93-114).  Every array covers the WHOLE

@@ -23,7 +23,7 @@ STAGE_DEBLOCK_VER, STAGE_DEBLOCK_HOR, STAGE_SAO, STAGE_RECON = 1, 2, 4, 8
 class SeqParams(C.Structure):
     _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("bit_depth_luma", C.c_int32), ("bit_depth_chroma", C.c_int32),
                 ("chroma_format", C.c_int32), ("log2_ctu_size", C.c_int32), ("max_pictures", C.c_int32),
-                ("pcm_loop_filter_disable", C.c_int32), ("reserved", C.c_int32 * 8)]
+                ("pcm_loop_filter_disable", C.c_int32), ("strong_intra_smoothing", C.c_int32), ("reserved", C.c_int32 * 7)]
 
 
 class SliceParams(C.Structure):
@@ -31,7 +31,7 @@ class SliceParams(C.Structure):
                 ("pps_cb_qp_offset", C.c_int32), ("pps_cr_qp_offset", C.c_int32), ("deblocking_disable", C.c_int32),
                 ("beta_offset_div2", C.c_int32), ("tc_offset_div2", C.c_int32), ("lf_across_slices", C.c_int32),
                 ("weighted_pred", C.c_int32), ("lf_across_tiles", C.c_int32), ("num_ref_idx", C.c_int32 * 2),
-                ("ref_pic", (C.c_int32 * MAX_REF) * 2), ("ref_poc", (C.c_int32 * MAX_REF) * 2), ("reserved", C.c_int32 * 5)]
+                ("ref_pic", (C.c_int32 * MAX_REF) * 2), ("ref_poc", (C.c_int32 * MAX_REF) * 2), ("constrained_intra_pred", C.c_int32), ("reserved", C.c_int32 * 4)]
 
 
 class CtuMeta(C.Structure):
@@ -64,7 +64,7 @@ def _ptr(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p).value
 
 
-def make_seq(width, height, bd_luma, bd_chroma=None, log2_ctu=6, max_pictures=8):
+def make_seq(width, height, bd_luma, bd_chroma=None, log2_ctu=6, max_pictures=8, strong_intra_smoothing=1):
     s = SeqParams()
     s.width, s.height = width, height
     s.bit_depth_luma = bd_luma
@@ -72,6 +72,7 @@ def make_seq(width, height, bd_luma, bd_chroma=None, log2_ctu=6, max_pictures=8)
     s.chroma_format = 1
     s.log2_ctu_size = log2_ctu
     s.max_pictures = max_pictures
+    s.strong_intra_smoothing = strong_intra_smoothing
     return s
 
 

@@ -479,6 +479,232 @@ static int pu_layout(int part_size, int cu_size, int num_part, int z_off[4], int
   return n;
 }
 
+/* ------------------------------------------------------------------------------------------------ intra prediction
+ * TDecCu::xReconIntraQT / xIntraRecQT / xIntraRecBlk (TDecCu.cpp:484-730), TComPrediction::initAdiPatternChType and
+ * fillReferenceSamples (TComPattern.cpp:107-500), predIntraAng / xPredIntraAng / xPredIntraPlanar / xDCPredFiltering
+ * (TComPrediction.cpp:182-228, 245-491, 746-840).  4:2:0, no RDPCM / cross-component prediction / PCM. */
+
+/* is the 4x4 luma partition at luma sample (px, py) usable as intra reference for the TU whose first partition is
+ * (cur_ctu, cur_z)?  TComDataCU::getPULeft/Above/AboveLeft/AboveRightAdi/BelowLeftAdi (TComDataCU.cpp:1177-1530) boil
+ * down to: inside the picture, decoded before the current TU, same slice and tile; with constrained intra prediction
+ * also "is intra" (TComPattern.cpp:558-700) */
+static int intra_avail(const geom* g, int cur_ctu, int cur_z, int px, int py, int cip)
+{
+  int nctu, nz;
+  if (px < 0 || py < 0 || px >= g->seq->width || py >= g->seq->height) return 0;
+  nctu = (py >> g->seq->log2_ctu_size) * g->ctus_w + (px >> g->seq->log2_ctu_size);
+  nz = xy2z((px & (g->ctu - 1)) >> 2, (py & (g->ctu - 1)) >> 2);
+  if (nctu == cur_ctu) { if (nz >= cur_z) return 0; }
+  else
+  {
+    if (nctu > cur_ctu) return 0;
+    if (slice_id(g, nctu) != slice_id(g, cur_ctu) || tile_id(g, nctu) != tile_id(g, cur_ctu)) return 0;
+  }
+  if (cip && PM(pred_mode, nctu, nz) != HMGPU_MODE_INTRA) return 0;
+  return 1;
+}
+
+/* reference line of a TU, 4N+1 samples: [0, 2N) left column from the bottom-most below-left sample up to the row of the
+ * TU's first line, [2N] the corner, (2N, 4N] the row above from left to right (fillReferenceSamples with the
+ * substitution of 8.4.4.2.2, which HM performs unit by unit: TComPattern.cpp:336-478) */
+static void intra_ref_line(const cu_ctx* c, int comp, int z_tu, int n, int x0, int y0, int* line)
+{
+  const geom* g = c->g;
+  const int cs = comp ? 1 : 0, unit = 4 >> cs, units = n / unit;       /* units per TU side = 4x4 luma partitions */
+  const int cip = slice_of(g, c->ctu_addr)->constrained_intra_pred;
+  const int lx = x0 << cs, ly = y0 << cs;                              /* TU origin in luma samples */
+  const int16_t* pl = c->cur->plane[comp];
+  const int stride = g->w[comp];
+  const int total = 4 * n + 1, corner = 2 * n;
+  uint8_t ok[4 * 32 + 1];
+  int i, any = 0;
+  for (i = 0; i < 2 * units; i++)
+  {
+    const int al = intra_avail(g, c->ctu_addr, z_tu, lx - 4, ly + 4 * i, cip);        /* left column, unit i from the top */
+    const int aa = intra_avail(g, c->ctu_addr, z_tu, lx + 4 * i, ly - 4, cip);        /* row above, unit i from the left */
+    int k;
+    for (k = 0; k < unit; k++)
+    {
+      ok[corner - 1 - (i * unit + k)] = (uint8_t)al;
+      ok[corner + 1 + i * unit + k] = (uint8_t)aa;
+    }
+    any |= al | aa;
+  }
+  ok[corner] = (uint8_t)intra_avail(g, c->ctu_addr, z_tu, lx - 4, ly - 4, cip);
+  any |= ok[corner];
+  if (!any) { for (i = 0; i < total; i++) line[i] = 1 << (g->bd[comp] - 1); return; }
+  for (i = 0; i < total; i++)
+  {
+    if (!ok[i]) continue;
+    if (i < corner) { const int r = corner - 1 - i; line[i] = pl[(size_t)(y0 + r) * stride + x0 - 1]; }
+    else if (i == corner) line[i] = pl[(size_t)(y0 - 1) * stride + x0 - 1];
+    else line[i] = pl[(size_t)(y0 - 1) * stride + x0 + (i - corner - 1)];
+  }
+  if (!ok[0])
+  {
+    int first = 1;
+    while (first < total && !ok[first]) first++;
+    line[0] = line[first];
+  }
+  for (i = 1; i < total; i++) if (!ok[i]) line[i] = line[i - 1];
+}
+
+/* TComPrediction::filteringIntraReferenceSamples + the smoothing of initAdiPatternChType (TComPattern.cpp:186-296, 531-556) */
+static void intra_smooth(const geom* g, int comp, int mode, int n, int log2n, const int* in, int* out)
+{
+  static const int thr[6] = { 0, 0, 10, 7, 1, 0 };                     /* m_aucIntraFilter by log2 size: TComPrediction.cpp:49-66 */
+  const int total = 4 * n + 1, corner = 2 * n;
+  int i, filt = 0;
+  if (comp == 0 && mode != 1 /* DC_IDX */)
+  {
+    const int d0 = iabs(mode - 10), d1 = iabs(mode - 26);
+    filt = imin(d0, d1) > thr[log2n];
+  }
+  for (i = 0; i < total; i++) out[i] = in[i];
+  if (!filt) return;
+  if (g->seq->strong_intra_smoothing && n == 32)
+  {
+    const int t = 1 << (g->bd[0] - 5);
+    const int bl = in[0], tl = in[corner], tr = in[total - 1];
+    if (iabs(bl + tl - 2 * in[n]) < t && iabs(tl + tr - 2 * in[corner + n]) < t)
+    {
+      for (i = 1; i < 2 * n; i++)
+      {
+        out[i] = ((2 * n - i) * bl + i * tl + n) >> (log2n + 1);
+        out[corner + i] = ((2 * n - i) * tl + i * tr + n) >> (log2n + 1);
+      }
+      return;
+    }
+  }
+  for (i = 1; i < total - 1; i++) out[i] = (in[i - 1] + 2 * in[i] + in[i + 1] + 2) >> 2;
+}
+
+/* predIntraAng: planar, DC (+ edge filter) and the 33 angular modes; pred is n x n, stride n */
+static void intra_predict(int comp, int bd, int mode, int n, int log2n, const int* line, int16_t* pred)
+{
+  const int corner = 2 * n;
+  const int* left = line + corner - 1;          /* left[-r] = row r */
+  const int* above = line + corner + 1;         /* above[x] */
+  const int maxv = (1 << bd) - 1;
+  const int edge = comp == 0 && n <= 16;        /* MAXIMUM_INTRA_FILTERED_WIDTH: TypeDef.h:117 */
+  int x, y;
+  if (mode == 0)
+  {
+    const int bl = left[-n], tr = above[n];
+    for (y = 0; y < n; y++)
+      for (x = 0; x < n; x++)
+      {
+        const int hor = (left[-y] << log2n) + n + (x + 1) * (tr - left[-y]);
+        const int ver = (above[x] << log2n) + (y + 1) * (bl - above[x]);
+        pred[y * n + x] = (int16_t)((hor + ver) >> (log2n + 1));
+      }
+    return;
+  }
+  if (mode == 1)
+  {
+    int sum = n, dc;
+    for (x = 0; x < n; x++) sum += above[x] + left[-x];
+    dc = sum >> (log2n + 1);
+    for (y = 0; y < n * n; y++) pred[y] = (int16_t)dc;
+    if (edge)
+    {
+      pred[0] = (int16_t)((above[0] + left[0] + 2 * dc + 2) >> 2);
+      for (x = 1; x < n; x++) pred[x] = (int16_t)((above[x] + 3 * dc + 2) >> 2);
+      for (y = 1; y < n; y++) pred[y * n] = (int16_t)((left[-y] + 3 * dc + 2) >> 2);
+    }
+    return;
+  }
+  {
+    static const int ang_table[9] = { 0, 2, 5, 9, 13, 17, 21, 26, 32 };
+    static const int inv_table[9] = { 0, 4096, 1638, 910, 630, 482, 390, 315, 256 };
+    const int ver = mode >= 18;
+    const int am = ver ? mode - 26 : -(mode - 10);
+    const int ang = (am < 0 ? -1 : 1) * ang_table[iabs(am)], inv = inv_table[iabs(am)];
+    int ref_buf[3 * 32 + 2];
+    int* ref = ref_buf + 32;                     /* ref[0] = corner, ref[1..] main side, ref[-1..] projected side samples */
+    int k;
+    /* main = above for vertical modes, left for horizontal ones; side = the other */
+#define MAIN(i) (ver ? line[corner + (i)] : line[corner - (i)])
+#define SIDE(i) (ver ? line[corner - (i)] : line[corner + (i)])
+    if (ang < 0)
+    {
+      int inv_sum = 128;
+      for (k = 0; k <= n; k++) ref[k] = MAIN(k);
+      for (k = -1; k > ((n * ang) >> 5); k--) { inv_sum += inv; ref[k] = SIDE(inv_sum >> 8); }
+    }
+    else
+      for (k = 0; k <= 2 * n; k++) ref[k] = MAIN(k);
+    for (y = 0; y < n; y++)
+    {
+      const int pos = (y + 1) * ang, di = pos >> 5, df = pos & 31;
+      for (x = 0; x < n; x++)
+      {
+        int v = df ? ((32 - df) * ref[x + di + 1] + df * ref[x + di + 2] + 16) >> 5 : ref[x + di + 1];
+        if (ang == 0 && edge && x == 0) v = CLIP3(0, maxv, v + ((SIDE(y + 1) - SIDE(0)) >> 1));
+        if (ver) pred[y * n + x] = (int16_t)v; else pred[x * n + y] = (int16_t)v;
+      }
+    }
+#undef MAIN
+#undef SIDE
+  }
+}
+
+/* xIntraRecBlk: prediction, residual, reconstruction straight into the picture (later TUs predict from it) */
+static void intra_tu(cu_ctx* c, int comp, int z_tu, int log2n, int cbf_depth, int coef_off)
+{
+  const geom* g = c->g;
+  const int a = c->ctu_addr, cs = comp ? 1 : 0, n = 1 << log2n;
+  const int x0 = ((a % g->ctus_w) * g->ctu + zx(z_tu) * 4) >> cs, y0 = ((a / g->ctus_w) * g->ctu + zy(z_tu) * 4) >> cs;
+  const hmgpu_slice_params* sl = slice_of(g, a);
+  int mode = comp == 0 ? g->m->intra_dir[0][(size_t)a * g->parts + z_tu] : g->m->intra_dir[1][(size_t)a * g->parts + z_tu];
+  int line[4 * 32 + 1], fl[4 * 32 + 1];
+  int16_t pred[32 * 32], resi[32 * 32];
+  int16_t* dst = c->cur->plane[comp] + (size_t)y0 * g->w[comp] + x0;
+  const int maxv = (1 << g->bd[comp]) - 1;
+  int x, y;
+  if (comp != 0 && mode == 36) mode = g->m->intra_dir[0][(size_t)a * g->parts + (z_tu & ~3)];   /* DM_CHROMA_IDX: TDecCu.cpp:523-524 */
+  intra_ref_line(c, comp, z_tu, n, x0, y0, line);
+  intra_smooth(g, comp, mode, n, log2n, line, fl);
+  intra_predict(comp, g->bd[comp], mode, n, log2n, fl, pred);
+  memset(resi, 0, sizeof(int16_t) * n * n);
+  if ((g->m->cbf[comp][(size_t)a * g->parts + z_tu] >> cbf_depth) & 1)
+  {
+    int per, rem, flags = comp == 0 ? 1 : 0;
+    const int cqo = comp == 1 ? sl->cb_qp_offset : (comp == 2 ? sl->cr_qp_offset : 0);
+    const int16_t* lev = c->co->level[comp] + (size_t)a * ((g->ctu * g->ctu) >> (comp ? 2 : 0)) + coef_off;
+    hmo_qp_param(PM(qp, a, c->cu_z), comp, g->bd[comp], cqo, &per, &rem);
+    if (g->m->transform_skip[comp] && g->m->transform_skip[comp][(size_t)a * g->parts + z_tu]) flags |= 2;
+    hmo_inverse_transform_tu(lev, resi, n, log2n, g->bd[comp], per, rem, flags);
+  }
+  for (y = 0; y < n; y++)
+    for (x = 0; x < n; x++)
+      dst[(size_t)y * g->w[comp] + x] = (int16_t)CLIP3(0, maxv, pred[y * n + x] + resi[y * n + x]);
+}
+
+/* xIntraRecQT for one channel type (ch 0 luma, 1 chroma = Cb then Cr per TU) */
+static void intra_recurse(cu_ctx* c, int ch, int z, int tr_depth, int log2_luma)
+{
+  const geom* g = c->g;
+  if (tr_depth == PM(tr_idx, c->ctu_addr, z))
+  {
+    if (ch == 0) intra_tu(c, 0, z, log2_luma, tr_depth, 16 * z);
+    else { intra_tu(c, 1, z, log2_luma - 1, tr_depth, 4 * z); intra_tu(c, 2, z, log2_luma - 1, tr_depth, 4 * z); }
+    return;
+  }
+  if (ch != 0 && log2_luma == 3)
+  {
+    /* four 4x4 luma TUs, one 4x4 chroma TU per component with the first of them (TComTU.cpp:141-171), cbf at the child depth */
+    intra_tu(c, 1, z, 2, tr_depth + 1, 4 * z);
+    intra_tu(c, 2, z, 2, tr_depth + 1, 4 * z);
+    return;
+  }
+  {
+    const int q = 1 << (2 * (log2_luma - 1 - 2));
+    int i;
+    for (i = 0; i < 4; i++) intra_recurse(c, ch, z + i * q, tr_depth + 1, log2_luma - 1);
+  }
+}
+
 /* TDecCu::xDecompressCU: TLibDecoder/TDecCu.cpp:373-447 */
 static void decompress_cu(cu_ctx* c, int z, int depth, int64_t* n_intra)
 {
@@ -501,7 +727,14 @@ static void decompress_cu(cu_ctx* c, int z, int depth, int64_t* n_intra)
     return;
   }
   c->cu_z = z; c->cu_x = lx; c->cu_y = ty; c->cu_size = size;
-  if (PM(pred_mode, a, z) == HMGPU_MODE_INTRA) { *n_intra += num_part; return; }     /* xReconIntraQT: not restated yet */
+  if (PM(pred_mode, a, z) == HMGPU_MODE_INTRA)
+  {
+    *n_intra += num_part;
+    if (!g->m->intra_dir[0] || !g->m->intra_dir[1]) return;      /* no intra modes supplied: the CU's samples are left alone */
+    intra_recurse(c, 0, z, 0, g->seq->log2_ctu_size - depth);       /* xReconIntraQT: luma of the whole CU, then chroma (:665-690) */
+    intra_recurse(c, 1, z, 0, g->seq->log2_ctu_size - depth);
+    return;
+  }
   {
     /* xReconInter: TDecCu.cpp:449-482 */
     int z_off[4], xr[4], yr[4], w[4], h[4], i, comp, x, y;

@@ -28,7 +28,7 @@ HM_CFG = "/root/reference/cfg"
 
 
 # ------------------------------------------------------------------------------------------ synthetic clips
-def synth_clip(w, h, frames, bit_depth, seed):
+def synth_clip(w, h, frames, bit_depth, seed, novel=False):
     """gradient + checker + moving textured blobs + seeded noise, 4:2:0 planar, returns list of (Y,U,V) uint16"""
     rng = np.random.RandomState(seed)
     maxv = (1 << bit_depth) - 1
@@ -54,6 +54,12 @@ def synth_clip(w, h, frames, bit_depth, seed):
         x2, y2 = min(ox + bw, w), min(oy + bh, h)
         if x2 > x1 and y2 > y1:
             img[y1:y2, x1:x2] = tex2[100 + y1 - oy:100 + y2 - oy, 100 + x1 - ox:100 + x2 - ox]
+        if novel and f > 0:
+            # content with no counterpart in any earlier frame (a new smooth ramp + stripes patch per frame): intra CUs in P pictures
+            pw_, ph_ = 56, 48
+            px_, py_ = int(w * 0.5) + 9 * f, int(h * 0.08) + 5 * f
+            gy, gx = np.mgrid[0:ph_, 0:pw_].astype(np.float64)
+            img[py_:py_ + ph_, px_:px_ + pw_] = 0.5 + 0.4 * np.sin(gx / (2.0 + f) + f) * np.cos(gy / (3.0 + 0.5 * f)) * (1 if f % 2 else -1)
         img = img + 0.012 * rng.randn(h, w)
         Y = np.clip(np.round(img * maxv), 0, maxv).astype(np.uint16)
         U = np.clip(np.round((0.5 + 0.2 * np.sin((xx[:h // 2, :w // 2] + 3 * f) / 11.0)) * maxv), 0, maxv).astype(np.uint16)
@@ -79,13 +85,15 @@ STREAMS = {
     # NOTE: multi-slice inter streams (--SliceMode=1) are not used: HM 16.0's own TAppDecoder asserts
     # (TComBitStream.h:191) on the streams its encoder writes for them, at every optimisation level.
     "intra_main10_208x120": ("encoder_intra_main10.cfg", 208, 120, 1, 10, 10, 30, []),
+    # constrained intra prediction (inter neighbours are not intra references) and no strong smoothing, P pictures with intra CUs
+    "ldp_cip_main10_208x120": ("encoder_lowdelay_P_main10.cfg", 208, 120, 3, 10, 10, 30, ["--ConstrainedIntraPred=1", "--StrongIntraSmoothing=0"]),
 }
 
 
 def encode(name, tmp):
     cfg, w, h, frames, ibd, bd, qp, extra = STREAMS[name]
     yuv = os.path.join(tmp, name + ".yuv")
-    clip = synth_clip(w, h, frames, ibd, seed=0x484D + sum(map(ord, name)))
+    clip = synth_clip(w, h, frames, ibd, seed=0x484D + sum(map(ord, name)), novel="cip" in name)
     write_yuv(yuv, clip, ibd)
     bs = os.path.join(tmp, name + ".bin")
     rec = os.path.join(tmp, name + "_rec.yuv")

@@ -246,7 +246,7 @@ void ref_dec_info(void* h, int32_t* info)
  * 0 sliceType 1 sliceQp 2 ppsCbOff 3 ppsCrOff 4 sliceCbDelta 5 sliceCrDelta 6 deblockDisable 7 betaOffDiv2 8 tcOffDiv2
  * 9 lfAcrossSlices 10 saoLuma 11 saoChroma 12 numRefIdx0 13 numRefIdx1 14 useWP 15 wpBiPred 16 transquantBypassEnable
  * 17 usePCM 18 pcmFilterDisable 19 sliceCurStartCUAddr(in partitions) 20 scalingListEnabled 21 signHiding(unused)
- * 22 useTransformSkip 23 sliceCurEndCUAddr 24 chromaQpAdjTableSize
+ * 22 useTransformSkip 23 sliceCurEndCUAddr 24 chromaQpAdjTableSize 25 strongIntraSmoothing 26 constrainedIntraPred 27 flagsValid(=1)
  * 32..47 refPOC L0, 48..63 refPOC L1                                                                               */
 void ref_dec_slices(void* h, int32_t* out)
 {
@@ -271,6 +271,9 @@ void ref_dec_slices(void* h, int32_t* out)
     o[20] = s->getSPS()->getScalingListFlag() ? 1 : 0;
     o[22] = s->getPPS()->getUseTransformSkip() ? 1 : 0;
     o[23] = s->getSliceCurEndCUAddr();
+    o[25] = s->getSPS()->getUseStrongIntraSmoothing() ? 1 : 0;
+    o[26] = s->getPPS()->getConstrainedIntraPred() ? 1 : 0;
+    o[27] = 1;
     for (int l = 0; l < 2; l++)
       for (int r = 0; r < o[12 + l] && r < 16; r++)
         o[32 + 16 * l + r] = s->getRefPOC(RefPicList(l), r);

@@ -7,7 +7,7 @@ import numpy as np
 from libhm_amd import abi
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-STREAMS = ["ldp_main8_416x240", "ra_main10_208x120", "ldp_main10_208x120", "intra_main10_208x120"]
+STREAMS = ["ldp_main8_416x240", "ra_main10_208x120", "ldp_main10_208x120", "intra_main10_208x120", "ldp_cip_main10_208x120"]
 _cache = {}
 
 
@@ -26,7 +26,9 @@ class Picture:
         (self.width, self.height, self.bd_y, self.bd_c, self.poc, self.slice_type, self.num_ctus, self.ctus_w, self.parts,
          self.ctu_size, self.num_slices, self.use_sao, self.lf_across_tiles) = (int(v) for v in info[:13])
         self.index = idx
-        self.seq = abi.make_seq(self.width, self.height, self.bd_y, self.bd_c, log2_ctu=int(np.log2(self.ctu_size)), max_pictures=12)
+        s0 = z[k + "slices"][0]
+        self.seq = abi.make_seq(self.width, self.height, self.bd_y, self.bd_c, log2_ctu=int(np.log2(self.ctu_size)), max_pictures=12,
+                                strong_intra_smoothing=int(s0[25]) if int(s0[27]) else 1)
         self.slices = []
         self.ref_pocs = set()
         for s in z[k + "slices"]:
@@ -40,6 +42,7 @@ class Picture:
             self.slices.append(abi.make_slice(int(s[0]), refs, pocs, cb_qp_offset=int(s[2] + s[4]), cr_qp_offset=int(s[3] + s[5]),
                                               pps_cb=int(s[2]), pps_cr=int(s[3]), deblocking_disable=int(s[6]),
                                               beta_offset_div2=int(s[7]), tc_offset_div2=int(s[8]), lf_across_slices=int(s[9])))
+            self.slices[-1].constrained_intra_pred = int(s[26])
         m = {n: z[k + "meta_" + n] for n in ("depth", "part_size", "pred_mode", "qp", "tr_idx", "cbf_y", "cbf_u", "cbf_v", "ts_y",
                                              "ts_u", "ts_v", "mv0", "mv1", "ref_idx0", "ref_idx1", "intra_dir_l", "intra_dir_c",
                                              "bypass", "ipcm")}

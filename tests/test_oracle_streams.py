@@ -7,26 +7,30 @@ from tests import golden_util as gu
 
 
 @pytest.mark.parametrize("name", gu.STREAMS)
-def test_reconstruction_of_inter_cus_matches_hm(oracle, name):
+def test_reconstruction_matches_hm(oracle, name):
+    """every sample of every picture -- inter CUs (MC + residual) and intra CUs (reference samples, smoothing, planar / DC /
+    angular prediction, residual, in decoding order) -- recomputed from the parsed data alone"""
     pics = gu.stream_pictures(name)
     finals = []
-    n_checked = 0
+    n_intra_total = 0
     for p in pics:
-        # start from HM's own pre-deblock planes so that intra CUs (not restated) carry HM's samples; then wipe the
-        # inter CUs to prove they are really recomputed
-        cur = [a.copy() for a in p.pre]
-        masks = [p.inter_mask(c) for c in range(3)]
-        for c in range(3):
-            cur[c][masks[c]] = -1
+        cur = [np.full_like(a, -1) for a in p.pre]
         n_intra = oracle.decompress_ctus(p.seq, p.slices, p.meta, p.coeffs, cur, finals)
         for c in range(3):
             assert np.array_equal(cur[c], p.pre[c]), "%s pic %d comp %d" % (name, p.index, c)
-            n_checked += int(masks[c].sum())
-        assert n_intra == int(((p.meta_np["pred_mode"] == 1) & (p.meta_np["part_size"] != 8)
-                               & _inside(p)).sum())
+        assert n_intra == int(((p.meta_np["pred_mode"] == 1) & (p.meta_np["part_size"] != 8) & _inside(p)).sum())
+        n_intra_total += n_intra
         finals.append(p.fin)
-    if name != "intra_main10_208x120":
-        assert n_checked > 0
+    assert n_intra_total > 0
+
+
+def test_constrained_intra_fixture_really_is_constrained():
+    pics = gu.stream_pictures("ldp_cip_main10_208x120")
+    assert all(sl.constrained_intra_pred == 1 for p in pics for sl in p.slices)
+    assert pics[0].seq.strong_intra_smoothing == 0
+    # P pictures with both intra and inter CUs, otherwise the flag would not matter
+    assert any(((p.meta_np["pred_mode"] == 1) & (p.meta_np["part_size"] != 8)).any() and (p.meta_np["pred_mode"] == 0).any()
+               for p in pics[1:])
 
 
 def _inside(p):
