@@ -17,9 +17,9 @@ using namespace hmgpu;
 
 namespace {
 
-enum { K_PREP = 0, K_MC_LUMA, K_MC_CHROMA, K_ITX, K_DBK_VER, K_DBK_HOR, K_SAO, K_EXTEND, K_H2D, K_RES9, K_RES10, K_RES11 };
+enum { K_PREP = 0, K_MC_LUMA, K_MC_CHROMA, K_ITX, K_DBK_VER, K_DBK_HOR, K_SAO, K_EXTEND, K_H2D, K_INTRA, K_RES10, K_RES11 };
 const char* const kKernelNames[HMGPU_NUM_KERNELS] = {"prep", "mc_luma", "mc_chroma", "itx", "deblock_ver", "deblock_hor", "sao",
-                                                     "extend_border", "h2d_stage", "", "", ""};
+                                                     "extend_border", "h2d_stage", "intra", "", ""};
 
 struct SliceCall { int first_ctu, num_ctus, slice_idx; };
 
@@ -134,6 +134,7 @@ hmgpu_status alloc_picture(hmgpu_ctx* c, Picture& p) {
     for (int k = 0; k < 3; k++) d.tskip[k] = m.take<uint8_t>(np);
     for (int k = 0; k < 2; k++) d.mv[k] = m.take<int16_t>(np * 2);
     for (int k = 0; k < 2; k++) d.ref_idx[k] = m.take<int8_t>(np);
+    for (int k = 0; k < 2; k++) d.intra_dir[k] = m.take<uint8_t>(np);
     d.slice_idx = m.take<uint16_t>(c->num_ctus); d.tile_idx = m.take<uint16_t>(c->num_ctus);
     if (!pass) { HIP_TRY(c, hipMalloc(&p.meta, m.off)); HIP_TRY(c, hipMemset(p.meta, 0, m.off)); }
   }
@@ -154,6 +155,8 @@ hmgpu_status alloc_picture(hmgpu_ctx* c, Picture& p) {
     d.stats = m.take<unsigned long long>(2 * kTuShards);
     d.saoprm = m.take<SaoDev>((size_t)c->num_ctus * 3);
     d.slices = m.take<SliceDev>(HMGPU_MAX_SLICES);
+    d.ctu_intra = m.take<uint8_t>((size_t)c->num_ctus);
+    d.intra_progress = m.take<uint32_t>((size_t)3 * c->ctus_h);
     if (!pass) { HIP_TRY(c, hipMalloc(&p.derived, m.off)); HIP_TRY(c, hipMemset(p.derived, 0, m.off)); }
   }
   PicDev& d = p.dev;
@@ -163,6 +166,7 @@ hmgpu_status alloc_picture(hmgpu_ctx* c, Picture& p) {
   for (int k = 0; k < 3; k++) d.pitch[k] = c->pitch[k];
   d.grid_w = c->grid_w; d.grid_h = c->grid_h;
   d.lf_across_tiles = 1; d.sao_applied = 0;
+  d.has_intra_dir = 0; d.strong_intra_smoothing = s.strong_intra_smoothing ? 1 : 0;
   for (int k = 0; k < 4; k++) d.tu_cap[k] = c->tu_cap[k];
   {
     // plane pointers address sample (0,0); the margins lie at negative coordinates
@@ -232,6 +236,10 @@ hmgpu_status run_recon(hmgpu_ctx* c, const Batch& b) {
   int cmask = 0;
   if (const char* e = getenv("HMGPU_ITX_CLASSES")) cmask = atoi(e);              // tuning aid (wrong output unless 15)
   { ProfScope ps(c, K_ITX); launch_itx(c->d_pics, b, cmask, bps, c->stream); }
+  // intra CUs predict from finished neighbours (inter ones included): after motion compensation and the inter residuals
+  bool any_intra = false;
+  for (int i = 0; i < b.n; i++) any_intra |= c->pics[b.pic[i]].dev.has_intra_dir != 0;
+  if (any_intra) { ProfScope ps(c, K_INTRA); launch_intra(c->d_pics, b, c->ctus_h, c->stream); }
   HIP_TRY(c, hipGetLastError());
   return HMGPU_OK;
 }
@@ -535,6 +543,7 @@ hmgpu_status hmgpu_decompress_slice(hmgpu_ctx* c, hmgpu_pic cur, int32_t slice_i
   sd.pps_cb_qp_offset = sl->pps_cb_qp_offset; sd.pps_cr_qp_offset = sl->pps_cr_qp_offset;
   sd.deblocking_disable = sl->deblocking_disable; sd.beta_offset_div2 = sl->beta_offset_div2; sd.tc_offset_div2 = sl->tc_offset_div2;
   sd.lf_across_slices = sl->lf_across_slices;
+  sd.constrained_intra_pred = sl->constrained_intra_pred ? 1 : 0;
   for (int l = 0; l < 2; l++)
     for (int i = 0; i < HMGPU_MAX_REF; i++) {
       sd.ref_poc[l][i] = i < sl->num_ref_idx[l] ? sl->ref_poc[l][i] : 0;
@@ -543,6 +552,7 @@ hmgpu_status hmgpu_decompress_slice(hmgpu_ctx* c, hmgpu_pic cur, int32_t slice_i
   p.slices[slice_idx] = sd;
   p.max_slice = std::max(p.max_slice, (int)slice_idx);
   p.dev.lf_across_tiles = sl->lf_across_tiles;
+  p.dev.has_intra_dir = (m->intra_dir[0] && m->intra_dir[1]) ? 1 : 0;      // without the modes intra CUs are left untouched
   {
     ProfScope ps(c, K_H2D);
     HIP_TRY(c, hipMemcpyAsync((void*)(p.dev.slices + slice_idx), &p.slices[slice_idx], sizeof(SliceDev), hipMemcpyHostToDevice, c->stream));
@@ -555,6 +565,7 @@ hmgpu_status hmgpu_decompress_slice(hmgpu_ctx* c, hmgpu_pic cur, int32_t slice_i
     STAGE(p.dev.qp, m->qp, 1); STAGE(p.dev.tr_idx, m->tr_idx, 1);
     for (int k = 0; k < 3; k++) { STAGE(p.dev.cbf[k], m->cbf[k], 1); STAGE(p.dev.tskip[k], m->transform_skip[k], 1); }
     for (int k = 0; k < 2; k++) { STAGE(p.dev.mv[k], m->mv[k], 4); STAGE(p.dev.ref_idx[k], m->ref_idx[k], 1); }
+    if (p.dev.has_intra_dir) { STAGE(p.dev.intra_dir[0], m->intra_dir[0], 1); STAGE(p.dev.intra_dir[1], m->intra_dir[1], 1); }
 #undef STAGE
     // per-CTU slice / tile index (the slice index of this call wins over a missing array)
     {

@@ -61,6 +61,7 @@ struct SliceDev {
   int32_t deblocking_disable, beta_offset_div2, tc_offset_div2, lf_across_slices;
   int32_t ref_poc[2][HMGPU_MAX_REF];
   int8_t  ref_pic[2][HMGPU_MAX_REF];
+  int32_t constrained_intra_pred;
 };
 
 struct SaoDev {                 // reconstructed SAO parameters of one CTU component, 12 bytes
@@ -90,6 +91,7 @@ struct PicDev {
   const uint8_t* depth; const int8_t* part_size; const int8_t* pred_mode; const int8_t* qp; const uint8_t* tr_idx;
   const uint8_t* cbf[3]; const uint8_t* tskip[3];
   const int16_t* mv[2]; const int8_t* ref_idx[2];
+  const uint8_t* intra_dir[2];     // m_puhIntraDir[luma, chroma]
   const uint16_t* slice_idx; const uint16_t* tile_idx;
   const int16_t* coef[3];
   const SliceDev* slices;
@@ -100,6 +102,11 @@ struct PicDev {
   uint32_t tu_cap[4];              // capacity of ONE shard
   SaoDev* saoprm;                  // [num_ctus][3]
   unsigned long long* stats;       // [2][kTuShards]: intra / inter partitions seen by the prep kernel
+  // intra reconstruction (k_intra.hip)
+  int32_t has_intra_dir;           // the caller supplied intra prediction modes (else intra CUs are left untouched)
+  int32_t strong_intra_smoothing;  // SPS flag
+  uint8_t* ctu_intra;              // [num_ctus] 1 = the CTU holds intra CUs (written by k_prep)
+  uint32_t* intra_progress;        // [3][ctus_h]: CTU columns of a row that are complete, per component (wavefront over CTU rows)
 };
 
 // batched launch descriptor, passed by value
@@ -163,6 +170,7 @@ void launch_mc_luma(const PicDev* pics, const PlaneSet* finals, const Batch& b, 
 int launch_mc_luma_stamped(const PicDev* pics, const PlaneSet* finals, const Batch& b, int max_ctus, int log2ctu, unsigned long long* stamps, hipStream_t s);
 void launch_mc_chroma(const PicDev* pics, const PlaneSet* finals, const Batch& b, int max_ctus, int log2ctu, hipStream_t s);
 void launch_itx(const PicDev* pics, const Batch& b, int log2size, uint32_t blocks_per_shard, hipStream_t s);
+void launch_intra(const PicDev* pics, const Batch& b, int ctus_h, hipStream_t s);
 void launch_deblock(const PicDev* pics, const Batch& b, int dir, int width, int height, hipStream_t s);
 void launch_sao(const PicDev* pics, const Batch& b, int width, int height, hipStream_t s);
 void launch_extend(const PicDev* pics, const Batch& b, int width, int height, int mx, int my, hipStream_t s);

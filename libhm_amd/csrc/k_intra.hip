@@ -1,0 +1,339 @@
+// k_intra.hip -- reconstruction of intra CUs: reference samples, smoothing, planar / DC / angular prediction, residual.
+//   TDecCu::xReconIntraQT -> xIntraRecQT -> xIntraRecBlk                                   TDecCu.cpp:484-730
+//   TComPrediction::initAdiPatternChType, fillReferenceSamples, availability helpers       TComPattern.cpp:107-700
+//   TComPrediction::predIntraAng, xPredIntraAng, xPredIntraPlanar, xDCPredFiltering        TComPrediction.cpp:182-491,746-840
+//
+// Intra prediction is the one serial chain of the reconstruction path: a TU predicts from the reconstructed samples of the
+// TUs before it in decoding order.  What IS independent: the three components (HM reconstructs the luma of a CU, then its
+// chroma, and chroma never reads luma samples: TDecCu.cpp:665-690), and CTU rows once the CTU above-right is done.  So one
+// wave walks one CTU row of one component; rows advance as a wavefront (row r may work on CTU column c when row r-1 has
+// finished column c+1), synchronised through one progress counter per row and component.  CTUs without intra CUs (flags
+// from k_prep) cost nothing: their samples were finished by the MC / residual kernels before this kernel started, and a row
+// only ever waits on behalf of a CTU that does hold intra CUs.  Inside a CTU the wave takes the TUs in z order; for each TU
+// the lanes build the 4N+1 reference samples together (availability per 4x4 unit as one ballot mask, the substitution
+// process of fillReferenceSamples as bit scans over that mask), lane n predicts row n, the residual comes from the same
+// itx_tu() the inter path uses, and the clipped row goes back to the picture.
+//
+// Samples written here are read by other waves on other XCDs (whose L2s are not coherent with each other): every access to
+// the picture planes in this kernel is an agent-scope atomic dword access (served at the coherent level), ordered against
+// the progress counters by release / acquire.
+#include "hmgpu_dev.h"
+#include "itx_core.h"
+#include <algorithm>
+
+namespace hmgpu {
+
+namespace {
+
+// QpParam (TComTrQuant.cpp:71-100) for 4:2:0
+__device__ inline void qp_param_tu(int qp_y, int comp, int bd, int chroma_off, int& per, int& rem) {
+  constexpr uint8_t chroma_scale_420[58] = {0,  1,  2,  3,  4,  5,  6,  7,  8,  9,  10, 11, 12, 13, 14, 15, 16, 17, 18, 19,
+                                            20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 29, 30, 31, 32, 33, 33, 34, 34, 35, 35,
+                                            36, 36, 37, 37, 38, 39, 40, 41, 42, 43, 44, 45, 46, 47, 48, 49, 50, 51};   // g_aucChromaScale[CHROMA_420], TComRom.cpp:503
+  const int bdo = 6 * (bd - 8);
+  int base;
+  if (comp == 0) base = qp_y + bdo;
+  else {
+    base = clip3(-bdo, 57, qp_y + chroma_off);
+    base = base < 0 ? base + bdo : chroma_scale_420[base] + bdo;
+  }
+  per = base / 6;
+  rem = base % 6;
+}
+
+// coherent accesses to the picture being reconstructed
+__device__ inline uint32_t ld_coh(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ inline void st_coh(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ inline int ld_sample(const int16_t* p) {
+  const uintptr_t a = reinterpret_cast<uintptr_t>(p);
+  const uint32_t w = ld_coh(reinterpret_cast<const uint32_t*>(a & ~(uintptr_t)3));
+  return (int)(int16_t)((a & 2) ? (w >> 16) : (w & 0xffffu));
+}
+
+struct IntraLds {
+  int line[4 * 32 + 4];                  // reference line: [0,2N) left column bottom-up, [2N] corner, (2N,4N] row above
+  int filt[4 * 32 + 4];                  // the same after smoothing
+  int proj[3 * 32 + 4];                  // angular modes: main reference incl. the projected side samples, index k + 32
+  __attribute__((aligned(16))) int tile[2 * 32 * 36];      // itx_tu scratch, sized for the largest class (two 32x32 slots per wave)
+  __attribute__((aligned(16))) int16_t ctile[2 * 32 * 32];
+};
+
+struct TuCtx {
+  int comp, ctu, z_tu, log2n, mode, cbf, x0, y0, qp_cu;     // x0, y0: component samples
+};
+
+// availability of the 4x4 luma partition at luma sample (px, py) as intra reference of the TU at (ctu, z_tu)
+__device__ inline bool intra_avail(const PicDev& P, int ctu, int z_tu, int px, int py, bool cip) {
+  if (px < 0 || py < 0 || px >= P.width || py >= P.height) return false;
+  const int ctu_mask = (1 << P.log2ctu) - 1;
+  const int nctu = (py >> P.log2ctu) * P.ctus_w + (px >> P.log2ctu);
+  const int bx = (px & ctu_mask) >> 2, by = (py & ctu_mask) >> 2;
+  int nz = 0;
+#pragma unroll
+  for (int k = 0; k < 4; k++) nz |= (((bx >> k) & 1) << (2 * k)) | (((by >> k) & 1) << (2 * k + 1));
+  if (nctu == ctu) { if (nz >= z_tu) return false; }
+  else {
+    if (nctu > ctu) return false;
+    if (ldg(P.slice_idx + nctu) != ldg(P.slice_idx + ctu) || ldg(P.tile_idx + nctu) != ldg(P.tile_idx + ctu)) return false;
+  }
+  if (cip && ldg(P.pred_mode + (size_t)nctu * P.parts + nz) != HMGPU_MODE_INTRA) return false;
+  return true;
+}
+
+__device__ inline int wave_sum(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// one TU: everything between "the neighbours are reconstructed" and "this TU is reconstructed"
+template <int LOG2N>
+__device__ inline void intra_tu(const PicDev& P, const TuCtx& t, IntraLds& L) {
+  constexpr int N = 1 << LOG2N;
+  const int lane = threadIdx.x & 63;
+  const int comp = t.comp, cs = comp ? 1 : 0;
+  const int bd = P.bd[comp], maxv = (1 << bd) - 1;
+  const int pitch = P.pitch[comp];
+  int16_t* plane = P.rec[comp];
+  const int us = 4 >> cs, U = N / us;                      // samples per availability unit, units per TU side
+  const int corner = 2 * N, total = 4 * N + 1;
+  const int lx = t.x0 << cs, ly = t.y0 << cs;              // TU origin in luma samples
+  const bool cip = ldg(&P.slices[ldg(P.slice_idx + t.ctu)].constrained_intra_pred) != 0;
+
+  // ---- A. availability per unit: units [0, 2U) left column bottom-up, 2U the corner, (2U, 4U] the row above
+  bool av = false;
+  if (lane <= 4 * U) {
+    int px, py;
+    if (lane < 2 * U) { px = lx - 4; py = ly + 4 * (2 * U - 1 - lane); }
+    else if (lane == 2 * U) { px = lx - 4; py = ly - 4; }
+    else { px = lx + 4 * (lane - 2 * U - 1); py = ly - 4; }
+    av = intra_avail(P, t.ctu, t.z_tu, px, py, cip);
+  }
+  const unsigned long long am = __builtin_amdgcn_ballot_w64(av);
+  for (int i = lane; i < total; i += 64) {
+    int v = 1 << (bd - 1);
+    if (am) {
+      const int u = i < corner ? i / us : (i == corner ? 2 * U : 2 * U + 1 + (i - corner - 1) / us);
+      int src = i;
+      if (!((am >> u) & 1)) {
+        const unsigned long long lower = am & ((1ull << u) - 1);
+        int j, last;
+        if (lower) { j = 63 - __builtin_clzll(lower); last = 1; } else { j = __builtin_ctzll(am); last = 0; }
+        const int first_of = j < 2 * U ? j * us : (j == 2 * U ? corner : corner + 1 + (j - 2 * U - 1) * us);
+        src = first_of + ((last && j != 2 * U) ? us - 1 : 0);
+      }
+      const int16_t* q;
+      if (src < corner) q = plane + (ptrdiff_t)(t.y0 + (corner - 1 - src)) * pitch + t.x0 - 1;
+      else if (src == corner) q = plane + (ptrdiff_t)(t.y0 - 1) * pitch + t.x0 - 1;
+      else q = plane + (ptrdiff_t)(t.y0 - 1) * pitch + t.x0 + (src - corner - 1);
+      v = ld_sample(q);
+    }
+    L.line[i] = v;
+  }
+  wave_lds_sync();
+
+  // ---- B. smoothing (filteringIntraReferenceSamples + initAdiPatternChType)
+  {
+    const int thr = LOG2N == 2 ? 10 : LOG2N == 3 ? 7 : LOG2N == 4 ? 1 : 0;
+    const int d0 = abs(t.mode - 10), d1 = abs(t.mode - 26);
+    const bool filt = comp == 0 && t.mode != 1 && min(d0, d1) > thr;
+    bool strong = false;
+    int bl = 0, tl = 0, tr = 0;
+    if (filt && N == 32 && P.strong_intra_smoothing) {
+      bl = L.line[0]; tl = L.line[corner]; tr = L.line[total - 1];
+      const int th = 1 << (bd - 5);
+      strong = abs(bl + tl - 2 * L.line[N]) < th && abs(tl + tr - 2 * L.line[corner + N]) < th;
+    }
+    for (int i = lane; i < total; i += 64) {
+      int v = L.line[i];
+      if (filt && i > 0 && i < total - 1) {
+        if (strong) {
+          if (i < corner) v = ((2 * N - i) * bl + i * tl + N) >> (LOG2N + 1);
+          else if (i > corner) v = ((2 * N - (i - corner)) * tl + (i - corner) * tr + N) >> (LOG2N + 1);
+        } else {
+          v = (L.line[i - 1] + 2 * v + L.line[i + 1] + 2) >> 2;
+        }
+      }
+      L.filt[i] = v;
+    }
+  }
+  wave_lds_sync();
+
+  // ---- C. prediction of row n by lane n
+  const int n = lane & (N - 1);
+  const bool active = lane < N;
+  const int* f = L.filt;
+  const bool edge = comp == 0 && N <= 16;                   // MAXIMUM_INTRA_FILTERED_WIDTH (TypeDef.h:117)
+  int p[N];
+  if (t.mode == 0) {
+    const int left = f[corner - 1 - n], bl = f[corner - 1 - N], tr = f[corner + 1 + N];
+#pragma unroll
+    for (int x = 0; x < N; x++) {
+      const int ab = f[corner + 1 + x];
+      p[x] = ((left << LOG2N) + N + (x + 1) * (tr - left) + (ab << LOG2N) + (n + 1) * (bl - ab)) >> (LOG2N + 1);
+    }
+  } else if (t.mode == 1) {
+    const int dc = (wave_sum(active ? f[corner + 1 + n] + f[corner - 1 - n] : 0) + N) >> (LOG2N + 1);
+#pragma unroll
+    for (int x = 0; x < N; x++) p[x] = dc;
+    if (edge) {
+      if (n == 0) {
+#pragma unroll
+        for (int x = 1; x < N; x++) p[x] = (f[corner + 1 + x] + 3 * dc + 2) >> 2;
+        p[0] = (f[corner + 1] + f[corner - 1] + 2 * dc + 2) >> 2;
+      } else {
+        p[0] = (f[corner - 1 - n] + 3 * dc + 2) >> 2;
+      }
+    }
+  } else {
+    const bool ver = t.mode >= 18;
+    const int am_ = ver ? t.mode - 26 : -(t.mode - 10);
+    const int aa = abs(am_);
+    const int ang_abs = aa == 0 ? 0 : aa == 1 ? 2 : aa == 2 ? 5 : aa == 3 ? 9 : aa == 4 ? 13 : aa == 5 ? 17 : aa == 6 ? 21 : aa == 7 ? 26 : 32;
+    const int inv = aa == 0 ? 0 : aa == 1 ? 4096 : aa == 2 ? 1638 : aa == 3 ? 910 : aa == 4 ? 630 : aa == 5 ? 482 : aa == 6 ? 390 : aa == 7 ? 315 : 256;
+    const int ang = am_ < 0 ? -ang_abs : ang_abs;
+    // main reference with its extension: proj[k + 32], k in [-N, 2N]; main = row above for vertical modes, left column otherwise
+    const int sgn = ver ? 1 : -1;                           // MAIN(i) = f[corner + sgn*i], SIDE(i) = f[corner - sgn*i]
+    for (int k = lane - N; k <= 2 * N; k += 64) {
+      int v = 0;
+      if (k >= 0) { if (ang >= 0 || k <= N) v = f[corner + sgn * min(k, 2 * N)]; }
+      else if (ang < 0 && k > ((N * ang) >> 5)) v = f[corner - sgn * ((128 + (-k) * inv) >> 8)];
+      L.proj[k + 32] = v;
+    }
+    wave_lds_sync();
+    const int* r = L.proj + 32;
+#pragma unroll
+    for (int x = 0; x < N; x++) {
+      const int a_ = ver ? n : x, b_ = ver ? x : n;        // a_: index along the prediction direction, b_: across it
+      const int pos = (a_ + 1) * ang, di = pos >> 5, df = pos & 31;
+      int v = df ? ((32 - df) * r[b_ + di + 1] + df * r[b_ + di + 2] + 16) >> 5 : r[b_ + di + 1];
+      if (ang == 0 && edge && b_ == 0) v = clip3(0, maxv, v + ((f[corner - sgn * (a_ + 1)] - f[corner]) >> 1));
+      p[x] = v;
+    }
+  }
+
+  // ---- D. residual
+  int res[N];
+#pragma unroll
+  for (int x = 0; x < N; x++) res[x] = 0;
+  if (t.cbf) {
+    uint32_t lv[N / 2];
+#pragma unroll
+    for (int i = 0; i < N / 2; i++) lv[i] = 0;
+    if (active) {
+      const int16_t* lev = P.coef[comp] + (size_t)t.ctu * ((size_t)(1 << (2 * P.log2ctu)) >> (comp ? 2 : 0)) + (comp ? 4 : 16) * t.z_tu + n * N;
+      if constexpr (N == 4) { const u32x2 a = ldg2(lev); lv[0] = a.x; lv[1] = a.y; }
+      else {
+#pragma unroll
+        for (int i = 0; i < N / 8; i++) { const u32x4 a = ldg4(lev + i * 8); lv[4 * i] = a.x; lv[4 * i + 1] = a.y; lv[4 * i + 2] = a.z; lv[4 * i + 3] = a.w; }
+      }
+    }
+    int per, rem;
+    const SliceDev& sd = P.slices[ldg(P.slice_idx + t.ctu)];
+    qp_param_tu(t.qp_cu, comp, bd, comp == 1 ? ldg(&sd.cb_qp_offset) : comp == 2 ? ldg(&sd.cr_qp_offset) : 0, per, rem);
+    const int flags = ((comp == 0 && LOG2N == 2) ? 1 : 0) | (ldg(P.tskip[comp] + (size_t)t.ctu * P.parts + t.z_tu) ? 2 : 0);
+    const int j = lane / N;                                  // idle lanes run through their own scratch slots
+    itx_tu<LOG2N>(lv, n, per, rem, flags, bd, L.tile + j * N * ItxCfg<LOG2N>::STRIDE, L.ctile + j * N * N, res);
+  }
+
+  // ---- E. reconstruction of row n, two samples per coherent dword store
+  if (active) {
+    uint32_t* row = reinterpret_cast<uint32_t*>(plane + (ptrdiff_t)(t.y0 + n) * pitch + t.x0);
+#pragma unroll
+    for (int x = 0; x < N; x += 2) {
+      const int a = clip3(0, maxv, p[x] + res[x]), c = clip3(0, maxv, p[x + 1] + res[x + 1]);
+      st_coh(row + x / 2, (uint32_t)a | ((uint32_t)c << 16));
+    }
+  }
+  // the next TU of this wave reads these samples: stores done, LDS free
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  wave_lds_sync();
+}
+
+__device__ inline void intra_tu_any(const PicDev& P, const TuCtx& t, IntraLds& L) {
+  switch (t.log2n) {
+    case 2: intra_tu<2>(P, t, L); break;
+    case 3: intra_tu<3>(P, t, L); break;
+    case 4: intra_tu<4>(P, t, L); break;
+    default: intra_tu<5>(P, t, L); break;
+  }
+}
+
+// all intra CUs of one CTU, one component, in decoding order (xReconIntraQT per CU, xIntraRecQT over its TU tree)
+__device__ inline void intra_ctu(const PicDev& P, int comp, int ctu, IntraLds& L) {
+  const int parts = P.parts;
+  const size_t base = (size_t)ctu * parts;
+  const int ctu_x = (ctu % P.ctus_w) << P.log2ctu, ctu_y = (ctu / P.ctus_w) << P.log2ctu;
+  const int cs = comp ? 1 : 0;
+  int z = 0;
+  while (z < parts) {
+    const int px = ctu_x + 4 * zscan_x(z), py = ctu_y + 4 * zscan_y(z);
+    const int ps = ldg(P.part_size + base + z);
+    if (px >= P.width || py >= P.height || ps == HMGPU_SIZE_NONE) { z++; continue; }
+    const int depth = ldg(P.depth + base + z);
+    const int cu_parts = parts >> (2 * depth);
+    if (ldg(P.pred_mode + base + z) != HMGPU_MODE_INTRA) { z += cu_parts; continue; }
+    const int log2cu = P.log2ctu - depth;
+    const int qp_cu = ldg(P.qp + base + z);
+    const int cu_end = z + cu_parts;
+    int zc = z;
+    while (zc < cu_end) {
+      const int tr = ldg(P.tr_idx + base + zc);
+      const int log2tu = log2cu - tr;
+      TuCtx t;
+      t.comp = comp; t.ctu = ctu; t.z_tu = zc; t.qp_cu = qp_cu;
+      t.x0 = (ctu_x + 4 * zscan_x(zc)) >> cs; t.y0 = (ctu_y + 4 * zscan_y(zc)) >> cs;
+      bool run = true;
+      if (comp == 0) t.log2n = log2tu;
+      else if (log2tu >= 3) t.log2n = log2tu - 1;
+      else { t.log2n = 2; run = (zc & 3) == 0; }            // four 4x4 luma TUs share one 4x4 chroma TU, with the first of them (TComTU.cpp:141-171)
+      if (run) {
+        int mode = ldg(P.intra_dir[comp ? 1 : 0] + base + zc);
+        if (comp && mode == 36) mode = ldg(P.intra_dir[0] + base + (zc & ~3));         // DM_CHROMA_IDX (TDecCu.cpp:523-524)
+        t.mode = mode;
+        t.cbf = (ldg(P.cbf[comp] + base + zc) >> tr) & 1;
+        intra_tu_any(P, t, L);
+      }
+      zc += 1 << (2 * (log2tu - 2));
+    }
+    z = cu_end;
+  }
+}
+
+}  // namespace
+
+// grid: x = CTU row, y = component, z = picture of the batch; one wave per block.  Blocks of a picture/component are
+// dispatched in row order and a row only waits for the row above, so a waiting block never waits for one not yet started.
+__global__ void __launch_bounds__(64) k_intra(const PicDev* __restrict__ pics, Batch b) {
+  __shared__ IntraLds L;
+  const int slot = blockIdx.z, comp = blockIdx.y, row = blockIdx.x;
+  const PicDev& P = pics[b.pic[slot]];
+  if (!P.has_intra_dir || row >= P.ctus_h) return;
+  const int first = b.first_ctu[slot], last = first + b.num_ctus[slot] - 1;
+  const int row_first = row * P.ctus_w;
+  const int c_begin = max(first, row_first) - row_first, c_end = min(last, row_first + P.ctus_w - 1) - row_first + 1;
+  if (c_begin >= c_end) return;
+  const int row0 = first / P.ctus_w;
+  uint32_t* mine = P.intra_progress + comp * P.ctus_h + row;
+  const uint32_t* above = mine - 1;
+  const int lane = threadIdx.x & 63;
+  for (int c = c_begin; c < c_end; c++) {
+    if (!ldg(P.ctu_intra + row_first + c)) continue;
+    // everything of this row before column c is complete
+    if (lane == 0) __hip_atomic_store(mine, (uint32_t)c, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    if (row > row0) {
+      const uint32_t need = (uint32_t)min(c + 2, P.ctus_w);
+      while (__hip_atomic_load(above, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < need) __builtin_amdgcn_s_sleep(8);
+    }
+    intra_ctu(P, comp, row_first + c, L);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+  }
+  if (lane == 0) __hip_atomic_store(mine, (uint32_t)P.ctus_w, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+void launch_intra(const PicDev* pics, const Batch& b, int ctus_h, hipStream_t s) {
+  hipLaunchKernelGGL(k_intra, dim3((unsigned)ctus_h, 3, (unsigned)b.n), dim3(64), 0, s, pics, b);
+}
+
+}  // namespace hmgpu

@@ -186,6 +186,7 @@ __global__ void __launch_bounds__(256) k_prep(const PicDev* __restrict__ pics, B
       stg4(&P.blk[(size_t)gy * P.grid_w + gx], __builtin_bit_cast(u32x4, bi));
     }
     if (q.valid) atomicAdd(&lds_stat[q.intra ? 0 : 1], 4u);
+    if (q.valid && q.intra) stg(P.ctu_intra + q.ctu, (uint8_t)1);        // same value from every writer
     // ---- which transform units originate in this 8x8 area (intra CUs: not on the device yet)
     // cbf bit d of a partition = cbf of its ancestor TU node at transform depth d (TComDataCU.h:310); HM descends only
     // while every node on the way has its bit set (TComTrQuant.cpp:1558-1564)
@@ -244,6 +245,9 @@ __global__ void __launch_bounds__(256) k_prep(const PicDev* __restrict__ pics, B
 __global__ void k_zero_counts(const PicDev* __restrict__ pics, Batch b) {
   const PicDev& P = pics[b.pic[blockIdx.x]];
   if (threadIdx.x < 4 * kTuShards) stg(P.tu_count + threadIdx.x, 0u);
+  // intra wavefront state of this call: per-CTU "holds intra CUs" flags of the CTU range, progress counters of all rows
+  for (int i = threadIdx.x; i < b.num_ctus[blockIdx.x]; i += blockDim.x) stg(P.ctu_intra + b.first_ctu[blockIdx.x] + i, (uint8_t)0);
+  for (int i = threadIdx.x; i < 3 * P.ctus_h; i += blockDim.x) stg(P.intra_progress + i, 0u);
 }
 
 void launch_prep(const PicDev* pics, const Batch& b, int max_ctus, int parts, hipStream_t s) {

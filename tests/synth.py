@@ -128,6 +128,11 @@ def make_picture(width, height, bit_depth=10, seed=1, bi=False, intra_frac=0.0, 
         b1 = np.take_along_axis(flat, cu_idx * 4 + child, axis=1)
         bits = np.where(tr_idx == 0, b0_unsplit.astype(np.int64), b0_split.astype(np.int64) | (b1.astype(np.int64) << 1))
         cbf.append(bits)
+    # ---- intra prediction modes: one luma mode per CU (2Nx2N), chroma mode from HM's candidate set incl. DM (36)
+    luma_mode_cu = rng.randint(0, 35, size=(n, n_cu_max))
+    intra_dir_l = np.take_along_axis(luma_mode_cu, cu_idx, axis=1)
+    chroma_mode_cu = np.array([0, 1, 10, 26, 34, 36])[rng.randint(0, 6, size=(n, n_cu_max))]
+    intra_dir_c = np.take_along_axis(chroma_mode_cu, cu_idx, axis=1)
     qp_ctu = rng.randint(slice_qp_range[0], slice_qp_range[1] + 1, size=n)
     qp = np.repeat(qp_ctu[:, None], parts, axis=1)
 
@@ -204,7 +209,8 @@ def make_picture(width, height, bit_depth=10, seed=1, bi=False, intra_frac=0.0, 
     l1 = list(handles[1])[:1] if bi else []
     p.slice = abi.make_slice(abi.B_SLICE if bi else abi.P_SLICE, (l0, l1), ([100 + i for i in range(len(l0))], [200 + i for i in range(len(l1))]))
     m = {"depth": depth, "part_size": part_size, "pred_mode": pred_mode, "qp": qp, "tr_idx": tr_idx, "cbf_y": cbf[0], "cbf_u": cbf[1],
-         "cbf_v": cbf[2], "mv0": mv0, "mv1": mv1, "ref_idx0": ref_idx0, "ref_idx1": ref_idx1}
+         "cbf_v": cbf[2], "mv0": mv0, "mv1": mv1, "ref_idx0": ref_idx0, "ref_idx1": ref_idx1,
+         "intra_dir_l": np.where(intra, intra_dir_l, 1), "intra_dir_c": np.where(intra, intra_dir_c, 36)}
     p.meta_np = m
     p.meta = abi.MetaHolder(m)
     p.coeffs = abi.CoeffHolder(*coef)

@@ -21,13 +21,14 @@ def _oracle_chain(oracle, p, cur, refs):
 
 
 @pytest.mark.parametrize("width,height,bd,bi,intra", [(3840, 2160, 10, False, 0.1), (3840, 2160, 10, True, 0.0),
-                                                      (1920, 1080, 10, False, 0.05), (416, 240, 8, True, 0.1)])
+                                                      (1920, 1080, 10, False, 0.05), (416, 240, 8, True, 0.1),
+                                                      (1920, 1080, 10, False, 1.0), (832, 480, 8, False, 0.5)])
 def test_synthetic_picture_matches_oracle(oracle, width, height, bd, bi, intra):
     import libhm_amd
     p = synth.make_picture(width, height, bd, seed=width + bd + int(bi), bi=bi, intra_frac=intra, ref_handles=([0], [1]))
     ref0 = synth.noise_planes(width, height, bd, 11)
     ref1 = synth.blocky_planes(width, height, bd, 12)
-    cur = synth.blocky_planes(width, height, bd, 13)          # supplies the samples of intra CUs
+    cur = synth.blocky_planes(width, height, bd, 13)          # overwritten everywhere: inter AND intra CUs are reconstructed
     want_rec, want_dbk, want_fin = _oracle_chain(oracle, p, cur, [ref0, ref1])
     with libhm_amd.Context(p.seq) as ctx:
         h0, h1, hc = ctx.acquire(), ctx.acquire(), ctx.acquire()
