@@ -64,6 +64,9 @@ def algorithmic_bytes(p):
     out["deblock_hor"] = 2 * samples
     out["sao"] = 4 * samples
     out["prep"] = int(decoded.sum()) * (21 + 16)           # HM arrays read + BlkInfo written per partition
+    # intra CUs: levels read (coded TUs), reconstruction written once, reference samples read (~ 4N+1 per N x N TU: counted as 2 B/sample)
+    intra_p = decoded & (m["pred_mode"] == 1)
+    out["intra"] = int(intra_p.sum()) * 24 * (2 + 2 + 2)
     # replicated margins written around the three final planes (128/64 samples left+right, 80/40 rows above+below)
     out["extend_border"] = 2 * ((2 * 128 * (p.height + 160) + 160 * p.width) + 2 * (2 * 64 * (p.height // 2 + 80) + 80 * (p.width // 2)))
     return out
@@ -78,7 +81,7 @@ def main():
     ap.add_argument("--width", type=int, default=3840)
     ap.add_argument("--height", type=int, default=2160)
     ap.add_argument("--bi", type=int, default=0, help="1: B pictures (bi-prediction) instead of P")
-    ap.add_argument("--workload", default="full", choices=("full", "idct", "mc", "mc_bi", "filter", "gop"))
+    ap.add_argument("--workload", default="full", choices=("full", "idct", "mc", "mc_bi", "filter", "intra", "gop"))
     ap.add_argument("--mode-probs", default=None, help="experiment: CTU partition probabilities 64x64,32x32,16x16,8x8,AMP (comma separated)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-steps", type=int, default=5)
@@ -111,6 +114,10 @@ def main():
         # the reconstruction stages run too: they regenerate the pre-filter picture that the in-place deblocking consumed
         roof_kernel = "sao"
         kw = dict(intra_frac=0.25)
+    if wl == "intra":
+        # all-intra pictures (I pictures): the serial chain of the path, a CTU-row wavefront on the device
+        roof_kernel = "intra"
+        kw = dict(intra_frac=1.0)
     if args.mode_probs:
         kw["mode_probs"] = tuple(float(v) for v in args.mode_probs.split(","))
     # two distinct parsed pictures, staged alternately into nb device pictures with their own buffers
@@ -189,7 +196,8 @@ def main():
                                    "batch of %d independent pictures per step, inputs resident in HBM" %
                                    (w, h, "B (bi-pred)" if args.bi else "lowdelay_P",
                                     {"full": "prep+MC+dequant/IT/recon+deblock+SAO", "idct": "prep+MC+dequant/IT/recon, 32x32 luma / 16x16 chroma TUs, stress levels",
-                                     "mc": "prep+MC+dequant/IT/recon", "mc_bi": "prep+MC+dequant/IT/recon", "filter": "prep+MC+dequant/IT/recon+deblock+SAO, 25% intra CUs (Bs 2 edges)"}[wl], nb),
+                                     "mc": "prep+MC+dequant/IT/recon", "mc_bi": "prep+MC+dequant/IT/recon",
+                                     "intra": "all-intra pictures: prep+intra prediction/dequant/IT/recon (CTU-row wavefront)+deblock+SAO", "filter": "prep+MC+dequant/IT/recon+deblock+SAO, 25% intra CUs (Bs 2 edges)"}[wl], nb),
                        "sub_benchmark": wl,
                        "pictures_per_step": nb, "parallelism": "frame-parallel, 1 process per GPU, no data-path collective"},
             "roofline": roof, "kernels": kernels, "device_ms_per_step_sum_of_kernels": round(dev_ms, 4),

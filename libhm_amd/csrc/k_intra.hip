@@ -318,16 +318,22 @@ __global__ void __launch_bounds__(64) k_intra(const PicDev* __restrict__ pics, B
   uint32_t* mine = P.intra_progress + comp * P.ctus_h + row;
   const uint32_t* above = mine - 1;
   const int lane = threadIdx.x & 63;
-  for (int c = c_begin; c < c_end; c++) {
-    if (!ldg(P.ctu_intra + row_first + c)) continue;
-    // everything of this row before column c is complete
-    if (lane == 0) __hip_atomic_store(mine, (uint32_t)c, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-    if (row > row0) {
-      const uint32_t need = (uint32_t)min(c + 2, P.ctus_w);
-      while (__hip_atomic_load(above, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < need) __builtin_amdgcn_s_sleep(8);
+  // the row's CTUs that hold intra CUs, 64 columns per ballot: a row without any costs one load
+  for (int cb = c_begin & ~63; cb < c_end; cb += 64) {
+    const int cl = cb + lane;
+    unsigned long long todo = __builtin_amdgcn_ballot_w64(cl >= c_begin && cl < c_end && ldg(P.ctu_intra + row_first + cl) != 0);
+    while (todo) {
+      const int c = cb + __builtin_ctzll(todo);
+      todo &= todo - 1;
+      // everything of this row before column c is complete
+      if (lane == 0) __hip_atomic_store(mine, (uint32_t)c, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      if (row > row0) {
+        const uint32_t need = (uint32_t)min(c + 2, P.ctus_w);
+        while (__hip_atomic_load(above, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < need) __builtin_amdgcn_s_sleep(8);
+      }
+      intra_ctu(P, comp, row_first + c, L);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     }
-    intra_ctu(P, comp, row_first + c, L);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
   }
   if (lane == 0) __hip_atomic_store(mine, (uint32_t)P.ctus_w, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 }
