@@ -231,7 +231,7 @@ hmgpu_status run_recon(hmgpu_ctx* c, const Batch& b) {
   { ProfScope ps(c, K_MC_LUMA); launch_mc_luma(c->d_pics, c->d_finals, b, max_ctus, c->seq.log2_ctu_size, c->stream); }
   { ProfScope ps(c, K_MC_CHROMA); launch_mc_chroma(c->d_pics, c->d_finals, b, max_ctus, c->seq.log2_ctu_size, c->stream); }
   // blocks per shard: enough to keep the chip busy on a full picture, few enough that a short list costs nothing
-  uint32_t bps = (uint32_t)std::max(4, std::min(16, max_ctus / 8 + 1));   // blocks per shard; 16 measured best at 2160p
+  uint32_t bps = (uint32_t)std::max(4, std::min(24, max_ctus / 8 + 1));   // blocks per shard; 24 measured best at 2160p (768 blocks, 3 per CU)
   if (const char* e = getenv("HMGPU_ITX_BPS")) bps = (uint32_t)std::max(1, atoi(e));   // tuning knob
   int cmask = 0;
   if (const char* e = getenv("HMGPU_ITX_CLASSES")) cmask = atoi(e);              // tuning aid (wrong output unless 15)
