@@ -83,6 +83,7 @@ def main():
     ap.add_argument("--bi", type=int, default=0, help="1: B pictures (bi-prediction) instead of P")
     ap.add_argument("--workload", default="full", choices=("full", "idct", "mc", "mc_bi", "filter", "intra", "gop"))
     ap.add_argument("--mode-probs", default=None, help="experiment: CTU partition probabilities 64x64,32x32,16x16,8x8,AMP (comma separated)")
+    ap.add_argument("--intra-frac", type=float, default=None, help="experiment: fraction of CUs that are intra (with intra modes: reconstructed on the GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-steps", type=int, default=5)
     args = ap.parse_args()
@@ -113,11 +114,13 @@ def main():
     if wl == "filter":
         # the reconstruction stages run too: they regenerate the pre-filter picture that the in-place deblocking consumed
         roof_kernel = "sao"
-        kw = dict(intra_frac=0.25)
+        kw = dict(intra_frac=0.25, intra_modes=False)      # the intra CUs only supply Bs = 2 edges; their reconstruction is the "intra" workload
     if wl == "intra":
         # all-intra pictures (I pictures): the serial chain of the path, a CTU-row wavefront on the device
         roof_kernel = "intra"
         kw = dict(intra_frac=1.0)
+    if args.intra_frac is not None:
+        kw["intra_frac"] = args.intra_frac
     if args.mode_probs:
         kw["mode_probs"] = tuple(float(v) for v in args.mode_probs.split(","))
     # two distinct parsed pictures, staged alternately into nb device pictures with their own buffers

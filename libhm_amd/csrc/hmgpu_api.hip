@@ -59,6 +59,7 @@ struct hmgpu_ctx {
   std::vector<Picture> pics;
   PicDev* d_pics = nullptr;
   PlaneSet* d_finals = nullptr;
+  int32_t* d_ctu_order = nullptr;     // CTU addresses by anti-diagonal (dispatch order of the intra wavefront)
   std::vector<PlaneSet> h_finals;
   // profiling
   bool profiling = false;
@@ -156,7 +157,7 @@ hmgpu_status alloc_picture(hmgpu_ctx* c, Picture& p) {
     d.saoprm = m.take<SaoDev>((size_t)c->num_ctus * 3);
     d.slices = m.take<SliceDev>(HMGPU_MAX_SLICES);
     d.ctu_intra = m.take<uint8_t>((size_t)c->num_ctus);
-    d.intra_progress = m.take<uint32_t>((size_t)3 * c->ctus_h);
+    d.intra_done = m.take<uint32_t>((size_t)3 * c->num_ctus);
     if (!pass) { HIP_TRY(c, hipMalloc(&p.derived, m.off)); HIP_TRY(c, hipMemset(p.derived, 0, m.off)); }
   }
   PicDev& d = p.dev;
@@ -239,7 +240,7 @@ hmgpu_status run_recon(hmgpu_ctx* c, const Batch& b) {
   // intra CUs predict from finished neighbours (inter ones included): after motion compensation and the inter residuals
   bool any_intra = false;
   for (int i = 0; i < b.n; i++) any_intra |= c->pics[b.pic[i]].dev.has_intra_dir != 0;
-  if (any_intra) { ProfScope ps(c, K_INTRA); launch_intra(c->d_pics, b, c->ctus_h, c->stream); }
+  if (any_intra) { ProfScope ps(c, K_INTRA); launch_intra(c->d_pics, b, c->d_ctu_order, c->num_ctus, c->stream); }
   HIP_TRY(c, hipGetLastError());
   return HMGPU_OK;
 }
@@ -387,6 +388,13 @@ hmgpu_status hmgpu_create(const hmgpu_seq_params* seq, int device_ordinal, hmgpu
   hmgpu_status st = HMGPU_OK;
   for (int i = 0; i < seq->max_pictures && st == HMGPU_OK; i++) st = alloc_picture(c, c->pics[i]);
   if (st == HMGPU_OK) {
+    {
+      std::vector<int32_t> order;
+      for (int d = 0; d <= 2 * (c->ctus_h - 1) + c->ctus_w - 1; d++)
+        for (int r = 0; r < c->ctus_h; r++) { const int col = d - 2 * r; if (col >= 0 && col < c->ctus_w) order.push_back(r * c->ctus_w + col); }
+      if (hipMalloc((void**)&c->d_ctu_order, order.size() * sizeof(int32_t)) != hipSuccess ||
+          hipMemcpy(c->d_ctu_order, order.data(), order.size() * sizeof(int32_t), hipMemcpyHostToDevice) != hipSuccess) st = HMGPU_EDEVICE;
+    }
     if (hipMalloc((void**)&c->d_pics, sizeof(PicDev) * seq->max_pictures) != hipSuccess ||
         hipMalloc((void**)&c->d_finals, sizeof(PlaneSet) * seq->max_pictures) != hipSuccess) st = HMGPU_EDEVICE;
   }
@@ -408,6 +416,7 @@ void hmgpu_destroy(hmgpu_ctx* c) {
   for (Picture& p : c->pics) free_picture(p);
   if (c->d_pics) hipFree(c->d_pics);
   if (c->d_finals) hipFree(c->d_finals);
+  if (c->d_ctu_order) hipFree(c->d_ctu_order);
   if (c->stream) hipStreamDestroy(c->stream);
   delete c;
 }

@@ -106,7 +106,7 @@ struct PicDev {
   int32_t has_intra_dir;           // the caller supplied intra prediction modes (else intra CUs are left untouched)
   int32_t strong_intra_smoothing;  // SPS flag
   uint8_t* ctu_intra;              // [num_ctus] 1 = the CTU holds intra CUs (written by k_prep)
-  uint32_t* intra_progress;        // [3][ctus_h]: CTU columns of a row that are complete, per component (wavefront over CTU rows)
+  uint32_t* intra_done;            // [3][num_ctus]: the CTU's intra CUs of that component are reconstructed
 };
 
 // batched launch descriptor, passed by value
@@ -170,7 +170,7 @@ void launch_mc_luma(const PicDev* pics, const PlaneSet* finals, const Batch& b, 
 int launch_mc_luma_stamped(const PicDev* pics, const PlaneSet* finals, const Batch& b, int max_ctus, int log2ctu, unsigned long long* stamps, hipStream_t s);
 void launch_mc_chroma(const PicDev* pics, const PlaneSet* finals, const Batch& b, int max_ctus, int log2ctu, hipStream_t s);
 void launch_itx(const PicDev* pics, const Batch& b, int log2size, uint32_t blocks_per_shard, hipStream_t s);
-void launch_intra(const PicDev* pics, const Batch& b, int ctus_h, hipStream_t s);
+void launch_intra(const PicDev* pics, const Batch& b, const int32_t* order, int num_ctus, hipStream_t s);
 void launch_deblock(const PicDev* pics, const Batch& b, int dir, int width, int height, hipStream_t s);
 void launch_sao(const PicDev* pics, const Batch& b, int width, int height, hipStream_t s);
 void launch_extend(const PicDev* pics, const Batch& b, int width, int height, int mx, int my, hipStream_t s);

@@ -6,10 +6,9 @@
 // Intra prediction is the one serial chain of the reconstruction path: a TU predicts from the reconstructed samples of the
 // TUs before it in decoding order.  What IS independent: the three components (HM reconstructs the luma of a CU, then its
 // chroma, and chroma never reads luma samples: TDecCu.cpp:665-690), and CTU rows once the CTU above-right is done.  So one
-// wave walks one CTU row of one component; rows advance as a wavefront (row r may work on CTU column c when row r-1 has
-// finished column c+1), synchronised through one progress counter per row and component.  CTUs without intra CUs (flags
-// from k_prep) cost nothing: their samples were finished by the MC / residual kernels before this kernel started, and a row
-// only ever waits on behalf of a CTU that does hold intra CUs.  Inside a CTU the wave takes the TUs in z order; for each TU
+// wave per CTU and component; a CTU starts when those of its left / above-left / above / above-right neighbours that hold intra
+// CUs are done (one flag per CTU and component).  CTUs without intra CUs (flags from k_prep) cost nothing: their samples were
+// finished by the MC / residual kernels before this kernel started.  Inside a CTU the wave takes the TUs in z order; for each TU
 // the lanes build the 4N+1 reference samples together (availability per 4x4 unit as one ballot mask, the substitution
 // process of fillReferenceSamples as bit scans over that mask), lane n predicts row n, the residual comes from the same
 // itx_tu() the inter path uses, and the clipped row goes back to the picture.
@@ -54,8 +53,7 @@ struct IntraLds {
   int line[4 * 32 + 4];                  // reference line: [0,2N) left column bottom-up, [2N] corner, (2N,4N] row above
   int filt[4 * 32 + 4];                  // the same after smoothing
   int proj[3 * 32 + 4];                  // angular modes: main reference incl. the projected side samples, index k + 32
-  __attribute__((aligned(16))) int tile[2 * 32 * 36];      // itx_tu scratch, sized for the largest class (two 32x32 slots per wave)
-  __attribute__((aligned(16))) int16_t ctile[2 * 32 * 32];
+  __attribute__((aligned(16))) int16_t tile[PkCfg<5>::TU_ELEMS];   // itx_tu_pk scratch: one TU at a time, the largest is 32x32
 };
 
 struct TuCtx {
@@ -212,38 +210,31 @@ __device__ inline void intra_tu(const PicDev& P, const TuCtx& t, IntraLds& L) {
     }
   }
 
-  // ---- D. residual
-  int res[N];
+  // ---- D. residual (lanes beyond N have no part in it: the hand-offs inside itx_tu_pk are wave-local orderings, not barriers)
+  uint32_t res[N / 2];
 #pragma unroll
-  for (int x = 0; x < N; x++) res[x] = 0;
-  if (t.cbf) {
+  for (int i = 0; i < N / 2; i++) res[i] = 0;
+  if (t.cbf && active) {
     uint32_t lv[N / 2];
+    const int16_t* lev = P.coef[comp] + (size_t)t.ctu * ((size_t)(1 << (2 * P.log2ctu)) >> (comp ? 2 : 0)) + (comp ? 4 : 16) * t.z_tu + n * N;
+    if constexpr (N == 4) { const u32x2 a = ldg2(lev); lv[0] = a.x; lv[1] = a.y; }
+    else {
 #pragma unroll
-    for (int i = 0; i < N / 2; i++) lv[i] = 0;
-    if (active) {
-      const int16_t* lev = P.coef[comp] + (size_t)t.ctu * ((size_t)(1 << (2 * P.log2ctu)) >> (comp ? 2 : 0)) + (comp ? 4 : 16) * t.z_tu + n * N;
-      if constexpr (N == 4) { const u32x2 a = ldg2(lev); lv[0] = a.x; lv[1] = a.y; }
-      else {
-#pragma unroll
-        for (int i = 0; i < N / 8; i++) { const u32x4 a = ldg4(lev + i * 8); lv[4 * i] = a.x; lv[4 * i + 1] = a.y; lv[4 * i + 2] = a.z; lv[4 * i + 3] = a.w; }
-      }
+      for (int i = 0; i < N / 8; i++) { const u32x4 a = ldg4(lev + i * 8); lv[4 * i] = a.x; lv[4 * i + 1] = a.y; lv[4 * i + 2] = a.z; lv[4 * i + 3] = a.w; }
     }
     int per, rem;
     const SliceDev& sd = P.slices[ldg(P.slice_idx + t.ctu)];
     qp_param_tu(t.qp_cu, comp, bd, comp == 1 ? ldg(&sd.cb_qp_offset) : comp == 2 ? ldg(&sd.cr_qp_offset) : 0, per, rem);
-    const int flags = ((comp == 0 && LOG2N == 2) ? 1 : 0) | (ldg(P.tskip[comp] + (size_t)t.ctu * P.parts + t.z_tu) ? 2 : 0);
-    const int j = lane / N;                                  // idle lanes run through their own scratch slots
-    itx_tu<LOG2N>(lv, n, per, rem, flags, bd, L.tile + j * N * ItxCfg<LOG2N>::STRIDE, L.ctile + j * N * N, res);
+    const bool skip = ldg(P.tskip[comp] + (size_t)t.ctu * P.parts + t.z_tu) != 0;
+    itx_tu_pk<LOG2N>(lv, n, per, rem, skip, bd, L.tile, res, comp == 0 && LOG2N == 2);          // TComTU::useDST: 4x4 intra luma
   }
 
   // ---- E. reconstruction of row n, two samples per coherent dword store
   if (active) {
     uint32_t* row = reinterpret_cast<uint32_t*>(plane + (ptrdiff_t)(t.y0 + n) * pitch + t.x0);
+    const uint32_t maxv2 = (uint32_t)maxv * 0x10001u;
 #pragma unroll
-    for (int x = 0; x < N; x += 2) {
-      const int a = clip3(0, maxv, p[x] + res[x]), c = clip3(0, maxv, p[x + 1] + res[x + 1]);
-      st_coh(row + x / 2, (uint32_t)a | ((uint32_t)c << 16));
-    }
+    for (int x = 0; x < N; x += 2) st_coh(row + x / 2, pk_clip_u(pk_add_sat(cvt_pk_sat(p[x], p[x + 1]), res[x / 2]), maxv2));
   }
   // the next TU of this wave reads these samples: stores done, LDS free
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -303,43 +294,37 @@ __device__ inline void intra_ctu(const PicDev& P, int comp, int ctu, IntraLds& L
 
 }  // namespace
 
-// grid: x = CTU row, y = component, z = picture of the batch; one wave per block.  Blocks of a picture/component are
-// dispatched in row order and a row only waits for the row above, so a waiting block never waits for one not yet started.
-__global__ void __launch_bounds__(64) k_intra(const PicDev* __restrict__ pics, Batch b) {
+// grid: x = (picture of the batch, component), y = position in `order`; one wave per block.  A CTU that holds intra CUs waits
+// for its left, above-left, above and above-right neighbours -- those of them that hold intra CUs themselves and belong to
+// this call -- and nothing else: intra CUs scattered over a P picture are reconstructed side by side, an I picture
+// degenerates into the classic CTU wavefront.  `order` lists the CTUs by anti-diagonal (2*row + column): all four
+// neighbours lie on earlier diagonals, so every block a block can wait for has a smaller linear index and was dispatched
+// before it (no deadlock however few blocks are resident), and the blocks resident at any time are the wavefront itself.
+__global__ void __launch_bounds__(64) k_intra(const PicDev* __restrict__ pics, Batch b, const int32_t* __restrict__ order) {
   __shared__ IntraLds L;
-  const int slot = blockIdx.z, comp = blockIdx.y, row = blockIdx.x;
+  const int slot = blockIdx.x / 3, comp = blockIdx.x % 3, ctu = ldg(order + blockIdx.y);
   const PicDev& P = pics[b.pic[slot]];
-  if (!P.has_intra_dir || row >= P.ctus_h) return;
   const int first = b.first_ctu[slot], last = first + b.num_ctus[slot] - 1;
-  const int row_first = row * P.ctus_w;
-  const int c_begin = max(first, row_first) - row_first, c_end = min(last, row_first + P.ctus_w - 1) - row_first + 1;
-  if (c_begin >= c_end) return;
-  const int row0 = first / P.ctus_w;
-  uint32_t* mine = P.intra_progress + comp * P.ctus_h + row;
-  const uint32_t* above = mine - 1;
-  const int lane = threadIdx.x & 63;
-  // the row's CTUs that hold intra CUs, 64 columns per ballot: a row without any costs one load
-  for (int cb = c_begin & ~63; cb < c_end; cb += 64) {
-    const int cl = cb + lane;
-    unsigned long long todo = __builtin_amdgcn_ballot_w64(cl >= c_begin && cl < c_end && ldg(P.ctu_intra + row_first + cl) != 0);
-    while (todo) {
-      const int c = cb + __builtin_ctzll(todo);
-      todo &= todo - 1;
-      // everything of this row before column c is complete
-      if (lane == 0) __hip_atomic_store(mine, (uint32_t)c, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-      if (row > row0) {
-        const uint32_t need = (uint32_t)min(c + 2, P.ctus_w);
-        while (__hip_atomic_load(above, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < need) __builtin_amdgcn_s_sleep(8);
-      }
-      intra_ctu(P, comp, row_first + c, L);
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    }
+  if (!P.has_intra_dir || ctu < first || ctu > last || !ldg(P.ctu_intra + ctu)) return;
+  uint32_t* done = P.intra_done + (size_t)comp * P.num_ctus;
+  const int cx = ctu % P.ctus_w, cy = ctu / P.ctus_w;
+  const int nb[4] = {cx > 0 ? ctu - 1 : -1, (cx > 0 && cy > 0) ? ctu - P.ctus_w - 1 : -1, cy > 0 ? ctu - P.ctus_w : -1,
+                     (cy > 0 && cx + 1 < P.ctus_w) ? ctu - P.ctus_w + 1 : -1};
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const int n = nb[k];
+    if (n < first || !ldg(P.ctu_intra + n)) continue;      // outside the picture / finished by an earlier call / no intra CUs: complete already
+    // poll with plain coherent loads (an acquire per poll would invalidate the caches of the CU's working waves over and over)
+    while (__hip_atomic_load(done + n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) __builtin_amdgcn_s_sleep(64);
   }
-  if (lane == 0) __hip_atomic_store(mine, (uint32_t)P.ctus_w, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  intra_ctu(P, comp, ctu, L);
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+  if ((threadIdx.x & 63) == 0) __hip_atomic_store(done + ctu, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-void launch_intra(const PicDev* pics, const Batch& b, int ctus_h, hipStream_t s) {
-  hipLaunchKernelGGL(k_intra, dim3((unsigned)ctus_h, 3, (unsigned)b.n), dim3(64), 0, s, pics, b);
+void launch_intra(const PicDev* pics, const Batch& b, const int32_t* order, int num_ctus, hipStream_t s) {
+  hipLaunchKernelGGL(k_intra, dim3((unsigned)b.n * 3, (unsigned)num_ctus), dim3(64), 0, s, pics, b, order);
 }
 
 }  // namespace hmgpu

@@ -245,9 +245,9 @@ __global__ void __launch_bounds__(256) k_prep(const PicDev* __restrict__ pics, B
 __global__ void k_zero_counts(const PicDev* __restrict__ pics, Batch b) {
   const PicDev& P = pics[b.pic[blockIdx.x]];
   if (threadIdx.x < 4 * kTuShards) stg(P.tu_count + threadIdx.x, 0u);
-  // intra wavefront state of this call: per-CTU "holds intra CUs" flags of the CTU range, progress counters of all rows
+  // intra state of this call: per-CTU "holds intra CUs" flags of the CTU range, "done" flags of all CTUs
   for (int i = threadIdx.x; i < b.num_ctus[blockIdx.x]; i += blockDim.x) stg(P.ctu_intra + b.first_ctu[blockIdx.x] + i, (uint8_t)0);
-  for (int i = threadIdx.x; i < 3 * P.ctus_h; i += blockDim.x) stg(P.intra_progress + i, 0u);
+  for (int i = threadIdx.x; i < 3 * P.num_ctus; i += blockDim.x) stg(P.intra_done + i, 0u);
 }
 
 void launch_prep(const PicDev* pics, const Batch& b, int max_ctus, int parts, hipStream_t s) {

@@ -31,7 +31,7 @@ class SynthPicture:
 
 def make_picture(width, height, bit_depth=10, seed=1, bi=False, intra_frac=0.0, num_refs=1, slice_qp_range=(22, 37),
                  cbf_prob=0.5, sao=True, mode_probs=(0.1, 0.3, 0.3, 0.2, 0.1), ref_handles=None, mv_range=64,
-                 coef_dist="typical", tr_split_prob=0.35):
+                 coef_dist="typical", tr_split_prob=0.35, intra_modes=True):
     """Returns a SynthPicture with .seq, .slice (abi.SliceParams), .meta (MetaHolder), .coeffs (CoeffHolder),
     .sao_raw [num_ctus,3,35], .pp, .meta_np.  ref_handles: device picture handles of list-0 / list-1 references.
     coef_dist: "typical" (see above) or "stress" (every level of a coded TU uniform over the full int16 range, SURVEY 8d #2)."""
@@ -211,6 +211,8 @@ def make_picture(width, height, bit_depth=10, seed=1, bi=False, intra_frac=0.0, 
     m = {"depth": depth, "part_size": part_size, "pred_mode": pred_mode, "qp": qp, "tr_idx": tr_idx, "cbf_y": cbf[0], "cbf_u": cbf[1],
          "cbf_v": cbf[2], "mv0": mv0, "mv1": mv1, "ref_idx0": ref_idx0, "ref_idx1": ref_idx1,
          "intra_dir_l": np.where(intra, intra_dir_l, 1), "intra_dir_c": np.where(intra, intra_dir_c, 36)}
+    if not intra_modes:                 # the caller leaves intra CUs to somebody else: no modes, nothing reconstructed there
+        del m["intra_dir_l"], m["intra_dir_c"]
     p.meta_np = m
     p.meta = abi.MetaHolder(m)
     p.coeffs = abi.CoeffHolder(*coef)
