@@ -54,14 +54,23 @@ struct IntraLds {
   int filt[4 * 32 + 4];                  // the same after smoothing
   int proj[3 * 32 + 4];                  // angular modes: main reference incl. the projected side samples, index k + 32
   __attribute__((aligned(16))) int16_t tile[PkCfg<5>::TU_ELEMS];   // itx_tu_pk scratch: one TU at a time, the largest is 32x32
+  // the CTU's samples of this component (columns -2..63 at index x + 2) and the row above it (columns -2..127): references
+  // inside the CTU never leave the chip, and a TU does not wait for its stores before the next one starts
+  __attribute__((aligned(4))) int16_t pix[64][66];
+  __attribute__((aligned(4))) int16_t top[132];
+  // the CTU's TComDataCU arrays, fetched once with one dword per lane and array (the walk over CUs and TUs is a serial chain:
+  // every byte it had to wait for from global memory would cost a round trip)
+  __attribute__((aligned(4))) uint8_t m_depth[256], m_part[256], m_pred[256], m_tr[256], m_qp[256], m_cbf[256], m_ts[256], m_dir[256], m_dirl[256];
 };
 
 struct TuCtx {
-  int comp, ctu, z_tu, log2n, mode, cbf, x0, y0, qp_cu;     // x0, y0: component samples
+  int comp, ctu, z_tu, log2n, mode, cbf, skip, x0, y0, qp_cu;     // x0, y0: component samples
+  int cip, cqo, slice, tile;                                      // per-CTU constants: constrained intra pred, chroma QP offset, slice / tile index
+  int cx0, cy0;                                                   // CTU origin in component samples
 };
 
 // availability of the 4x4 luma partition at luma sample (px, py) as intra reference of the TU at (ctu, z_tu)
-__device__ inline bool intra_avail(const PicDev& P, int ctu, int z_tu, int px, int py, bool cip) {
+__device__ inline bool intra_avail(const PicDev& P, int ctu, int z_tu, int px, int py, bool cip, int slice, int tile) {
   if (px < 0 || py < 0 || px >= P.width || py >= P.height) return false;
   const int ctu_mask = (1 << P.log2ctu) - 1;
   const int nctu = (py >> P.log2ctu) * P.ctus_w + (px >> P.log2ctu);
@@ -72,7 +81,7 @@ __device__ inline bool intra_avail(const PicDev& P, int ctu, int z_tu, int px, i
   if (nctu == ctu) { if (nz >= z_tu) return false; }
   else {
     if (nctu > ctu) return false;
-    if (ldg(P.slice_idx + nctu) != ldg(P.slice_idx + ctu) || ldg(P.tile_idx + nctu) != ldg(P.tile_idx + ctu)) return false;
+    if (ldg(P.slice_idx + nctu) != slice || ldg(P.tile_idx + nctu) != tile) return false;
   }
   if (cip && ldg(P.pred_mode + (size_t)nctu * P.parts + nz) != HMGPU_MODE_INTRA) return false;
   return true;
@@ -96,7 +105,22 @@ __device__ inline void intra_tu(const PicDev& P, const TuCtx& t, IntraLds& L) {
   const int us = 4 >> cs, U = N / us;                      // samples per availability unit, units per TU side
   const int corner = 2 * N, total = 4 * N + 1;
   const int lx = t.x0 << cs, ly = t.y0 << cs;              // TU origin in luma samples
-  const bool cip = ldg(&P.slices[ldg(P.slice_idx + t.ctu)].constrained_intra_pred) != 0;
+  const bool cip = t.cip != 0;
+
+  // the levels are not needed before step D: request them now, their latency hides behind the reference samples
+  const int n = lane & (N - 1);
+  const bool active = lane < N;
+  uint32_t lv[N / 2];
+#pragma unroll
+  for (int i = 0; i < N / 2; i++) lv[i] = 0;
+  if (t.cbf && active) {
+    const int16_t* lev = P.coef[comp] + (size_t)t.ctu * ((size_t)(1 << (2 * P.log2ctu)) >> (comp ? 2 : 0)) + (comp ? 4 : 16) * t.z_tu + n * N;
+    if constexpr (N == 4) { const u32x2 a = ldg2(lev); lv[0] = a.x; lv[1] = a.y; }
+    else {
+#pragma unroll
+      for (int i = 0; i < N / 8; i++) { const u32x4 a = ldg4(lev + i * 8); lv[4 * i] = a.x; lv[4 * i + 1] = a.y; lv[4 * i + 2] = a.z; lv[4 * i + 3] = a.w; }
+    }
+  }
 
   // ---- A. availability per unit: units [0, 2U) left column bottom-up, 2U the corner, (2U, 4U] the row above
   bool av = false;
@@ -105,7 +129,7 @@ __device__ inline void intra_tu(const PicDev& P, const TuCtx& t, IntraLds& L) {
     if (lane < 2 * U) { px = lx - 4; py = ly + 4 * (2 * U - 1 - lane); }
     else if (lane == 2 * U) { px = lx - 4; py = ly - 4; }
     else { px = lx + 4 * (lane - 2 * U - 1); py = ly - 4; }
-    av = intra_avail(P, t.ctu, t.z_tu, px, py, cip);
+    av = intra_avail(P, t.ctu, t.z_tu, px, py, cip, t.slice, t.tile);
   }
   const unsigned long long am = __builtin_amdgcn_ballot_w64(av);
   for (int i = lane; i < total; i += 64) {
@@ -120,11 +144,13 @@ __device__ inline void intra_tu(const PicDev& P, const TuCtx& t, IntraLds& L) {
         const int first_of = j < 2 * U ? j * us : (j == 2 * U ? corner : corner + 1 + (j - 2 * U - 1) * us);
         src = first_of + ((last && j != 2 * U) ? us - 1 : 0);
       }
-      const int16_t* q;
-      if (src < corner) q = plane + (ptrdiff_t)(t.y0 + (corner - 1 - src)) * pitch + t.x0 - 1;
-      else if (src == corner) q = plane + (ptrdiff_t)(t.y0 - 1) * pitch + t.x0 - 1;
-      else q = plane + (ptrdiff_t)(t.y0 - 1) * pitch + t.x0 + (src - corner - 1);
-      v = ld_sample(q);
+      // position of the source sample relative to the CTU: row -1 lives in top[], everything else in pix[]
+      int sx, sy;
+      if (src < corner) { sx = t.x0 - 1; sy = t.y0 + (corner - 1 - src); }
+      else if (src == corner) { sx = t.x0 - 1; sy = t.y0 - 1; }
+      else { sx = t.x0 + (src - corner - 1); sy = t.y0 - 1; }
+      sx -= t.cx0; sy -= t.cy0;
+      v = sy < 0 ? L.top[sx + 2] : L.pix[sy][sx + 2];
     }
     L.line[i] = v;
   }
@@ -158,8 +184,6 @@ __device__ inline void intra_tu(const PicDev& P, const TuCtx& t, IntraLds& L) {
   wave_lds_sync();
 
   // ---- C. prediction of row n by lane n
-  const int n = lane & (N - 1);
-  const bool active = lane < N;
   const int* f = L.filt;
   const bool edge = comp == 0 && N <= 16;                   // MAXIMUM_INTRA_FILTERED_WIDTH (TypeDef.h:117)
   int p[N];
@@ -215,30 +239,24 @@ __device__ inline void intra_tu(const PicDev& P, const TuCtx& t, IntraLds& L) {
 #pragma unroll
   for (int i = 0; i < N / 2; i++) res[i] = 0;
   if (t.cbf && active) {
-    uint32_t lv[N / 2];
-    const int16_t* lev = P.coef[comp] + (size_t)t.ctu * ((size_t)(1 << (2 * P.log2ctu)) >> (comp ? 2 : 0)) + (comp ? 4 : 16) * t.z_tu + n * N;
-    if constexpr (N == 4) { const u32x2 a = ldg2(lev); lv[0] = a.x; lv[1] = a.y; }
-    else {
-#pragma unroll
-      for (int i = 0; i < N / 8; i++) { const u32x4 a = ldg4(lev + i * 8); lv[4 * i] = a.x; lv[4 * i + 1] = a.y; lv[4 * i + 2] = a.z; lv[4 * i + 3] = a.w; }
-    }
     int per, rem;
-    const SliceDev& sd = P.slices[ldg(P.slice_idx + t.ctu)];
-    qp_param_tu(t.qp_cu, comp, bd, comp == 1 ? ldg(&sd.cb_qp_offset) : comp == 2 ? ldg(&sd.cr_qp_offset) : 0, per, rem);
-    const bool skip = ldg(P.tskip[comp] + (size_t)t.ctu * P.parts + t.z_tu) != 0;
-    itx_tu_pk<LOG2N>(lv, n, per, rem, skip, bd, L.tile, res, comp == 0 && LOG2N == 2);          // TComTU::useDST: 4x4 intra luma
+    qp_param_tu(t.qp_cu, comp, bd, t.cqo, per, rem);
+    itx_tu_pk<LOG2N>(lv, n, per, rem, t.skip != 0, bd, L.tile, res, comp == 0 && LOG2N == 2);          // TComTU::useDST: 4x4 intra luma
   }
 
-  // ---- E. reconstruction of row n, two samples per coherent dword store
+  // ---- E. reconstruction of row n: into the LDS copy (what later TUs of this CTU predict from) and, two samples per
+  // coherent dword store, into the picture (what other CTUs and the loop filters read; nobody here waits for it)
   if (active) {
     uint32_t* row = reinterpret_cast<uint32_t*>(plane + (ptrdiff_t)(t.y0 + n) * pitch + t.x0);
+    uint32_t* lrow = reinterpret_cast<uint32_t*>(&L.pix[t.y0 - t.cy0 + n][t.x0 - t.cx0 + 2]);
     const uint32_t maxv2 = (uint32_t)maxv * 0x10001u;
 #pragma unroll
-    for (int x = 0; x < N; x += 2) st_coh(row + x / 2, pk_clip_u(pk_add_sat(cvt_pk_sat(p[x], p[x + 1]), res[x / 2]), maxv2));
+    for (int x = 0; x < N; x += 2) {
+      const uint32_t v = pk_clip_u(pk_add_sat(cvt_pk_sat(p[x], p[x + 1]), res[x / 2]), maxv2);
+      lrow[x / 2] = v;
+      st_coh(row + x / 2, v);
+    }
   }
-  // the next TU of this wave reads these samples: stores done, LDS free
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   wave_lds_sync();
 }
 
@@ -257,33 +275,68 @@ __device__ inline void intra_ctu(const PicDev& P, int comp, int ctu, IntraLds& L
   const size_t base = (size_t)ctu * parts;
   const int ctu_x = (ctu % P.ctus_w) << P.log2ctu, ctu_y = (ctu / P.ctus_w) << P.log2ctu;
   const int cs = comp ? 1 : 0;
+  const int lane = threadIdx.x & 63;
+  if (4 * lane < parts) {
+    const size_t o = base + 4 * lane;
+    auto dw = [&](const void* p) { return ldg(reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint8_t*>(p) + o)); };
+    const uint32_t a0 = dw(P.depth), a1 = dw(P.part_size), a2 = dw(P.pred_mode), a3 = dw(P.tr_idx), a4 = dw(P.qp), a5 = dw(P.cbf[comp]),
+                   a6 = dw(P.tskip[comp]), a7 = dw(P.intra_dir[comp ? 1 : 0]), a8 = dw(P.intra_dir[0]);
+    auto put = [&](uint8_t* d, uint32_t v) { *reinterpret_cast<uint32_t*>(d + 4 * lane) = v; };
+    put(L.m_depth, a0); put(L.m_part, a1); put(L.m_pred, a2); put(L.m_tr, a3); put(L.m_qp, a4); put(L.m_cbf, a5); put(L.m_ts, a6);
+    put(L.m_dir, a7); put(L.m_dirl, a8);
+  }
+  {
+    // samples: the CTU itself (inter CUs are final, intra ones get overwritten below), its left column and the row above
+    const int S = (1 << P.log2ctu) >> cs;                   // CTU size in samples of this component
+    const int16_t* org = P.rec[comp] + (ptrdiff_t)(ctu_y >> cs) * P.pitch[comp] + (ctu_x >> cs);
+    // the interior was written by the MC / residual kernels (earlier launches): plain 16-byte loads; the left neighbour's
+    // columns and the row above may come from other waves of THIS launch: coherent loads
+    const int vpr = S / 8;                                  // 16-byte vectors per row
+    for (int i = lane; i < S * vpr; i += 64) {
+      const int r = i / vpr, v = i % vpr;
+      const u32x4 q = ldg4(org + (ptrdiff_t)r * P.pitch[comp] + 8 * v);
+      uint32_t* d = reinterpret_cast<uint32_t*>(&L.pix[r][2 + 8 * v]);
+      d[0] = q.x; d[1] = q.y; d[2] = q.z; d[3] = q.w;
+    }
+    for (int r = lane; r < S; r += 64)
+      reinterpret_cast<uint32_t*>(&L.pix[r][0])[0] = ld_coh(reinterpret_cast<const uint32_t*>(org + (ptrdiff_t)r * P.pitch[comp] - 2));
+    for (int d = lane; d < S + 1; d += 64)                  // row -1, columns -2..2S-1
+      reinterpret_cast<uint32_t*>(L.top)[d] = ld_coh(reinterpret_cast<const uint32_t*>(org - P.pitch[comp] - 2) + d);
+  }
+  const int slice = ldg(P.slice_idx + ctu), tile = ldg(P.tile_idx + ctu);
+  const SliceDev& sd = P.slices[slice];
+  const int cip = ldg(&sd.constrained_intra_pred);
+  const int cqo = comp == 1 ? ldg(&sd.cb_qp_offset) : comp == 2 ? ldg(&sd.cr_qp_offset) : 0;
+  wave_lds_sync();
   int z = 0;
   while (z < parts) {
     const int px = ctu_x + 4 * zscan_x(z), py = ctu_y + 4 * zscan_y(z);
-    const int ps = ldg(P.part_size + base + z);
+    const int ps = (int8_t)L.m_part[z];
     if (px >= P.width || py >= P.height || ps == HMGPU_SIZE_NONE) { z++; continue; }
-    const int depth = ldg(P.depth + base + z);
+    const int depth = L.m_depth[z];
     const int cu_parts = parts >> (2 * depth);
-    if (ldg(P.pred_mode + base + z) != HMGPU_MODE_INTRA) { z += cu_parts; continue; }
+    if ((int8_t)L.m_pred[z] != HMGPU_MODE_INTRA) { z += cu_parts; continue; }
     const int log2cu = P.log2ctu - depth;
-    const int qp_cu = ldg(P.qp + base + z);
+    const int qp_cu = (int8_t)L.m_qp[z];
     const int cu_end = z + cu_parts;
     int zc = z;
     while (zc < cu_end) {
-      const int tr = ldg(P.tr_idx + base + zc);
+      const int tr = L.m_tr[zc];
       const int log2tu = log2cu - tr;
       TuCtx t;
-      t.comp = comp; t.ctu = ctu; t.z_tu = zc; t.qp_cu = qp_cu;
+      t.comp = comp; t.ctu = ctu; t.z_tu = zc; t.qp_cu = qp_cu; t.cip = cip; t.cqo = cqo; t.slice = slice; t.tile = tile;
+      t.cx0 = ctu_x >> cs; t.cy0 = ctu_y >> cs;
       t.x0 = (ctu_x + 4 * zscan_x(zc)) >> cs; t.y0 = (ctu_y + 4 * zscan_y(zc)) >> cs;
       bool run = true;
       if (comp == 0) t.log2n = log2tu;
       else if (log2tu >= 3) t.log2n = log2tu - 1;
       else { t.log2n = 2; run = (zc & 3) == 0; }            // four 4x4 luma TUs share one 4x4 chroma TU, with the first of them (TComTU.cpp:141-171)
       if (run) {
-        int mode = ldg(P.intra_dir[comp ? 1 : 0] + base + zc);
-        if (comp && mode == 36) mode = ldg(P.intra_dir[0] + base + (zc & ~3));         // DM_CHROMA_IDX (TDecCu.cpp:523-524)
+        int mode = L.m_dir[zc];
+        if (comp && mode == 36) mode = L.m_dirl[zc & ~3];                              // DM_CHROMA_IDX (TDecCu.cpp:523-524)
         t.mode = mode;
-        t.cbf = (ldg(P.cbf[comp] + base + zc) >> tr) & 1;
+        t.cbf = (L.m_cbf[zc] >> tr) & 1;
+        t.skip = L.m_ts[zc];
         intra_tu_any(P, t, L);
       }
       zc += 1 << (2 * (log2tu - 2));
@@ -310,17 +363,41 @@ __global__ void __launch_bounds__(64) k_intra(const PicDev* __restrict__ pics, B
   const int cx = ctu % P.ctus_w, cy = ctu / P.ctus_w;
   const int nb[4] = {cx > 0 ? ctu - 1 : -1, (cx > 0 && cy > 0) ? ctu - P.ctus_w - 1 : -1, cy > 0 ? ctu - P.ctus_w : -1,
                      (cy > 0 && cx + 1 < P.ctus_w) ? ctu - P.ctus_w + 1 : -1};
+  // which borders matter: an intra CU reads neighbouring samples only across a border it touches, and only the samples of the
+  // neighbour's intra CUs are still being written.  One dword of pred_mode per lane = four z-consecutive partitions = one 8x8 area.
+  const int lane = threadIdx.x & 63, pw = P.pw;
+  auto border_mask = [&](int c, unsigned& left, unsigned& right, unsigned& top, unsigned& bottom) {
+    // bit masks over 8x8 areas of CTU c that hold an intra partition in the first / last column or row of the CTU
+    bool l = false, r = false, t = false, bm = false;
+    if (4 * lane < P.parts) {
+      const uint32_t pm = ldg(reinterpret_cast<const uint32_t*>(P.pred_mode + (size_t)c * P.parts) + lane);
+      const int x = zscan_x(4 * lane), y = zscan_y(4 * lane);               // partition coordinates of the area's first partition
+      const bool i0 = (pm & 0xff) == HMGPU_MODE_INTRA, i1 = ((pm >> 8) & 0xff) == HMGPU_MODE_INTRA,
+                 i2 = ((pm >> 16) & 0xff) == HMGPU_MODE_INTRA, i3 = (pm >> 24) == HMGPU_MODE_INTRA;      // (x,y) (x+1,y) (x,y+1) (x+1,y+1)
+      l = x == 0 && (i0 || i2); r = x + 2 == pw && (i1 || i3); t = y == 0 && (i0 || i1); bm = y + 2 == pw && (i2 || i3);
+    }
+    left = __builtin_amdgcn_ballot_w64(l) != 0; right = __builtin_amdgcn_ballot_w64(r) != 0;
+    top = __builtin_amdgcn_ballot_w64(t) != 0; bottom = __builtin_amdgcn_ballot_w64(bm) != 0;
+  };
+  unsigned my_l, my_r, my_t, my_b;
+  border_mask(ctu, my_l, my_r, my_t, my_b);
 #pragma unroll
   for (int k = 0; k < 4; k++) {
     const int n = nb[k];
     if (n < first || !ldg(P.ctu_intra + n)) continue;      // outside the picture / finished by an earlier call / no intra CUs: complete already
+    unsigned n_l, n_r, n_t, n_b;
+    border_mask(n, n_l, n_r, n_t, n_b);
+    // left: my first column against its last column; above-left: the corner (covered by column and row tests, conservatively);
+    // above and above-right: my first row against its last row
+    const bool need = k == 0 ? (my_l && n_r) : k == 1 ? ((my_l || my_t) && n_r && n_b) : (my_t && n_b);
+    if (!need) continue;
     // poll with plain coherent loads (an acquire per poll would invalidate the caches of the CU's working waves over and over)
     while (__hip_atomic_load(done + n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) __builtin_amdgcn_s_sleep(64);
   }
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   intra_ctu(P, comp, ctu, L);
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-  if ((threadIdx.x & 63) == 0) __hip_atomic_store(done + ctu, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  if (lane == 0) __hip_atomic_store(done + ctu, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 void launch_intra(const PicDev* pics, const Batch& b, const int32_t* order, int num_ctus, hipStream_t s) {
