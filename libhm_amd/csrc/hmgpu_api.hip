@@ -21,7 +21,7 @@ enum { K_PREP = 0, K_MC_LUMA, K_MC_CHROMA, K_ITX, K_DBK_VER, K_DBK_HOR, K_SAO, K
 const char* const kKernelNames[HMGPU_NUM_KERNELS] = {"prep", "mc_luma", "mc_chroma", "itx", "deblock_ver", "deblock_hor", "sao",
                                                      "extend_border", "h2d_stage", "intra", "", ""};
 
-struct SliceCall { int first_ctu, num_ctus, slice_idx; };
+struct SliceCall { int first_ctu, num_ctus, slice_idx; bool intra; };   // intra: the range holds intra CUs the device reconstructs
 
 struct Picture {
   bool in_use = false;
@@ -225,10 +225,10 @@ hmgpu_status ensure_refs_extended(hmgpu_ctx* c, const Batch& b, size_t call_idx)
 }
 
 // device work of one batch of slice calls (one call per picture): counters, prep, MC, inverse transforms
-hmgpu_status run_recon(hmgpu_ctx* c, const Batch& b) {
+hmgpu_status run_recon(hmgpu_ctx* c, const Batch& b, bool any_intra) {
   int max_ctus = 0;
   for (int i = 0; i < b.n; i++) max_ctus = std::max(max_ctus, b.num_ctus[i]);
-  { ProfScope ps(c, K_PREP); launch_prep(c->d_pics, b, max_ctus, c->parts, c->stream); }
+  { ProfScope ps(c, K_PREP); launch_prep(c->d_pics, b, max_ctus, c->parts, any_intra, c->stream); }
   { ProfScope ps(c, K_MC_LUMA); launch_mc_luma(c->d_pics, c->d_finals, b, max_ctus, c->seq.log2_ctu_size, c->stream); }
   { ProfScope ps(c, K_MC_CHROMA); launch_mc_chroma(c->d_pics, c->d_finals, b, max_ctus, c->seq.log2_ctu_size, c->stream); }
   // blocks per shard: enough to keep the chip busy on a full picture, few enough that a short list costs nothing
@@ -238,8 +238,6 @@ hmgpu_status run_recon(hmgpu_ctx* c, const Batch& b) {
   if (const char* e = getenv("HMGPU_ITX_CLASSES")) cmask = atoi(e);              // tuning aid (wrong output unless 15)
   { ProfScope ps(c, K_ITX); launch_itx(c->d_pics, b, cmask, bps, c->stream); }
   // intra CUs predict from finished neighbours (inter ones included): after motion compensation and the inter residuals
-  bool any_intra = false;
-  for (int i = 0; i < b.n; i++) any_intra |= c->pics[b.pic[i]].dev.has_intra_dir != 0;
   if (any_intra) { ProfScope ps(c, K_INTRA); launch_intra(c->d_pics, b, c->d_ctu_order, c->num_ctus, c->stream); }
   HIP_TRY(c, hipGetLastError());
   return HMGPU_OK;
@@ -595,7 +593,9 @@ hmgpu_status hmgpu_decompress_slice(hmgpu_ctx* c, hmgpu_pic cur, int32_t slice_i
   // a range decoded again (picture buffer reused without release/acquire) replaces the earlier record
   p.calls.erase(std::remove_if(p.calls.begin(), p.calls.end(), [&](const SliceCall& o) {
                   return o.first_ctu < first_ctu + num_ctus && first_ctu < o.first_ctu + o.num_ctus; }), p.calls.end());
-  SliceCall call = {first_ctu, num_ctus, slice_idx};
+  // the caller's arrays are at hand: whether the range holds intra CUs at all decides if the intra kernel is launched
+  const bool has_intra = p.dev.has_intra_dir && memchr(m->pred_mode + po, HMGPU_MODE_INTRA, pn) != nullptr;
+  SliceCall call = {first_ctu, num_ctus, slice_idx, has_intra};
   p.calls.push_back(call);
 
   Batch b; memset(&b, 0, sizeof(b));
@@ -603,7 +603,7 @@ hmgpu_status hmgpu_decompress_slice(hmgpu_ctx* c, hmgpu_pic cur, int32_t slice_i
   p.extended = false;
   hmgpu_status st = ensure_refs_extended(c, b, p.calls.size() - 1);
   if (st != HMGPU_OK) return st;
-  return run_recon(c, b);
+  return run_recon(c, b, has_intra);
 }
 
 hmgpu_status hmgpu_filter_picture_stages(hmgpu_ctx* c, hmgpu_pic cur, const hmgpu_pic_params* pp, const hmgpu_sao_param* sao,
@@ -656,12 +656,14 @@ hmgpu_status hmgpu_replay_batch(hmgpu_ctx* c, const hmgpu_pic* pics, int32_t n, 
       for (size_t k = 0; k < ncalls; k++) {
         Batch b; memset(&b, 0, sizeof(b));
         b.n = n;
+        bool any_intra = false;
         for (int i = 0; i < n; i++) {
           const SliceCall& sc = c->pics[pics[i]].calls[k];
           b.pic[i] = pics[i]; b.first_ctu[i] = sc.first_ctu; b.num_ctus[i] = sc.num_ctus;
+          any_intra |= sc.intra;
         }
         hmgpu_status st = ensure_refs_extended(c, b, k);
-        if (st == HMGPU_OK) st = run_recon(c, b);
+        if (st == HMGPU_OK) st = run_recon(c, b, any_intra);
         if (st != HMGPU_OK) return st;
       }
     }

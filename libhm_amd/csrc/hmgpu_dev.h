@@ -165,7 +165,7 @@ __host__ inline int xcd_grid(int n, int nb) {
 }
 
 // ---- launchers (one per kernel family; defined in the .hip files) ---------------------------------------------------
-void launch_prep(const PicDev* pics, const Batch& b, int max_ctus, int parts, hipStream_t s);
+void launch_prep(const PicDev* pics, const Batch& b, int max_ctus, int parts, bool intra, hipStream_t s);
 void launch_mc_luma(const PicDev* pics, const PlaneSet* finals, const Batch& b, int max_ctus, int log2ctu, hipStream_t s);
 int launch_mc_luma_stamped(const PicDev* pics, const PlaneSet* finals, const Batch& b, int max_ctus, int log2ctu, unsigned long long* stamps, hipStream_t s);
 void launch_mc_chroma(const PicDev* pics, const PlaneSet* finals, const Batch& b, int max_ctus, int log2ctu, hipStream_t s);

@@ -242,16 +242,16 @@ __global__ void __launch_bounds__(256) k_prep(const PicDev* __restrict__ pics, B
 }
 
 // resets the TU list lengths of every picture of the batch (one launch instead of one memset per picture)
-__global__ void k_zero_counts(const PicDev* __restrict__ pics, Batch b) {
+__global__ void k_zero_counts(const PicDev* __restrict__ pics, Batch b, int intra) {
   const PicDev& P = pics[b.pic[blockIdx.x]];
   if (threadIdx.x < 4 * kTuShards) stg(P.tu_count + threadIdx.x, 0u);
   // intra state of this call: per-CTU "holds intra CUs" flags of the CTU range, "done" flags of all CTUs
   for (int i = threadIdx.x; i < b.num_ctus[blockIdx.x]; i += blockDim.x) stg(P.ctu_intra + b.first_ctu[blockIdx.x] + i, (uint8_t)0);
-  for (int i = threadIdx.x; i < 3 * P.num_ctus; i += blockDim.x) stg(P.intra_done + i, 0u);
+  if (intra) for (int i = threadIdx.x; i < 3 * P.num_ctus; i += blockDim.x) stg(P.intra_done + i, 0u);
 }
 
-void launch_prep(const PicDev* pics, const Batch& b, int max_ctus, int parts, hipStream_t s) {
-  hipLaunchKernelGGL(k_zero_counts, dim3((unsigned)b.n), dim3(64), 0, s, pics, b);
+void launch_prep(const PicDev* pics, const Batch& b, int max_ctus, int parts, bool intra, hipStream_t s) {
+  hipLaunchKernelGGL(k_zero_counts, dim3((unsigned)b.n), dim3(256), 0, s, pics, b, intra ? 1 : 0);
   dim3 grid((unsigned)(((size_t)max_ctus * (parts / 4) + 255) / 256), 1, (unsigned)b.n);
   hipLaunchKernelGGL(k_prep, grid, dim3(256), 0, s, pics, b);
 }

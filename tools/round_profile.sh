@@ -10,6 +10,9 @@ python3 bench.py > $out/bench_full.json 2> $out/bench_full.err
 for wl in idct mc mc_bi filter; do
   python3 bench.py --workload $wl --steps 10 --no-cpu-baseline > $out/bench_$wl.json 2> $out/bench_$wl.err
 done
+python3 bench.py --workload intra --batch 1 --steps 5 --warmup 1 --profile-steps 2 --no-cpu-baseline > $out/bench_intra_1pic.json 2> $out/bench_intra_1pic.err
+python3 bench.py --workload intra --steps 5 --warmup 1 --profile-steps 2 --no-cpu-baseline > $out/bench_intra.json 2> $out/bench_intra.err
+python3 bench.py --workload gop --steps 10 > $out/bench_gop.json 2> $out/bench_gop.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline > $out/stats.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -- python3 bench.py --steps 2 --warmup 1 --profile-steps 1 --no-cpu-baseline > $out/pmc_fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/pmc_write -- python3 bench.py --steps 2 --warmup 1 --profile-steps 1 --no-cpu-baseline > $out/pmc_write.log 2>&1
