@@ -31,7 +31,7 @@ class SynthPicture:
 
 def make_picture(width, height, bit_depth=10, seed=1, bi=False, intra_frac=0.0, num_refs=1, slice_qp_range=(22, 37),
                  cbf_prob=0.5, sao=True, mode_probs=(0.1, 0.3, 0.3, 0.2, 0.1), ref_handles=None, mv_range=64,
-                 coef_dist="typical", tr_split_prob=0.35, intra_modes=True):
+                 coef_dist="typical", tr_split_prob=0.35, intra_modes=True, num_slices=1, lf_across_slices=1):
     """Returns a SynthPicture with .seq, .slice (abi.SliceParams), .meta (MetaHolder), .coeffs (CoeffHolder),
     .sao_raw [num_ctus,3,35], .pp, .meta_np.  ref_handles: device picture handles of list-0 / list-1 references.
     coef_dist: "typical" (see above) or "stress" (every level of a coded TU uniform over the full int16 range, SURVEY 8d #2)."""
@@ -208,9 +208,28 @@ def make_picture(width, height, bit_depth=10, seed=1, bi=False, intra_frac=0.0, 
     l0 = list(handles[0])[:max(num_refs, 1)]
     l1 = list(handles[1])[:1] if bi else []
     p.slice = abi.make_slice(abi.B_SLICE if bi else abi.P_SLICE, (l0, l1), ([100 + i for i in range(len(l0))], [200 + i for i in range(len(l1))]))
+    # slices: contiguous CTU ranges starting at seeded CTU addresses (mid-row starts included); slice k may differ in its
+    # deblocking offsets and chroma QP offsets, all share the reference lists
+    p.slices, p.slice_ranges = [p.slice], [(0, n)]
+    slice_idx = np.zeros(n, dtype=np.uint16)
+    if num_slices > 1:
+        starts = [0] + sorted(int(v) for v in rng.choice(np.arange(1, n), size=num_slices - 1, replace=False))
+        p.slices, p.slice_ranges = [], []
+        for k, a in enumerate(starts):
+            b_ = starts[k + 1] if k + 1 < len(starts) else n
+            sl = abi.make_slice(abi.B_SLICE if bi else abi.P_SLICE, (l0, l1), ([100 + i for i in range(len(l0))], [200 + i for i in range(len(l1))]),
+                                cb_qp_offset=int(rng.randint(-3, 4)), cr_qp_offset=int(rng.randint(-3, 4)),
+                                beta_offset_div2=int(rng.randint(-2, 3)), tc_offset_div2=int(rng.randint(-2, 3)),
+                                lf_across_slices=lf_across_slices)
+            sl.pps_cb_qp_offset, sl.pps_cr_qp_offset = sl.cb_qp_offset, sl.cr_qp_offset
+            p.slices.append(sl)
+            p.slice_ranges.append((a, b_ - a))
+            slice_idx[a:b_] = k
+        p.slice = p.slices[0]
     m = {"depth": depth, "part_size": part_size, "pred_mode": pred_mode, "qp": qp, "tr_idx": tr_idx, "cbf_y": cbf[0], "cbf_u": cbf[1],
          "cbf_v": cbf[2], "mv0": mv0, "mv1": mv1, "ref_idx0": ref_idx0, "ref_idx1": ref_idx1,
          "intra_dir_l": np.where(intra, intra_dir_l, 1), "intra_dir_c": np.where(intra, intra_dir_c, 36)}
+    m["slice_idx"] = slice_idx
     if not intra_modes:                 # the caller leaves intra CUs to somebody else: no modes, nothing reconstructed there
         del m["intra_dir_l"], m["intra_dir_c"]
     p.meta_np = m

@@ -52,6 +52,42 @@ def test_synthetic_picture_matches_oracle(oracle, width, height, bd, bi, intra):
         assert st["inter_partitions"] == int((p.inside & ~p.intra).sum())
 
 
+@pytest.mark.parametrize("across", [0, 1])
+def test_multi_slice_picture_matches_oracle(oracle, across):
+    """five slices starting at arbitrary CTUs (own QP / deblocking offsets), one hmgpu_decompress_slice call per slice: slice
+    borders bound intra references, deblocking (slice_loop_filter_across_slices_enabled_flag) and SAO neighbourhoods"""
+    import libhm_amd
+    w, h, bd = 832, 480, 10
+    p = synth.make_picture(w, h, bd, seed=91 + across, intra_frac=0.3, ref_handles=([0], [0]), num_slices=5, lf_across_slices=across)
+    assert len(p.slices) == 5 and any(a % p.ctus_w for a, _ in p.slice_ranges)
+    ref = synth.noise_planes(w, h, bd, 5)
+    cur = synth.blocky_planes(w, h, bd, 6)
+    want = [a.copy() for a in cur]
+    oracle.decompress_ctus(p.seq, p.slices, p.meta, p.coeffs, want, [ref])
+    want_rec = [a.copy() for a in want]
+    oracle.loop_filter_pic(p.seq, p.slices, p.meta, p.pp, want, 3)
+    prm = oracle.sao_reconstruct_params(p.seq, p.pp, p.meta, p.sao_raw)
+    want_fin = oracle.sao_process(p.seq, p.slices, p.pp, p.meta, prm, want)
+    with libhm_amd.Context(p.seq) as ctx:
+        h0, hc = ctx.acquire(), ctx.acquire()
+        ctx.upload(h0, ref)
+        ctx.upload(hc, cur)
+        for k, (first, num) in enumerate(p.slice_ranges):
+            ctx.decompress_slice(hc, k, p.slices[k], p.meta, p.coeffs, first_ctu=first, num_ctus=num)
+        got = ctx.download(hc)
+        for c in range(3):
+            assert np.array_equal(got[c], want_rec[c]), "reconstruction comp %d" % c
+        ctx.filter_picture(hc, p.pp, p.sao_raw)
+        got = ctx.download(hc)
+        for c in range(3):
+            assert np.array_equal(got[c], want_fin[c]), "filtered comp %d" % c
+        # the same picture again as a batched replay (five slice calls per picture)
+        ctx.replay([hc], 15, 1)
+        got = ctx.download(hc)
+        for c in range(3):
+            assert np.array_equal(got[c], want_fin[c]), "replayed comp %d" % c
+
+
 def test_identical_motion_collapses_to_uni(oracle):
     """B slice, both lists point at the same POC with the same MV: xCheckIdenticalMotion -> uni-prediction rounding"""
     import libhm_amd
