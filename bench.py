@@ -84,6 +84,7 @@ def main():
     ap.add_argument("--workload", default="full", choices=("full", "idct", "mc", "mc_bi", "filter", "intra", "gop"))
     ap.add_argument("--mode-probs", default=None, help="experiment: CTU partition probabilities 64x64,32x32,16x16,8x8,AMP (comma separated)")
     ap.add_argument("--intra-frac", type=float, default=None, help="experiment: fraction of CUs that are intra (with intra modes: reconstructed on the GPU)")
+    ap.add_argument("--cbf-prob", type=float, default=None, help="experiment: probability that a TU is coded")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-steps", type=int, default=5)
     args = ap.parse_args()
@@ -119,6 +120,8 @@ def main():
         # all-intra pictures (I pictures): the serial chain of the path, a CTU-row wavefront on the device
         roof_kernel = "intra"
         kw = dict(intra_frac=1.0)
+    if args.cbf_prob is not None:
+        kw["cbf_prob"] = args.cbf_prob
     if args.intra_frac is not None:
         kw["intra_frac"] = args.intra_frac
     if args.mode_probs:

@@ -80,13 +80,20 @@ typedef struct hmgpu_slice_params {
   int32_t deblocking_disable;           /* getDeblockingFilterDisable() */
   int32_t beta_offset_div2, tc_offset_div2;
   int32_t lf_across_slices;             /* getLFCrossSliceBoundaryFlag() */
-  int32_t weighted_pred;                /* PPS weighted_pred_flag / weighted_bipred_flag for this slice type: must be 0 */
+  int32_t weighted_pred;                /* TComSlice::applyWP(): explicit weighted prediction is active for this slice (P slice with
+                                           weighted_pred_flag, B slice with weighted_bipred_flag); the tables below are then read */
   int32_t lf_across_tiles;              /* PPS loop_filter_across_tiles_enabled_flag (TDecGop.cpp:165) */
   int32_t num_ref_idx[2];
   hmgpu_pic ref_pic[2][HMGPU_MAX_REF];  /* getRefPic(list, idx) as device picture handles */
   int32_t ref_poc[2][HMGPU_MAX_REF];    /* getRefPOC(list, idx) (identical-motion test, TComPrediction.cpp:497-512) */
   int32_t constrained_intra_pred;       /* PPS constrained_intra_pred_flag (TComPattern.cpp:558-572) */
   int32_t reserved[4];
+  /* explicit weighted prediction (TComWeightPrediction.cpp:44-57, 211-271), after TComSlice::initWpScaling: per list,
+   * reference index and component the weight (iWeight; 1 << log2 denominator where the header carried none) and the offset
+   * already scaled to the bit depth (iOffset << (bitDepth - 8) unless high_precision_offsets) */
+  int32_t wp_log2_denom[2];             /* luma, chroma */
+  int16_t wp_weight[2][HMGPU_MAX_REF][3];
+  int16_t wp_offset[2][HMGPU_MAX_REF][3];
 } hmgpu_slice_params;
 
 /* The picture-persistent TComDataCU arrays of TComPicSym (TComPicSym.cpp:93-114).  Every array covers the WHOLE

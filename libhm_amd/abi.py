@@ -31,7 +31,8 @@ class SliceParams(C.Structure):
                 ("pps_cb_qp_offset", C.c_int32), ("pps_cr_qp_offset", C.c_int32), ("deblocking_disable", C.c_int32),
                 ("beta_offset_div2", C.c_int32), ("tc_offset_div2", C.c_int32), ("lf_across_slices", C.c_int32),
                 ("weighted_pred", C.c_int32), ("lf_across_tiles", C.c_int32), ("num_ref_idx", C.c_int32 * 2),
-                ("ref_pic", (C.c_int32 * MAX_REF) * 2), ("ref_poc", (C.c_int32 * MAX_REF) * 2), ("constrained_intra_pred", C.c_int32), ("reserved", C.c_int32 * 4)]
+                ("ref_pic", (C.c_int32 * MAX_REF) * 2), ("ref_poc", (C.c_int32 * MAX_REF) * 2), ("constrained_intra_pred", C.c_int32), ("reserved", C.c_int32 * 4),
+                ("wp_log2_denom", C.c_int32 * 2), ("wp_weight", ((C.c_int16 * 3) * MAX_REF) * 2), ("wp_offset", ((C.c_int16 * 3) * MAX_REF) * 2)]
 
 
 class CtuMeta(C.Structure):

@@ -21,7 +21,7 @@ enum { K_PREP = 0, K_MC_LUMA, K_MC_CHROMA, K_ITX, K_DBK_VER, K_DBK_HOR, K_SAO, K
 const char* const kKernelNames[HMGPU_NUM_KERNELS] = {"prep", "mc_luma", "mc_chroma", "itx", "deblock_ver", "deblock_hor", "sao",
                                                      "extend_border", "h2d_stage", "intra", "", ""};
 
-struct SliceCall { int first_ctu, num_ctus, slice_idx; bool intra; };   // intra: the range holds intra CUs the device reconstructs
+struct SliceCall { int first_ctu, num_ctus, slice_idx; bool intra, wp; };   // intra: the range holds intra CUs the device reconstructs
 
 struct Picture {
   bool in_use = false;
@@ -225,12 +225,12 @@ hmgpu_status ensure_refs_extended(hmgpu_ctx* c, const Batch& b, size_t call_idx)
 }
 
 // device work of one batch of slice calls (one call per picture): counters, prep, MC, inverse transforms
-hmgpu_status run_recon(hmgpu_ctx* c, const Batch& b, bool any_intra) {
+hmgpu_status run_recon(hmgpu_ctx* c, const Batch& b, bool any_intra, bool any_wp) {
   int max_ctus = 0;
   for (int i = 0; i < b.n; i++) max_ctus = std::max(max_ctus, b.num_ctus[i]);
   { ProfScope ps(c, K_PREP); launch_prep(c->d_pics, b, max_ctus, c->parts, any_intra, c->stream); }
-  { ProfScope ps(c, K_MC_LUMA); launch_mc_luma(c->d_pics, c->d_finals, b, max_ctus, c->seq.log2_ctu_size, c->stream); }
-  { ProfScope ps(c, K_MC_CHROMA); launch_mc_chroma(c->d_pics, c->d_finals, b, max_ctus, c->seq.log2_ctu_size, c->stream); }
+  { ProfScope ps(c, K_MC_LUMA); launch_mc_luma(c->d_pics, c->d_finals, b, max_ctus, c->seq.log2_ctu_size, any_wp, c->stream); }
+  { ProfScope ps(c, K_MC_CHROMA); launch_mc_chroma(c->d_pics, c->d_finals, b, max_ctus, c->seq.log2_ctu_size, any_wp, c->stream); }
   // blocks per shard: enough to keep the chip busy on a full picture, few enough that a short list costs nothing
   uint32_t bps = (uint32_t)std::max(4, std::min(24, max_ctus / 8 + 1));   // blocks per shard; 24 measured best at 2160p (768 blocks, 3 per CU)
   if (const char* e = getenv("HMGPU_ITX_BPS")) bps = (uint32_t)std::max(1, atoi(e));   // tuning knob
@@ -526,7 +526,7 @@ hmgpu_status hmgpu_decompress_slice(hmgpu_ctx* c, hmgpu_pic cur, int32_t slice_i
   if (!m->depth || !m->part_size || !m->pred_mode || !m->qp || !m->tr_idx || !m->cbf[0] || !m->cbf[1] || !m->cbf[2] ||
       !m->mv[0] || !m->mv[1] || !m->ref_idx[0] || !m->ref_idx[1] || !co->level[0] || !co->level[1] || !co->level[2])
     return HMGPU_EINVAL;
-  if (sl->weighted_pred) return HMGPU_EUNSUPPORTED;
+  if (sl->weighted_pred && (sl->wp_log2_denom[0] < 0 || sl->wp_log2_denom[0] > 7 || sl->wp_log2_denom[1] < 0 || sl->wp_log2_denom[1] > 7)) return HMGPU_EINVAL;
   Picture& p = c->pics[cur];
   if (p.sao_applied) {                 // picture buffer decoded again without release/acquire: reconstruction planes again
     p.sao_applied = false; p.dev.sao_applied = 0;
@@ -551,6 +551,10 @@ hmgpu_status hmgpu_decompress_slice(hmgpu_ctx* c, hmgpu_pic cur, int32_t slice_i
   sd.deblocking_disable = sl->deblocking_disable; sd.beta_offset_div2 = sl->beta_offset_div2; sd.tc_offset_div2 = sl->tc_offset_div2;
   sd.lf_across_slices = sl->lf_across_slices;
   sd.constrained_intra_pred = sl->constrained_intra_pred ? 1 : 0;
+  sd.weighted_pred = sl->weighted_pred ? 1 : 0;
+  sd.wp_log2_denom[0] = sl->wp_log2_denom[0]; sd.wp_log2_denom[1] = sl->wp_log2_denom[1];
+  memcpy(sd.wp_weight, sl->wp_weight, sizeof(sd.wp_weight));
+  memcpy(sd.wp_offset, sl->wp_offset, sizeof(sd.wp_offset));
   for (int l = 0; l < 2; l++)
     for (int i = 0; i < HMGPU_MAX_REF; i++) {
       sd.ref_poc[l][i] = i < sl->num_ref_idx[l] ? sl->ref_poc[l][i] : 0;
@@ -595,7 +599,7 @@ hmgpu_status hmgpu_decompress_slice(hmgpu_ctx* c, hmgpu_pic cur, int32_t slice_i
                   return o.first_ctu < first_ctu + num_ctus && first_ctu < o.first_ctu + o.num_ctus; }), p.calls.end());
   // the caller's arrays are at hand: whether the range holds intra CUs at all decides if the intra kernel is launched
   const bool has_intra = p.dev.has_intra_dir && memchr(m->pred_mode + po, HMGPU_MODE_INTRA, pn) != nullptr;
-  SliceCall call = {first_ctu, num_ctus, slice_idx, has_intra};
+  SliceCall call = {first_ctu, num_ctus, slice_idx, has_intra, sl->weighted_pred != 0};
   p.calls.push_back(call);
 
   Batch b; memset(&b, 0, sizeof(b));
@@ -603,7 +607,7 @@ hmgpu_status hmgpu_decompress_slice(hmgpu_ctx* c, hmgpu_pic cur, int32_t slice_i
   p.extended = false;
   hmgpu_status st = ensure_refs_extended(c, b, p.calls.size() - 1);
   if (st != HMGPU_OK) return st;
-  return run_recon(c, b, has_intra);
+  return run_recon(c, b, has_intra, sl->weighted_pred != 0);
 }
 
 hmgpu_status hmgpu_filter_picture_stages(hmgpu_ctx* c, hmgpu_pic cur, const hmgpu_pic_params* pp, const hmgpu_sao_param* sao,
@@ -656,14 +660,14 @@ hmgpu_status hmgpu_replay_batch(hmgpu_ctx* c, const hmgpu_pic* pics, int32_t n, 
       for (size_t k = 0; k < ncalls; k++) {
         Batch b; memset(&b, 0, sizeof(b));
         b.n = n;
-        bool any_intra = false;
+        bool any_intra = false, any_wp = false;
         for (int i = 0; i < n; i++) {
           const SliceCall& sc = c->pics[pics[i]].calls[k];
           b.pic[i] = pics[i]; b.first_ctu[i] = sc.first_ctu; b.num_ctus[i] = sc.num_ctus;
-          any_intra |= sc.intra;
+          any_intra |= sc.intra; any_wp |= sc.wp;
         }
         hmgpu_status st = ensure_refs_extended(c, b, k);
-        if (st == HMGPU_OK) st = run_recon(c, b, any_intra);
+        if (st == HMGPU_OK) st = run_recon(c, b, any_intra, any_wp);
         if (st != HMGPU_OK) return st;
       }
     }
@@ -704,31 +708,6 @@ hmgpu_status hmgpu_get_stats(hmgpu_ctx* c, hmgpu_stats* out, int32_t reset) {
     if (reset) HIP_TRY(c, hipMemset(p.dev.stats, 0, sizeof(st)));
   }
   if (reset) for (int k = 0; k < HMGPU_NUM_KERNELS; k++) { c->kernel_ms[k] = 0; c->kernel_launches[k] = 0; }
-  return HMGPU_OK;
-}
-
-// diagnostic (not part of the product surface): per-wave phase times of the luma MC kernel for picture `cur`, in shader
-// cycles: out[0] = entry -> BlkInfo arrived, out[1] = BlkInfo -> tile stored, out[2] = waves measured, out[3] = span of the launch
-hmgpu_status hmgpu_debug_mc_stamps(hmgpu_ctx* c, hmgpu_pic cur, double* out) {
-  if (!c || !valid_pic(c, cur) || !out || c->pics[cur].calls.empty()) return HMGPU_EINVAL;
-  Batch b; memset(&b, 0, sizeof(b));
-  b.n = 1; b.pic[0] = cur; b.first_ctu[0] = 0; b.num_ctus[0] = c->num_ctus;
-  const int nw = launch_mc_luma_stamped(c->d_pics, c->d_finals, b, c->num_ctus, c->seq.log2_ctu_size, nullptr, c->stream);
-  unsigned long long* d = nullptr;
-  HIP_TRY(c, hipMalloc((void**)&d, (size_t)nw * 24));
-  HIP_TRY(c, hipMemset(d, 0, (size_t)nw * 24));
-  launch_mc_luma_stamped(c->d_pics, c->d_finals, b, c->num_ctus, c->seq.log2_ctu_size, d, c->stream);
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
-  std::vector<unsigned long long> h((size_t)nw * 3);
-  HIP_TRY(c, hipMemcpy(h.data(), d, h.size() * 8, hipMemcpyDeviceToHost));
-  hipFree(d);
-  double s0 = 0, s1 = 0, n = 0; unsigned long long lo = ~0ull, hi = 0;
-  for (int w = 0; w < nw; w++) {
-    if (!h[w * 3 + 2]) continue;
-    s0 += (double)(h[w * 3 + 1] - h[w * 3]); s1 += (double)(h[w * 3 + 2] - h[w * 3 + 1]); n += 1;
-    lo = std::min(lo, h[w * 3]); hi = std::max(hi, h[w * 3 + 2]);
-  }
-  out[0] = n ? s0 / n : 0; out[1] = n ? s1 / n : 0; out[2] = n; out[3] = n ? (double)(hi - lo) : 0;
   return HMGPU_OK;
 }
 

@@ -62,6 +62,10 @@ struct SliceDev {
   int32_t ref_poc[2][HMGPU_MAX_REF];
   int8_t  ref_pic[2][HMGPU_MAX_REF];
   int32_t constrained_intra_pred;
+  int32_t weighted_pred;                // explicit weighted prediction active (TComSlice::applyWP)
+  int32_t wp_log2_denom[2];
+  int16_t wp_weight[2][HMGPU_MAX_REF][3];
+  int16_t wp_offset[2][HMGPU_MAX_REF][3];
 };
 
 struct SaoDev {                 // reconstructed SAO parameters of one CTU component, 12 bytes
@@ -166,9 +170,8 @@ __host__ inline int xcd_grid(int n, int nb) {
 
 // ---- launchers (one per kernel family; defined in the .hip files) ---------------------------------------------------
 void launch_prep(const PicDev* pics, const Batch& b, int max_ctus, int parts, bool intra, hipStream_t s);
-void launch_mc_luma(const PicDev* pics, const PlaneSet* finals, const Batch& b, int max_ctus, int log2ctu, hipStream_t s);
-int launch_mc_luma_stamped(const PicDev* pics, const PlaneSet* finals, const Batch& b, int max_ctus, int log2ctu, unsigned long long* stamps, hipStream_t s);
-void launch_mc_chroma(const PicDev* pics, const PlaneSet* finals, const Batch& b, int max_ctus, int log2ctu, hipStream_t s);
+void launch_mc_luma(const PicDev* pics, const PlaneSet* finals, const Batch& b, int max_ctus, int log2ctu, bool wp, hipStream_t s);
+void launch_mc_chroma(const PicDev* pics, const PlaneSet* finals, const Batch& b, int max_ctus, int log2ctu, bool wp, hipStream_t s);
 void launch_itx(const PicDev* pics, const Batch& b, int log2size, uint32_t blocks_per_shard, hipStream_t s);
 void launch_intra(const PicDev* pics, const Batch& b, const int32_t* order, int num_ctus, hipStream_t s);
 void launch_deblock(const PicDev* pics, const Batch& b, int dir, int width, int height, hipStream_t s);

@@ -126,10 +126,45 @@ __device__ inline int finish_uni(int v6, int head, int maxv) { return clip3(0, m
 // TComYuv::addAvg: clip((a + b + 2^head + 2*8192) >> (head+1))
 __device__ inline int finish_bi(int a, int b, int head, int maxv) { return clip3(0, maxv, (a + b + (1 << head) + 16384) >> (head + 1)); }
 
+// explicit weighted prediction of one lane's block (TComWeightPrediction.cpp:44-57, 211-271): weight / offset per list for this
+// component, log2 of the weight denominator; active = the block's slice uses it (TComSlice::applyWP)
+struct WpLane { bool active; int w[2], o[2], log2wd; };
+
+// the reference index of a 4x4 block: BlkInfo keeps the reference PICTURE (what the filter needs), weighted prediction is
+// indexed by reference INDEX (two indices may name the same picture with different weights): read it back from HM's array
+__device__ inline int ref_idx_at(const PicDev& P, int list, int x, int y) {
+  const int m = (1 << P.log2ctu) - 1;
+  const int ctu = (y >> P.log2ctu) * P.ctus_w + (x >> P.log2ctu);
+  const int bx = (x & m) >> 2, by = (y & m) >> 2;
+  int z = 0;
+#pragma unroll
+  for (int k = 0; k < 4; k++) z |= (((bx >> k) & 1) << (2 * k)) | (((by >> k) & 1) << (2 * k + 1));
+  return ldg(P.ref_idx[list] + (size_t)ctu * P.parts + z);
+}
+__device__ inline WpLane wp_lane(const PicDev& P, const BlkInfo& bi, int comp, int x, int y) {
+  WpLane w;
+  const SliceDev& sd = P.slices[bi.slice];
+  w.active = ldg(&sd.weighted_pred) != 0;
+  w.w[0] = w.w[1] = 1; w.o[0] = w.o[1] = 0; w.log2wd = 0;
+  if (w.active) {
+    w.log2wd = ldg(&sd.wp_log2_denom[comp ? 1 : 0]);
+#pragma unroll
+    for (int l = 0; l < 2; l++)
+      if (bi.flags & (l ? BF_MC_L1 : BF_MC_L0)) {
+        const int r = ref_idx_at(P, l, x, y);
+        w.w[l] = ldg(&sd.wp_weight[l][r][comp]);
+        w.o[l] = ldg(&sd.wp_offset[l][r][comp]);
+      }
+  }
+  return w;
+}
+
 // prediction of one W x H tile of component `comp` with the motion of `bi`, written to dst (the picture being decoded)
-template <int TAPS, int W, int H>
+template <int TAPS, int W, int H, bool WP = false>
 __device__ inline void predict_tile(const PicDev& P, const PlaneSet* __restrict__ finals, int comp, int x0, int y0,
-                                    const BlkInfo& bi, int cu_x, int cu_y, int16_t* __restrict__ dst) {
+                                    const BlkInfo& bi, int cu_x, int cu_y, int16_t* __restrict__ dst, int lx = 0, int ly = 0) {
+  WpLane wp = {false, {1, 1}, {0, 0}, 0};
+  if constexpr (WP) wp = wp_lane(P, bi, comp, lx, ly);
   const int bd = P.bd[comp];
   const int head = bd >= 12 ? 2 : 14 - bd;
   const int maxv = (1 << bd) - 1;
@@ -147,7 +182,13 @@ __device__ inline void predict_tile(const PicDev& P, const PlaneSet* __restrict_
 #pragma unroll
       for (int x = 0; x < W; x += 2) {
         // bi: park the 14-bit intermediates (they fit 16 bits) while the second list is computed
-        const int v0 = both ? (a[y][x] >> 6) : finish_uni(a[y][x], head, maxv), v1 = both ? (a[y][x + 1] >> 6) : finish_uni(a[y][x + 1], head, maxv);
+        int v0 = both ? (a[y][x] >> 6) : finish_uni(a[y][x], head, maxv), v1 = both ? (a[y][x + 1] >> 6) : finish_uni(a[y][x + 1], head, maxv);
+        if (WP && wp.active && !both) {
+          // weightUnidir on HM's 14-bit intermediate (xPredInterUni with bi = true, then addWeightUni)
+          const int shift = wp.log2wd + head, round = shift > 0 ? 1 << (shift - 1) : 0;
+          v0 = clip3(0, maxv, ((wp.w[l0] * ((a[y][x] >> 6) + 8192) + round) >> shift) + wp.o[l0]);
+          v1 = clip3(0, maxv, ((wp.w[l0] * ((a[y][x + 1] >> 6) + 8192) + round) >> shift) + wp.o[l0]);
+        }
         res[y][x / 2] = __builtin_amdgcn_perm((uint32_t)v1, (uint32_t)v0, 0x05040100u);
       }
   }
@@ -161,7 +202,13 @@ __device__ inline void predict_tile(const PicDev& P, const PlaneSet* __restrict_
 #pragma unroll
       for (int x = 0; x < W; x += 2) {
         const int a0 = (int)(int16_t)(res[y][x / 2] & 0xffffu), a1 = (int)(int16_t)(res[y][x / 2] >> 16);
-        const int v0 = finish_bi(a0, b[y][x] >> 6, head, maxv), v1 = finish_bi(a1, b[y][x + 1] >> 6, head, maxv);
+        int v0 = finish_bi(a0, b[y][x] >> 6, head, maxv), v1 = finish_bi(a1, b[y][x + 1] >> 6, head, maxv);
+        if (WP && wp.active) {
+          // weightBidir (addWeightBi): shift = log2Wd + 1 + shiftNum, the offsets of both lists enter at half weight
+          const int shift = wp.log2wd + 1 + head, add = (1 << (shift - 1)) + ((wp.o[0] + wp.o[1]) << (shift - 1));
+          v0 = clip3(0, maxv, (wp.w[0] * (a0 + 8192) + wp.w[1] * ((b[y][x] >> 6) + 8192) + add) >> shift);
+          v1 = clip3(0, maxv, (wp.w[0] * (a1 + 8192) + wp.w[1] * ((b[y][x + 1] >> 6) + 8192) + add) >> shift);
+        }
         res[y][x / 2] = __builtin_amdgcn_perm((uint32_t)v1, (uint32_t)v0, 0x05040100u);
       }
   }
@@ -185,14 +232,16 @@ __device__ inline bool is_inter(const BlkInfo& b) { return (b.flags & BF_VALID) 
 // one 4x4 luma cell / its 2x2 chroma samples on their own: only where the four cells of an 8x8 area do not share
 // their motion (8x4 / 4x8 PUs, AMP parts of 16x16 CUs, picture borders).  Out of line: rare, and it keeps the common
 // path's register budget small.
+template <bool WP>
 __device__ __attribute__((noinline)) void luma_cell(const PicDev& P, const PlaneSet* __restrict__ finals, const BlkInfo& c, int x, int y) {
   const int cs = 1 << c.log2cu;
-  predict_tile<8, 4, 4>(P, finals, 0, x, y, c, x & ~(cs - 1), y & ~(cs - 1), P.rec[0]);
+  predict_tile<8, 4, 4, WP>(P, finals, 0, x, y, c, x & ~(cs - 1), y & ~(cs - 1), P.rec[0], x, y);
 }
+template <bool WP>
 __device__ __attribute__((noinline)) void chroma_cell(const PicDev& P, const PlaneSet* __restrict__ finals, const BlkInfo& c, int lx, int ly) {
   const int cs = 1 << c.log2cu;
-  predict_tile<4, 2, 2>(P, finals, 1, lx >> 1, ly >> 1, c, lx & ~(cs - 1), ly & ~(cs - 1), P.rec[1]);
-  predict_tile<4, 2, 2>(P, finals, 2, lx >> 1, ly >> 1, c, lx & ~(cs - 1), ly & ~(cs - 1), P.rec[2]);
+  predict_tile<4, 2, 2, WP>(P, finals, 1, lx >> 1, ly >> 1, c, lx & ~(cs - 1), ly & ~(cs - 1), P.rec[1], lx, ly);
+  predict_tile<4, 2, 2, WP>(P, finals, 2, lx >> 1, ly >> 1, c, lx & ~(cs - 1), ly & ~(cs - 1), P.rec[2], lx, ly);
 }
 
 // lane -> 8x8 luma area: a wave covers 8x8 areas = 64x64 luma samples, a block four such squares in CTU order
@@ -211,40 +260,46 @@ __device__ inline bool tile_origin(const PicDev& P, const Batch& b, int slot, in
   return x0 < cx + ctu_sz && y0 < cy + ctu_sz && x0 < P.width && y0 < P.height;
 }
 
-// STAMP: diagnostic build only (hmgpu_debug_mc_stamps): lane 0 of every wave records s_memtime at entry, after the
-// BlkInfo records arrived, and at exit, into a buffer nothing else reads.
-template <bool STAMP>
-__global__ void __launch_bounds__(256) k_mc_luma(const PicDev* __restrict__ pics, const PlaneSet* __restrict__ finals, Batch b, int nblocks,
-                                                 unsigned long long* __restrict__ stamps) {
-  unsigned long long t0 = 0, t1 = 0;
-  if (STAMP) t0 = __builtin_amdgcn_s_memtime();
+// with explicit weighted prediction two cells share a tile only if their reference INDICES agree too
+template <bool WP>
+__device__ inline bool tile_is_uniform(const PicDev& P, const BlkInfo& c00, const BlkInfo& c01, const BlkInfo& c10, const BlkInfo& c11, int x0, int y0) {
+  if (!(is_inter(c00) && same_motion(c00, c01) && same_motion(c00, c10) && same_motion(c00, c11))) return false;
+  if constexpr (WP) {
+    if (ldg(&P.slices[c00.slice].weighted_pred)) {
+#pragma unroll
+      for (int l = 0; l < 2; l++)
+        if (c00.flags & (l ? BF_MC_L1 : BF_MC_L0)) {
+          const int r = ref_idx_at(P, l, x0, y0);
+          if (ref_idx_at(P, l, x0 + 4, y0) != r || ref_idx_at(P, l, x0, y0 + 4) != r || ref_idx_at(P, l, x0 + 4, y0 + 4) != r) return false;
+        }
+    }
+  }
+  return true;
+}
+
+// WP: the variant for calls whose slice uses explicit weighted prediction (chosen on the host: the common kernels do not
+// carry its code or its registers)
+template <bool WP>
+__global__ void __launch_bounds__(256) k_mc_luma(const PicDev* __restrict__ pics, const PlaneSet* __restrict__ finals, Batch b, int nblocks) {
   int slot, lb, x0, y0;
   if (!xcd_remap(blockIdx.x, b.n, nblocks, slot, lb)) return;
   const PicDev& P = pics[b.pic[slot]];
   if (!tile_origin(P, b, slot, lb, x0, y0)) return;
   const BlkInfo* g = P.blk + (size_t)(y0 >> 2) * P.grid_w + (x0 >> 2);
   const BlkInfo c00 = ld_blk(g), c01 = ld_blk(g + 1), c10 = ld_blk(g + P.grid_w), c11 = ld_blk(g + P.grid_w + 1);
-  if (STAMP) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); t1 = __builtin_amdgcn_s_memtime(); }
-  if (is_inter(c00) && same_motion(c00, c01) && same_motion(c00, c10) && same_motion(c00, c11)) {
+  if (tile_is_uniform<WP>(P, c00, c01, c10, c11, x0, y0)) {
     const int cs = 1 << c00.log2cu;
-    predict_tile<8, 8, 8>(P, finals, 0, x0, y0, c00, x0 & ~(cs - 1), y0 & ~(cs - 1), P.rec[0]);
-    if (STAMP) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      const unsigned long long t2 = __builtin_amdgcn_s_memtime();
-      if ((threadIdx.x & 63) == 0) {
-        const size_t w = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-        stamps[w * 3] = t0; stamps[w * 3 + 1] = t1; stamps[w * 3 + 2] = t2;
-      }
-    }
+    predict_tile<8, 8, 8, WP>(P, finals, 0, x0, y0, c00, x0 & ~(cs - 1), y0 & ~(cs - 1), P.rec[0], x0, y0);
   } else {
-    if (is_inter(c00)) luma_cell(P, finals, c00, x0, y0);
-    if (is_inter(c01)) luma_cell(P, finals, c01, x0 + 4, y0);
-    if (is_inter(c10)) luma_cell(P, finals, c10, x0, y0 + 4);
-    if (is_inter(c11)) luma_cell(P, finals, c11, x0 + 4, y0 + 4);
+    if (is_inter(c00)) luma_cell<WP>(P, finals, c00, x0, y0);
+    if (is_inter(c01)) luma_cell<WP>(P, finals, c01, x0 + 4, y0);
+    if (is_inter(c10)) luma_cell<WP>(P, finals, c10, x0, y0 + 4);
+    if (is_inter(c11)) luma_cell<WP>(P, finals, c11, x0 + 4, y0 + 4);
   }
 }
 
 // chroma: the 4x4 tile of BOTH chroma planes that belongs to the 8x8 luma area
+template <bool WP>
 __global__ void __launch_bounds__(256) k_mc_chroma(const PicDev* __restrict__ pics, const PlaneSet* __restrict__ finals, Batch b, int nblocks) {
   int slot, lb, x0, y0;
   if (!xcd_remap(blockIdx.x, b.n, nblocks, slot, lb)) return;
@@ -252,16 +307,16 @@ __global__ void __launch_bounds__(256) k_mc_chroma(const PicDev* __restrict__ pi
   if (!tile_origin(P, b, slot, lb, x0, y0)) return;
   const BlkInfo* g = P.blk + (size_t)(y0 >> 2) * P.grid_w + (x0 >> 2);
   const BlkInfo c00 = ld_blk(g), c01 = ld_blk(g + 1), c10 = ld_blk(g + P.grid_w), c11 = ld_blk(g + P.grid_w + 1);
-  if (is_inter(c00) && same_motion(c00, c01) && same_motion(c00, c10) && same_motion(c00, c11)) {
+  if (tile_is_uniform<WP>(P, c00, c01, c10, c11, x0, y0)) {
     const int cs = 1 << c00.log2cu;
     const int cux = x0 & ~(cs - 1), cuy = y0 & ~(cs - 1);
-    predict_tile<4, 4, 4>(P, finals, 1, x0 >> 1, y0 >> 1, c00, cux, cuy, P.rec[1]);
-    predict_tile<4, 4, 4>(P, finals, 2, x0 >> 1, y0 >> 1, c00, cux, cuy, P.rec[2]);
+    predict_tile<4, 4, 4, WP>(P, finals, 1, x0 >> 1, y0 >> 1, c00, cux, cuy, P.rec[1], x0, y0);
+    predict_tile<4, 4, 4, WP>(P, finals, 2, x0 >> 1, y0 >> 1, c00, cux, cuy, P.rec[2], x0, y0);
   } else {
-    if (is_inter(c00)) chroma_cell(P, finals, c00, x0, y0);
-    if (is_inter(c01)) chroma_cell(P, finals, c01, x0 + 4, y0);
-    if (is_inter(c10)) chroma_cell(P, finals, c10, x0, y0 + 4);
-    if (is_inter(c11)) chroma_cell(P, finals, c11, x0 + 4, y0 + 4);
+    if (is_inter(c00)) chroma_cell<WP>(P, finals, c00, x0, y0);
+    if (is_inter(c01)) chroma_cell<WP>(P, finals, c01, x0 + 4, y0);
+    if (is_inter(c10)) chroma_cell<WP>(P, finals, c10, x0, y0 + 4);
+    if (is_inter(c11)) chroma_cell<WP>(P, finals, c11, x0 + 4, y0 + 4);
   }
 }
 
@@ -269,19 +324,15 @@ static int mc_blocks(int max_ctus, int log2ctu) {
   const int sq = std::max(1, (1 << log2ctu) / 64);
   return (max_ctus * sq * sq + 3) / 4;
 }
-void launch_mc_luma(const PicDev* pics, const PlaneSet* finals, const Batch& b, int max_ctus, int log2ctu, hipStream_t s) {
+void launch_mc_luma(const PicDev* pics, const PlaneSet* finals, const Batch& b, int max_ctus, int log2ctu, bool wp, hipStream_t s) {
   const int nb = mc_blocks(max_ctus, log2ctu);
-  hipLaunchKernelGGL(k_mc_luma<false>, dim3((unsigned)xcd_grid(b.n, nb)), dim3(256), 0, s, pics, finals, b, nb, (unsigned long long*)nullptr);
+  if (wp) hipLaunchKernelGGL(k_mc_luma<true>, dim3((unsigned)xcd_grid(b.n, nb)), dim3(256), 0, s, pics, finals, b, nb);
+  else hipLaunchKernelGGL(k_mc_luma<false>, dim3((unsigned)xcd_grid(b.n, nb)), dim3(256), 0, s, pics, finals, b, nb);
 }
-int launch_mc_luma_stamped(const PicDev* pics, const PlaneSet* finals, const Batch& b, int max_ctus, int log2ctu, unsigned long long* stamps, hipStream_t s) {
+void launch_mc_chroma(const PicDev* pics, const PlaneSet* finals, const Batch& b, int max_ctus, int log2ctu, bool wp, hipStream_t s) {
   const int nb = mc_blocks(max_ctus, log2ctu);
-  const int grid = xcd_grid(b.n, nb);
-  if (stamps) hipLaunchKernelGGL(k_mc_luma<true>, dim3((unsigned)grid), dim3(256), 0, s, pics, finals, b, nb, stamps);
-  return grid * 4;
-}
-void launch_mc_chroma(const PicDev* pics, const PlaneSet* finals, const Batch& b, int max_ctus, int log2ctu, hipStream_t s) {
-  const int nb = mc_blocks(max_ctus, log2ctu);
-  hipLaunchKernelGGL(k_mc_chroma, dim3((unsigned)xcd_grid(b.n, nb)), dim3(256), 0, s, pics, finals, b, nb);
+  if (wp) hipLaunchKernelGGL(k_mc_chroma<true>, dim3((unsigned)xcd_grid(b.n, nb)), dim3(256), 0, s, pics, finals, b, nb);
+  else hipLaunchKernelGGL(k_mc_chroma<false>, dim3((unsigned)xcd_grid(b.n, nb)), dim3(256), 0, s, pics, finals, b, nb);
 }
 
 // ---- kernel-level seam: xPredInterBlk on a list of blocks of one plane (tests).  The plane carries replicated margins

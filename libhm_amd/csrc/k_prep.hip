@@ -107,6 +107,7 @@ __global__ void __launch_bounds__(256) k_prep(const PicDev* __restrict__ pics, B
     const bool deblock = q.valid && !ldg(&sl->deblocking_disable);
     const int lf_across_slices = ldg(&sl->lf_across_slices);
     const int slice_type = ldg(&sl->slice_type);
+    const bool wp = ldg(&sl->weighted_pred) != 0;
     const uint32_t mvw0[4] = {mv0.x, mv0.y, mv0.z, mv0.w}, mvw1[4] = {mv1.x, mv1.y, mv1.z, mv1.w};
 #pragma unroll
     for (int j = 0; j < 4; j++) {
@@ -128,7 +129,8 @@ __global__ void __launch_bounds__(256) k_prep(const PicDev* __restrict__ pics, B
           if (use0) { bi.mv[0][0] = (int16_t)(mvw0[j] & 0xffff); bi.mv[0][1] = (int16_t)(mvw0[j] >> 16); bi.ref[0] = ldg(&sl->ref_pic[0][r0]); }
           if (use1) { bi.mv[1][0] = (int16_t)(mvw1[j] & 0xffff); bi.mv[1][1] = (int16_t)(mvw1[j] >> 16); bi.ref[1] = ldg(&sl->ref_pic[1][r1]); }
           // xCheckIdenticalMotion (TComPrediction.cpp:497-512): B slice, both lists, same POC and same MV -> list 0 only
-          if (slice_type == HMGPU_B_SLICE && use0 && use1 && ldg(&sl->ref_poc[0][r0]) == ldg(&sl->ref_poc[1][r1]) && mvw0[j] == mvw1[j]) use1 = 0;
+          // (not with weighted bi-prediction: the two lists may carry different weights, :499)
+          if (slice_type == HMGPU_B_SLICE && !wp && use0 && use1 && ldg(&sl->ref_poc[0][r0]) == ldg(&sl->ref_poc[1][r1]) && mvw0[j] == mvw1[j]) use1 = 0;
           bi.flags |= (use0 ? BF_MC_L0 : 0) | (use1 ? BF_MC_L1 : 0);
         }
         // ---- deblocking edge flags (TComLoopFilter.cpp:269-409); only partitions on the 8x8 grid carry an edge

@@ -435,6 +435,47 @@ static void pred_pu(cu_ctx* c, int z_pu, int xr, int yr, int w, int h)
   const int r0 = g->m->ref_idx[0][pi], r1 = g->m->ref_idx[1][pi];
   int16_t* out[3] = { c->pred[0], c->pred[1], c->pred[2] };
   int identical = 0;
+  if (sl->weighted_pred)
+  {
+    /* explicit weighted prediction: xPredInterBi with bi = true for every used list, then xWeightedPredictionBi / Uni
+     * (TComPrediction.cpp:596-644; TComWeightPrediction.cpp:44-57 weightBidir / weightUnidir, :211-271 getWpScaling).
+     * xCheckIdenticalMotion is off for B slices with weighted_bipred_flag (:499). */
+    static int16_t t0[3][64 * 64], t1[3][64 * 64];
+    int16_t* a[3] = { t0[0], t0[1], t0[2] };
+    int16_t* b[3] = { t1[0], t1[1], t1[2] };
+    int comp, x, y;
+    if (r0 >= 0) pred_uni(c, 0, z_pu, xr, yr, w, h, 1, a);
+    if (r1 >= 0) pred_uni(c, 1, z_pu, xr, yr, w, h, 1, b);
+    for (comp = 0; comp < 3; comp++)
+    {
+      const int cs = comp ? 1 : 0, stride = c->cu_size >> cs;
+      const int o = (yr >> cs) * stride + (xr >> cs);
+      const int bd = g->bd[comp], maxv = (1 << bd) - 1;
+      const int shift_num = imax(2, 14 - bd), log2wd = sl->wp_log2_denom[comp ? 1 : 0];
+      for (y = 0; y < (h >> cs); y++)
+        for (x = 0; x < (w >> cs); x++)
+        {
+          const int i = o + y * stride + x;
+          int v;
+          if (r0 >= 0 && r1 >= 0)
+          {
+            const int shift = log2wd + 1 + shift_num, round = 1 << (shift - 1);
+            const int off = sl->wp_offset[0][r0][comp] + sl->wp_offset[1][r1][comp];
+            v = (sl->wp_weight[0][r0][comp] * (a[comp][i] + 8192) + sl->wp_weight[1][r1][comp] * (b[comp][i] + 8192) + round +
+                 (off << (shift - 1))) >> shift;
+          }
+          else
+          {
+            const int l = r0 >= 0 ? 0 : 1, r = l ? r1 : r0;
+            const int shift = log2wd + shift_num, round = shift > 0 ? 1 << (shift - 1) : 0;
+            const int p = l ? b[comp][i] : a[comp][i];
+            v = ((sl->wp_weight[l][r][comp] * (p + 8192) + round) >> shift) + sl->wp_offset[l][r][comp];
+          }
+          out[comp][i] = (int16_t)CLIP3(0, maxv, v);
+        }
+    }
+    return;
+  }
   if (sl->slice_type == HMGPU_B_SLICE && r0 >= 0 && r1 >= 0)                      /* xCheckIdenticalMotion :497-512 */
     identical = sl->ref_poc[0][r0] == sl->ref_poc[1][r1] && g->m->mv[0][pi * 2] == g->m->mv[1][pi * 2] &&
                 g->m->mv[0][pi * 2 + 1] == g->m->mv[1][pi * 2 + 1];

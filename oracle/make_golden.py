@@ -28,7 +28,7 @@ HM_CFG = "/root/reference/cfg"
 
 
 # ------------------------------------------------------------------------------------------ synthetic clips
-def synth_clip(w, h, frames, bit_depth, seed, novel=False):
+def synth_clip(w, h, frames, bit_depth, seed, novel=False, fade=False):
     """gradient + checker + moving textured blobs + seeded noise, 4:2:0 planar, returns list of (Y,U,V) uint16"""
     rng = np.random.RandomState(seed)
     maxv = (1 << bit_depth) - 1
@@ -61,6 +61,8 @@ def synth_clip(w, h, frames, bit_depth, seed, novel=False):
             gy, gx = np.mgrid[0:ph_, 0:pw_].astype(np.float64)
             img[py_:py_ + ph_, px_:px_ + pw_] = 0.5 + 0.4 * np.sin(gx / (2.0 + f) + f) * np.cos(gy / (3.0 + 0.5 * f)) * (1 if f % 2 else -1)
         img = img + 0.012 * rng.randn(h, w)
+        if fade:                            # brightness ramps from frame to frame: what explicit weighted prediction is for
+            img = img * (1.0 - 0.09 * f) + 0.02 * f
         Y = np.clip(np.round(img * maxv), 0, maxv).astype(np.uint16)
         U = np.clip(np.round((0.5 + 0.2 * np.sin((xx[:h // 2, :w // 2] + 3 * f) / 11.0)) * maxv), 0, maxv).astype(np.uint16)
         V = np.clip(np.round((0.5 + 0.2 * np.cos((yy[:h // 2, :w // 2] - 2 * f) / 17.0)
@@ -85,6 +87,9 @@ STREAMS = {
     # NOTE: multi-slice inter streams (--SliceMode=1) are not used: HM 16.0's own TAppDecoder asserts
     # (TComBitStream.h:191) on the streams its encoder writes for them, at every optimisation level.
     "intra_main10_208x120": ("encoder_intra_main10.cfg", 208, 120, 1, 10, 10, 30, []),
+    # explicit weighted prediction on a fading clip: P slices (weighted_pred_flag) and B slices (weighted_bipred_flag)
+    "ldp_wp_main10_208x120": ("encoder_lowdelay_P_main10.cfg", 208, 120, 4, 10, 10, 30, ["--WeightedPredP=1"]),
+    "ra_wp_main8_208x120": ("encoder_randomaccess_main.cfg", 208, 120, 5, 8, 8, 32, ["--IntraPeriod=8", "--WeightedPredP=1", "--WeightedPredB=1"]),
     # constrained intra prediction (inter neighbours are not intra references) and no strong smoothing, P pictures with intra CUs
     "ldp_cip_main10_208x120": ("encoder_lowdelay_P_main10.cfg", 208, 120, 3, 10, 10, 30, ["--ConstrainedIntraPred=1", "--StrongIntraSmoothing=0"]),
 }
@@ -93,7 +98,7 @@ STREAMS = {
 def encode(name, tmp):
     cfg, w, h, frames, ibd, bd, qp, extra = STREAMS[name]
     yuv = os.path.join(tmp, name + ".yuv")
-    clip = synth_clip(w, h, frames, ibd, seed=0x484D + sum(map(ord, name)), novel="cip" in name)
+    clip = synth_clip(w, h, frames, ibd, seed=0x484D + sum(map(ord, name)), novel="cip" in name, fade="wp" in name)
     write_yuv(yuv, clip, ibd)
     bs = os.path.join(tmp, name + ".bin")
     rec = os.path.join(tmp, name + "_rec.yuv")
@@ -124,6 +129,7 @@ def dump_stream(name, bitstream, enc_rec, geom):
                                                       "ctus_w", "parts", "ctu_size", "num_slices", "use_sao",
                                                       "lf_across_tiles", "chroma_format", "tid", "max_depth"]], dtype=np.int32)
         out[k + "slices"] = dec.slices(ns)
+        out[k + "wp"] = dec.wp(ns)
         meta = dec.meta(info)
         for n2, a in meta.items():
             out[k + "meta_" + n2] = a

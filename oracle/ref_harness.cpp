@@ -280,6 +280,33 @@ void ref_dec_slices(void* h, int32_t* out)
   }
 }
 
+/* explicit weighted prediction tables after initWpScaling (TComSlice.cpp:1495-1522), 195 ints per slice:
+ * 0 applyWP (TComSlice.h:1477), 1 log2WeightDenom luma, 2 chroma, then weight[list][ref 0..15][comp] (96 ints) and
+ * offset[list][ref][comp] (96 ints, already scaled to the bit depth as TComWeightPrediction::getWpScaling does, :230-271) */
+void ref_dec_wp(void* h, int32_t* out)
+{
+  RefDec* d = (RefDec*)h; TComPic* p = cur(d);
+  for (UInt i = 0; i < d->top.m_uiSliceIdx; i++)
+  {
+    TComSlice* s = p->getSlice(i); int32_t* o = out + 195 * i;
+    memset(o, 0, 195 * sizeof(int32_t));
+    o[0] = s->applyWP() ? 1 : 0;
+    if (!o[0]) continue;
+    const Bool hp = s->getSPS()->getUseHighPrecisionPredictionWeighting();
+    for (int l = 0; l < 2; l++)
+      for (int r = 0; r < 16 && r < MAX_NUM_REF; r++)
+      {
+        WPScalingParam* wp; s->getWpScaling(RefPicList(l), r, wp);
+        for (int c = 0; c < 3; c++)
+        {
+          if (l == 0 && r == 0) o[1 + (c ? 1 : 0)] = wp[c].uiLog2WeightDenom;
+          o[3 + (l * 16 + r) * 3 + c] = wp[c].iWeight;
+          o[99 + (l * 16 + r) * 3 + c] = wp[c].iOffset * (hp ? 1 : (1 << (g_bitDepth[c ? CHANNEL_TYPE_CHROMA : CHANNEL_TYPE_LUMA] - 8)));
+        }
+      }
+  }
+}
+
 /* HM-layout per-CTU metadata.  All arrays [numCTUs][partsPerCTU] in z-scan order (TComDataCU.h:86-157)
  * except sliceIdx [numCTUs].  mv: [numCTUs][parts][2] (hor,ver).  Any pointer may be NULL.            */
 void ref_dec_meta(void* h, uint8_t* depth, int8_t* partSize, int8_t* predMode, int8_t* qp, uint8_t* trIdx,

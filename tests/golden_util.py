@@ -7,7 +7,8 @@ import numpy as np
 from libhm_amd import abi
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-STREAMS = ["ldp_main8_416x240", "ra_main10_208x120", "ldp_main10_208x120", "intra_main10_208x120", "ldp_cip_main10_208x120"]
+STREAMS = ["ldp_main8_416x240", "ra_main10_208x120", "ldp_main10_208x120", "intra_main10_208x120", "ldp_cip_main10_208x120",
+           "ldp_wp_main10_208x120", "ra_wp_main8_208x120"]
 _cache = {}
 
 
@@ -31,8 +32,8 @@ class Picture:
                                 strong_intra_smoothing=int(s0[25]) if int(s0[27]) else 1)
         self.slices = []
         self.ref_pocs = set()
-        for s in z[k + "slices"]:
-            assert s[14] == 0 and s[15] == 0, "weighted prediction not expected in fixtures"
+        wp_all = z[k + "wp"] if (k + "wp") in z.files else None
+        for si, s in enumerate(z[k + "slices"]):
             refs, pocs = [], []
             for l in range(2):
                 p = [int(v) for v in s[32 + 16 * l: 32 + 16 * l + int(s[12 + l])]]
@@ -43,6 +44,17 @@ class Picture:
                                               pps_cb=int(s[2]), pps_cr=int(s[3]), deblocking_disable=int(s[6]),
                                               beta_offset_div2=int(s[7]), tc_offset_div2=int(s[8]), lf_across_slices=int(s[9])))
             self.slices[-1].constrained_intra_pred = int(s[26])
+            if wp_all is not None and wp_all[si][0]:
+                wp, sl = wp_all[si], self.slices[-1]
+                sl.weighted_pred = 1
+                sl.wp_log2_denom[0], sl.wp_log2_denom[1] = int(wp[1]), int(wp[2])
+                for l in range(2):
+                    for r in range(16):
+                        for c in range(3):
+                            sl.wp_weight[l][r][c] = int(wp[3 + (l * 16 + r) * 3 + c])
+                            sl.wp_offset[l][r][c] = int(wp[99 + (l * 16 + r) * 3 + c])
+            else:
+                assert s[14] == 0 or int(s[0]) != 1      # weighted_pred_flag on a P slice needs its table
         m = {n: z[k + "meta_" + n] for n in ("depth", "part_size", "pred_mode", "qp", "tr_idx", "cbf_y", "cbf_u", "cbf_v", "ts_y",
                                              "ts_u", "ts_v", "mv0", "mv1", "ref_idx0", "ref_idx1", "intra_dir_l", "intra_dir_c",
                                              "bypass", "ipcm")}

@@ -154,11 +154,6 @@ def test_unsupported_tools_are_refused():
     p = synth.make_picture(128, 64, 8, seed=2, ref_handles=([0], [0]))
     with libhm_amd.Context(p.seq) as ctx:
         h0, hc = ctx.acquire(), ctx.acquire()
-        p.slice.weighted_pred = 1
-        with pytest.raises(libhm_amd.HmgpuError) as e:
-            ctx.decompress_slice(hc, 0, p.slice, p.meta, p.coeffs)
-        assert e.value.status == abi.HMGPU_EUNSUPPORTED
-        p.slice.weighted_pred = 0
         m = dict(p.meta_np)
         m["ipcm"] = np.ones_like(m["depth"])
         with pytest.raises(libhm_amd.HmgpuError) as e:
