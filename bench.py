@@ -297,10 +297,10 @@ def cpu_baseline(p, w, h, bd):
     """the oracle (C restatement of HM, pinned against HM goldens) on this box's host: single thread, whole pictures"""
     from oracle import hmoracle
     from tests import synth
-    import copy
+    from libhm_amd import abi
     hmoracle.lib()
     refs = [synth.noise_planes(w, h, bd, 100), synth.blocky_planes(w, h, bd, 200)]
-    sl = copy.copy(p.slice)             # the device run re-pointed the reference handles at its own pictures
+    sl = abi.clone_slice(p.slice)             # the device run re-pointed the reference handles at its own pictures
     for l in range(2):
         if sl.num_ref_idx[l] > 0:
             sl.ref_pic[l][0] = l

@@ -72,6 +72,14 @@ typedef struct hmgpu_seq_params {
   int32_t reserved[7];
 } hmgpu_seq_params;
 
+/* Scaling lists as TDecTop activates them for a slice (TDecTop.cpp:651-668: PPS lists, else SPS lists, else the defaults):
+ * TComScalingList's own storage.  De-quantisation with them: TComTrQuant.cpp:1238-1275, tables :2992-3012, 3092-3106. */
+typedef struct hmgpu_scaling_lists {
+  int32_t coef[4][6][64];   /* getScalingListAddress(sizeId 4x4..32x32, listId = 3 * inter + component): raster order; 16 values for
+                               4x4, 8x8 values otherwise (16x16 / 32x32 replicate every value over ratio x ratio positions) */
+  int32_t dc[4][6];         /* getScalingListDC: replaces position 0 for 16x16 and 32x32 */
+} hmgpu_scaling_lists;
+
 /* Per-slice constants the hot path reads through pcCU->getSlice() */
 typedef struct hmgpu_slice_params {
   int32_t slice_type;                   /* HMGPU_{B,P,I}_SLICE */
@@ -94,6 +102,7 @@ typedef struct hmgpu_slice_params {
   int32_t wp_log2_denom[2];             /* luma, chroma */
   int16_t wp_weight[2][HMGPU_MAX_REF][3];
   int16_t wp_offset[2][HMGPU_MAX_REF][3];
+  const hmgpu_scaling_lists* scaling_lists;   /* SPS scaling_list_enabled_flag: the lists in force, else NULL (flat, m = 16) */
 } hmgpu_slice_params;
 
 /* The picture-persistent TComDataCU arrays of TComPicSym (TComPicSym.cpp:93-114).  Every array covers the WHOLE

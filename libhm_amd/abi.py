@@ -26,13 +26,18 @@ class SeqParams(C.Structure):
                 ("pcm_loop_filter_disable", C.c_int32), ("strong_intra_smoothing", C.c_int32), ("reserved", C.c_int32 * 7)]
 
 
+class ScalingLists(C.Structure):
+    _fields_ = [("coef", ((C.c_int32 * 64) * 6) * 4), ("dc", (C.c_int32 * 6) * 4)]
+
+
 class SliceParams(C.Structure):
     _fields_ = [("slice_type", C.c_int32), ("cb_qp_offset", C.c_int32), ("cr_qp_offset", C.c_int32),
                 ("pps_cb_qp_offset", C.c_int32), ("pps_cr_qp_offset", C.c_int32), ("deblocking_disable", C.c_int32),
                 ("beta_offset_div2", C.c_int32), ("tc_offset_div2", C.c_int32), ("lf_across_slices", C.c_int32),
                 ("weighted_pred", C.c_int32), ("lf_across_tiles", C.c_int32), ("num_ref_idx", C.c_int32 * 2),
                 ("ref_pic", (C.c_int32 * MAX_REF) * 2), ("ref_poc", (C.c_int32 * MAX_REF) * 2), ("constrained_intra_pred", C.c_int32), ("reserved", C.c_int32 * 4),
-                ("wp_log2_denom", C.c_int32 * 2), ("wp_weight", ((C.c_int16 * 3) * MAX_REF) * 2), ("wp_offset", ((C.c_int16 * 3) * MAX_REF) * 2)]
+                ("wp_log2_denom", C.c_int32 * 2), ("wp_weight", ((C.c_int16 * 3) * MAX_REF) * 2), ("wp_offset", ((C.c_int16 * 3) * MAX_REF) * 2),
+                ("scaling_lists", C.POINTER(ScalingLists))]
 
 
 class CtuMeta(C.Structure):
@@ -144,6 +149,11 @@ def make_slice(slice_type, ref_pic=((), ()), ref_poc=((), ()), cb_qp_offset=0, c
             s.ref_pic[l][i] = int(h)
             s.ref_poc[l][i] = int(p)
     return s
+
+
+def clone_slice(s):
+    """byte copy of a SliceParams (copy.copy refuses ctypes structures that hold pointers)"""
+    return SliceParams.from_buffer_copy(s)
 
 
 def make_pic_params(sao_enabled=1, lf_across_tiles=1):

@@ -35,6 +35,8 @@ struct Picture {
   void* meta = nullptr;                 // raw HM arrays
   void* coef = nullptr;
   void* derived = nullptr;              // blk, tu lists, counters, sao params, slices
+  uint8_t* sl_table = nullptr;          // device: expanded scaling-list matrices (inside `derived`)
+  std::vector<uint8_t> sl_host;         // host copy the asynchronous upload reads from
   PicDev dev;                           // host mirror of the device descriptor
   std::vector<SliceDev> slices;         // host mirror of the slice table
   int max_slice = -1;
@@ -157,6 +159,7 @@ hmgpu_status alloc_picture(hmgpu_ctx* c, Picture& p) {
     d.saoprm = m.take<SaoDev>((size_t)c->num_ctus * 3);
     d.slices = m.take<SliceDev>(HMGPU_MAX_SLICES);
     d.ctu_intra = m.take<uint8_t>((size_t)c->num_ctus);
+    p.sl_table = m.take<uint8_t>(4 * 6 * 1024);
     d.intra_done = m.take<uint32_t>((size_t)3 * c->num_ctus);
     if (!pass) { HIP_TRY(c, hipMalloc(&p.derived, m.off)); HIP_TRY(c, hipMemset(p.derived, 0, m.off)); }
   }
@@ -168,6 +171,7 @@ hmgpu_status alloc_picture(hmgpu_ctx* c, Picture& p) {
   d.grid_w = c->grid_w; d.grid_h = c->grid_h;
   d.lf_across_tiles = 1; d.sao_applied = 0;
   d.has_intra_dir = 0; d.strong_intra_smoothing = s.strong_intra_smoothing ? 1 : 0;
+  d.sl_m = nullptr;
   for (int k = 0; k < 4; k++) d.tu_cap[k] = c->tu_cap[k];
   {
     // plane pointers address sample (0,0); the margins lie at negative coordinates
@@ -564,6 +568,25 @@ hmgpu_status hmgpu_decompress_slice(hmgpu_ctx* c, hmgpu_pic cur, int32_t slice_i
   p.max_slice = std::max(p.max_slice, (int)slice_idx);
   p.dev.lf_across_tiles = sl->lf_across_tiles;
   p.dev.has_intra_dir = (m->intra_dir[0] && m->intra_dir[1]) ? 1 : 0;      // without the modes intra CUs are left untouched
+  p.dev.sl_m = nullptr;
+  if (sl->scaling_lists) {
+    // xSetScalingListDec / processScalingListDec (TComTrQuant.cpp:2992-3012, 3092-3106) without the per-QP factor: m per position
+    const hmgpu_scaling_lists& L = *sl->scaling_lists;
+    p.sl_host.assign(4 * 6 * 1024, 16);
+    for (int sz = 0; sz < 4; sz++)
+      for (int l = 0; l < 6; l++) {
+        const int n = 4 << sz, ratio = n > 8 ? n / 8 : 1, mn = n > 8 ? 8 : n;
+        uint8_t* t = p.sl_host.data() + (sz * 6 + l) * 1024;
+        for (int y = 0; y < n; y++)
+          for (int x = 0; x < n; x++) {
+            const int v = (ratio > 1 && x == 0 && y == 0) ? L.dc[sz][l] : L.coef[sz][l][mn * (y / ratio) + x / ratio];
+            if (v < 1 || v > 255) return HMGPU_EINVAL;
+            t[y * n + x] = (uint8_t)v;
+          }
+      }
+    HIP_TRY(c, hipMemcpyAsync(p.sl_table, p.sl_host.data(), p.sl_host.size(), hipMemcpyHostToDevice, c->stream));
+    p.dev.sl_m = p.sl_table;
+  }
   {
     ProfScope ps(c, K_H2D);
     HIP_TRY(c, hipMemcpyAsync((void*)(p.dev.slices + slice_idx), &p.slices[slice_idx], sizeof(SliceDev), hipMemcpyHostToDevice, c->stream));

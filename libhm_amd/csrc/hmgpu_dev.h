@@ -106,6 +106,8 @@ struct PicDev {
   uint32_t tu_cap[4];              // capacity of ONE shard
   SaoDev* saoprm;                  // [num_ctus][3]
   unsigned long long* stats;       // [2][kTuShards]: intra / inter partitions seen by the prep kernel
+  // scaling lists: one byte per position, [size 4x4..32x32][list = 3 * inter + component][1024], or null (flat)
+  const uint8_t* sl_m;
   // intra reconstruction (k_intra.hip)
   int32_t has_intra_dir;           // the caller supplied intra prediction modes (else intra CUs are left untouched)
   int32_t strong_intra_smoothing;  // SPS flag

@@ -165,16 +165,40 @@ __device__ inline void idst4_pk(const uint32_t (&p)[N / 2], int seed, int (&out)
     for (int k = 0; k < 4; k++) out[k] = dot2c(p[1], pkc(dst4(2, k), dst4(0, k)), dot2_v(p[0], pkc(dst4(1, k), dst4(3, k)), seed));
   }
 }
+// mrow: row n of the TU's scaling-list matrix (one byte per position, already replicated / DC-patched for 16x16 and 32x32:
+// TComTrQuant.cpp:2992-3012, 3092-3106), or nullptr for flat scaling.
 template <int LOG2N>
 __device__ inline void itx_tu_pk(const uint32_t (&lv)[(1 << LOG2N) / 2], int n, int per, int rem, bool skip, int bd,
-                                 int16_t* __restrict__ buf, uint32_t (&res)[(1 << LOG2N) / 2], bool dst = false) {
+                                 int16_t* __restrict__ buf, uint32_t (&res)[(1 << LOG2N) / 2], bool dst = false,
+                                 const uint8_t* __restrict__ mrow = nullptr) {
   constexpr int N = 1 << LOG2N, S = PkCfg<LOG2N>::S;
   // ---- xDeQuant, flat scaling (TComTrQuant.cpp:1276-1311), on the row this lane loaded
   const int tshift = 15 - bd - LOG2N;                     // getTransformShift
   const int rshift = 6 - (tshift + per);                  // IQUANT_SHIFT - (transformShift + per)
   const int scale = rem == 0 ? 40 : rem == 1 ? 45 : rem == 2 ? 51 : rem == 3 ? 57 : rem == 4 ? 64 : 72;
   uint32_t d[N / 2];
-  if (rshift <= 0) {
+  if (mrow != nullptr) {
+    // scaling lists (TComTrQuant.cpp:1238-1275): factor scale * m per position, four more fractional bits, 32-bit products;
+    // the level is first clipped to what keeps level * factor inside 32 bits (only binding for rshift < -1)
+    const int rs = rshift + 4;
+    const int tb = min(16, 17 + rs), in_max = (1 << (tb - 1)) - 1, in_min = -in_max - 1;
+    uint32_t mw[N / 4];
+    if constexpr (N == 4) mw[0] = ldg(reinterpret_cast<const uint32_t*>(mrow));
+    else {
+#pragma unroll
+      for (int i = 0; i < N / 16; i++) { const u32x4 a = ldg4(mrow + 16 * i); mw[4 * i] = a.x; mw[4 * i + 1] = a.y; mw[4 * i + 2] = a.z; mw[4 * i + 3] = a.w; }
+      if constexpr (N == 8) { const u32x2 a = ldg2(mrow); mw[0] = a.x; mw[1] = a.y; }
+    }
+#pragma unroll
+    for (int i = 0; i < N / 2; i++) {
+      const int m0 = (mw[i / 2] >> (16 * (i & 1))) & 0xff, m1 = (mw[i / 2] >> (16 * (i & 1) + 8)) & 0xff;
+      const int q0 = clip3(in_min, in_max, half_of(lv[i], 0)), q1 = clip3(in_min, in_max, half_of(lv[i], 1));
+      int c0 = __mul24(q0, scale * m0), c1 = __mul24(q1, scale * m1);
+      if (rs > 0) { c0 = (c0 + (1 << (rs - 1))) >> rs; c1 = (c1 + (1 << (rs - 1))) >> rs; }
+      else { c0 = (int)((unsigned)c0 << (-rs)); c1 = (int)((unsigned)c1 << (-rs)); }
+      d[i] = cvt_pk_sat(c0, c1);
+    }
+  } else if (rshift <= 0) {
     const uint32_t sp = (uint32_t)(scale << (-rshift)) * 0x10001u;
 #pragma unroll
     for (int i = 0; i < N / 2; i++) d[i] = pk_mad_sat(lv[i], sp);

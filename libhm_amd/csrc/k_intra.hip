@@ -241,7 +241,8 @@ __device__ inline void intra_tu(const PicDev& P, const TuCtx& t, IntraLds& L) {
   if (t.cbf && active) {
     int per, rem;
     qp_param_tu(t.qp_cu, comp, bd, t.cqo, per, rem);
-    itx_tu_pk<LOG2N>(lv, n, per, rem, t.skip != 0, bd, L.tile, res, comp == 0 && LOG2N == 2);          // TComTU::useDST: 4x4 intra luma
+    const uint8_t* mrow = (P.sl_m != nullptr && (!t.skip || N == 4)) ? P.sl_m + (((LOG2N - 2) * 6 + comp) << 10) + n * N : nullptr;   // intra lists: 0 + component
+    itx_tu_pk<LOG2N>(lv, n, per, rem, t.skip != 0, bd, L.tile, res, comp == 0 && LOG2N == 2, mrow);      // TComTU::useDST: 4x4 intra luma
   }
 
   // ---- E. reconstruction of row n: into the LDS copy (what later TUs of this CTU predict from) and, two samples per

@@ -171,13 +171,50 @@ void hmo_itr(int bit_depth, const int32_t* coeff, int32_t* block, int n, int use
 }
 
 /* invTransformNxN: TLibCommon/TComTrQuant.cpp:1423-1548 (no bypass, no RDPCM, no rotation) */
+/* xDeQuant with scaling lists (TComTrQuant.cpp:1238-1275): per-position factor invQuantScale[rem] * m, m from the list of this
+ * size and type, replicated over ratio x ratio positions for 16x16 / 32x32 with the DC entry at position 0
+ * (xSetScalingListDec / processScalingListDec, :2992-3012, 3092-3106); four more fractional bits than the flat path */
+static void dequant_lists(const int16_t* level, int32_t* coef, int log2_size, int bit_depth, int qp_per, int qp_rem,
+                          const hmgpu_scaling_lists* sl, int list_id)
+{
+  const int n = 1 << log2_size, size_id = log2_size - 2;
+  const int ratio = n > 8 ? n / 8 : 1, mn = n > 8 ? 8 : n;
+  const int transform_shift = 15 - bit_depth - log2_size;
+  const int right_shift = 6 - (transform_shift + qp_per) + 4;      /* + LOG2_SCALING_LIST_NEUTRAL_VALUE */
+  const int scale = k_inv_quant_scales[qp_rem];
+  int target_bits = 32 + right_shift - 15;                         /* dequantCoefBits = 1 + IQUANT_SHIFT + SCALING_LIST_BITS */
+  int x, y;
+  if (target_bits > 16) target_bits = 16;
+  {
+    const int in_min = -(1 << (target_bits - 1)), in_max = (1 << (target_bits - 1)) - 1;
+    for (y = 0; y < n; y++)
+      for (x = 0; x < n; x++)
+      {
+        const int m = (ratio > 1 && x == 0 && y == 0) ? sl->dc[size_id][list_id] : sl->coef[size_id][list_id][mn * (y / ratio) + x / ratio];
+        const int q = CLIP3(in_min, in_max, (int)level[y * n + x]);
+        int c;
+        if (right_shift > 0) c = (q * (scale * m) + (1 << (right_shift - 1))) >> right_shift;
+        else c = (int)((unsigned)(q * (scale * m)) << (-right_shift));
+        coef[y * n + x] = CLIP3(-32768, 32767, c);
+      }
+  }
+}
+
 void hmo_inverse_transform_tu(const int16_t* level, int16_t* resid, int resid_stride, int log2_size, int bit_depth,
                               int qp_per, int qp_rem, int flags)
 {
+  hmo_inverse_transform_tu_sl(level, resid, resid_stride, log2_size, bit_depth, qp_per, qp_rem, flags, NULL, 0);
+}
+
+void hmo_inverse_transform_tu_sl(const int16_t* level, int16_t* resid, int resid_stride, int log2_size, int bit_depth,
+                                 int qp_per, int qp_rem, int flags, const hmgpu_scaling_lists* sl, int list_id)
+{
   const int n = 1 << log2_size;
-  int32_t coef[32 * 32], block[32 * 32];
+  int32_t coef[32 * 32] = { 0 }, block[32 * 32];
   int x, y;
-  hmo_dequant(level, coef, n * n, log2_size, bit_depth, qp_per, qp_rem);
+  /* getUseScalingList (TComTrQuant.h:180): not for transform-skip blocks other than 4x4 */
+  if (sl && (!(flags & 2) || log2_size == 2)) dequant_lists(level, coef, log2_size, bit_depth, qp_per, qp_rem, sl, list_id);
+  else hmo_dequant(level, coef, n * n, log2_size, bit_depth, qp_per, qp_rem);
   if (flags & 2)
   {
     /* xITransformSkip: TComTrQuant.cpp:1920-1959 */
@@ -361,7 +398,9 @@ static void tu_leaf(cu_ctx* c, int comp, int z_tu, int log2_size, int x_rel, int
   hmo_qp_param(PM(qp, c->ctu_addr, c->cu_z), comp, g->bd[comp], cqo, &per, &rem);       /* QpParam(cu, compID): getQP(0) */
   if (comp == 0 && PM(pred_mode, c->ctu_addr, z_tu) == HMGPU_MODE_INTRA) flags |= 1;    /* TComTU::useDST, TComTU.cpp:218 */
   if (g->m->transform_skip[comp] && g->m->transform_skip[comp][(size_t)c->ctu_addr * g->parts + z_tu]) flags |= 2;
-  hmo_inverse_transform_tu(lev, &c->resi[comp][y_rel * stride + x_rel], stride, log2_size, g->bd[comp], per, rem, flags);
+  /* getScalingListType (TComTrQuant.h): 3 * inter + component */
+  hmo_inverse_transform_tu_sl(lev, &c->resi[comp][y_rel * stride + x_rel], stride, log2_size, g->bd[comp], per, rem, flags, sl->scaling_lists,
+                              (PM(pred_mode, c->ctu_addr, z_tu) == HMGPU_MODE_INTRA ? 0 : 3) + comp);
 }
 
 /* invRecurTransformNxN (TComTrQuant.cpp:1550-1615) with the TComTU child rules for 4:2:0 (TComTU.cpp:89-171) */
@@ -715,7 +754,7 @@ static void intra_tu(cu_ctx* c, int comp, int z_tu, int log2n, int cbf_depth, in
     const int16_t* lev = c->co->level[comp] + (size_t)a * ((g->ctu * g->ctu) >> (comp ? 2 : 0)) + coef_off;
     hmo_qp_param(PM(qp, a, c->cu_z), comp, g->bd[comp], cqo, &per, &rem);
     if (g->m->transform_skip[comp] && g->m->transform_skip[comp][(size_t)a * g->parts + z_tu]) flags |= 2;
-    hmo_inverse_transform_tu(lev, resi, n, log2n, g->bd[comp], per, rem, flags);
+    hmo_inverse_transform_tu_sl(lev, resi, n, log2n, g->bd[comp], per, rem, flags, sl->scaling_lists, comp);
   }
   for (y = 0; y < n; y++)
     for (x = 0; x < n; x++)

@@ -28,6 +28,9 @@ void hmo_itr(int bit_depth, const int32_t* coeff, int32_t* block, int n, int use
 /* dequant + (IT | transform skip) of one TU: invTransformNxN (TComTrQuant.cpp:1423-1548), flags bit0 DST, bit1 skip */
 void hmo_inverse_transform_tu(const int16_t* level, int16_t* resid, int resid_stride, int log2_size, int bit_depth,
                               int qp_per, int qp_rem, int flags);
+/* the same with scaling lists (NULL = flat): list_id = 3 * inter + component (getScalingListType) */
+void hmo_inverse_transform_tu_sl(const int16_t* level, int16_t* resid, int resid_stride, int log2_size, int bit_depth,
+                                 int qp_per, int qp_rem, int flags, const hmgpu_scaling_lists* sl, int list_id);
 /* QpParam (TComTrQuant.cpp:71-100): comp 0..2 */
 void hmo_qp_param(int qp_y, int comp, int bit_depth, int chroma_qp_offset, int* per, int* rem);
 /* xPredInterBlk (TComPrediction.cpp:660-698) with the reference addressed by clamped coordinates.

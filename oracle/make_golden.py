@@ -87,12 +87,38 @@ STREAMS = {
     # NOTE: multi-slice inter streams (--SliceMode=1) are not used: HM 16.0's own TAppDecoder asserts
     # (TComBitStream.h:191) on the streams its encoder writes for them, at every optimisation level.
     "intra_main10_208x120": ("encoder_intra_main10.cfg", 208, 120, 1, 10, 10, 30, []),
+    # scaling lists from a file: every matrix different, DC values for 16x16 / 32x32 (I picture: intra lists, P pictures: inter lists)
+    "ldp_sl_main10_208x120": ("encoder_lowdelay_P_main10.cfg", 208, 120, 3, 10, 10, 28, ["--ScalingList=2", "--ScalingListFile=@SLFILE@"]),
+    "ldp_sldef_main8_208x120": ("encoder_lowdelay_P_main.cfg", 208, 120, 2, 8, 8, 34, ["--ScalingList=1"]),
     # explicit weighted prediction on a fading clip: P slices (weighted_pred_flag) and B slices (weighted_bipred_flag)
     "ldp_wp_main10_208x120": ("encoder_lowdelay_P_main10.cfg", 208, 120, 4, 10, 10, 30, ["--WeightedPredP=1"]),
     "ra_wp_main8_208x120": ("encoder_randomaccess_main.cfg", 208, 120, 5, 8, 8, 32, ["--IntraPeriod=8", "--WeightedPredP=1", "--WeightedPredB=1"]),
     # constrained intra prediction (inter neighbours are not intra references) and no strong smoothing, P pictures with intra CUs
     "ldp_cip_main10_208x120": ("encoder_lowdelay_P_main10.cfg", 208, 120, 3, 10, 10, 30, ["--ConstrainedIntraPred=1", "--StrongIntraSmoothing=0"]),
 }
+
+
+def write_scaling_list_file(path):
+    """a scaling list file in HM's text format (TComScalingList::xParseScalingList, TComSlice.cpp:2052-2138; names TComRom.cpp:580-638)
+    with a different seeded matrix for every size and list"""
+    rng = np.random.RandomState(0x5CA1E)
+    names = {0: "4X4", 1: "8X8", 2: "16X16", 3: "32X32"}
+    lists = ["INTRA%s_LUMA", "INTRA%s_CHROMAU", "INTRA%s_CHROMAV", "INTER%s_LUMA", "INTER%s_CHROMAU", "INTER%s_CHROMAV"]
+    with open(path, "w") as f:
+        for sz in range(4):
+            n = 4 if sz == 0 else 8
+            for l, pat in enumerate(lists):
+                if sz == 3 and l % 3:
+                    continue                                       # 32x32 chroma is derived from 16x16 chroma
+                base = pat % names[sz]
+                yy, xx = np.mgrid[0:n, 0:n]
+                m = np.clip(10 + 3 * (xx + yy) + rng.randint(-3, 4, size=(n, n)) + 2 * l, 4, 200)
+                f.write(base + "\n")
+                for r in range(n):
+                    f.write(",".join(str(int(v)) for v in m[r]) + ",\n")
+                if sz >= 2:
+                    f.write(base + "_DC\n%d\n" % int(rng.randint(8, 40)))
+                f.write("\n")
 
 
 def encode(name, tmp):
@@ -102,6 +128,10 @@ def encode(name, tmp):
     write_yuv(yuv, clip, ibd)
     bs = os.path.join(tmp, name + ".bin")
     rec = os.path.join(tmp, name + "_rec.yuv")
+    if any("@SLFILE@" in e for e in extra):
+        slf = os.path.join(tmp, name + "_sl.txt")
+        write_scaling_list_file(slf)
+        extra = [e.replace("@SLFILE@", slf) for e in extra]
     cmd = [hmref.ENCODER_PATH, "-c", os.path.join(HM_CFG, cfg), "-i", yuv, "-wdt", str(w), "-hgt", str(h), "-fr", "30",
            "-f", str(frames), "--InputBitDepth=%d" % ibd, "--InternalBitDepth=%d" % bd, "--OutputBitDepth=%d" % bd,
            "-q", str(qp), "-b", bs, "-o", rec, "--SEIDecodedPictureHash=1", "--Level=3.1"] + extra
@@ -130,6 +160,7 @@ def dump_stream(name, bitstream, enc_rec, geom):
                                                       "lf_across_tiles", "chroma_format", "tid", "max_depth"]], dtype=np.int32)
         out[k + "slices"] = dec.slices(ns)
         out[k + "wp"] = dec.wp(ns)
+        out[k + "scaling_lists"] = dec.scaling_lists()
         meta = dec.meta(info)
         for n2, a in meta.items():
             out[k + "meta_" + n2] = a

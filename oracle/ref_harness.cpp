@@ -307,6 +307,26 @@ void ref_dec_wp(void* h, int32_t* out)
   }
 }
 
+/* scaling lists of the picture's first slice as TDecTop activated them (TDecTop.cpp:651-668): out[0] = enabled, then
+ * coef[sizeId 0..3][listId 0..5][64] (TComScalingList::getScalingListAddress, raster order, first 16 used for 4x4) and
+ * dc[sizeId][listId] (getScalingListDC) */
+void ref_dec_scaling_lists(void* h, int32_t* out)
+{
+  RefDec* d = (RefDec*)h; TComPic* p = cur(d); TComSlice* s = p->getSlice(0);
+  memset(out, 0, (1 + 4 * 6 * 64 + 4 * 6) * sizeof(int32_t));
+  if (!s->getSPS()->getScalingListFlag()) return;
+  out[0] = 1;
+  TComScalingList* sl = s->getScalingList();
+  for (UInt sz = 0; sz < 4; sz++)
+    for (UInt l = 0; l < 6; l++)
+    {
+      const Int* c = sl->getScalingListAddress(sz, l);
+      const int n = sz == 0 ? 16 : 64;
+      for (int i = 0; i < n; i++) out[1 + (sz * 6 + l) * 64 + i] = c[i];
+      out[1 + 4 * 6 * 64 + sz * 6 + l] = sl->getScalingListDC(sz, l);
+    }
+}
+
 /* HM-layout per-CTU metadata.  All arrays [numCTUs][partsPerCTU] in z-scan order (TComDataCU.h:86-157)
  * except sliceIdx [numCTUs].  mv: [numCTUs][parts][2] (hor,ver).  Any pointer may be NULL.            */
 void ref_dec_meta(void* h, uint8_t* depth, int8_t* partSize, int8_t* predMode, int8_t* qp, uint8_t* trIdx,

@@ -8,7 +8,7 @@ from libhm_amd import abi
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 STREAMS = ["ldp_main8_416x240", "ra_main10_208x120", "ldp_main10_208x120", "intra_main10_208x120", "ldp_cip_main10_208x120",
-           "ldp_wp_main10_208x120", "ra_wp_main8_208x120"]
+           "ldp_wp_main10_208x120", "ra_wp_main8_208x120", "ldp_sl_main10_208x120", "ldp_sldef_main8_208x120"]
 _cache = {}
 
 
@@ -33,6 +33,16 @@ class Picture:
         self.slices = []
         self.ref_pocs = set()
         wp_all = z[k + "wp"] if (k + "wp") in z.files else None
+        self.scaling_lists = None
+        if (k + "scaling_lists") in z.files and int(z[k + "scaling_lists"][0]):
+            raw = z[k + "scaling_lists"]
+            self.scaling_lists = abi.ScalingLists()
+            coef, dc = raw[1:1 + 1536].reshape(4, 6, 64), raw[1 + 1536:].reshape(4, 6)
+            for sz in range(4):
+                for l in range(6):
+                    self.scaling_lists.dc[sz][l] = int(dc[sz, l]) if sz >= 2 else 16
+                    for i in range(64):
+                        self.scaling_lists.coef[sz][l][i] = int(coef[sz, l, i])
         for si, s in enumerate(z[k + "slices"]):
             refs, pocs = [], []
             for l in range(2):
@@ -44,6 +54,9 @@ class Picture:
                                               pps_cb=int(s[2]), pps_cr=int(s[3]), deblocking_disable=int(s[6]),
                                               beta_offset_div2=int(s[7]), tc_offset_div2=int(s[8]), lf_across_slices=int(s[9])))
             self.slices[-1].constrained_intra_pred = int(s[26])
+            if self.scaling_lists is not None:
+                import ctypes
+                self.slices[-1].scaling_lists = ctypes.pointer(self.scaling_lists)
             if wp_all is not None and wp_all[si][0]:
                 wp, sl = wp_all[si], self.slices[-1]
                 sl.weighted_pred = 1

@@ -2,12 +2,10 @@
 random-access GOP of 8 B pictures must give, picture by picture, the oracle's samples when the oracle decodes the same
 pictures one after the other; and a finished picture moved through hmgpu_picture_device_region (the region an RCCL
 send/recv would carry) must serve as a reference exactly like the original."""
-import copy
-
 import numpy as np
 import pytest
 
-from libhm_amd import frame_parallel as fp
+from libhm_amd import abi, frame_parallel as fp
 from tests import synth
 
 pytestmark = pytest.mark.gpu
@@ -30,7 +28,7 @@ def test_gop_of_8_matches_oracle(oracle):
     # oracle: decode order, every picture from the finished planes of its two references
     want = {0: anchor}
     for poc, (a, b) in fp.RA_GOP8.items():
-        sl = copy.copy(pics[poc].slice)
+        sl = abi.clone_slice(pics[poc].slice)
         sl.ref_pic[0][0], sl.ref_pic[1][0] = 0, 1
         want[poc] = _oracle_picture(oracle, pics[poc], sl, [want[a], want[b]])
     with libhm_amd.Context(abi.make_seq(w, h, bd, bd, log2_ctu=6, max_pictures=9)) as ctx:
