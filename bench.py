@@ -63,6 +63,7 @@ def algorithmic_bytes(p):
     out["deblock_ver"] = 2 * samples                       # each pass = half of the 4 B/sample two-pass budget
     out["deblock_hor"] = 2 * samples
     out["sao"] = 4 * samples
+    out["filter_fused"] = 4 * samples                      # deblocking (both directions) + SAO in one pass: picture read once, written once
     out["prep"] = int(decoded.sum()) * (21 + 16)           # HM arrays read + BlkInfo written per partition
     # intra CUs: levels read (coded TUs), reconstruction written once, reference samples read (~ 4N+1 per N x N TU: counted as 2 B/sample)
     intra_p = decoded & (m["pred_mode"] == 1)

@@ -1,0 +1,164 @@
+// filter_core.h -- device functions shared by the stand-alone loop-filter kernels (k_dbk.hip, k_sao.hip) and the fused one
+// (k_filter.hip): boundary strength, luma / chroma deblocking of one edge unit (TComLoopFilter.cpp:411-891), SAO offset
+// arithmetic (TComSampleAdaptiveOffset.cpp:404-631).
+#pragma once
+#include "hmgpu_dev.h"
+
+namespace hmgpu {
+
+static __constant__ uint8_t c_tc_table[54] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 1, 1, 1, 1,
+                                       2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 5, 5, 6, 6, 7, 8, 9, 10, 11, 13, 14, 16, 18, 20, 22, 24};
+static __constant__ uint8_t c_beta_table[52] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15,
+                                         16, 17, 18, 20, 22, 24, 26, 28, 30, 32, 34, 36, 38, 40, 42, 44, 46, 48, 50, 52, 54,
+                                         56, 58, 60, 62, 64};
+static __constant__ uint8_t c_chroma_scale_420_dbk[58] = {
+    0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29,
+    29, 30, 31, 32, 33, 33, 34, 34, 35, 35, 36, 36, 37, 37, 38, 39, 40, 41, 42, 43, 44, 45, 46, 47, 48, 49, 50, 51};
+
+__device__ inline bool mvd4(const int16_t* a, const int16_t* b) { return abs(a[0] - b[0]) >= 4 || abs(a[1] - b[1]) >= 4; }
+
+// xGetBoundaryStrengthSingle (TComLoopFilter.cpp:411-537).  `transform_edge` is the m_aapucBS marker.  The P-slice
+// branch (:515-532) is the B-slice branch with list 1 absent on both sides, so one formula serves both.
+__device__ inline int boundary_strength(const BlkInfo& p, const BlkInfo& q, bool transform_edge) {
+  if ((p.flags | q.flags) & BF_INTRA) return 2;
+  if (transform_edge && ((p.flags | q.flags) & BF_CBFY)) return 1;
+  const int p0 = p.ref[0], p1 = p.ref[1], q0 = q.ref[0], q1 = q.ref[1];
+  if ((p0 == q0 && p1 == q1) || (p0 == q1 && p1 == q0)) {
+    if (p0 != p1) {
+      if (p0 == q0) return (mvd4(q.mv[0], p.mv[0]) || mvd4(q.mv[1], p.mv[1])) ? 1 : 0;
+      return (mvd4(q.mv[1], p.mv[0]) || mvd4(q.mv[0], p.mv[1])) ? 1 : 0;
+    }
+    return ((mvd4(q.mv[0], p.mv[0]) || mvd4(q.mv[1], p.mv[1])) && (mvd4(q.mv[1], p.mv[0]) || mvd4(q.mv[0], p.mv[1]))) ? 1 : 0;
+  }
+  return 1;
+}
+
+// one line across a luma edge: s[0..7] = p3 p2 p1 p0 q0 q1 q2 q3   (xPelFilterLuma, :800-859)
+__device__ inline void filter_luma_line(int (&s)[8], int tc, bool strong, int thr_cut, bool filt_p, bool filt_q, int maxv) {
+  const int m0 = s[0], m1 = s[1], m2 = s[2], m3 = s[3], m4 = s[4], m5 = s[5], m6 = s[6], m7 = s[7];
+  if (strong) {
+    s[3] = clip3(m3 - 2 * tc, m3 + 2 * tc, (m1 + 2 * m2 + 2 * m3 + 2 * m4 + m5 + 4) >> 3);
+    s[4] = clip3(m4 - 2 * tc, m4 + 2 * tc, (m2 + 2 * m3 + 2 * m4 + 2 * m5 + m6 + 4) >> 3);
+    s[2] = clip3(m2 - 2 * tc, m2 + 2 * tc, (m1 + m2 + m3 + m4 + 2) >> 2);
+    s[5] = clip3(m5 - 2 * tc, m5 + 2 * tc, (m3 + m4 + m5 + m6 + 2) >> 2);
+    s[1] = clip3(m1 - 2 * tc, m1 + 2 * tc, (2 * m0 + 3 * m1 + m2 + m3 + m4 + 4) >> 3);
+    s[6] = clip3(m6 - 2 * tc, m6 + 2 * tc, (m3 + m4 + m5 + 3 * m6 + 2 * m7 + 4) >> 3);
+  } else {
+    int delta = (9 * (m4 - m3) - 3 * (m5 - m2) + 8) >> 4;
+    if (abs(delta) < thr_cut) {
+      const int tc2 = tc >> 1;
+      delta = clip3(-tc, tc, delta);
+      s[3] = clip3(0, maxv, m3 + delta);
+      s[4] = clip3(0, maxv, m4 - delta);
+      if (filt_p) s[2] = clip3(0, maxv, m2 + clip3(-tc2, tc2, (((m1 + m3 + 1) >> 1) - m2 + delta) >> 1));
+      if (filt_q) s[5] = clip3(0, maxv, m5 + clip3(-tc2, tc2, (((m6 + m4 + 1) >> 1) - m5 - delta) >> 1));
+    }
+  }
+}
+
+__device__ inline void unpack8(const uint4 v, int (&s)[8]) {
+  s[0] = v.x & 0xffff; s[1] = v.x >> 16; s[2] = v.y & 0xffff; s[3] = v.y >> 16;
+  s[4] = v.z & 0xffff; s[5] = v.z >> 16; s[6] = v.w & 0xffff; s[7] = v.w >> 16;
+}
+__device__ inline uint4 pack8(const int (&s)[8]) {
+  return make_uint4((uint32_t)s[0] | ((uint32_t)s[1] << 16), (uint32_t)s[2] | ((uint32_t)s[3] << 16),
+                    (uint32_t)s[4] | ((uint32_t)s[5] << 16), (uint32_t)s[6] | ((uint32_t)s[7] << 16));
+}
+struct __attribute__((aligned(8))) U4a8 { uint32_t x, y, z, w; };    // 16 bytes at 8-byte alignment
+
+// luma decisions for one 4-line unit (xEdgeFilterLuma :587-650); l[i] = line i, 8 samples across the edge
+__device__ inline void filter_luma_unit(int (&l)[4][8], int bs, int qp, int tc_offset_div2, int beta_offset_div2, int bd) {
+  const int scale = 1 << (bd - 8);
+  const int tc = c_tc_table[clip3(0, 53, qp + 2 * (bs - 1) + (tc_offset_div2 << 1))] * scale;
+  const int beta = c_beta_table[clip3(0, 51, qp + (beta_offset_div2 << 1))] * scale;
+  const int side = (beta + (beta >> 1)) >> 3;
+  const int dp0 = abs(l[0][1] - 2 * l[0][2] + l[0][3]), dq0 = abs(l[0][4] - 2 * l[0][5] + l[0][6]);
+  const int dp3 = abs(l[3][1] - 2 * l[3][2] + l[3][3]), dq3 = abs(l[3][4] - 2 * l[3][5] + l[3][6]);
+  const int d0 = dp0 + dq0, d3 = dp3 + dq3, d = d0 + d3;
+  if (d >= beta) return;
+  const bool fp = (dp0 + dp3) < side, fq = (dq0 + dq3) < side;
+  const bool s0 = (abs(l[0][0] - l[0][3]) + abs(l[0][7] - l[0][4]) < (beta >> 3)) && (2 * d0 < (beta >> 2)) &&
+                  (abs(l[0][3] - l[0][4]) < ((tc * 5 + 1) >> 1));
+  const bool s3 = (abs(l[3][0] - l[3][3]) + abs(l[3][7] - l[3][4]) < (beta >> 3)) && (2 * d3 < (beta >> 2)) &&
+                  (abs(l[3][3] - l[3][4]) < ((tc * 5 + 1) >> 1));
+  const int maxv = (1 << bd) - 1;
+#pragma unroll
+  for (int i = 0; i < 4; i++) filter_luma_line(l[i], tc, s0 && s3, tc * 10, fp, fq, maxv);
+}
+
+// chroma tc for one component (xEdgeFilterChroma :759-775, 4:2:0)
+__device__ inline int chroma_tc(int qp_avg, int pps_off, int tc_offset_div2, int bd) {
+  int qp = qp_avg + pps_off;
+  if (qp >= 58) qp -= 6;
+  else if (qp >= 0) qp = c_chroma_scale_420_dbk[qp];
+  return c_tc_table[clip3(0, 53, qp + 2 + (tc_offset_div2 << 1))] * (1 << (bd - 8));     // Bs == 2: + DEFAULT_INTRA_TC_OFFSET
+}
+
+
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+__device__ inline s16x2 as_s16x2(uint32_t v) { return __builtin_bit_cast(s16x2, v); }
+__device__ inline uint32_t as_u32(s16x2 v) { return __builtin_bit_cast(uint32_t, v); }
+__device__ inline s16x2 splat(int v) { return (s16x2){(short)v, (short)v}; }
+
+// availability bit (SaoDev::avail order L,R,A,B,AL,AR,BL,BR; 8 = inside the CTB) of the CTU that holds a position with
+// vertical class v (0 above, 1 inside, 2 below) and horizontal class hcls (0 left, 1 inside, 2 right)
+__device__ inline int region_bit(int v, int hcls) {
+  return v == 1 ? (hcls == 0 ? 0 : (hcls == 2 ? 1 : 8)) : (v == 0 ? (hcls == 0 ? 4 : (hcls == 2 ? 5 : 2)) : (hcls == 0 ? 6 : (hcls == 2 ? 7 : 3)));
+}
+
+// neighbour samples x+DX .. x+7+DX of a row as four packed pairs; `e` = the row's 8 samples, l / r = samples x-1 / x+8
+template <int DX>
+__device__ inline void shifted(const u32x4 e, uint32_t l, uint32_t r, uint32_t (&n)[4]) {
+  if constexpr (DX == 0) { n[0] = e.x; n[1] = e.y; n[2] = e.z; n[3] = e.w; }
+  else if constexpr (DX < 0) {
+    n[0] = (e.x << 16) | l; n[1] = __builtin_amdgcn_alignbit(e.y, e.x, 16);
+    n[2] = __builtin_amdgcn_alignbit(e.z, e.y, 16); n[3] = __builtin_amdgcn_alignbit(e.w, e.z, 16);
+  } else {
+    n[0] = __builtin_amdgcn_alignbit(e.y, e.x, 16); n[1] = __builtin_amdgcn_alignbit(e.z, e.y, 16);
+    n[2] = __builtin_amdgcn_alignbit(e.w, e.z, 16); n[3] = (e.w >> 16) | (r << 16);
+  }
+}
+
+// offsets by table index (two indices 0..7 packed as 16-bit halves) -> two sign-extended 16-bit offsets.  v_perm_b32 does
+// the 8-entry byte-table lookup for both halves at once: indices are moved to the odd bytes so that the second v_perm can
+// replicate the sign bits (selector codes 8 / 9 = sign of byte 1 / 3).
+__device__ inline s16x2 lut_offsets(uint32_t idx_pk, uint32_t tab_lo, uint32_t tab_hi) {
+  const uint32_t looked = __builtin_amdgcn_perm(tab_hi, tab_lo, idx_pk << 8);   // bytes 1,3 = table[idx]; bytes 0,2 = table[0] (unused)
+  return as_s16x2(__builtin_amdgcn_perm(0u, looked, 0x09030801u));
+}
+
+// edge-offset arithmetic of one row of 8 samples once the two neighbour rows are at hand (na / nb = the samples at
+// (x+DX, row+DY) / (x-DX, row-DY) as four packed pairs): shared by k_sao (neighbours from global memory) and the fused
+// filter kernel (neighbours from its LDS tile)
+template <int DX, int DY>
+__device__ inline void sao_eo_core(int x, int row, const u32x4 cur, const uint32_t (&na)[4], const uint32_t (&nb)[4], uint32_t off_lo, uint32_t off_hi,
+                                   unsigned av, int x0, int y0, int x1, int y1, int maxv, uint32_t (&out)[4]) {
+  const int ya = row + DY, yb = row - DY;
+  // availability: interior samples face positions in the CTB's own columns; sample 0 / the last sample may face the
+  // left / right CTU column
+  const int va = ya < y0 ? 0 : (ya > y1 ? 2 : 1), vb = yb < y0 ? 0 : (yb > y1 ? 2 : 1);
+  const bool mid_ok = ((av >> region_bit(va, 1)) & 1) && ((av >> region_bit(vb, 1)) & 1);
+  const int last = min(7, x1 - x);                          // last sample of the group that lies inside the CTB / picture
+  const int ha0 = (x + DX) < x0 ? 0 : 1, hb0 = (x - DX) < x0 ? 0 : 1;
+  const int hal = (x + last + DX) > x1 ? 2 : 1, hbl = (x + last - DX) > x1 ? 2 : 1;
+  const bool ok0 = ((av >> region_bit(va, ha0)) & 1) && ((av >> region_bit(vb, hb0)) & 1);
+  const bool okl = ((av >> region_bit(va, hal)) & 1) && ((av >> region_bit(vb, hbl)) & 1);
+  const uint32_t c[4] = {cur.x, cur.y, cur.z, cur.w};
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const s16x2 cc = as_s16x2(c[j]);
+    const s16x2 one = splat(1), mone = splat(-1);
+    const s16x2 sa = __builtin_elementwise_max(__builtin_elementwise_min(cc - as_s16x2(na[j]), one), mone);
+    const s16x2 sb = __builtin_elementwise_max(__builtin_elementwise_min(cc - as_s16x2(nb[j]), one), mone);
+    const uint32_t et = as_u32(sa + sb + splat(2));         // edge class 0..4 in each half
+    const s16x2 off = lut_offsets(et, off_lo, off_hi);
+    const s16x2 res = __builtin_elementwise_min(__builtin_elementwise_max(cc + off, splat(0)), splat(maxv));
+    // per-half enable mask
+    const bool ok_lo = (2 * j == 0) ? ok0 : ((2 * j == last) ? okl : mid_ok);
+    const bool ok_hi = (2 * j + 1 == last) ? okl : mid_ok;
+    const uint32_t m = (ok_lo ? 0xffffu : 0u) | (ok_hi ? 0xffff0000u : 0u);
+    out[j] = (as_u32(res) & m) | (c[j] & ~m);
+  }
+}
+
+}  // namespace hmgpu

@@ -17,9 +17,9 @@ using namespace hmgpu;
 
 namespace {
 
-enum { K_PREP = 0, K_MC_LUMA, K_MC_CHROMA, K_ITX, K_DBK_VER, K_DBK_HOR, K_SAO, K_EXTEND, K_H2D, K_INTRA, K_RES10, K_RES11 };
+enum { K_PREP = 0, K_MC_LUMA, K_MC_CHROMA, K_ITX, K_DBK_VER, K_DBK_HOR, K_SAO, K_EXTEND, K_H2D, K_INTRA, K_FILTER, K_RES11 };
 const char* const kKernelNames[HMGPU_NUM_KERNELS] = {"prep", "mc_luma", "mc_chroma", "itx", "deblock_ver", "deblock_hor", "sao",
-                                                     "extend_border", "h2d_stage", "intra", "", ""};
+                                                     "extend_border", "h2d_stage", "intra", "filter_fused", ""};
 
 struct SliceCall { int first_ctu, num_ctus, slice_idx; bool intra, wp; };   // intra: the range holds intra CUs the device reconstructs
 
@@ -248,6 +248,14 @@ hmgpu_status run_recon(hmgpu_ctx* c, const Batch& b, bool any_intra, bool any_wp
 }
 
 hmgpu_status run_filter(hmgpu_ctx* c, const Batch& b, int stages) {
+  // all three stages on pictures that all carry SAO: one pass through LDS instead of three through HBM (k_filter.hip)
+  bool all_sao = stages == 7 && !getenv("HMGPU_NO_FUSED_FILTER");
+  for (int i = 0; i < b.n && all_sao; i++) all_sao = c->pics[b.pic[i]].sao_any;
+  if (all_sao) {
+    { ProfScope ps(c, K_FILTER); launch_filter_fused(c->d_pics, b, c->seq.width, c->seq.height, c->stream); }
+    HIP_TRY(c, hipGetLastError());
+    return HMGPU_OK;
+  }
   if (stages & 1) { ProfScope ps(c, K_DBK_VER); launch_deblock(c->d_pics, b, 0, c->seq.width, c->seq.height, c->stream); }
   if (stages & 2) { ProfScope ps(c, K_DBK_HOR); launch_deblock(c->d_pics, b, 1, c->seq.width, c->seq.height, c->stream); }
   if (stages & 4) {

@@ -1,0 +1,251 @@
+// k_filter.hip -- deblocking of both edge directions and SAO in ONE pass over the picture
+// (TComLoopFilter::loopFilterPic + TComSampleAdaptiveOffset::SAOProcess, TDecGop.cpp:165-173).
+//
+// The stand-alone kernels (k_dbk.hip x 2, k_sao.hip) each stream the whole picture through HBM: ~1.0 GB of real traffic per
+// batch of eight 2160p pictures, at 85-100 % of the achievable bandwidth -- the remaining lever is to move fewer bytes.
+// Here a workgroup owns a 64x64 luma tile (+ the 32x32 tiles of Cb and Cr), loads it ONCE with the halo the filters reach
+// through, runs vertical-edge deblocking, horizontal-edge deblocking and SAO on the copy in LDS, and writes only the SAO
+// planes: read ~1.5 x picture + BlkInfo, write 1 x picture.  The deblocked picture itself is never stored (with SAO on, the
+// SAO planes are the picture's final planes; pictures without SAO take the stand-alone path).
+//
+// Halo arithmetic (luma; chroma is the same at half scale with a 1-sample filter): SAO of the tile needs deblocked samples
+// one sample around it; a deblocked sample belongs to exactly one edge per direction (edges lie on the 8x8 grid, an edge
+// rewrites 3 samples on each side and reads 4); so the horizontal edges y0, y0+8 .. y0+64 must be filtered over the columns
+// [x0-4, x0+68), on input that has seen the vertical edges x0 .. x0+64 over the rows [y0-4, y0+68), which read the
+// unfiltered columns [x0-4, x0+68).  Edge units on a tile border are computed by both neighbours, from the same unfiltered
+// samples, hence identically.  Every decision and every filter is the code of the stand-alone kernels (filter_core.h).
+#include "hmgpu_dev.h"
+#include "filter_core.h"
+#include <type_traits>
+
+namespace hmgpu {
+
+namespace {
+constexpr int kTW = 64, kTH = 64;                 // luma tile
+constexpr int kYC = kTW + 16, kYH = kTH + 8;      // luma copy: columns [x0-8, x0+72) (16-byte aligned rows), rows [y0-4, y0+68)
+constexpr int kCC = kTW / 2 + 16, kCH = kTH / 2 + 4;   // chroma copy: columns [cx0-8, cx0+40), rows [cy0-2, cy0+34)
+constexpr int kYW = kYC + 8, kCW = kCC + 8;       // row pitch in LDS: an odd number of 16-byte units (conflict-free 16-byte row accesses)
+
+struct FilterLds {
+  __attribute__((aligned(16))) int16_t y[kYH][kYW];
+  __attribute__((aligned(16))) int16_t c[2][kCH][kCW];
+};
+
+// SAO of one group of 8 samples at (x, row) of component comp, reading the deblocked copy; (ox, oy) = picture coordinates
+// of copy element [0][0]
+struct SaoPrm { uint32_t w0, off_lo, off_hi; };               // SaoDev as three dwords
+__device__ inline SaoPrm sao_fetch(const PicDev& P, int comp, int x, int row) {
+  const int log2ctb = P.log2ctu - (comp ? 1 : 0);
+  const int w = P.width >> (comp ? 1 : 0), h = P.height >> (comp ? 1 : 0);
+  SaoPrm r = {0xffu, 0u, 0u};
+  if (x < w && row < h) {
+    const uint32_t* pw = reinterpret_cast<const uint32_t*>(P.saoprm + ((size_t)(row >> log2ctb) * P.ctus_w + (x >> log2ctb)) * 3 + comp);
+    r.w0 = ldg(pw); r.off_lo = ldg(pw + 1); r.off_hi = ldg(pw + 2);
+  }
+  return r;
+}
+
+template <int W>
+__device__ inline void sao_group(const PicDev& P, int comp, const int16_t (*t)[W], int ox, int oy, int x, int row, const SaoPrm& prm) {
+  const int cs = comp ? 1 : 0;
+  const int w = P.width >> cs, h = P.height >> cs;
+  const int pitch = P.pitch[comp];
+  const int log2ctb = P.log2ctu - cs;
+  const int cx = x >> log2ctb, cy = row >> log2ctb;
+  const uint32_t w0 = prm.w0;
+  const int type = (int)(int8_t)(w0 & 0xff);
+  const int16_t* line = &t[row - oy][x - ox];
+  const u32x4 cur = *reinterpret_cast<const u32x4*>(line);
+  int16_t* dst = P.sao[comp] + (size_t)row * pitch + x;
+  if (type < 0) { stg4(dst, cur); return; }
+  const uint32_t off_lo = prm.off_lo, off_hi = prm.off_hi;
+  const int bd = P.bd[comp], maxv = (1 << bd) - 1;
+  uint32_t out[4];
+  if (type == HMGPU_SAO_BO) {
+    const int shift = bd - 5, band0 = (w0 >> 16) & 0xff;
+    const uint32_t c[4] = {cur.x, cur.y, cur.z, cur.w};
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const uint32_t lo = c[j] & 0xffffu, hi = c[j] >> 16;
+      const uint32_t k0 = min(((lo >> shift) - band0) & 31u, 4u), k1 = min(((hi >> shift) - band0) & 31u, 4u);
+      const s16x2 off = lut_offsets(k0 | (k1 << 16), off_lo, 0u);
+      out[j] = as_u32(__builtin_elementwise_min(__builtin_elementwise_max(as_s16x2(c[j]) + off, splat(0)), splat(maxv)));
+    }
+  } else {
+    const int ctb = 1 << log2ctb;
+    const int x0 = cx << log2ctb, y0 = cy << log2ctb;
+    const int x1 = min(x0 + ctb, w) - 1, y1 = min(y0 + ctb, h) - 1;
+    const unsigned av = ((w0 >> 8) & 0xff) | 0x100u;
+    // neighbour rows straight from the copy (its halo holds the deblocked samples around the tile; positions outside the
+    // picture hold margin samples, which the availability mask never lets through)
+    auto run = [&](auto dxc, auto dyc) {
+      constexpr int DX = decltype(dxc)::value, DY = decltype(dyc)::value;
+      const int16_t* ra = line + DY * W;
+      const int16_t* rb = line - DY * W;
+      const u32x4 ea = *reinterpret_cast<const u32x4*>(ra), eb = *reinterpret_cast<const u32x4*>(rb);
+      uint32_t na[4], nb[4];
+      uint32_t la = 0, raa = 0, lb = 0, rbb = 0;
+      if constexpr (DX < 0) { la = (uint16_t)ra[-1]; rbb = (uint16_t)rb[8]; }
+      if constexpr (DX > 0) { raa = (uint16_t)ra[8]; lb = (uint16_t)rb[-1]; }
+      shifted<DX>(ea, la, raa, na);
+      shifted<-DX>(eb, lb, rbb, nb);
+      sao_eo_core<DX, DY>(x, row, cur, na, nb, off_lo, off_hi, av, x0, y0, x1, y1, maxv, out);
+    };
+    switch (type) {
+      case HMGPU_SAO_EO_0:   run(std::integral_constant<int, -1>{}, std::integral_constant<int, 0>{}); break;
+      case HMGPU_SAO_EO_90:  run(std::integral_constant<int, 0>{}, std::integral_constant<int, -1>{}); break;
+      case HMGPU_SAO_EO_135: run(std::integral_constant<int, -1>{}, std::integral_constant<int, -1>{}); break;
+      default:               run(std::integral_constant<int, 1>{}, std::integral_constant<int, -1>{}); break;
+    }
+  }
+  u32x4 res = {out[0], out[1], out[2], out[3]};
+  stg4(dst, res);
+}
+
+// the two BlkInfo records facing each other across an edge unit of direction DIR whose Q block is at luma (x, y); requested
+// at kernel entry, long before the unit is filtered (their latency hides behind the tile load)
+struct EdgeBlk { u32x4 q, p; bool on; };
+template <int DIR>
+__device__ inline EdgeBlk edge_fetch(const PicDev& P, int x, int y, bool mine) {
+  EdgeBlk e;
+  e.q = e.p = (u32x4){0, 0, 0, 0};
+  const int gx = x >> 2, gy = y >> 2;
+  e.on = mine && x >= 0 && y >= 0 && x < P.width && y < P.height && (DIR == 0 ? gx != 0 : gy != 0);
+  if (e.on) {
+    const BlkInfo* g = P.blk + (size_t)gy * P.grid_w + gx;
+    e.q = ldg4(g);
+    e.p = ldg4(DIR == 0 ? g - 1 : g - P.grid_w);
+  }
+  return e;
+}
+
+// one deblocking edge unit of direction DIR at luma (x, y) (its Q block), on the copies
+struct SliceLf { int tc_off, beta_off, cb_off, cr_off; };     // the deblocking constants of one slice
+__device__ inline SliceLf slice_lf(const SliceDev* s) {
+  return {ldg(&s->tc_offset_div2), ldg(&s->beta_offset_div2), ldg(&s->pps_cb_qp_offset), ldg(&s->pps_cr_qp_offset)};
+}
+
+template <int DIR>
+__device__ inline void edge_unit(const PicDev& P, FilterLds& L, int x0, int y0, int x, int y, const EdgeBlk& e, const SliceLf& s0) {
+  if (!e.on) return;
+  const BlkInfo q = __builtin_bit_cast(BlkInfo, e.q), p = __builtin_bit_cast(BlkInfo, e.p);
+  if (!(q.edge & (DIR == 0 ? BE_VER_FILTER : BE_HOR_FILTER))) return;
+  const int bs = boundary_strength(p, q, (q.edge & (DIR == 0 ? BE_VER_TRANSFORM : BE_HOR_TRANSFORM)) != 0);
+  if (bs == 0) return;
+  // offsets come from the Q side's slice (TComLoopFilter.cpp:565-566); slice 0's were fetched at kernel entry
+  const SliceLf sl = q.slice == 0 ? s0 : slice_lf(P.slices + q.slice);
+  const int tc_off = sl.tc_off, beta_off = sl.beta_off;
+  const int qp = ((int)p.qp + (int)q.qp + 1) >> 1;
+  int16_t* base = &L.y[y - (y0 - 4)][x - (x0 - 8)];
+  int l[4][8];
+  if (DIR == 0) {
+    // a line = 8 contiguous samples starting 4 before the edge: 8-byte aligned in the copy
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const u32x2 a = *reinterpret_cast<const u32x2*>(base + i * kYW - 4), c = *reinterpret_cast<const u32x2*>(base + i * kYW);
+      l[i][0] = a.x & 0xffff; l[i][1] = a.x >> 16; l[i][2] = a.y & 0xffff; l[i][3] = a.y >> 16;
+      l[i][4] = c.x & 0xffff; l[i][5] = c.x >> 16; l[i][6] = c.y & 0xffff; l[i][7] = c.y >> 16;
+    }
+  } else {
+    // a row of the unit = 4 contiguous samples: one 8-byte access
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+      const u32x2 a = *reinterpret_cast<const u32x2*>(base + (r - 4) * kYW);
+      l[0][r] = a.x & 0xffff; l[1][r] = a.x >> 16; l[2][r] = a.y & 0xffff; l[3][r] = a.y >> 16;
+    }
+  }
+  filter_luma_unit(l, bs, qp, tc_off, beta_off, P.bd[0]);
+  if (DIR == 0) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      u32x2 a = {(uint32_t)l[i][0] | ((uint32_t)l[i][1] << 16), (uint32_t)l[i][2] | ((uint32_t)l[i][3] << 16)};
+      u32x2 c = {(uint32_t)l[i][4] | ((uint32_t)l[i][5] << 16), (uint32_t)l[i][6] | ((uint32_t)l[i][7] << 16)};
+      *reinterpret_cast<u32x2*>(base + i * kYW - 4) = a;
+      *reinterpret_cast<u32x2*>(base + i * kYW) = c;
+    }
+  } else {
+#pragma unroll
+    for (int r = 1; r < 7; r++) {
+      u32x2 a = {(uint32_t)l[0][r] | ((uint32_t)l[1][r] << 16), (uint32_t)l[2][r] | ((uint32_t)l[3][r] << 16)};
+      *reinterpret_cast<u32x2*>(base + (r - 4) * kYW) = a;
+    }
+  }
+  // chroma: Bs 2 only, edges on the 8-sample chroma grid (TComLoopFilter.cpp:225-229, 684-692, 727)
+  if (bs == 2 && ((DIR == 0 ? x : y) & 15) == 0) {
+    const int maxc = (1 << P.bd[1]) - 1;
+#pragma unroll
+    for (int comp = 1; comp < 3; comp++) {
+      const int tc = chroma_tc(qp, comp == 1 ? sl.cb_off : sl.cr_off, tc_off, P.bd[comp]);
+      int16_t* cb = &L.c[comp - 1][(y >> 1) - ((y0 >> 1) - 2)][(x >> 1) - ((x0 >> 1) - 8)];
+#pragma unroll
+      for (int i = 0; i < 2; i++) {
+        int16_t* s = DIR == 0 ? cb + i * kCW : cb + i;
+        const int o = DIR == 0 ? 1 : kCW;
+        const int m2 = (uint16_t)s[-2 * o], m3 = (uint16_t)s[-o], m4 = (uint16_t)s[0], m5 = (uint16_t)s[o];
+        const int delta = clip3(-tc, tc, ((((m4 - m3) << 2) + m2 - m5 + 4) >> 3));
+        s[-o] = (int16_t)clip3(0, maxc, m3 + delta);
+        s[0] = (int16_t)clip3(0, maxc, m4 - delta);
+      }
+    }
+  }
+}
+
+}  // namespace
+
+__global__ void __launch_bounds__(256) k_filter_fused(const PicDev* __restrict__ pics, Batch b) {
+  __shared__ FilterLds L;
+  const PicDev& P = pics[b.pic[blockIdx.z]];
+  const int x0 = blockIdx.x * kTW, y0 = blockIdx.y * kTH;
+  const int t = threadIdx.x;
+  // edge units of this thread: vertical edges x0, x0+8 .. x0+64 over the rows [y0-4, y0+68) (9 edges x 18 units), horizontal
+  // edges y0 .. y0+64 over the columns [x0-4, x0+68)
+  const int vx = x0 + 8 * (t % 9), vy = y0 - 4 + 4 * (t / 9), hx = x0 - 4 + 4 * (t % 18), hy = y0 + 8 * (t / 18);
+  const EdgeBlk ev = edge_fetch<0>(P, vx, vy, t < 9 * 18), eh = edge_fetch<1>(P, hx, hy, t < 9 * 18);
+  const SliceLf s0 = slice_lf(P.slices);
+  // SAO groups of this thread (8 samples each): two of luma (64 rows x 8 groups), one of Cb or Cr (32 rows x 4 groups each);
+  // their parameters are requested now as well
+  int lx[2], ly[2];
+  SaoPrm sl[2];
+#pragma unroll
+  for (int k = 0; k < 2; k++) {
+    const int g = t + 256 * k;
+    lx[k] = x0 + (g & 7) * 8; ly[k] = y0 + (g >> 3);
+    sl[k] = sao_fetch(P, 0, lx[k], ly[k]);
+  }
+  const int ccomp = 1 + (t >> 7), ccx = (x0 >> 1) + (t & 3) * 8, ccy = (y0 >> 1) + ((t & 127) >> 2);
+  const SaoPrm sc = sao_fetch(P, ccomp, ccx, ccy);
+  // ---- 1. the tile and its halo, before any filtering (pictures carry margins: every address is inside the allocation)
+  {
+    const int16_t* src = P.rec[0] + (ptrdiff_t)(y0 - 4) * P.pitch[0] + (x0 - 8);
+    constexpr int VPR = kYC / 8;
+    for (int i = t; i < kYH * VPR; i += 256) {
+      const int r = i / VPR, v = i % VPR;
+      *reinterpret_cast<u32x4*>(&L.y[r][8 * v]) = ldg4(src + (ptrdiff_t)r * P.pitch[0] + 8 * v);
+    }
+    constexpr int VPC = kCC / 8;
+    for (int i = t; i < 2 * kCH * VPC; i += 256) {
+      const int comp = i / (kCH * VPC), j = i % (kCH * VPC), r = j / VPC, v = j % VPC;
+      const int16_t* cs = P.rec[1 + comp] + (ptrdiff_t)((y0 >> 1) - 2 + r) * P.pitch[1] + ((x0 >> 1) - 8) + 8 * v;
+      *reinterpret_cast<u32x4*>(&L.c[comp][r][8 * v]) = ldg4(cs);
+    }
+  }
+  __syncthreads();
+  // ---- 2. vertical edges
+  edge_unit<0>(P, L, x0, y0, vx, vy, ev, s0);
+  __syncthreads();
+  // ---- 3. horizontal edges
+  edge_unit<1>(P, L, x0, y0, hx, hy, eh, s0);
+  __syncthreads();
+  // ---- 4. SAO of the tile from the deblocked copy
+#pragma unroll
+  for (int k = 0; k < 2; k++)
+    if (lx[k] < P.width && ly[k] < P.height) sao_group<kYW>(P, 0, L.y, x0 - 8, y0 - 4, lx[k], ly[k], sl[k]);
+  if (ccx < (P.width >> 1) && ccy < (P.height >> 1)) sao_group<kCW>(P, ccomp, L.c[ccomp - 1], (x0 >> 1) - 8, (y0 >> 1) - 2, ccx, ccy, sc);
+}
+
+void launch_filter_fused(const PicDev* pics, const Batch& b, int width, int height, hipStream_t s) {
+  dim3 grid((unsigned)((width + kTW - 1) / kTW), (unsigned)((height + kTH - 1) / kTH), (unsigned)b.n);
+  hipLaunchKernelGGL(k_filter_fused, grid, dim3(256), 0, s, pics, b);
+}
+
+}  // namespace hmgpu

@@ -10,40 +10,9 @@
 // whose availability bit is set (derivation in DESIGN.md "SAO bounds"); only the first and last sample of a thread's
 // group can face another CTU horizontally, so the rule costs a handful of scalar-like operations per thread.
 #include "hmgpu_dev.h"
+#include "filter_core.h"
 
 namespace hmgpu {
-
-typedef short s16x2 __attribute__((ext_vector_type(2)));
-__device__ inline s16x2 as_s16x2(uint32_t v) { return __builtin_bit_cast(s16x2, v); }
-__device__ inline uint32_t as_u32(s16x2 v) { return __builtin_bit_cast(uint32_t, v); }
-__device__ inline s16x2 splat(int v) { return (s16x2){(short)v, (short)v}; }
-
-// availability bit (SaoDev::avail order L,R,A,B,AL,AR,BL,BR; 8 = inside the CTB) of the CTU that holds a position with
-// vertical class v (0 above, 1 inside, 2 below) and horizontal class hcls (0 left, 1 inside, 2 right)
-__device__ inline int region_bit(int v, int hcls) {
-  return v == 1 ? (hcls == 0 ? 0 : (hcls == 2 ? 1 : 8)) : (v == 0 ? (hcls == 0 ? 4 : (hcls == 2 ? 5 : 2)) : (hcls == 0 ? 6 : (hcls == 2 ? 7 : 3)));
-}
-
-// neighbour samples x+DX .. x+7+DX of a row as four packed pairs; `e` = the row's 8 samples, l / r = samples x-1 / x+8
-template <int DX>
-__device__ inline void shifted(const u32x4 e, uint32_t l, uint32_t r, uint32_t (&n)[4]) {
-  if constexpr (DX == 0) { n[0] = e.x; n[1] = e.y; n[2] = e.z; n[3] = e.w; }
-  else if constexpr (DX < 0) {
-    n[0] = (e.x << 16) | l; n[1] = __builtin_amdgcn_alignbit(e.y, e.x, 16);
-    n[2] = __builtin_amdgcn_alignbit(e.z, e.y, 16); n[3] = __builtin_amdgcn_alignbit(e.w, e.z, 16);
-  } else {
-    n[0] = __builtin_amdgcn_alignbit(e.y, e.x, 16); n[1] = __builtin_amdgcn_alignbit(e.z, e.y, 16);
-    n[2] = __builtin_amdgcn_alignbit(e.w, e.z, 16); n[3] = (e.w >> 16) | (r << 16);
-  }
-}
-
-// offsets by table index (two indices 0..7 packed as 16-bit halves) -> two sign-extended 16-bit offsets.  v_perm_b32 does
-// the 8-entry byte-table lookup for both halves at once: indices are moved to the odd bytes so that the second v_perm can
-// replicate the sign bits (selector codes 8 / 9 = sign of byte 1 / 3).
-__device__ inline s16x2 lut_offsets(uint32_t idx_pk, uint32_t tab_lo, uint32_t tab_hi) {
-  const uint32_t looked = __builtin_amdgcn_perm(tab_hi, tab_lo, idx_pk << 8);   // bytes 1,3 = table[idx]; bytes 0,2 = table[0] (unused)
-  return as_s16x2(__builtin_amdgcn_perm(0u, looked, 0x09030801u));
-}
 
 // edge offset of one row of 8 samples, compile-time direction (DX, DY in {-1,0,1}); everything stays packed (2 samples / register)
 template <int DX, int DY>
@@ -61,31 +30,7 @@ __device__ inline void sao_eo_row(const int16_t* __restrict__ src, int pitch, in
     shifted<DX>(ea, la, raa, na);
     shifted<-DX>(eb, lb, rbb, nb);
   }
-  // availability: interior samples face positions in the CTB's own columns; sample 0 / the last sample may face the
-  // left / right CTU column
-  const int va = ya < y0 ? 0 : (ya > y1 ? 2 : 1), vb = yb < y0 ? 0 : (yb > y1 ? 2 : 1);
-  const bool mid_ok = ((av >> region_bit(va, 1)) & 1) && ((av >> region_bit(vb, 1)) & 1);
-  const int last = min(7, x1 - x);                          // last sample of the group that lies inside the CTB / picture
-  const int ha0 = (x + DX) < x0 ? 0 : 1, hb0 = (x - DX) < x0 ? 0 : 1;
-  const int hal = (x + last + DX) > x1 ? 2 : 1, hbl = (x + last - DX) > x1 ? 2 : 1;
-  const bool ok0 = ((av >> region_bit(va, ha0)) & 1) && ((av >> region_bit(vb, hb0)) & 1);
-  const bool okl = ((av >> region_bit(va, hal)) & 1) && ((av >> region_bit(vb, hbl)) & 1);
-  const uint32_t c[4] = {cur.x, cur.y, cur.z, cur.w};
-#pragma unroll
-  for (int j = 0; j < 4; j++) {
-    const s16x2 cc = as_s16x2(c[j]);
-    const s16x2 one = splat(1), mone = splat(-1);
-    const s16x2 sa = __builtin_elementwise_max(__builtin_elementwise_min(cc - as_s16x2(na[j]), one), mone);
-    const s16x2 sb = __builtin_elementwise_max(__builtin_elementwise_min(cc - as_s16x2(nb[j]), one), mone);
-    const uint32_t et = as_u32(sa + sb + splat(2));         // edge class 0..4 in each half
-    const s16x2 off = lut_offsets(et, off_lo, off_hi);
-    const s16x2 res = __builtin_elementwise_min(__builtin_elementwise_max(cc + off, splat(0)), splat(maxv));
-    // per-half enable mask
-    const bool ok_lo = (2 * j == 0) ? ok0 : ((2 * j == last) ? okl : mid_ok);
-    const bool ok_hi = (2 * j + 1 == last) ? okl : mid_ok;
-    const uint32_t m = (ok_lo ? 0xffffu : 0u) | (ok_hi ? 0xffff0000u : 0u);
-    out[j] = (as_u32(res) & m) | (c[j] & ~m);
-  }
+  sao_eo_core<DX, DY>(x, row, cur, na, nb, off_lo, off_hi, av, x0, y0, x1, y1, maxv, out);
 }
 
 // One wave = one 64x8 luma block (8 lanes across, 8 rows) or one 32x16 chroma block (4 lanes across, 16 rows): always
