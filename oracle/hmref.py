@@ -25,7 +25,7 @@ def lib():
         _lib = C.CDLL(LIB_PATH)
         _lib.ref_dec_open.restype = C.c_void_p
         _lib.ref_dec_open.argtypes = [C.c_void_p, C.c_int64, C.c_int]
-        for n in ("ref_dec_close", "ref_dec_info", "ref_dec_slices", "ref_dec_sao_params", "ref_dec_wp", "ref_dec_scaling_lists"):
+        for n in ("ref_dec_close", "ref_dec_info", "ref_dec_slices", "ref_dec_sao_params", "ref_dec_wp", "ref_dec_scaling_lists", "ref_dec_tile_idx"):
             getattr(_lib, n).restype = None
         _lib.ref_dec_next.argtypes = [C.c_void_p]
         _lib.ref_dec_filter_step.argtypes = [C.c_void_p]
@@ -36,6 +36,7 @@ def lib():
         _lib.ref_dec_sao_params.argtypes = [C.c_void_p, C.c_void_p]
         _lib.ref_dec_wp.argtypes = [C.c_void_p, C.c_void_p]
         _lib.ref_dec_scaling_lists.argtypes = [C.c_void_p, C.c_void_p]
+        _lib.ref_dec_tile_idx.argtypes = [C.c_void_p, C.c_void_p]
         _lib.ref_dec_coeffs.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         _lib.ref_dec_planes.argtypes = [C.c_void_p] + [C.c_void_p] * 3
         _lib.ref_dec_dpb_planes.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 3
@@ -127,6 +128,11 @@ class RefDecoder:
     def slices(self, n):
         a = np.zeros((n, 64), dtype=np.int32)
         lib().ref_dec_slices(self._h, _p(a))
+        return a
+
+    def tile_idx(self, num_ctus):
+        a = np.zeros(num_ctus, dtype=np.int32)
+        lib().ref_dec_tile_idx(self._h, _p(a))
         return a
 
     def scaling_lists(self):

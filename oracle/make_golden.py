@@ -87,6 +87,9 @@ STREAMS = {
     # NOTE: multi-slice inter streams (--SliceMode=1) are not used: HM 16.0's own TAppDecoder asserts
     # (TComBitStream.h:191) on the streams its encoder writes for them, at every optimisation level.
     "intra_main10_208x120": ("encoder_intra_main10.cfg", 208, 120, 1, 10, 10, 30, []),
+    # 3 x 2 tiles (HEVC wants tiles >= 256 x 64), no loop filtering across tile borders: tile-bounded intra references, deblocking and SAO neighbourhoods
+    "ldp_tiles_main10_832x128": ("encoder_lowdelay_P_main10.cfg", 832, 128, 3, 10, 10, 30,
+                                 ["--TileUniformSpacing=1", "--NumTileColumnsMinus1=2", "--NumTileRowsMinus1=1", "--LFCrossTileBoundaryFlag=0"]),
     # scaling lists from a file: every matrix different, DC values for 16x16 / 32x32 (I picture: intra lists, P pictures: inter lists)
     "ldp_sl_main10_208x120": ("encoder_lowdelay_P_main10.cfg", 208, 120, 3, 10, 10, 28, ["--ScalingList=2", "--ScalingListFile=@SLFILE@"]),
     "ldp_sldef_main8_208x120": ("encoder_lowdelay_P_main.cfg", 208, 120, 2, 8, 8, 34, ["--ScalingList=1"]),
@@ -161,6 +164,7 @@ def dump_stream(name, bitstream, enc_rec, geom):
         out[k + "slices"] = dec.slices(ns)
         out[k + "wp"] = dec.wp(ns)
         out[k + "scaling_lists"] = dec.scaling_lists()
+        out[k + "tile_idx"] = dec.tile_idx(info["num_ctus"])
         meta = dec.meta(info)
         for n2, a in meta.items():
             out[k + "meta_" + n2] = a

@@ -307,6 +307,13 @@ void ref_dec_wp(void* h, int32_t* out)
   }
 }
 
+/* TComPicSym::getTileIdxMap per CTU (raster address) */
+void ref_dec_tile_idx(void* h, int32_t* out)
+{
+  RefDec* d = (RefDec*)h; TComPic* p = cur(d);
+  for (UInt a = 0; a < p->getNumCUsInFrame(); a++) out[a] = (int32_t)p->getPicSym()->getTileIdxMap(a);
+}
+
 /* scaling lists of the picture's first slice as TDecTop activated them (TDecTop.cpp:651-668): out[0] = enabled, then
  * coef[sizeId 0..3][listId 0..5][64] (TComScalingList::getScalingListAddress, raster order, first 16 used for 4x4) and
  * dc[sizeId][listId] (getScalingListDC) */

@@ -8,7 +8,7 @@ from libhm_amd import abi
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 STREAMS = ["ldp_main8_416x240", "ra_main10_208x120", "ldp_main10_208x120", "intra_main10_208x120", "ldp_cip_main10_208x120",
-           "ldp_wp_main10_208x120", "ra_wp_main8_208x120", "ldp_sl_main10_208x120", "ldp_sldef_main8_208x120"]
+           "ldp_wp_main10_208x120", "ra_wp_main8_208x120", "ldp_sl_main10_208x120", "ldp_sldef_main8_208x120", "ldp_tiles_main10_832x128"]
 _cache = {}
 
 
@@ -54,6 +54,7 @@ class Picture:
                                               pps_cb=int(s[2]), pps_cr=int(s[3]), deblocking_disable=int(s[6]),
                                               beta_offset_div2=int(s[7]), tc_offset_div2=int(s[8]), lf_across_slices=int(s[9])))
             self.slices[-1].constrained_intra_pred = int(s[26])
+            self.slices[-1].lf_across_tiles = self.lf_across_tiles
             if self.scaling_lists is not None:
                 import ctypes
                 self.slices[-1].scaling_lists = ctypes.pointer(self.scaling_lists)
@@ -72,6 +73,8 @@ class Picture:
                                              "ts_u", "ts_v", "mv0", "mv1", "ref_idx0", "ref_idx1", "intra_dir_l", "intra_dir_c",
                                              "bypass", "ipcm")}
         m["slice_idx"] = z[k + "meta_slice_idx"].astype(np.uint16)
+        if (k + "tile_idx") in z.files:
+            m["tile_idx"] = z[k + "tile_idx"].astype(np.uint16)
         self.meta_np = m
         self.meta = abi.MetaHolder(m)
         self.coeffs = abi.CoeffHolder(z[k + "coeff0"], z[k + "coeff1"], z[k + "coeff2"])
