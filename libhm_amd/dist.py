@@ -21,7 +21,9 @@ def init_from_env(backend=None):
     os.environ.setdefault("MASTER_PORT", "29511")
     os.environ.setdefault("NCCL_DEBUG", "WARN")          # keep RCCL's version banner off stdout (bench.py prints ONE JSON line)
     if backend is None:
-        backend = "nccl" if torch.cuda.is_available() else "gloo"
+        backend = os.environ.get("HMGPU_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+    if os.environ.get("HMGPU_SINGLE_DEVICE"):        # rehearsal of N ranks on a one-GPU box (gloo only: RCCL refuses two ranks on one GPU)
+        local_rank = 0
     kw = {}
     if backend == "nccl":
         torch.cuda.set_device(local_rank)
@@ -49,6 +51,11 @@ def shard(num_units, world, rank):
     return begin, begin + base + (1 if rank < rem else 0)
 
 
+def reduce_device(dist, device):
+    """where the MAX-over-ranks scalar lives: on the GPU for RCCL, on the host for gloo"""
+    return device if (dist is not None and dist.get_backend() == "nccl") else "cpu"
+
+
 def timed_region(dist, run, sync, device=None):
     """barrier + sync, run(), sync + barrier; returns the MAX elapsed seconds over all ranks (the contract of bench.py)"""
     sync()
@@ -60,7 +67,7 @@ def timed_region(dist, run, sync, device=None):
     elapsed = time.perf_counter() - t0
     if dist is not None:
         import torch
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device if device is not None else "cpu")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=reduce_device(dist, device) if device is not None else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
         dist.barrier()
