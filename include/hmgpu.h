@@ -69,7 +69,8 @@ typedef struct hmgpu_seq_params {
   int32_t max_pictures;           /* device pictures to pre-allocate (DPB size + pictures in flight) */
   int32_t pcm_loop_filter_disable;/* SPS pcm_loop_filter_disabled_flag && pcm_enabled_flag */
   int32_t strong_intra_smoothing; /* SPS strong_intra_smoothing_enabled_flag (TComPattern.cpp:201-216) */
-  int32_t reserved[7];
+  int32_t pcm_bit_depth_luma, pcm_bit_depth_chroma;   /* SPS pcm_sample_bit_depth_*: PCM samples are shifted up to the coding bit depth (TDecCu.cpp:770-789) */
+  int32_t reserved[5];
 } hmgpu_seq_params;
 
 /* Scaling lists as TDecTop activates them for a slice (TDecTop.cpp:651-668: PPS lists, else SPS lists, else the defaults):
@@ -119,8 +120,8 @@ typedef struct hmgpu_ctu_meta {
   const int16_t* mv[2];              /* m_acCUMvField[list].m_pcMv as {hor,ver} pairs: [num_ctus][parts][2] */
   const int8_t*  ref_idx[2];         /* m_acCUMvField[list].m_piRefIdx (-1 = list unused) */
   const uint8_t* intra_dir[2];       /* m_puhIntraDir[luma,chroma]                          (optional; intra path) */
-  const uint8_t* transquant_bypass;  /* m_CUTransquantBypass                                (optional; must be 0) */
-  const uint8_t* ipcm;               /* m_pbIPCMFlag                                        (optional; must be 0) */
+  const uint8_t* transquant_bypass;  /* m_CUTransquantBypass: lossless CUs (residual = levels, exempt from the loop filters)  (optional) */
+  const uint8_t* ipcm;               /* m_pbIPCMFlag: PCM CUs (samples from coeffs->pcm_sample)                               (optional) */
   const uint16_t* slice_idx;         /* [num_ctus] index into the picture's slice table     (optional: all 0) */
   const uint16_t* tile_idx;          /* [num_ctus] TComPicSym::getTileIdxMap                (optional: all 0) */
 } hmgpu_ctu_meta;
@@ -130,6 +131,8 @@ typedef struct hmgpu_ctu_meta {
  * y: [num_ctus][ctu*ctu], cb/cr: [num_ctus][ctu*ctu/4]. */
 typedef struct hmgpu_coeffs {
   const int16_t* level[3];
+  const int16_t* pcm_sample[3];   /* TComDataCU::getPCMSample (m_pcIPCMSample*): the transmitted samples of PCM CUs, same layout as
+                                     the levels; needed only if meta->ipcm marks PCM CUs (may be NULL otherwise) */
 } hmgpu_coeffs;
 
 /* SAOBlkParam as parsed (TDecSbac::parseSAOBlkParam), before reconstructBlkSAOParams: [num_ctus][3] */
@@ -187,7 +190,8 @@ void* hmgpu_stream(hmgpu_ctx* ctx);
  * slice `slice_idx` of picture `cur`: motion compensation of every inter PU (TComPrediction::motionCompensation),
  * de-quantisation + inverse transform of every coded TU (TComTrQuant::invRecurTransformNxN) and
  * recon = ClipBD(pred + resid) into the picture (TComYuv::addClip, TDecCu::xCopyToPic).
- * Intra CUs: see DESIGN.md (round 1: left untouched, reported through hmgpu_get_stats).
+ * Intra CUs (TDecCu::xReconIntraQT) are reconstructed too, in decoding order, when meta->intra_dir[] is supplied; without
+ * the modes they are left untouched.  hmgpu_get_stats counts both kinds of partitions.
  * The metadata/coefficients are copied to the device before the call returns to the caller's thread?  No:
  * they are staged with hipMemcpyAsync from the caller's (ideally pinned) buffers, which must stay valid until
  * hmgpu_sync() or until a later call on the same context returns HMGPU_OK after a sync. */
@@ -238,7 +242,7 @@ hmgpu_status hmgpu_replay_batch(hmgpu_ctx* ctx, const hmgpu_pic* pics, int32_t n
 typedef struct hmgpu_stats {
   double   kernel_ms[HMGPU_NUM_KERNELS];      /* accumulated device time per kernel class since the last reset */
   uint64_t kernel_launches[HMGPU_NUM_KERNELS];
-  uint64_t intra_partitions;                  /* 4x4 partitions of intra CUs seen (not reconstructed in round 1) */
+  uint64_t intra_partitions;                  /* 4x4 partitions of intra CUs seen */
   uint64_t inter_partitions;
   uint64_t coded_tus[4][3];                   /* TUs with cbf by log2 size-2 and component */
 } hmgpu_stats;

@@ -23,7 +23,8 @@ STAGE_DEBLOCK_VER, STAGE_DEBLOCK_HOR, STAGE_SAO, STAGE_RECON = 1, 2, 4, 8
 class SeqParams(C.Structure):
     _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("bit_depth_luma", C.c_int32), ("bit_depth_chroma", C.c_int32),
                 ("chroma_format", C.c_int32), ("log2_ctu_size", C.c_int32), ("max_pictures", C.c_int32),
-                ("pcm_loop_filter_disable", C.c_int32), ("strong_intra_smoothing", C.c_int32), ("reserved", C.c_int32 * 7)]
+                ("pcm_loop_filter_disable", C.c_int32), ("strong_intra_smoothing", C.c_int32), ("pcm_bit_depth_luma", C.c_int32), ("pcm_bit_depth_chroma", C.c_int32),
+                ("reserved", C.c_int32 * 5)]
 
 
 class ScalingLists(C.Structure):
@@ -48,7 +49,7 @@ class CtuMeta(C.Structure):
 
 
 class Coeffs(C.Structure):
-    _fields_ = [("level", C.c_void_p * 3)]
+    _fields_ = [("level", C.c_void_p * 3), ("pcm_sample", C.c_void_p * 3)]
 
 
 class SaoParam(C.Structure):
@@ -124,11 +125,14 @@ class MetaHolder:
 
 
 class CoeffHolder:
-    def __init__(self, y, cb, cr):
+    def __init__(self, y, cb, cr, pcm=None):
         self.arrays = [np.ascontiguousarray(a, dtype=np.int16) for a in (y, cb, cr)]
+        self.pcm = [np.ascontiguousarray(a, dtype=np.int16) for a in pcm] if pcm is not None else None
         self.struct = Coeffs()
         for i in range(3):
             self.struct.level[i] = _ptr(self.arrays[i])
+            if self.pcm is not None:
+                self.struct.pcm_sample[i] = _ptr(self.pcm[i])
 
 
 def make_slice(slice_type, ref_pic=((), ()), ref_poc=((), ()), cb_qp_offset=0, cr_qp_offset=0, pps_cb=0, pps_cr=0,

@@ -189,7 +189,7 @@ __global__ void __launch_bounds__(256) k_prep(const PicDev* __restrict__ pics, B
     }
     if (q.valid) atomicAdd(&lds_stat[q.intra ? 0 : 1], 4u);
     if (q.valid && q.intra) stg(P.ctu_intra + q.ctu, (uint8_t)1);        // same value from every writer
-    // ---- which transform units originate in this 8x8 area (intra CUs: not on the device yet)
+    // ---- which transform units originate in this 8x8 area (the TUs of intra CUs are not listed: k_intra.hip walks them in decoding order)
     // cbf bit d of a partition = cbf of its ancestor TU node at transform depth d (TComDataCU.h:310); HM descends only
     // while every node on the way has its bit set (TComTrQuant.cpp:1558-1564)
     if (q.valid && !q.intra && q.log2tu <= 5) {

@@ -374,6 +374,15 @@ static int slice_id(const geom* g, int ctu) { return g->m->slice_idx ? g->m->sli
 static int tile_id(const geom* g, int ctu) { return g->m->tile_idx ? g->m->tile_idx[ctu] : 0; }
 #define PM(field, ctu, z) (g->m->field[(size_t)(ctu) * g->parts + (z)])
 
+/* partitions the loop filters must leave alone: lossless CUs and, with pcm_loop_filter_disabled_flag, PCM CUs
+ * (TComLoopFilter.cpp:558,629-634; TComSampleAdaptiveOffset.cpp:790) */
+static int no_filter(const geom* g, int ctu, int z)
+{
+  const size_t i = (size_t)ctu * g->parts + z;
+  if (g->m->transquant_bypass && g->m->transquant_bypass[i]) return 1;
+  return g->seq->pcm_loop_filter_disable && g->m->ipcm && g->m->ipcm[i];
+}
+
 /* ------------------------------------------------------------------------------------------------ CU reconstruction */
 typedef struct
 {
@@ -398,6 +407,14 @@ static void tu_leaf(cu_ctx* c, int comp, int z_tu, int log2_size, int x_rel, int
   hmo_qp_param(PM(qp, c->ctu_addr, c->cu_z), comp, g->bd[comp], cqo, &per, &rem);       /* QpParam(cu, compID): getQP(0) */
   if (comp == 0 && PM(pred_mode, c->ctu_addr, z_tu) == HMGPU_MODE_INTRA) flags |= 1;    /* TComTU::useDST, TComTU.cpp:218 */
   if (g->m->transform_skip[comp] && g->m->transform_skip[comp][(size_t)c->ctu_addr * g->parts + z_tu]) flags |= 2;
+  if (g->m->transquant_bypass && g->m->transquant_bypass[(size_t)c->ctu_addr * g->parts + z_tu])
+  {
+    /* cu_transquant_bypass: the residual IS the level block (invTransformNxN, TComTrQuant.cpp:1440-1470; no rotation / RDPCM outside RExt) */
+    const int n = 1 << log2_size;
+    int x, y;
+    for (y = 0; y < n; y++) for (x = 0; x < n; x++) c->resi[comp][(y_rel + y) * stride + x_rel + x] = lev[y * n + x];
+    return;
+  }
   /* getScalingListType (TComTrQuant.h): 3 * inter + component */
   hmo_inverse_transform_tu_sl(lev, &c->resi[comp][y_rel * stride + x_rel], stride, log2_size, g->bd[comp], per, rem, flags, sl->scaling_lists,
                               (PM(pred_mode, c->ctu_addr, z_tu) == HMGPU_MODE_INTRA ? 0 : 3) + comp);
@@ -752,9 +769,13 @@ static void intra_tu(cu_ctx* c, int comp, int z_tu, int log2n, int cbf_depth, in
     int per, rem, flags = comp == 0 ? 1 : 0;
     const int cqo = comp == 1 ? sl->cb_qp_offset : (comp == 2 ? sl->cr_qp_offset : 0);
     const int16_t* lev = c->co->level[comp] + (size_t)a * ((g->ctu * g->ctu) >> (comp ? 2 : 0)) + coef_off;
+    if (g->m->transquant_bypass && g->m->transquant_bypass[(size_t)a * g->parts + z_tu]) memcpy(resi, lev, sizeof(int16_t) * n * n);
+    else
+    {
     hmo_qp_param(PM(qp, a, c->cu_z), comp, g->bd[comp], cqo, &per, &rem);
     if (g->m->transform_skip[comp] && g->m->transform_skip[comp][(size_t)a * g->parts + z_tu]) flags |= 2;
     hmo_inverse_transform_tu_sl(lev, resi, n, log2n, g->bd[comp], per, rem, flags, sl->scaling_lists, comp);
+    }
   }
   for (y = 0; y < n; y++)
     for (x = 0; x < n; x++)
@@ -807,6 +828,21 @@ static void decompress_cu(cu_ctx* c, int z, int depth, int64_t* n_intra)
     return;
   }
   c->cu_z = z; c->cu_x = lx; c->cu_y = ty; c->cu_size = size;
+  if (g->m->ipcm && g->m->ipcm[(size_t)a * g->parts + z] && c->co->pcm_sample[0])
+  {
+    /* xReconPCM / xDecodePCMTexture (TDecCu.cpp:770-830): the transmitted samples, shifted up to the coding bit depth */
+    int comp, x, y;
+    *n_intra += num_part;
+    for (comp = 0; comp < 3; comp++)
+    {
+      const int cs = comp ? 1 : 0, cw = size >> cs;
+      const int shift = g->bd[comp] - (comp ? g->seq->pcm_bit_depth_chroma : g->seq->pcm_bit_depth_luma);
+      const int16_t* src = c->co->pcm_sample[comp] + (size_t)a * ((g->ctu * g->ctu) >> (comp ? 2 : 0)) + (comp ? 4 : 16) * z;
+      int16_t* dst = c->cur->plane[comp] + (size_t)(ty >> cs) * g->w[comp] + (lx >> cs);
+      for (y = 0; y < cw; y++) for (x = 0; x < cw; x++) dst[(size_t)y * g->w[comp] + x] = (int16_t)(src[y * cw + x] << shift);
+    }
+    return;
+  }
   if (PM(pred_mode, a, z) == HMGPU_MODE_INTRA)
   {
     *n_intra += num_part;
@@ -1059,7 +1095,17 @@ static void edge_filter_luma(lf_ctx* l, int ctu, int z_cu, int depth, int dir, i
         {
           const int fp = dp < side, fq = dq < side;
           const int sw = use_strong(off, 2 * d0, beta, tc, s) && use_strong(off, 2 * d3, beta, tc, s + step * 3);
-          for (i = 0; i < 4; i++) pel_filter_luma(s + step * i, off, tc, sw, thr_cut, fp, fq, maxv);
+          const int np = no_filter(g, pctu, zp), nq = no_filter(g, ctu, zq);             /* bPartPNoFilter / bPartQNoFilter: :629-634 */
+          for (i = 0; i < 4; i++)
+          {
+            int16_t* t = s + step * i;
+            int16_t keep[8];
+            int k;
+            for (k = 0; k < 8; k++) keep[k] = t[(k - 4) * off];
+            pel_filter_luma(t, off, tc, sw, thr_cut, fp, fq, maxv);
+            if (np) for (k = 0; k < 4; k++) t[(k - 4) * off] = keep[k];                   /* xPelFilterLuma :847-858 */
+            if (nq) for (k = 4; k < 8; k++) t[(k - 4) * off] = keep[k];
+          }
         }
       }
     }
@@ -1104,8 +1150,8 @@ static void edge_filter_chroma(lf_ctx* l, int ctu, int z_cu, int depth, int dir,
           int16_t* s = base + step * (stp + idx * 2);
           const int m4 = s[0], m3 = s[-off], m5 = s[off], m2 = s[-off * 2];
           const int delta = CLIP3(-tc, tc, ((((m4 - m3) << 2) + m2 - m5 + 4) >> 3));
-          s[-off] = (int16_t)CLIP3(0, maxv, m3 + delta);
-          s[0] = (int16_t)CLIP3(0, maxv, m4 - delta);
+          if (!no_filter(g, pctu, zp)) s[-off] = (int16_t)CLIP3(0, maxv, m3 + delta);      /* xPelFilterChroma :883-890 */
+          if (!no_filter(g, ctu, zq)) s[0] = (int16_t)CLIP3(0, maxv, m4 - delta);
         }
       }
     }
@@ -1380,6 +1426,28 @@ int hmo_sao_process(const hmgpu_seq_params* seq, const hmgpu_slice_params* slice
                            src->plane[comp] + (size_t)(yp >> cs) * g.w[comp] + (xp >> cs),
                            dst->plane[comp] + (size_t)(yp >> cs) * g.w[comp] + (xp >> cs),
                            g.w[comp], g.w[comp], ww >> cs, hh >> cs, av);
+    }
+  }
+  /* PCMLFDisableProcess (TComSampleAdaptiveOffset.cpp:742-835): PCM (filter disabled) and lossless CUs get their
+   * reconstruction back; deblocking never touched them, so the SAO input already holds it */
+  for (a = 0; a < g.num_ctus; a++)
+  {
+    int z;
+    for (z = 0; z < g.parts; z++)
+    {
+      const int px = (a % g.ctus_w) * g.ctu + zx(z) * 4, py = (a / g.ctus_w) * g.ctu + zy(z) * 4;
+      if (px >= seq->width || py >= seq->height || !no_filter(&g, a, z)) continue;
+      for (comp = 0; comp < 3; comp++)
+      {
+        const int cs = comp ? 1 : 0, n = 4 >> cs;
+        int x, y;
+        for (y = 0; y < n; y++)
+          for (x = 0; x < n; x++)
+          {
+            const size_t o = (size_t)((py >> cs) + y) * g.w[comp] + (px >> cs) + x;
+            dst->plane[comp][o] = src->plane[comp][o];
+          }
+      }
     }
   }
   return HMGPU_OK;

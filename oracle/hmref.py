@@ -25,7 +25,7 @@ def lib():
         _lib = C.CDLL(LIB_PATH)
         _lib.ref_dec_open.restype = C.c_void_p
         _lib.ref_dec_open.argtypes = [C.c_void_p, C.c_int64, C.c_int]
-        for n in ("ref_dec_close", "ref_dec_info", "ref_dec_slices", "ref_dec_sao_params", "ref_dec_wp", "ref_dec_scaling_lists", "ref_dec_tile_idx"):
+        for n in ("ref_dec_close", "ref_dec_info", "ref_dec_slices", "ref_dec_sao_params", "ref_dec_wp", "ref_dec_scaling_lists", "ref_dec_tile_idx", "ref_dec_pcm", "ref_dec_pcm_info"):
             getattr(_lib, n).restype = None
         _lib.ref_dec_next.argtypes = [C.c_void_p]
         _lib.ref_dec_filter_step.argtypes = [C.c_void_p]
@@ -37,6 +37,8 @@ def lib():
         _lib.ref_dec_wp.argtypes = [C.c_void_p, C.c_void_p]
         _lib.ref_dec_scaling_lists.argtypes = [C.c_void_p, C.c_void_p]
         _lib.ref_dec_tile_idx.argtypes = [C.c_void_p, C.c_void_p]
+        _lib.ref_dec_pcm.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        _lib.ref_dec_pcm_info.argtypes = [C.c_void_p, C.c_void_p]
         _lib.ref_dec_coeffs.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         _lib.ref_dec_planes.argtypes = [C.c_void_p] + [C.c_void_p] * 3
         _lib.ref_dec_dpb_planes.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 3
@@ -129,6 +131,18 @@ class RefDecoder:
         a = np.zeros((n, 64), dtype=np.int32)
         lib().ref_dec_slices(self._h, _p(a))
         return a
+
+    def pcm(self, info):
+        """(info[5], [3 sample arrays])"""
+        pi = np.zeros(5, dtype=np.int32)
+        lib().ref_dec_pcm_info(self._h, _p(pi))
+        n, cs = info["num_ctus"], info["ctu_size"]
+        res = []
+        for c in range(3):
+            a = np.zeros((n, (cs * cs) >> (2 if c else 0)), dtype=np.int16)
+            lib().ref_dec_pcm(self._h, c, _p(a))
+            res.append(a)
+        return pi, res
 
     def tile_idx(self, num_ctus):
         a = np.zeros(num_ctus, dtype=np.int32)

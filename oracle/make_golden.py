@@ -28,7 +28,7 @@ HM_CFG = "/root/reference/cfg"
 
 
 # ------------------------------------------------------------------------------------------ synthetic clips
-def synth_clip(w, h, frames, bit_depth, seed, novel=False, fade=False):
+def synth_clip(w, h, frames, bit_depth, seed, novel=False, fade=False, noisy=False):
     """gradient + checker + moving textured blobs + seeded noise, 4:2:0 planar, returns list of (Y,U,V) uint16"""
     rng = np.random.RandomState(seed)
     maxv = (1 << bit_depth) - 1
@@ -61,6 +61,8 @@ def synth_clip(w, h, frames, bit_depth, seed, novel=False, fade=False):
             gy, gx = np.mgrid[0:ph_, 0:pw_].astype(np.float64)
             img[py_:py_ + ph_, px_:px_ + pw_] = 0.5 + 0.4 * np.sin(gx / (2.0 + f) + f) * np.cos(gy / (3.0 + 0.5 * f)) * (1 if f % 2 else -1)
         img = img + 0.012 * rng.randn(h, w)
+        if noisy:                           # a patch of full-range white noise (new every frame): cheaper to send raw than to predict
+            img[h // 4:h // 4 + 64, w // 3:w // 3 + 96] = rng.rand(64, 96)
         if fade:                            # brightness ramps from frame to frame: what explicit weighted prediction is for
             img = img * (1.0 - 0.09 * f) + 0.02 * f
         Y = np.clip(np.round(img * maxv), 0, maxv).astype(np.uint16)
@@ -90,6 +92,12 @@ STREAMS = {
     # 3 x 2 tiles (HEVC wants tiles >= 256 x 64), no loop filtering across tile borders: tile-bounded intra references, deblocking and SAO neighbourhoods
     "ldp_tiles_main10_832x128": ("encoder_lowdelay_P_main10.cfg", 832, 128, 3, 10, 10, 30,
                                  ["--TileUniformSpacing=1", "--NumTileColumnsMinus1=2", "--NumTileRowsMinus1=1", "--LFCrossTileBoundaryFlag=0"]),
+    # lossless CUs (cu_transquant_bypass_flag forced: HM's RD never picks it on its own here); PCM CUs on a noisy patch, chosen by
+    # RD in I and P pictures, with PCM samples exempt from the loop filters
+    "ldp_lossless_main10_208x120": ("encoder_lowdelay_P_main10.cfg", 208, 120, 3, 10, 10, 30, ["--TransquantBypassEnableFlag=1", "--CUTransquantBypassFlagForce=1"]),
+    "ldp_pcm_main8_208x120": ("encoder_lowdelay_P_main.cfg", 208, 120, 3, 8, 8, 6,
+                              ["--PCMEnabledFlag=1", "--PCMLog2MaxSize=5", "--PCMLog2MinSize=3", "--PCMFilterDisableFlag=1",
+                               "--DeblockingFilterControlPresent=1", "--LoopFilterOffsetInPPS=1", "--LoopFilterBetaOffset_div2=6", "--LoopFilterTcOffset_div2=6"]),
     # scaling lists from a file: every matrix different, DC values for 16x16 / 32x32 (I picture: intra lists, P pictures: inter lists)
     "ldp_sl_main10_208x120": ("encoder_lowdelay_P_main10.cfg", 208, 120, 3, 10, 10, 28, ["--ScalingList=2", "--ScalingListFile=@SLFILE@"]),
     "ldp_sldef_main8_208x120": ("encoder_lowdelay_P_main.cfg", 208, 120, 2, 8, 8, 34, ["--ScalingList=1"]),
@@ -127,7 +135,7 @@ def write_scaling_list_file(path):
 def encode(name, tmp):
     cfg, w, h, frames, ibd, bd, qp, extra = STREAMS[name]
     yuv = os.path.join(tmp, name + ".yuv")
-    clip = synth_clip(w, h, frames, ibd, seed=0x484D + sum(map(ord, name)), novel="cip" in name, fade="wp" in name)
+    clip = synth_clip(w, h, frames, ibd, seed=0x484D + sum(map(ord, name)), novel="cip" in name, fade="wp" in name, noisy="pcm" in name or "lossless" in name)
     write_yuv(yuv, clip, ibd)
     bs = os.path.join(tmp, name + ".bin")
     rec = os.path.join(tmp, name + "_rec.yuv")
@@ -168,6 +176,11 @@ def dump_stream(name, bitstream, enc_rec, geom):
         meta = dec.meta(info)
         for n2, a in meta.items():
             out[k + "meta_" + n2] = a
+        pcm_info, pcm = dec.pcm(info)
+        out[k + "pcm_info"] = pcm_info
+        if pcm_info[2] and np.any(meta["ipcm"]):                  # PCM samples only where PCM CUs exist (they are large)
+            for c in range(3):
+                out[k + "pcm%d" % c] = pcm[c]
         co = dec.coeffs(info)
         for c in range(3):
             assert co[c].min() >= -32768 and co[c].max() <= 32767

@@ -392,6 +392,27 @@ void ref_dec_coeffs(void* h, int comp, int32_t* out)
     memcpy(out + a * n, p->getCU(a)->getCoeff(ComponentID(comp)), n * sizeof(TCoeff));
 }
 
+/* PCM sample buffers (TComDataCU::getPCMSample: the transmitted samples of PCM CUs; for lossless CUs the decoder parks the
+ * reconstruction there, TDecCu::xFillPCMBuffer), same layout as the coefficients.  out[0] of ref_dec_pcm_info: PCM bit depth
+ * luma, [1] chroma, [2] pcm enabled, [3] pcm loop filter disabled, [4] transquant bypass enabled */
+void ref_dec_pcm(void* h, int comp, int16_t* out)
+{
+  RefDec* d = (RefDec*)h; TComPic* p = cur(d);
+  const size_t n = (size_t)(g_uiMaxCUWidth * g_uiMaxCUHeight) >> (comp ? 2 : 0);
+  for (UInt a = 0; a < p->getNumCUsInFrame(); a++)
+  {
+    const Pel* s = p->getCU(a)->getPCMSample(ComponentID(comp));
+    for (size_t i = 0; i < n; i++) out[a * n + i] = (int16_t)s[i];
+  }
+}
+void ref_dec_pcm_info(void* h, int32_t* out)
+{
+  RefDec* d = (RefDec*)h; TComSlice* s = cur(d)->getSlice(0);
+  out[0] = s->getSPS()->getPCMBitDepth(CHANNEL_TYPE_LUMA); out[1] = s->getSPS()->getPCMBitDepth(CHANNEL_TYPE_CHROMA);
+  out[2] = s->getSPS()->getUsePCM() ? 1 : 0; out[3] = s->getSPS()->getPCMFilterDisableFlag() ? 1 : 0;
+  out[4] = s->getPPS()->getTransquantBypassEnableFlag() ? 1 : 0;
+}
+
 /* SAO parameters as they stand in TComPicSym (raw as parsed before ref_dec_deblock_sao stage 2,
  * reconstructed after).  out: [numCTUs][3][35] = modeIdc, typeIdc, typeAuxInfo, offset[32]             */
 void ref_dec_sao_params(void* h, int32_t* out)

@@ -8,7 +8,7 @@ from libhm_amd import abi
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 STREAMS = ["ldp_main8_416x240", "ra_main10_208x120", "ldp_main10_208x120", "intra_main10_208x120", "ldp_cip_main10_208x120",
-           "ldp_wp_main10_208x120", "ra_wp_main8_208x120", "ldp_sl_main10_208x120", "ldp_sldef_main8_208x120", "ldp_tiles_main10_832x128"]
+           "ldp_wp_main10_208x120", "ra_wp_main8_208x120", "ldp_sl_main10_208x120", "ldp_sldef_main8_208x120", "ldp_tiles_main10_832x128", "ldp_lossless_main10_208x120", "ldp_pcm_main8_208x120"]
 _cache = {}
 
 
@@ -77,7 +77,12 @@ class Picture:
             m["tile_idx"] = z[k + "tile_idx"].astype(np.uint16)
         self.meta_np = m
         self.meta = abi.MetaHolder(m)
-        self.coeffs = abi.CoeffHolder(z[k + "coeff0"], z[k + "coeff1"], z[k + "coeff2"])
+        pcm = [z[k + "pcm%d" % c] for c in range(3)] if (k + "pcm0") in z.files else None
+        self.coeffs = abi.CoeffHolder(z[k + "coeff0"], z[k + "coeff1"], z[k + "coeff2"], pcm)
+        if (k + "pcm_info") in z.files:
+            pi = z[k + "pcm_info"]
+            self.seq.pcm_bit_depth_luma, self.seq.pcm_bit_depth_chroma = int(pi[0]), int(pi[1])
+            self.seq.pcm_loop_filter_disable = int(pi[2] and pi[3])
         self.sao_raw = z[k + "sao_raw"]
         self.sao_rec = z[k + "sao_rec"]
         self.pre = [z[k + "pre%d" % c] for c in range(3)]
