@@ -67,7 +67,8 @@ __device__ inline uint4 pack8(const int (&s)[8]) {
 struct __attribute__((aligned(8))) U4a8 { uint32_t x, y, z, w; };    // 16 bytes at 8-byte alignment
 
 // luma decisions for one 4-line unit (xEdgeFilterLuma :587-650); l[i] = line i, 8 samples across the edge
-__device__ inline void filter_luma_unit(int (&l)[4][8], int bs, int qp, int tc_offset_div2, int beta_offset_div2, int bd) {
+__device__ inline void filter_luma_unit(int (&l)[4][8], int bs, int qp, int tc_offset_div2, int beta_offset_div2, int bd,
+                                        bool p_nofilt = false, bool q_nofilt = false) {
   const int scale = 1 << (bd - 8);
   const int tc = c_tc_table[clip3(0, 53, qp + 2 * (bs - 1) + (tc_offset_div2 << 1))] * scale;
   const int beta = c_beta_table[clip3(0, 51, qp + (beta_offset_div2 << 1))] * scale;
@@ -83,7 +84,13 @@ __device__ inline void filter_luma_unit(int (&l)[4][8], int bs, int qp, int tc_o
                   (abs(l[3][3] - l[3][4]) < ((tc * 5 + 1) >> 1));
   const int maxv = (1 << bd) - 1;
 #pragma unroll
-  for (int i = 0; i < 4; i++) filter_luma_line(l[i], tc, s0 && s3, tc * 10, fp, fq, maxv);
+  for (int i = 0; i < 4; i++) {
+    // bPartPNoFilter / bPartQNoFilter (xPelFilterLuma :847-858): a lossless / PCM side keeps its samples
+    const int k0 = l[i][0], k1 = l[i][1], k2 = l[i][2], k3 = l[i][3], k4 = l[i][4], k5 = l[i][5], k6 = l[i][6], k7 = l[i][7];
+    filter_luma_line(l[i], tc, s0 && s3, tc * 10, fp, fq, maxv);
+    if (p_nofilt) { l[i][0] = k0; l[i][1] = k1; l[i][2] = k2; l[i][3] = k3; }
+    if (q_nofilt) { l[i][4] = k4; l[i][5] = k5; l[i][6] = k6; l[i][7] = k7; }
+  }
 }
 
 // chroma tc for one component (xEdgeFilterChroma :759-775, 4:2:0)
@@ -125,6 +132,20 @@ __device__ inline void shifted(const u32x4 e, uint32_t l, uint32_t r, uint32_t (
 __device__ inline s16x2 lut_offsets(uint32_t idx_pk, uint32_t tab_lo, uint32_t tab_hi) {
   const uint32_t looked = __builtin_amdgcn_perm(tab_hi, tab_lo, idx_pk << 8);   // bytes 1,3 = table[idx]; bytes 0,2 = table[0] (unused)
   return as_s16x2(__builtin_amdgcn_perm(0u, looked, 0x09030801u));
+}
+
+// PCMLFDisableProcess (TComSampleAdaptiveOffset.cpp:742-835) folded into SAO: which of the 8 samples at (x, row) of component
+// comp belong to lossless / PCM-unfiltered CUs and keep the SAO input.  Returns a mask with 0xffff per exempt sample pair half
+// packed like the samples (4 dwords); only called for pictures that hold such CUs (PicDev::any_nofilt).
+__device__ inline void sao_exempt_mask(const PicDev& P, int comp, int x, int row, uint32_t (&m)[4]) {
+  const int cs = comp ? 1 : 0;
+  const BlkInfo* g = P.blk + (size_t)((row << cs) >> 2) * P.grid_w + ((x << cs) >> 2);
+  // luma: samples 0-3 / 4-7 lie in two 4x4 blocks; chroma: every pair of samples in its own block (four blocks)
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const int blk = cs ? j : (j >> 1);
+    m[j] = (ldg(&g[blk].flags) & BF_NOFILT) ? 0xffffffffu : 0u;
+  }
 }
 
 // edge-offset arithmetic of one row of 8 samples once the two neighbour rows are at hand (na / nb = the samples at

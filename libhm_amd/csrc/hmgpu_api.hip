@@ -34,6 +34,7 @@ struct Picture {
   void* planes = nullptr;               // rec[3] + sao[3]
   void* meta = nullptr;                 // raw HM arrays
   void* coef = nullptr;
+  void* pcm = nullptr;                  // PCM sample buffers, allocated when the first PCM CU shows up
   void* derived = nullptr;              // blk, tu lists, counters, sao params, slices
   uint8_t* sl_table = nullptr;          // device: expanded scaling-list matrices (inside `derived`)
   std::vector<uint8_t> sl_host;         // host copy the asynchronous upload reads from
@@ -138,6 +139,7 @@ hmgpu_status alloc_picture(hmgpu_ctx* c, Picture& p) {
     for (int k = 0; k < 2; k++) d.mv[k] = m.take<int16_t>(np * 2);
     for (int k = 0; k < 2; k++) d.ref_idx[k] = m.take<int8_t>(np);
     for (int k = 0; k < 2; k++) d.intra_dir[k] = m.take<uint8_t>(np);
+    d.bypass = m.take<uint8_t>(np); d.ipcm = m.take<uint8_t>(np);
     d.slice_idx = m.take<uint16_t>(c->num_ctus); d.tile_idx = m.take<uint16_t>(c->num_ctus);
     if (!pass) { HIP_TRY(c, hipMalloc(&p.meta, m.off)); HIP_TRY(c, hipMemset(p.meta, 0, m.off)); }
   }
@@ -172,6 +174,8 @@ hmgpu_status alloc_picture(hmgpu_ctx* c, Picture& p) {
   d.lf_across_tiles = 1; d.sao_applied = 0;
   d.has_intra_dir = 0; d.strong_intra_smoothing = s.strong_intra_smoothing ? 1 : 0;
   d.sl_m = nullptr;
+  for (int k = 0; k < 3; k++) { d.pcm[k] = nullptr; d.pcm_shift[k] = 0; }
+  d.pcm_lf_disable = s.pcm_loop_filter_disable ? 1 : 0; d.any_nofilt = 0;
   for (int k = 0; k < 4; k++) d.tu_cap[k] = c->tu_cap[k];
   {
     // plane pointers address sample (0,0); the margins lie at negative coordinates
@@ -186,10 +190,11 @@ hmgpu_status alloc_picture(hmgpu_ctx* c, Picture& p) {
 
 void free_picture(Picture& p) {
   if (p.planes) hipFree(p.planes);
+  if (p.pcm) hipFree(p.pcm);
   if (p.meta) hipFree(p.meta);
   if (p.coef) hipFree(p.coef);
   if (p.derived) hipFree(p.derived);
-  p.planes = p.meta = p.coef = p.derived = nullptr;
+  p.planes = p.meta = p.coef = p.derived = nullptr; p.pcm = nullptr;
 }
 
 hmgpu_status push_picdev(hmgpu_ctx* c, int pic) {
@@ -447,7 +452,7 @@ hmgpu_status hmgpu_picture_acquire(hmgpu_ctx* c, hmgpu_pic* out) {
     if (!p.in_use) {
       p.in_use = true; p.sao_applied = false; p.filter_ready = false; p.sao_any = false; p.calls.clear(); p.max_slice = -1;
       p.extended = false;
-      p.dev.sao_applied = 0;
+      p.dev.sao_applied = 0; p.dev.any_nofilt = 0;
       *out = (hmgpu_pic)i;
       hmgpu_status st = push_final(c, (int)i);
       return st;
@@ -547,8 +552,11 @@ hmgpu_status hmgpu_decompress_slice(hmgpu_ctx* c, hmgpu_pic cur, int32_t slice_i
   }
   const size_t po = (size_t)first_ctu * c->parts, pn = (size_t)num_ctus * c->parts;
   // tools outside the envelope: lossless / PCM CUs
-  for (const uint8_t* arr : {m->transquant_bypass, m->ipcm})
-    if (arr) for (size_t i = 0; i < pn; i++) if (arr[po + i]) return HMGPU_EUNSUPPORTED;
+  const bool any_pcm = m->ipcm && memchr(m->ipcm + po, 1, pn) != nullptr;
+  const bool any_bypass = m->transquant_bypass && memchr(m->transquant_bypass + po, 1, pn) != nullptr;
+  if (any_pcm && (!co->pcm_sample[0] || !co->pcm_sample[1] || !co->pcm_sample[2] || !m->intra_dir[0])) return HMGPU_EINVAL;
+  if (any_pcm && (c->seq.pcm_bit_depth_luma < 1 || c->seq.pcm_bit_depth_luma > c->seq.bit_depth_luma ||
+                  c->seq.pcm_bit_depth_chroma < 1 || c->seq.pcm_bit_depth_chroma > c->seq.bit_depth_chroma)) return HMGPU_EINVAL;
   // reference pictures must be live device pictures
   for (int l = 0; l < 2; l++) {
     if (sl->num_ref_idx[l] < 0 || sl->num_ref_idx[l] > HMGPU_MAX_REF) return HMGPU_EINVAL;
@@ -608,6 +616,7 @@ hmgpu_status hmgpu_decompress_slice(hmgpu_ctx* c, hmgpu_pic cur, int32_t slice_i
     for (int k = 0; k < 3; k++) { STAGE(p.dev.cbf[k], m->cbf[k], 1); STAGE(p.dev.tskip[k], m->transform_skip[k], 1); }
     for (int k = 0; k < 2; k++) { STAGE(p.dev.mv[k], m->mv[k], 4); STAGE(p.dev.ref_idx[k], m->ref_idx[k], 1); }
     if (p.dev.has_intra_dir) { STAGE(p.dev.intra_dir[0], m->intra_dir[0], 1); STAGE(p.dev.intra_dir[1], m->intra_dir[1], 1); }
+    STAGE(p.dev.bypass, m->transquant_bypass, 1); STAGE(p.dev.ipcm, m->ipcm, 1);
 #undef STAGE
     // per-CTU slice / tile index (the slice index of this call wins over a missing array)
     {
@@ -622,6 +631,23 @@ hmgpu_status hmgpu_decompress_slice(hmgpu_ctx* c, hmgpu_pic cur, int32_t slice_i
       HIP_TRY(c, hipMemcpyAsync((void*)(p.dev.coef[k] + first_ctu * per), co->level[k] + first_ctu * per, (size_t)num_ctus * per * 2,
                                 hipMemcpyHostToDevice, c->stream));
     }
+    if (any_pcm) {
+      size_t bytes = 0;
+      for (int k = 0; k < 3; k++) bytes += align_up(c->coef_elems[k] * sizeof(int16_t), 256);
+      if (!p.pcm) {
+        HIP_TRY(c, hipMalloc(&p.pcm, bytes));
+        Carver cp(p.pcm);
+        for (int k = 0; k < 3; k++) p.dev.pcm[k] = cp.take<int16_t>(c->coef_elems[k]);
+      }
+      for (int k = 0; k < 3; k++) {
+        const size_t per = (size_t)(c->ctu * c->ctu) >> (k ? 2 : 0);
+        HIP_TRY(c, hipMemcpyAsync((void*)(p.dev.pcm[k] + first_ctu * per), co->pcm_sample[k] + first_ctu * per, (size_t)num_ctus * per * 2,
+                                  hipMemcpyHostToDevice, c->stream));
+      }
+      p.dev.pcm_shift[0] = c->seq.bit_depth_luma - c->seq.pcm_bit_depth_luma;
+      p.dev.pcm_shift[1] = p.dev.pcm_shift[2] = c->seq.bit_depth_chroma - c->seq.pcm_bit_depth_chroma;
+    }
+    if (any_bypass || (any_pcm && c->seq.pcm_loop_filter_disable)) p.dev.any_nofilt = 1;
     hmgpu_status st = push_picdev(c, cur);
     if (st != HMGPU_OK) return st;
   }

@@ -35,6 +35,7 @@ enum : uint8_t {
   BF_CBFY = 4,     // luma cbf at the partition's transform depth (Bs = 1 rule)
   BF_MC_L0 = 8,    // prediction uses list 0  (after the identical-motion collapse of xCheckIdenticalMotion)
   BF_MC_L1 = 16,   // prediction uses list 1
+  BF_NOFILT = 32,  // lossless CU, or PCM CU with pcm_loop_filter_disabled: deblocking and SAO leave its samples alone
 };
 enum : uint8_t {
   BE_VER_FILTER = 1,     // left edge of this block is a deblocking edge (m_aapbEdgeFilter[EDGE_VER]) on the 8x8 grid
@@ -96,6 +97,11 @@ struct PicDev {
   const uint8_t* cbf[3]; const uint8_t* tskip[3];
   const int16_t* mv[2]; const int8_t* ref_idx[2];
   const uint8_t* intra_dir[2];     // m_puhIntraDir[luma, chroma]
+  const uint8_t* bypass; const uint8_t* ipcm;   // m_CUTransquantBypass, m_pbIPCMFlag
+  const int16_t* pcm[3];           // PCM sample buffers (allocated on first use), layout of coef[]
+  int32_t pcm_shift[3];            // bit depth - PCM bit depth per component
+  int32_t pcm_lf_disable;          // SPS pcm_loop_filter_disabled_flag (with PCM enabled)
+  int32_t any_nofilt;              // some partition of the picture carries BF_NOFILT (host-side scan): SAO looks at the flags
   const uint16_t* slice_idx; const uint16_t* tile_idx;
   const int16_t* coef[3];
   const SliceDev* slices;

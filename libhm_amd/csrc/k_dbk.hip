@@ -48,7 +48,8 @@ __global__ void __launch_bounds__(256) k_deblock(const PicDev* __restrict__ pics
       l[0][r] = v.x & 0xffff; l[1][r] = v.x >> 16; l[2][r] = v.y & 0xffff; l[3][r] = v.y >> 16;
     }
   }
-  filter_luma_unit(l, bs, qp, tc_off, beta_off, P.bd[0]);
+  const bool p_nf = (p.flags & BF_NOFILT) != 0, q_nf = (q.flags & BF_NOFILT) != 0;
+  filter_luma_unit(l, bs, qp, tc_off, beta_off, P.bd[0], p_nf, q_nf);
   if (DIR == 0) {
 #pragma unroll
     for (int i = 0; i < 4; i++) {
@@ -79,8 +80,8 @@ __global__ void __launch_bounds__(256) k_deblock(const PicDev* __restrict__ pics
         const ptrdiff_t o = DIR == 0 ? 1 : cp;
         const int m2 = (uint16_t)ldg(s - 2 * o), m3 = (uint16_t)ldg(s - o), m4 = (uint16_t)ldg(s), m5 = (uint16_t)ldg(s + o);
         const int delta = clip3(-tc, tc, ((((m4 - m3) << 2) + m2 - m5 + 4) >> 3));
-        stg(s - o, (int16_t)clip3(0, maxc, m3 + delta));
-        stg(s, (int16_t)clip3(0, maxc, m4 - delta));
+        if (!p_nf) stg(s - o, (int16_t)clip3(0, maxc, m3 + delta));          // xPelFilterChroma :883-890
+        if (!q_nf) stg(s, (int16_t)clip3(0, maxc, m4 - delta));
       }
     }
   }

@@ -98,6 +98,13 @@ __device__ inline void sao_group(const PicDev& P, int comp, const int16_t (*t)[W
       default:               run(std::integral_constant<int, 1>{}, std::integral_constant<int, -1>{}); break;
     }
   }
+  if (P.any_nofilt) {
+    uint32_t m[4];
+    sao_exempt_mask(P, comp, x, row, m);
+    const uint32_t c[4] = {cur.x, cur.y, cur.z, cur.w};
+#pragma unroll
+    for (int j = 0; j < 4; j++) out[j] = (c[j] & m[j]) | (out[j] & ~m[j]);
+  }
   u32x4 res = {out[0], out[1], out[2], out[3]};
   stg4(dst, res);
 }
@@ -154,7 +161,8 @@ __device__ inline void edge_unit(const PicDev& P, FilterLds& L, int x0, int y0, 
       l[0][r] = a.x & 0xffff; l[1][r] = a.x >> 16; l[2][r] = a.y & 0xffff; l[3][r] = a.y >> 16;
     }
   }
-  filter_luma_unit(l, bs, qp, tc_off, beta_off, P.bd[0]);
+  const bool p_nf = (p.flags & BF_NOFILT) != 0, q_nf = (q.flags & BF_NOFILT) != 0;
+  filter_luma_unit(l, bs, qp, tc_off, beta_off, P.bd[0], p_nf, q_nf);
   if (DIR == 0) {
 #pragma unroll
     for (int i = 0; i < 4; i++) {
@@ -183,8 +191,8 @@ __device__ inline void edge_unit(const PicDev& P, FilterLds& L, int x0, int y0, 
         const int o = DIR == 0 ? 1 : kCW;
         const int m2 = (uint16_t)s[-2 * o], m3 = (uint16_t)s[-o], m4 = (uint16_t)s[0], m5 = (uint16_t)s[o];
         const int delta = clip3(-tc, tc, ((((m4 - m3) << 2) + m2 - m5 + 4) >> 3));
-        s[-o] = (int16_t)clip3(0, maxc, m3 + delta);
-        s[0] = (int16_t)clip3(0, maxc, m4 - delta);
+        if (!p_nf) s[-o] = (int16_t)clip3(0, maxc, m3 + delta);              // xPelFilterChroma :883-890
+        if (!q_nf) s[0] = (int16_t)clip3(0, maxc, m4 - delta);
       }
     }
   }

@@ -60,11 +60,11 @@ struct IntraLds {
   __attribute__((aligned(4))) int16_t top[132];
   // the CTU's TComDataCU arrays, fetched once with one dword per lane and array (the walk over CUs and TUs is a serial chain:
   // every byte it had to wait for from global memory would cost a round trip)
-  __attribute__((aligned(4))) uint8_t m_depth[256], m_part[256], m_pred[256], m_tr[256], m_qp[256], m_cbf[256], m_ts[256], m_dir[256], m_dirl[256];
+  __attribute__((aligned(4))) uint8_t m_depth[256], m_part[256], m_pred[256], m_tr[256], m_qp[256], m_cbf[256], m_ts[256], m_dir[256], m_dirl[256], m_byp[256], m_pcm[256];
 };
 
 struct TuCtx {
-  int comp, ctu, z_tu, log2n, mode, cbf, skip, x0, y0, qp_cu;     // x0, y0: component samples
+  int comp, ctu, z_tu, log2n, mode, cbf, skip, bypass, x0, y0, qp_cu;     // x0, y0: component samples
   int cip, cqo, slice, tile;                                      // per-CTU constants: constrained intra pred, chroma QP offset, slice / tile index
   int cx0, cy0;                                                   // CTU origin in component samples
 };
@@ -242,6 +242,10 @@ __device__ inline void intra_tu(const PicDev& P, const TuCtx& t, IntraLds& L) {
     int per, rem;
     qp_param_tu(t.qp_cu, comp, bd, t.cqo, per, rem);
     const uint8_t* mrow = (P.sl_m != nullptr && (!t.skip || N == 4)) ? P.sl_m + (((LOG2N - 2) * 6 + comp) << 10) + n * N : nullptr;   // intra lists: 0 + component
+    if (t.bypass) {                                        // cu_transquant_bypass: the residual is the level block itself
+#pragma unroll
+      for (int i = 0; i < N / 2; i++) res[i] = lv[i];
+    } else
     itx_tu_pk<LOG2N>(lv, n, per, rem, t.skip != 0, bd, L.tile, res, comp == 0 && LOG2N == 2, mrow);      // TComTU::useDST: 4x4 intra luma
   }
 
@@ -281,10 +285,10 @@ __device__ inline void intra_ctu(const PicDev& P, int comp, int ctu, IntraLds& L
     const size_t o = base + 4 * lane;
     auto dw = [&](const void* p) { return ldg(reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint8_t*>(p) + o)); };
     const uint32_t a0 = dw(P.depth), a1 = dw(P.part_size), a2 = dw(P.pred_mode), a3 = dw(P.tr_idx), a4 = dw(P.qp), a5 = dw(P.cbf[comp]),
-                   a6 = dw(P.tskip[comp]), a7 = dw(P.intra_dir[comp ? 1 : 0]), a8 = dw(P.intra_dir[0]);
+                   a6 = dw(P.tskip[comp]), a7 = dw(P.intra_dir[comp ? 1 : 0]), a8 = dw(P.intra_dir[0]), a9 = dw(P.bypass), a10 = dw(P.ipcm);
     auto put = [&](uint8_t* d, uint32_t v) { *reinterpret_cast<uint32_t*>(d + 4 * lane) = v; };
     put(L.m_depth, a0); put(L.m_part, a1); put(L.m_pred, a2); put(L.m_tr, a3); put(L.m_qp, a4); put(L.m_cbf, a5); put(L.m_ts, a6);
-    put(L.m_dir, a7); put(L.m_dirl, a8);
+    put(L.m_dir, a7); put(L.m_dirl, a8); put(L.m_byp, a9); put(L.m_pcm, a10);
   }
   {
     // samples: the CTU itself (inter CUs are final, intra ones get overwritten below), its left column and the row above
@@ -320,6 +324,25 @@ __device__ inline void intra_ctu(const PicDev& P, int comp, int ctu, IntraLds& L
     const int log2cu = P.log2ctu - depth;
     const int qp_cu = (int8_t)L.m_qp[z];
     const int cu_end = z + cu_parts;
+    if (L.m_pcm[z] && P.pcm[comp] != nullptr) {
+      // PCM CU (TDecCu::xReconPCM, TDecCu.cpp:770-830): the transmitted samples, shifted up to the coding bit depth; lane n = row n
+      const int n_cu = (1 << log2cu) >> cs;
+      const int sx = (ctu_x + 4 * zscan_x(z)) >> cs, sy = (ctu_y + 4 * zscan_y(z)) >> cs;
+      if (lane < n_cu) {
+        const int16_t* src = P.pcm[comp] + (size_t)ctu * ((size_t)(1 << (2 * P.log2ctu)) >> (comp ? 2 : 0)) + (comp ? 4 : 16) * z + lane * n_cu;
+        uint32_t* row = reinterpret_cast<uint32_t*>(P.rec[comp] + (ptrdiff_t)(sy + lane) * P.pitch[comp] + sx);
+        uint32_t* lrow = reinterpret_cast<uint32_t*>(&L.pix[sy - (ctu_y >> cs) + lane][sx - (ctu_x >> cs) + 2]);
+        for (int x = 0; x < n_cu; x += 2) {
+          const uint32_t v = ldg(reinterpret_cast<const uint32_t*>(src + x));
+          const uint32_t o = ((v & 0xffffu) << P.pcm_shift[comp]) | ((v >> 16) << (16 + P.pcm_shift[comp]));
+          lrow[x / 2] = o;
+          st_coh(row + x / 2, o);
+        }
+      }
+      wave_lds_sync();
+      z = cu_end;
+      continue;
+    }
     int zc = z;
     while (zc < cu_end) {
       const int tr = L.m_tr[zc];
@@ -338,6 +361,7 @@ __device__ inline void intra_ctu(const PicDev& P, int comp, int ctu, IntraLds& L
         t.mode = mode;
         t.cbf = (L.m_cbf[zc] >> tr) & 1;
         t.skip = L.m_ts[zc];
+        t.bypass = L.m_byp[zc];
         intra_tu_any(P, t, L);
       }
       zc += 1 << (2 * (log2tu - 2));

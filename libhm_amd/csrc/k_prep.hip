@@ -43,6 +43,7 @@ struct Quad {
   int log2cu, log2tu, tr, part_size, qp_cu, sidx;
   bool valid, intra;
   uint32_t cbf[3], ts[3];          // four bytes each, partition j in byte j
+  uint32_t bypass;                 // m_CUTransquantBypass of the four partitions (one CU: 8x8 is the minimum CU size)
 };
 
 __device__ inline TuRec make_tu(const PicDev& P, const Quad& q, const SliceDev* sl, int gx, int gy, int comp, int flags, uint32_t coef_off) {
@@ -66,7 +67,7 @@ __global__ void __launch_bounds__(256) k_prep(const PicDev* __restrict__ pics, B
   const int gq = blockIdx.x * 256 + threadIdx.x;                 // quad index inside the call's CTU range
   const bool active = gq < b.num_ctus[blockIdx.z] * (parts >> 2);
   Quad q; q.valid = false; q.intra = false; q.log2tu = 3; q.tr = 0; q.ctu = 0; q.z0 = 0; q.gx0 = q.gy0 = 0;
-  q.log2cu = 3; q.part_size = 0; q.qp_cu = 0; q.sidx = 0;
+  q.log2cu = 3; q.part_size = 0; q.qp_cu = 0; q.sidx = 0; q.bypass = 0;
   bool has[6] = {false, false, false, false, false, false};      // slots: luma TU of partition 0..3 (or one larger TU in slot 0), Cb, Cr
   int cls[6] = {0, 0, 0, 0, 0, 0};
   uint32_t loc[6] = {0, 0, 0, 0, 0, 0};
@@ -84,6 +85,7 @@ __global__ void __launch_bounds__(256) k_prep(const PicDev* __restrict__ pics, B
     const uint32_t pred4 = ldg(reinterpret_cast<const uint32_t*>(P.pred_mode + idx));
     const uint32_t qp4 = ldg(reinterpret_cast<const uint32_t*>(P.qp + idx));
     const uint32_t tr4 = ldg(reinterpret_cast<const uint32_t*>(P.tr_idx + idx));
+    const uint32_t byp4 = ldg(reinterpret_cast<const uint32_t*>(P.bypass + idx)), pcm4 = ldg(reinterpret_cast<const uint32_t*>(P.ipcm + idx));
     const uint32_t r04 = ldg(reinterpret_cast<const uint32_t*>(P.ref_idx[0] + idx)), r14 = ldg(reinterpret_cast<const uint32_t*>(P.ref_idx[1] + idx));
     const u32x4 mv0 = ldg4(P.mv[0] + idx * 2), mv1 = ldg4(P.mv[1] + idx * 2);
 #pragma unroll
@@ -91,6 +93,7 @@ __global__ void __launch_bounds__(256) k_prep(const PicDev* __restrict__ pics, B
       q.cbf[c] = ldg(reinterpret_cast<const uint32_t*>(P.cbf[c] + idx));
       q.ts[c] = P.tskip[c] ? ldg(reinterpret_cast<const uint32_t*>(P.tskip[c] + idx)) : 0u;
     }
+    q.bypass = byp4;
     q.sidx = P.slice_idx ? ldg(P.slice_idx + q.ctu) : 0;
     sl = P.slices + q.sidx;
     q.part_size = (int)(int8_t)(part4 & 0xff);
@@ -120,6 +123,8 @@ __global__ void __launch_bounds__(256) k_prep(const PicDev* __restrict__ pics, B
       if (q.valid) {
         const int cbf_y = (q.cbf[0] >> (8 * j)) & 0xff;
         bi.flags = BF_VALID | (q.intra ? BF_INTRA : 0) | (((cbf_y >> q.tr) & 1) ? BF_CBFY : 0);
+        // lossless CUs and (with pcm_loop_filter_disabled) PCM CUs are exempt from the loop filters (TComLoopFilter.cpp:629-634)
+        if (((byp4 >> (8 * j)) & 0xff) || (P.pcm_lf_disable && ((pcm4 >> (8 * j)) & 0xff))) bi.flags |= BF_NOFILT;
         bi.qp = (int8_t)((qp4 >> (8 * j)) & 0xff);
         bi.log2cu = (uint8_t)q.log2cu;
         bi.slice = (uint16_t)q.sidx;
@@ -230,7 +235,7 @@ __global__ void __launch_bounds__(256) k_prep(const PicDev* __restrict__ pics, B
     const int comp = k < 4 ? 0 : k - 3;
     const int j = k < 4 ? k : 0;                          // partition the TU starts at
     const int ts = (q.ts[comp] >> (8 * j)) & 0xff;
-    const int flags = ((comp == 0 && q.log2tu == 2 && q.intra) ? 1 : 0) | (ts ? 2 : 0);
+    const int flags = ((comp == 0 && q.log2tu == 2 && q.intra) ? 1 : 0) | (ts ? 2 : 0) | ((q.bypass & 0xff) ? 4 : 0);      // bit 2: cu_transquant_bypass
     const uint32_t off = comp == 0 ? (uint32_t)q.ctu * ctu_luma + 16u * (q.z0 + j) : (uint32_t)q.ctu * (ctu_luma >> 2) + 4u * q.z0;
     const TuRec r = make_tu(P, q, sl, q.gx0 + (j & 1), q.gy0 + (j >> 1), comp, flags, off);
     const int c = cls[k];

@@ -87,6 +87,13 @@ __global__ void __launch_bounds__(256) k_sao(const PicDev* __restrict__ pics, Ba
       default:               sao_eo_row<1, -1>(src, pitch, w, h, x, row, cur, off_lo, off_hi, av, x0, y0, x1, y1, maxv, out); break;
     }
   }
+  if (P.any_nofilt) {
+    uint32_t m[4];
+    sao_exempt_mask(P, comp, x, row, m);
+    const uint32_t c[4] = {cur.x, cur.y, cur.z, cur.w};
+#pragma unroll
+    for (int j = 0; j < 4; j++) out[j] = (c[j] & m[j]) | (out[j] & ~m[j]);
+  }
   u32x4 res = {out[0], out[1], out[2], out[3]};
   stg4(dst + (size_t)row * pitch + x, res);
 }

@@ -156,9 +156,9 @@ def test_unsupported_tools_are_refused():
         h0, hc = ctx.acquire(), ctx.acquire()
         m = dict(p.meta_np)
         m["ipcm"] = np.ones_like(m["depth"])
-        with pytest.raises(libhm_amd.HmgpuError) as e:
+        with pytest.raises(libhm_amd.HmgpuError) as e:                     # PCM CUs without their sample buffers
             ctx.decompress_slice(hc, 0, p.slice, abi.MetaHolder(m), p.coeffs)
-        assert e.value.status == abi.HMGPU_EUNSUPPORTED
+        assert e.value.status == abi.HMGPU_EINVAL
         with pytest.raises(libhm_amd.HmgpuError) as e:                     # reference handle that is not a live picture
             p.slice.ref_pic[0][0] = 7
             ctx.decompress_slice(hc, 0, p.slice, p.meta, p.coeffs)
