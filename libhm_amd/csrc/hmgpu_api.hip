@@ -257,7 +257,9 @@ hmgpu_status run_filter(hmgpu_ctx* c, const Batch& b, int stages) {
   bool all_sao = stages == 7 && !getenv("HMGPU_NO_FUSED_FILTER");
   for (int i = 0; i < b.n && all_sao; i++) all_sao = c->pics[b.pic[i]].sao_any;
   if (all_sao) {
-    { ProfScope ps(c, K_FILTER); launch_filter_fused(c->d_pics, b, c->seq.width, c->seq.height, c->stream); }
+    bool nofilt = false;
+    for (int i = 0; i < b.n; i++) nofilt |= c->pics[b.pic[i]].dev.any_nofilt != 0;
+    { ProfScope ps(c, K_FILTER); launch_filter_fused(c->d_pics, b, c->seq.width, c->seq.height, nofilt, c->stream); }
     HIP_TRY(c, hipGetLastError());
     return HMGPU_OK;
   }

@@ -181,7 +181,7 @@ void launch_prep(const PicDev* pics, const Batch& b, int max_ctus, int parts, bo
 void launch_mc_luma(const PicDev* pics, const PlaneSet* finals, const Batch& b, int max_ctus, int log2ctu, bool wp, hipStream_t s);
 void launch_mc_chroma(const PicDev* pics, const PlaneSet* finals, const Batch& b, int max_ctus, int log2ctu, bool wp, hipStream_t s);
 void launch_itx(const PicDev* pics, const Batch& b, int log2size, uint32_t blocks_per_shard, hipStream_t s);
-void launch_filter_fused(const PicDev* pics, const Batch& b, int width, int height, hipStream_t s);
+void launch_filter_fused(const PicDev* pics, const Batch& b, int width, int height, bool nofilt, hipStream_t s);
 void launch_intra(const PicDev* pics, const Batch& b, const int32_t* order, int num_ctus, hipStream_t s);
 void launch_deblock(const PicDev* pics, const Batch& b, int dir, int width, int height, hipStream_t s);
 void launch_sao(const PicDev* pics, const Batch& b, int width, int height, hipStream_t s);

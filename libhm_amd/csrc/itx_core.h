@@ -170,8 +170,15 @@ __device__ inline void idst4_pk(const uint32_t (&p)[N / 2], int seed, int (&out)
 template <int LOG2N>
 __device__ inline void itx_tu_pk(const uint32_t (&lv)[(1 << LOG2N) / 2], int n, int per, int rem, bool skip, int bd,
                                  int16_t* __restrict__ buf, uint32_t (&res)[(1 << LOG2N) / 2], bool dst = false,
-                                 const uint8_t* __restrict__ mrow = nullptr) {
+                                 const uint8_t* __restrict__ mrow = nullptr, bool bypass = false) {
   constexpr int N = 1 << LOG2N, S = PkCfg<LOG2N>::S;
+  if (bypass) {
+    // cu_transquant_bypass: the residual IS the level block (invTransformNxN, TComTrQuant.cpp:1440-1470).  All N lanes of the TU
+    // take this exit together; the hand-offs below are wave-local orderings, not barriers, so other TUs of the wave go on.
+#pragma unroll
+    for (int i = 0; i < N / 2; i++) res[i] = lv[i];
+    return;
+  }
   // ---- xDeQuant, flat scaling (TComTrQuant.cpp:1276-1311), on the row this lane loaded
   const int tshift = 15 - bd - LOG2N;                     // getTransformShift
   const int rshift = 6 - (tshift + per);                  // IQUANT_SHIFT - (transformShift + per)

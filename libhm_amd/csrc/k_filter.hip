@@ -45,7 +45,7 @@ __device__ inline SaoPrm sao_fetch(const PicDev& P, int comp, int x, int row) {
   return r;
 }
 
-template <int W>
+template <int W, bool NF>
 __device__ inline void sao_group(const PicDev& P, int comp, const int16_t (*t)[W], int ox, int oy, int x, int row, const SaoPrm& prm) {
   const int cs = comp ? 1 : 0;
   const int w = P.width >> cs, h = P.height >> cs;
@@ -98,7 +98,7 @@ __device__ inline void sao_group(const PicDev& P, int comp, const int16_t (*t)[W
       default:               run(std::integral_constant<int, 1>{}, std::integral_constant<int, -1>{}); break;
     }
   }
-  if (P.any_nofilt) {
+  if (NF && P.any_nofilt) {
     uint32_t m[4];
     sao_exempt_mask(P, comp, x, row, m);
     const uint32_t c[4] = {cur.x, cur.y, cur.z, cur.w};
@@ -132,7 +132,7 @@ __device__ inline SliceLf slice_lf(const SliceDev* s) {
   return {ldg(&s->tc_offset_div2), ldg(&s->beta_offset_div2), ldg(&s->pps_cb_qp_offset), ldg(&s->pps_cr_qp_offset)};
 }
 
-template <int DIR>
+template <int DIR, bool NF>
 __device__ inline void edge_unit(const PicDev& P, FilterLds& L, int x0, int y0, int x, int y, const EdgeBlk& e, const SliceLf& s0) {
   if (!e.on) return;
   const BlkInfo q = __builtin_bit_cast(BlkInfo, e.q), p = __builtin_bit_cast(BlkInfo, e.p);
@@ -161,7 +161,7 @@ __device__ inline void edge_unit(const PicDev& P, FilterLds& L, int x0, int y0, 
       l[0][r] = a.x & 0xffff; l[1][r] = a.x >> 16; l[2][r] = a.y & 0xffff; l[3][r] = a.y >> 16;
     }
   }
-  const bool p_nf = (p.flags & BF_NOFILT) != 0, q_nf = (q.flags & BF_NOFILT) != 0;
+  const bool p_nf = NF && (p.flags & BF_NOFILT) != 0, q_nf = NF && (q.flags & BF_NOFILT) != 0;
   filter_luma_unit(l, bs, qp, tc_off, beta_off, P.bd[0], p_nf, q_nf);
   if (DIR == 0) {
 #pragma unroll
@@ -200,6 +200,8 @@ __device__ inline void edge_unit(const PicDev& P, FilterLds& L, int x0, int y0, 
 
 }  // namespace
 
+// NF: the variant for batches in which some picture holds lossless / unfiltered PCM CUs (chosen on the host)
+template <bool NF>
 __global__ void __launch_bounds__(256) k_filter_fused(const PicDev* __restrict__ pics, Batch b) {
   __shared__ FilterLds L;
   const PicDev& P = pics[b.pic[blockIdx.z]];
@@ -239,21 +241,22 @@ __global__ void __launch_bounds__(256) k_filter_fused(const PicDev* __restrict__
   }
   __syncthreads();
   // ---- 2. vertical edges
-  edge_unit<0>(P, L, x0, y0, vx, vy, ev, s0);
+  edge_unit<0, NF>(P, L, x0, y0, vx, vy, ev, s0);
   __syncthreads();
   // ---- 3. horizontal edges
-  edge_unit<1>(P, L, x0, y0, hx, hy, eh, s0);
+  edge_unit<1, NF>(P, L, x0, y0, hx, hy, eh, s0);
   __syncthreads();
   // ---- 4. SAO of the tile from the deblocked copy
 #pragma unroll
   for (int k = 0; k < 2; k++)
-    if (lx[k] < P.width && ly[k] < P.height) sao_group<kYW>(P, 0, L.y, x0 - 8, y0 - 4, lx[k], ly[k], sl[k]);
-  if (ccx < (P.width >> 1) && ccy < (P.height >> 1)) sao_group<kCW>(P, ccomp, L.c[ccomp - 1], (x0 >> 1) - 8, (y0 >> 1) - 2, ccx, ccy, sc);
+    if (lx[k] < P.width && ly[k] < P.height) sao_group<kYW, NF>(P, 0, L.y, x0 - 8, y0 - 4, lx[k], ly[k], sl[k]);
+  if (ccx < (P.width >> 1) && ccy < (P.height >> 1)) sao_group<kCW, NF>(P, ccomp, L.c[ccomp - 1], (x0 >> 1) - 8, (y0 >> 1) - 2, ccx, ccy, sc);
 }
 
-void launch_filter_fused(const PicDev* pics, const Batch& b, int width, int height, hipStream_t s) {
+void launch_filter_fused(const PicDev* pics, const Batch& b, int width, int height, bool nofilt, hipStream_t s) {
   dim3 grid((unsigned)((width + kTW - 1) / kTW), (unsigned)((height + kTH - 1) / kTH), (unsigned)b.n);
-  hipLaunchKernelGGL(k_filter_fused, grid, dim3(256), 0, s, pics, b);
+  if (nofilt) hipLaunchKernelGGL(k_filter_fused<true>, grid, dim3(256), 0, s, pics, b);
+  else hipLaunchKernelGGL(k_filter_fused<false>, grid, dim3(256), 0, s, pics, b);
 }
 
 }  // namespace hmgpu

@@ -242,11 +242,7 @@ __device__ inline void intra_tu(const PicDev& P, const TuCtx& t, IntraLds& L) {
     int per, rem;
     qp_param_tu(t.qp_cu, comp, bd, t.cqo, per, rem);
     const uint8_t* mrow = (P.sl_m != nullptr && (!t.skip || N == 4)) ? P.sl_m + (((LOG2N - 2) * 6 + comp) << 10) + n * N : nullptr;   // intra lists: 0 + component
-    if (t.bypass) {                                        // cu_transquant_bypass: the residual is the level block itself
-#pragma unroll
-      for (int i = 0; i < N / 2; i++) res[i] = lv[i];
-    } else
-    itx_tu_pk<LOG2N>(lv, n, per, rem, t.skip != 0, bd, L.tile, res, comp == 0 && LOG2N == 2, mrow);      // TComTU::useDST: 4x4 intra luma
+    itx_tu_pk<LOG2N>(lv, n, per, rem, t.skip != 0, bd, L.tile, res, comp == 0 && LOG2N == 2, mrow, t.bypass != 0);   // DST: 4x4 intra luma (TComTU::useDST)
   }
 
   // ---- E. reconstruction of row n: into the LDS copy (what later TUs of this CTU predict from) and, two samples per

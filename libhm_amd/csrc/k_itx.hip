@@ -90,11 +90,7 @@ __device__ inline void itx_class(const PicDev& P, int shard, int bx, int nbx, ch
       uint32_t res[N / 2];
       // scaling lists (inter TUs: list 3 + component; not for transform-skip blocks other than 4x4, TComTrQuant.h:180)
       const uint8_t* mrow = (P.sl_m != nullptr && (!(flags & 2) || N == 4)) ? P.sl_m + (((LOG2N - 2) * 6 + 3 + comp) << 10) + n * N : nullptr;
-      itx_tu_pk<LOG2N>(lv_c[u], n, per, rem, (flags & 2) != 0, bd, buf, res, false, mrow);
-      if (flags & 4) {                                                // cu_transquant_bypass: the residual IS the level block (TComTrQuant.cpp:1440-1470)
-#pragma unroll
-        for (int i = 0; i < N / 2; i++) res[i] = lv_c[u][i];
-      }
+      itx_tu_pk<LOG2N>(lv_c[u], n, per, rem, (flags & 2) != 0, bd, buf, res, false, mrow, (flags & 4) != 0);
       if (active) {
         // recon row n: ClipBD(pred + resid) in place, two samples per lane operation
         const uint32_t maxv2 = (uint32_t)((1 << bd) - 1) * 0x10001u;
