@@ -99,43 +99,55 @@ __global__ void __launch_bounds__(256) k_sao(const PicDev* __restrict__ pics, Ba
 }
 
 // TComPicYuv::extendPicBorder (TComPicYuv.cpp:173-217): replicate the edge samples of the picture's FINAL planes into the
-// margins so that motion compensation of later pictures never has to clamp coordinates.  One thread per margin sample
-// pair; every thread reads only samples of the visible picture, so there is no ordering between margin writes.
-__global__ void __launch_bounds__(256) k_extend(const PicDev* __restrict__ pics, Batch b, int total_luma_pairs, int total_chroma_pairs) {
+// margins so that motion compensation of later pictures never has to clamp coordinates.  One thread per 16-byte piece of
+// margin (8 samples): side bands first (every row of the padded plane, left and right), then the bands above and below the
+// picture columns.  Every thread reads only samples of the visible picture, so there is no ordering between margin writes.
+__global__ void __launch_bounds__(256) k_extend(const PicDev* __restrict__ pics, Batch b, int luma_vecs, int chroma_vecs) {
   const PicDev& P = pics[b.pic[blockIdx.z]];
   int idx = blockIdx.x * 256 + threadIdx.x;
   int comp = 0;
-  if (idx >= total_luma_pairs) { idx -= total_luma_pairs; comp = 1; if (idx >= total_chroma_pairs) { idx -= total_chroma_pairs; comp = 2; if (idx >= total_chroma_pairs) return; } }
+  if (idx >= luma_vecs) { idx -= luma_vecs; comp = 1; if (idx >= chroma_vecs) { idx -= chroma_vecs; comp = 2; if (idx >= chroma_vecs) return; } }
   const int cs = comp ? 1 : 0;
   const int w = P.width >> cs, h = P.height >> cs, mx = P.mx[comp], my = P.my[comp], pitch = P.pitch[comp];
   int16_t* pl = P.sao_applied ? P.sao[comp] : P.rec[comp];
-  // margin region in pairs of samples: first the left+right bands of the rows [-my, h+my), then the top+bottom bands over [0, w)
-  const int side_pairs_per_row = mx;                         // (mx left + mx right) / 2
+  const int side_vecs_per_row = 2 * mx / 8;                  // left + right band, 8 samples per vector
   const int rows = h + 2 * my;
-  int x, y;
-  if (idx < side_pairs_per_row * rows) {
-    y = idx / side_pairs_per_row - my;
-    const int k = (idx % side_pairs_per_row) * 2;            // 0 .. 2*mx-2
-    x = k < mx ? k - mx : w + (k - mx);
+  if (idx < side_vecs_per_row * rows) {
+    const int y = idx / side_vecs_per_row - my, k = idx % side_vecs_per_row;
+    const bool right = k >= mx / 8;
+    const int x = right ? w + (k - mx / 8) * 8 : -mx + k * 8;
+    const uint32_t v = (uint16_t)ldg(pl + (ptrdiff_t)clip3(0, h - 1, y) * pitch + (right ? w - 1 : 0)) * 0x10001u;
+    u32x4 o = {v, v, v, v};
+    if (right) stg4_a8(pl + (ptrdiff_t)y * pitch + x, o);    // a chroma width that is 4 mod 8 starts the band on an 8-byte boundary only
+    else stg4(pl + (ptrdiff_t)y * pitch + x, o);
   } else {
-    idx -= side_pairs_per_row * rows;
-    const int pairs_per_row = w >> 1;
-    const int r = idx / pairs_per_row;                       // 0 .. 2*my-1
+    idx -= side_vecs_per_row * rows;
+    const int vecs_per_row = (w + 7) / 8;
+    const int r = idx / vecs_per_row;                         // 0 .. 2*my-1
     if (r >= 2 * my) return;
-    y = r < my ? r - my : h + (r - my);
-    x = (idx % pairs_per_row) * 2;
+    const int y = r < my ? r - my : h + (r - my);
+    const int x = (idx % vecs_per_row) * 8;
+    // (a picture whose width is not a multiple of 8 samples lets the last vector run into the right band: same values)
+    u32x4 o = ldg4(pl + (ptrdiff_t)(r < my ? 0 : h - 1) * pitch + x);
+    if (x + 8 > w) {
+      const uint32_t e = (uint16_t)ldg(pl + (ptrdiff_t)(r < my ? 0 : h - 1) * pitch + w - 1) * 0x10001u;
+      uint32_t t[4] = {o.x, o.y, o.z, o.w};
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        if (x + 2 * j >= w) t[j] = e;
+        else if (x + 2 * j + 1 >= w) t[j] = (t[j] & 0xffffu) | (e & 0xffff0000u);
+      }
+      o = (u32x4){t[0], t[1], t[2], t[3]};
+    }
+    stg4(pl + (ptrdiff_t)y * pitch + x, o);
   }
-  const int sy = clip3(0, h - 1, y);
-  const uint32_t a = (uint16_t)ldg(pl + (ptrdiff_t)sy * pitch + clip3(0, w - 1, x));
-  const uint32_t c = (uint16_t)ldg(pl + (ptrdiff_t)sy * pitch + clip3(0, w - 1, x + 1));
-  stg(reinterpret_cast<uint32_t*>(pl + (ptrdiff_t)y * pitch + x), a | (c << 16));
 }
 
 void launch_extend(const PicDev* pics, const Batch& b, int width, int height, int mx, int my, hipStream_t s) {
   // luma margins (mx, my); chroma margins are half of them
-  const int luma = mx * (height + 2 * my) + (width / 2) * 2 * my;
+  const int luma = (2 * mx / 8) * (height + 2 * my) + ((width + 7) / 8) * 2 * my;
   const int cw = width / 2, chh = height / 2, cmx = mx / 2, cmy = my / 2;
-  const int chroma = cmx * (chh + 2 * cmy) + (cw / 2) * 2 * cmy;
+  const int chroma = (2 * cmx / 8) * (chh + 2 * cmy) + ((cw + 7) / 8) * 2 * cmy;
   dim3 grid((unsigned)((luma + 2 * chroma + 255) / 256), 1, (unsigned)b.n);
   hipLaunchKernelGGL(k_extend, grid, dim3(256), 0, s, pics, b, luma, chroma);
 }
