@@ -181,6 +181,8 @@ def main():
                              "frac": round(gbs / HBM_PEAK_GBS, 4)}
             if ms > dom_t:
                 dom, dom_t = name, ms
+        if roof_kernel == "sao" and "sao" not in kernels:
+            roof_kernel = "filter_fused"                   # all three loop-filter stages run as one kernel when every picture has SAO
         if roof_kernel is not None:
             dom = roof_kernel
         # HBM traffic per launch from the committed PMC passes of this same command (tools/round_profile.sh + pmc_summary.py):

@@ -202,10 +202,15 @@ __device__ inline void edge_unit(const PicDev& P, FilterLds& L, int x0, int y0, 
 
 // NF: the variant for batches in which some picture holds lossless / unfiltered PCM CUs (chosen on the host)
 template <bool NF>
-__global__ void __launch_bounds__(256) k_filter_fused(const PicDev* __restrict__ pics, Batch b) {
+__global__ void __launch_bounds__(256) k_filter_fused(const PicDev* __restrict__ pics, Batch b, int tiles_x, int tiles) {
   __shared__ FilterLds L;
-  const PicDev& P = pics[b.pic[blockIdx.z]];
-  const int x0 = blockIdx.x * kTW, y0 = blockIdx.y * kTH;
+  // XCD-aware tile order (xcd_remap): the tiles of one picture (band) run on one XCD in raster order, so that the halo a tile
+  // shares with its neighbours -- whole 128-byte lines to the left and right, rows above and below -- is found in that XCD's
+  // L2 instead of being fetched from memory once per neighbour (measured: 0.9 GB of reads per batch without)
+  int slot, lb;
+  if (!xcd_remap(blockIdx.x, b.n, tiles, slot, lb)) return;
+  const PicDev& P = pics[b.pic[slot]];
+  const int x0 = (lb % tiles_x) * kTW, y0 = (lb / tiles_x) * kTH;
   const int t = threadIdx.x;
   // edge units of this thread: vertical edges x0, x0+8 .. x0+64 over the rows [y0-4, y0+68) (9 edges x 18 units), horizontal
   // edges y0 .. y0+64 over the columns [x0-4, x0+68)
@@ -254,9 +259,10 @@ __global__ void __launch_bounds__(256) k_filter_fused(const PicDev* __restrict__
 }
 
 void launch_filter_fused(const PicDev* pics, const Batch& b, int width, int height, bool nofilt, hipStream_t s) {
-  dim3 grid((unsigned)((width + kTW - 1) / kTW), (unsigned)((height + kTH - 1) / kTH), (unsigned)b.n);
-  if (nofilt) hipLaunchKernelGGL(k_filter_fused<true>, grid, dim3(256), 0, s, pics, b);
-  else hipLaunchKernelGGL(k_filter_fused<false>, grid, dim3(256), 0, s, pics, b);
+  const int tiles_x = (width + kTW - 1) / kTW, tiles = tiles_x * ((height + kTH - 1) / kTH);
+  dim3 grid((unsigned)xcd_grid(b.n, tiles));
+  if (nofilt) hipLaunchKernelGGL(k_filter_fused<true>, grid, dim3(256), 0, s, pics, b, tiles_x, tiles);
+  else hipLaunchKernelGGL(k_filter_fused<false>, grid, dim3(256), 0, s, pics, b, tiles_x, tiles);
 }
 
 }  // namespace hmgpu

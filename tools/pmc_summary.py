@@ -8,8 +8,9 @@ import glob
 import json
 import sys
 
-BENCH_NAME = {"k_itx": "itx", "k_mc_luma<false>": "mc_luma", "k_mc_chroma": "mc_chroma", "k_deblock<0>": "deblock_ver",
-              "k_deblock<1>": "deblock_hor", "k_sao": "sao", "k_prep": "prep", "k_extend": "extend_border"}
+BENCH_NAME = {"k_itx": "itx", "k_mc_luma<false>": "mc_luma", "k_mc_chroma<false>": "mc_chroma", "k_deblock<0>": "deblock_ver",
+              "k_deblock<1>": "deblock_hor", "k_sao": "sao", "k_prep": "prep", "k_extend": "extend_border",
+              "k_filter_fused<false>": "filter_fused", "k_intra": "intra"}
 args = sys.argv[1:]
 json_out = None
 if "--json" in args:
