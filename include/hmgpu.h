@@ -170,6 +170,16 @@ hmgpu_status hmgpu_picture_release(hmgpu_ctx* ctx, hmgpu_pic pic);
 hmgpu_status hmgpu_picture_upload(hmgpu_ctx* ctx, hmgpu_pic pic, const int16_t* const planes[3], const int32_t strides[3]);
 hmgpu_status hmgpu_picture_download(hmgpu_ctx* ctx, hmgpu_pic pic, int16_t* const planes[3], const int32_t strides[3]);
 
+/* Output side.  hmgpu_picture_download_packed: the finished picture as the application wants it -- one or two
+ * bytes per sample (TVideoIOYuv::write, TVideoIOYuv.cpp:706-790: 8-bit files take the low byte), cropped to a window given in
+ * luma samples (conformance / display window; 0,0,0,0 = the whole picture) -- converted on the device, so an 8-bit picture crosses
+ * PCIe in half the bytes.  hmgpu_picture_hash: the decoded-picture-hash SEI check (TDecGop.cpp:199-208) without moving the
+ * picture: method 2 = CRC, 3 = checksum (TComPicYuvMD5.cpp:89-170); MD5 (method 1) is a serial chain over the whole plane and
+ * stays on the host (HMGPU_EUNSUPPORTED): download the picture for it. */
+hmgpu_status hmgpu_picture_download_packed(hmgpu_ctx* ctx, hmgpu_pic pic, void* const planes[3], const int32_t stride_bytes[3],
+                                           int32_t bytes_per_sample, int32_t crop_left, int32_t crop_right, int32_t crop_top, int32_t crop_bottom);
+hmgpu_status hmgpu_picture_hash(hmgpu_ctx* ctx, hmgpu_pic pic, int32_t method, uint8_t digest[3][16], int32_t* digest_len);
+
 /* Frame-parallel exchange (BASELINE config #5): a finished picture is ONE contiguous device region (three
  * planes, replicated margins included -- HM's TComPicYuv after extendPicBorder, TComPicYuv.cpp:89-100) that another GPU
  * needs before it can predict from the picture (TComPrediction.cpp:593).  The collective itself (RCCL broadcast /

@@ -70,6 +70,8 @@ def lib():
         L.hmgpu_picture_release.argtypes = [C.c_void_p, C.c_int32]
         L.hmgpu_picture_upload.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_int32)]
         L.hmgpu_picture_download.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_int32)]
+        L.hmgpu_picture_download_packed.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_int32)] + [C.c_int32] * 5
+        L.hmgpu_picture_hash.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.POINTER(C.c_int32)]
         L.hmgpu_picture_device_region.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]
         L.hmgpu_picture_commit_received.argtypes = [C.c_void_p, C.c_int32]
         L.hmgpu_stream.argtypes = [C.c_void_p]
@@ -146,6 +148,24 @@ class Context:
         strides = (C.c_int32 * 3)(*[p.shape[1] for p in planes])
         self._chk(lib().hmgpu_picture_download(self._h, pic, ptrs, strides), "hmgpu_picture_download")
         return planes
+
+    def download_packed(self, pic, bytes_per_sample, crop=(0, 0, 0, 0)):
+        """the picture as 8- or 16-bit planes cropped by (left, right, top, bottom) luma samples"""
+        l, r, t, b = crop
+        W, H = self.seq.width - l - r, self.seq.height - t - b
+        dt = np.uint8 if bytes_per_sample == 1 else np.uint16
+        planes = [np.zeros((H, W), dtype=dt), np.zeros((H // 2, W // 2), dtype=dt), np.zeros((H // 2, W // 2), dtype=dt)]
+        ptrs = (C.c_void_p * 3)(*[p.ctypes.data for p in planes])
+        strides = (C.c_int32 * 3)(*[p.strides[0] for p in planes])
+        self._chk(lib().hmgpu_picture_download_packed(self._h, pic, ptrs, strides, bytes_per_sample, l, r, t, b), "hmgpu_picture_download_packed")
+        return planes
+
+    def picture_hash(self, pic, method):
+        """method 2 = CRC, 3 = checksum (decoded-picture-hash SEI); returns the bytes of Y, Cb, Cr concatenated"""
+        dig = (C.c_uint8 * 48)()
+        n = C.c_int32()
+        self._chk(lib().hmgpu_picture_hash(self._h, pic, method, dig, C.byref(n)), "hmgpu_picture_hash")
+        return np.array([dig[16 * k + i] for k in range(3) for i in range(n.value)], dtype=np.uint8)
 
     # ---- frame-parallel exchange (hmgpu.h: hmgpu_picture_device_region)
     def device_region(self, pic, receive=False):

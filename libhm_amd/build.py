@@ -6,7 +6,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libhmgpu.so")
-SOURCES = ["k_prep.hip", "k_mc.hip", "k_itx.hip", "k_intra.hip", "k_dbk.hip", "k_sao.hip", "k_filter.hip", "hmgpu_api.hip"]
+SOURCES = ["k_prep.hip", "k_mc.hip", "k_itx.hip", "k_intra.hip", "k_dbk.hip", "k_sao.hip", "k_filter.hip", "k_out.hip", "hmgpu_api.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function", "-Wno-unused-value"]
 
 

@@ -503,6 +503,66 @@ hmgpu_status hmgpu_picture_download(hmgpu_ctx* c, hmgpu_pic pic, int16_t* const 
   return HMGPU_OK;
 }
 
+hmgpu_status hmgpu_picture_download_packed(hmgpu_ctx* c, hmgpu_pic pic, void* const planes[3], const int32_t stride_bytes[3],
+                                           int32_t bytes_per_sample, int32_t crop_left, int32_t crop_right, int32_t crop_top, int32_t crop_bottom) {
+  if (!c || !valid_pic(c, pic) || !planes || !stride_bytes || (bytes_per_sample != 1 && bytes_per_sample != 2)) return HMGPU_EINVAL;
+  if ((crop_left | crop_right | crop_top | crop_bottom) & 1) return HMGPU_EINVAL;          // 4:2:0: the window is even
+  const int W = c->seq.width - crop_left - crop_right, H = c->seq.height - crop_top - crop_bottom;
+  if (crop_left < 0 || crop_right < 0 || crop_top < 0 || crop_bottom < 0 || W <= 0 || H <= 0) return HMGPU_EINVAL;
+  hipSetDevice(c->device);
+  Picture& p = c->pics[pic];
+  size_t off[3], total = 0;
+  for (int k = 0; k < 3; k++) { off[k] = total; total += align_up((size_t)(W >> (k ? 1 : 0)) * bytes_per_sample * (H >> (k ? 1 : 0)), 256); }
+  uint8_t* d = nullptr;
+  HIP_TRY(c, hipMalloc((void**)&d, total));
+  hmgpu_status st = HMGPU_OK;
+  for (int k = 0; k < 3 && st == HMGPU_OK; k++) {
+    const int cs = k ? 1 : 0, w = W >> cs, h = H >> cs;
+    const int16_t* src = p.sao_applied ? p.dev.sao[k] : p.dev.rec[k];
+    launch_pack(src, c->pitch[k], crop_left >> cs, crop_top >> cs, w, h, bytes_per_sample, d + off[k], w * bytes_per_sample, c->stream);
+    if (hipGetLastError() != hipSuccess ||
+        hipMemcpy2DAsync(planes[k], (size_t)stride_bytes[k], d + off[k], (size_t)w * bytes_per_sample, (size_t)w * bytes_per_sample, h,
+                         hipMemcpyDeviceToHost, c->stream) != hipSuccess) st = HMGPU_EDEVICE;
+  }
+  if (hipStreamSynchronize(c->stream) != hipSuccess) st = HMGPU_EDEVICE;
+  hipFree(d);
+  prof_drain(c);
+  return st;
+}
+
+hmgpu_status hmgpu_picture_hash(hmgpu_ctx* c, hmgpu_pic pic, int32_t method, uint8_t digest[3][16], int32_t* digest_len) {
+  if (!c || !valid_pic(c, pic) || !digest || !digest_len) return HMGPU_EINVAL;
+  if (method == 1) return HMGPU_EUNSUPPORTED;              // MD5: a serial chain over the plane, host work
+  if (method != 2 && method != 3) return HMGPU_EINVAL;
+  hipSetDevice(c->device);
+  Picture& p = c->pics[pic];
+  uint32_t* d = nullptr;
+  const size_t words = 4 + (size_t)c->seq.height;          // three results + the per-row CRCs of one plane
+  HIP_TRY(c, hipMalloc((void**)&d, words * 4));
+  hmgpu_status st = HMGPU_OK;
+  if (hipMemsetAsync(d, 0, words * 4, c->stream) != hipSuccess) st = HMGPU_EDEVICE;
+  for (int k = 0; k < 3 && st == HMGPU_OK; k++) {
+    const int cs = k ? 1 : 0, w = c->seq.width >> cs, h = c->seq.height >> cs;
+    const int bd = k ? c->seq.bit_depth_chroma : c->seq.bit_depth_luma;
+    const int16_t* src = p.sao_applied ? p.dev.sao[k] : p.dev.rec[k];
+    if (method == 3) launch_checksum(src, c->pitch[k], w, h, bd, d + k, c->stream);
+    else launch_crc(src, c->pitch[k], w, h, bd, d + 4, d + k, c->stream);
+    if (hipGetLastError() != hipSuccess) st = HMGPU_EDEVICE;
+  }
+  uint32_t r[3] = {0, 0, 0};
+  if (st == HMGPU_OK && hipMemcpyAsync(r, d, sizeof(r), hipMemcpyDeviceToHost, c->stream) != hipSuccess) st = HMGPU_EDEVICE;
+  if (hipStreamSynchronize(c->stream) != hipSuccess) st = HMGPU_EDEVICE;
+  hipFree(d);
+  if (st != HMGPU_OK) return st;
+  memset(digest, 0, 48);
+  for (int k = 0; k < 3; k++) {
+    if (method == 2) { digest[k][0] = (uint8_t)(r[k] >> 8); digest[k][1] = (uint8_t)r[k]; }
+    else { digest[k][0] = (uint8_t)(r[k] >> 24); digest[k][1] = (uint8_t)(r[k] >> 16); digest[k][2] = (uint8_t)(r[k] >> 8); digest[k][3] = (uint8_t)r[k]; }
+  }
+  *digest_len = method == 2 ? 2 : 4;
+  return HMGPU_OK;
+}
+
 hmgpu_status hmgpu_picture_device_region(hmgpu_ctx* c, hmgpu_pic pic, int32_t which, void** base, int64_t* bytes) {
   if (!c || !valid_pic(c, pic) || !base || !bytes || (which != HMGPU_REGION_FINISHED && which != HMGPU_REGION_RECEIVE)) return HMGPU_EINVAL;
   hipSetDevice(c->device);

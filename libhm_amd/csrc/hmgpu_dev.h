@@ -182,6 +182,9 @@ void launch_mc_luma(const PicDev* pics, const PlaneSet* finals, const Batch& b, 
 void launch_mc_chroma(const PicDev* pics, const PlaneSet* finals, const Batch& b, int max_ctus, int log2ctu, bool wp, hipStream_t s);
 void launch_itx(const PicDev* pics, const Batch& b, int log2size, uint32_t blocks_per_shard, hipStream_t s);
 void launch_filter_fused(const PicDev* pics, const Batch& b, int width, int height, bool nofilt, hipStream_t s);
+void launch_pack(const int16_t* src, int pitch, int x0, int y0, int w, int h, int bytes, uint8_t* dst, int dst_stride, hipStream_t s);
+void launch_checksum(const int16_t* src, int pitch, int w, int h, int bd, uint32_t* out, hipStream_t s);
+void launch_crc(const int16_t* src, int pitch, int w, int h, int bd, uint32_t* rows, uint32_t* out, hipStream_t s);
 void launch_intra(const PicDev* pics, const Batch& b, const int32_t* order, int num_ctus, hipStream_t s);
 void launch_deblock(const PicDev* pics, const Batch& b, int dir, int width, int height, hipStream_t s);
 void launch_sao(const PicDev* pics, const Batch& b, int width, int height, hipStream_t s);

@@ -235,6 +235,39 @@ void hmo_inverse_transform_tu_sl(const int16_t* level, int16_t* resid, int resid
   for (y = 0; y < n; y++) for (x = 0; x < n; x++) resid[y * resid_stride + x] = (int16_t)block[y * n + x];   /* xIT: :1861-1865 */
 }
 
+/* ------------------------------------------------------------------------------------------------ picture hashes */
+/* compCRC: TComPicYuvMD5.cpp:89-125 */
+void hmo_plane_crc(int bit_depth, const int16_t* plane, int width, int height, int stride, uint8_t out[2])
+{
+  unsigned crc = 0xffff;
+  int x, y, b, k;
+  for (y = 0; y < height; y++)
+    for (x = 0; x < width; x++)
+      for (k = 0; k < (bit_depth > 8 ? 2 : 1); k++)
+        for (b = 0; b < 8; b++)
+        {
+          const unsigned msb = (crc >> 15) & 1, bit = ((unsigned)plane[(size_t)y * stride + x] >> ((k ? 15 : 7) - b)) & 1;
+          crc = (((crc << 1) + bit) & 0xffff) ^ (msb * 0x1021);
+        }
+  for (b = 0; b < 16; b++) { const unsigned msb = (crc >> 15) & 1; crc = ((crc << 1) & 0xffff) ^ (msb * 0x1021); }
+  out[0] = (uint8_t)(crc >> 8); out[1] = (uint8_t)crc;
+}
+
+/* compChecksum: TComPicYuvMD5.cpp:139-165 */
+void hmo_plane_checksum(int bit_depth, const int16_t* plane, int width, int height, int stride, uint8_t out[4])
+{
+  uint32_t sum = 0;
+  int x, y;
+  for (y = 0; y < height; y++)
+    for (x = 0; x < width; x++)
+    {
+      const unsigned mask = ((x & 0xff) ^ (y & 0xff) ^ (x >> 8) ^ (y >> 8)) & 0xff, v = (uint16_t)plane[(size_t)y * stride + x];
+      sum += (v & 0xff) ^ mask;
+      if (bit_depth > 8) sum += (v >> 8) ^ mask;
+    }
+  out[0] = (uint8_t)(sum >> 24); out[1] = (uint8_t)(sum >> 16); out[2] = (uint8_t)(sum >> 8); out[3] = (uint8_t)sum;
+}
+
 /* ------------------------------------------------------------------------------------------------ interpolation */
 /* TComInterpolationFilter::filter<N,isVertical,isFirst,isLast>: TLibCommon/TComInterpolationFilter.cpp:166-251 */
 static void fir(int ntaps, const int* c, int vertical, int is_first, int is_last, int bit_depth,

@@ -31,6 +31,9 @@ void hmo_inverse_transform_tu(const int16_t* level, int16_t* resid, int resid_st
 /* the same with scaling lists (NULL = flat): list_id = 3 * inter + component (getScalingListType) */
 void hmo_inverse_transform_tu_sl(const int16_t* level, int16_t* resid, int resid_stride, int log2_size, int bit_depth,
                                  int qp_per, int qp_rem, int flags, const hmgpu_scaling_lists* sl, int list_id);
+/* picture hashes of one plane (TComPicYuvMD5.cpp:89-170): CRC-16 (2 bytes, big endian in out) and checksum (4 bytes) */
+void hmo_plane_crc(int bit_depth, const int16_t* plane, int width, int height, int stride, uint8_t out[2]);
+void hmo_plane_checksum(int bit_depth, const int16_t* plane, int width, int height, int stride, uint8_t out[4]);
 /* QpParam (TComTrQuant.cpp:71-100): comp 0..2 */
 void hmo_qp_param(int qp_y, int comp, int bit_depth, int chroma_qp_offset, int* per, int* rem);
 /* xPredInterBlk (TComPrediction.cpp:660-698) with the reference addressed by clamped coordinates.

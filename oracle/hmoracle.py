@@ -119,6 +119,19 @@ def decompress_ctus(seq, slices, meta, coeffs, cur_planes, ref_planes_list, firs
     return n_intra.value
 
 
+def plane_hashes(planes, bit_depths):
+    """(crc bytes [6], checksum bytes [12]) of a picture, HM's decoded-picture-hash conventions"""
+    crc, chk = np.zeros(6, dtype=np.uint8), np.zeros(12, dtype=np.uint8)
+    for c, (pl, bd) in enumerate(zip(planes, bit_depths)):
+        pl = np.ascontiguousarray(pl, dtype=np.int16)
+        o2, o4 = (C.c_uint8 * 2)(), (C.c_uint8 * 4)()
+        lib().hmo_plane_crc(bd, pl.ctypes.data_as(C.c_void_p), pl.shape[1], pl.shape[0], pl.shape[1], o2)
+        lib().hmo_plane_checksum(bd, pl.ctypes.data_as(C.c_void_p), pl.shape[1], pl.shape[0], pl.shape[1], o4)
+        crc[2 * c:2 * c + 2] = list(o2)
+        chk[4 * c:4 * c + 4] = list(o4)
+    return crc, chk
+
+
 def loop_filter_pic(seq, slices, meta, pp, planes, dir_mask=3):
     pic = _pic(planes)
     sl = (abi.SliceParams * len(slices))(*slices)

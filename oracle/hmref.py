@@ -25,7 +25,7 @@ def lib():
         _lib = C.CDLL(LIB_PATH)
         _lib.ref_dec_open.restype = C.c_void_p
         _lib.ref_dec_open.argtypes = [C.c_void_p, C.c_int64, C.c_int]
-        for n in ("ref_dec_close", "ref_dec_info", "ref_dec_slices", "ref_dec_sao_params", "ref_dec_wp", "ref_dec_scaling_lists", "ref_dec_tile_idx", "ref_dec_pcm", "ref_dec_pcm_info"):
+        for n in ("ref_dec_close", "ref_dec_info", "ref_dec_slices", "ref_dec_sao_params", "ref_dec_wp", "ref_dec_scaling_lists", "ref_dec_tile_idx", "ref_dec_pcm", "ref_dec_pcm_info", "ref_dec_hashes"):
             getattr(_lib, n).restype = None
         _lib.ref_dec_next.argtypes = [C.c_void_p]
         _lib.ref_dec_filter_step.argtypes = [C.c_void_p]
@@ -39,6 +39,7 @@ def lib():
         _lib.ref_dec_tile_idx.argtypes = [C.c_void_p, C.c_void_p]
         _lib.ref_dec_pcm.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         _lib.ref_dec_pcm_info.argtypes = [C.c_void_p, C.c_void_p]
+        _lib.ref_dec_hashes.argtypes = [C.c_void_p, C.c_void_p]
         _lib.ref_dec_coeffs.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         _lib.ref_dec_planes.argtypes = [C.c_void_p] + [C.c_void_p] * 3
         _lib.ref_dec_dpb_planes.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 3
@@ -196,6 +197,11 @@ class RefDecoder:
 
     def filter_step(self):
         return int(lib().ref_dec_filter_step(self._h))
+
+    def hashes(self):
+        a = np.zeros(18, dtype=np.uint8)
+        lib().ref_dec_hashes(self._h, _p(a))
+        return a[:6].copy(), a[6:].copy()
 
     def finish(self):
         md5 = np.zeros(48, dtype=np.uint8)

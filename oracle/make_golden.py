@@ -196,6 +196,7 @@ def dump_stream(name, bitstream, enc_rec, geom):
         fin = dec.planes(info)
         for c, p in enumerate(fin):
             out[k + "fin%d" % c] = p
+        out[k + "crc"], out[k + "checksum"] = dec.hashes()
         ok, md5 = dec.finish()
         assert ok, "HM hash mismatch in %s pic %d" % (name, len(pics))
         out[k + "md5"] = md5

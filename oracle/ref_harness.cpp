@@ -493,6 +493,18 @@ int ref_dec_filter_step(void* h)
  * executeLoopFilters (list sort, CU decoder teardown).  Returns 1 if the SEI hash matched or none,
  * 0 on mismatch.  md5[16] receives the MD5 of plane `comp` bytes the way TComPicYuvMD5 computes it
  * (calcMD5, TComPicYuvMD5.cpp:183): 48 bytes = 3 planes x 16.                                        */
+/* the two other picture hashes of the decoded-picture-hash SEI (TComPicYuvMD5.cpp:89-170) on the finished picture:
+ * out[0..5] CRC (2 bytes per component), out[6..17] checksum (4 bytes per component).  Call after both filter steps. */
+void ref_dec_hashes(void* h, uint8_t* out)
+{
+  RefDec* d = (RefDec*)h; TComPic* p = cur(d);
+  TComDigest dig;
+  calcCRC(*p->getPicYuvRec(), dig);
+  for (size_t i = 0; i < 6 && i < dig.hash.size(); i++) out[i] = dig.hash[i];
+  calcChecksum(*p->getPicYuvRec(), dig);
+  for (size_t i = 0; i < 12 && i < dig.hash.size(); i++) out[6 + i] = dig.hash[i];
+}
+
 int ref_dec_finish(void* h, uint8_t* md5out)
 {
   RefDec* d = (RefDec*)h; TComPic* p = cur(d);

@@ -89,6 +89,8 @@ class Picture:
         self.dbk = [z[k + "dbk%d" % c] for c in range(3)]
         self.fin = [z[k + "fin%d" % c] for c in range(3)]
         self.md5 = bytes(z[k + "md5"])
+        self.crc = z[k + "crc"]              # decoded-picture-hash CRC (6 bytes) and checksum (12 bytes), TComPicYuvMD5.cpp
+        self.checksum = z[k + "checksum"]
         self.pp = abi.make_pic_params(sao_enabled=self.use_sao, lf_across_tiles=self.lf_across_tiles)
 
     def inter_mask(self, comp):

@@ -70,3 +70,34 @@ def test_single_call_filter_picture_matches_hm(name):
         ctx.decompress_slice(h, 0, p.slices[0], p.meta, p.coeffs)
         check(ctx, h, p)
     _run_stream(name, check2)
+
+
+@pytest.mark.parametrize("name", gu.STREAMS)
+def test_device_hash_and_packed_output_match_hm(name):
+    """f-4: the decoded-picture-hash check (CRC, checksum) and the output packing (8/16-bit, conformance window) happen on the
+    device; the hashes are the ones HM computed, the packed planes are HM's planes cropped (TVideoIOYuv.cpp:706-790)"""
+    import libhm_amd
+    def check(ctx, h, p):
+        ctx.upload(h, [np.full_like(a, 77) for a in p.pre])
+        ctx.decompress_slice(h, 0, p.slices[0], p.meta, p.coeffs)
+        ctx.filter_picture(h, p.pp, p.sao_raw)
+        assert np.array_equal(ctx.picture_hash(h, 2), p.crc), "%s pic %d CRC" % (name, p.index)
+        assert np.array_equal(ctx.picture_hash(h, 3), p.checksum), "%s pic %d checksum" % (name, p.index)
+        with pytest.raises(libhm_amd.HmgpuError) as e:
+            ctx.picture_hash(h, 1)                                   # MD5 stays with the host
+        assert e.value.status == abi.HMGPU_EUNSUPPORTED
+        nbytes = 1 if p.bd_y <= 8 else 2
+        for crop in [(0, 0, 0, 0), (2, 6, 4, 8)]:
+            l, r, t, b = crop
+            got = ctx.download_packed(h, nbytes, crop)
+            for c in range(3):
+                s = 1 if c else 0
+                want = p.fin[c][t >> s:p.fin[c].shape[0] - (b >> s), l >> s:p.fin[c].shape[1] - (r >> s)]
+                assert got[c].dtype == (np.uint8 if nbytes == 1 else np.uint16)
+                assert np.array_equal(got[c].astype(np.int16), want), "%s pic %d comp %d crop %s" % (name, p.index, c, crop)
+        if nbytes == 1:                                              # is16bit output of an 8-bit picture (file bit depth > 8)
+            wide = ctx.download_packed(h, 2)
+            assert all(np.array_equal(wide[c].astype(np.int16), p.fin[c]) for c in range(3))
+        with pytest.raises(libhm_amd.HmgpuError):
+            ctx.download_packed(h, 1, (1, 0, 0, 0))                  # odd window in 4:2:0
+    _run_stream(name, check)

@@ -76,3 +76,14 @@ def test_sao_matches_hm(oracle, name):
         # the reference's own self check (TDecGop.cpp:199-208): MD5 of the final planes
         assert gu.hm_md5(out, [p.bd_y, p.bd_c, p.bd_c]) == p.md5
     assert any_sao or "lossless" in name            # (lossless CUs get their reconstruction back after SAO: nothing may change)
+
+
+@pytest.mark.parametrize("name", gu.STREAMS)
+def test_picture_hashes_match_hm(name):
+    """the oracle's CRC / checksum restatement (TComPicYuvMD5.cpp:89-170) against the values HM computed for its own
+    output pictures -- the pin for the device hashes of the GPU suite"""
+    from oracle import hmoracle
+    for p in gu.stream_pictures(name):
+        crc, chk = hmoracle.plane_hashes(p.fin, [p.bd_y, p.bd_c, p.bd_c])
+        assert np.array_equal(crc, p.crc), "%s pic %d CRC" % (name, p.index)
+        assert np.array_equal(chk, p.checksum), "%s pic %d checksum" % (name, p.index)
