@@ -1,7 +1,7 @@
 // k_out.hip -- the output side of a finished picture: sample packing for the application and the
 // decoded-picture-hash check without moving the picture.
 //   TVideoIOYuv::write / writePlane (TVideoIOYuv.cpp:362-480, 706-790): 8- or 16-bit samples, cropped to the conformance window
-//   calcCRC / calcChecksum (TComPicYuvMD5.cpp:89-170)
+//   compCRC / compChecksum (TComPicYuvMD5.cpp:87-125, 139-163)
 #include "hmgpu_dev.h"
 
 namespace hmgpu {
@@ -56,7 +56,7 @@ __global__ void __launch_bounds__(256) k_crc_rows(const int16_t* __restrict__ sr
   const int16_t* s = src + (ptrdiff_t)y * pitch;
   for (int x = 0; x < w; x++) {
     const uint32_t v = (uint16_t)ldg(s + x);
-    crc = crc_byte(crc, v & 0xff);                          // HM feeds the low byte first, then the high byte (:102-118)
+    crc = crc_byte(crc, v & 0xff);                          // HM feeds the low byte first, then the high byte (:95-115)
     if (bd > 8) crc = crc_byte(crc, v >> 8);
   }
   rows[y] = crc;

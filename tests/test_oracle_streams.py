@@ -80,7 +80,7 @@ def test_sao_matches_hm(oracle, name):
 
 @pytest.mark.parametrize("name", gu.STREAMS)
 def test_picture_hashes_match_hm(name):
-    """the oracle's CRC / checksum restatement (TComPicYuvMD5.cpp:89-170) against the values HM computed for its own
+    """the oracle's CRC / checksum restatement (TComPicYuvMD5.cpp:87-181) against the values HM computed for its own
     output pictures -- the pin for the device hashes of the GPU suite"""
     from oracle import hmoracle
     for p in gu.stream_pictures(name):
