@@ -209,6 +209,13 @@ hmgpu_status hmgpu_decompress_slice(hmgpu_ctx* ctx, hmgpu_pic cur, int32_t slice
                                     const hmgpu_ctu_meta* meta, const hmgpu_coeffs* coeffs,
                                     int32_t first_ctu, int32_t num_ctus);
 
+/* The same for a whole picture at once: every slice's constants first, then all CTUs in one batch of launches (meta->slice_idx
+ * says which slice a CTU belongs to; required when num_slices > 1).  For callers that hold a complete parsed picture -- a decoder
+ * that parses ahead of reconstruction, as libhmdec does -- and for pictures whose slices are not contiguous CTU ranges in raster
+ * order (slices and tiles combined).  Equivalent to the hmgpu_decompress_slice calls of all slices. */
+hmgpu_status hmgpu_decompress_picture(hmgpu_ctx* ctx, hmgpu_pic cur, int32_t num_slices, const hmgpu_slice_params* const* slices,
+                                      const hmgpu_ctu_meta* meta, const hmgpu_coeffs* coeffs);
+
 /* ------------------------------------------------------------------------------------------------ call 2
  * Replaces TDecGop::filterPicture (TDecGop.cpp:157-217): TComLoopFilter::loopFilterPic (all vertical edges, then
  * all horizontal edges), then reconstructBlkSAOParams + SAOProcess.  Uses the metadata of every CTU handed to

@@ -50,5 +50,27 @@ def build(force=False, verbose=False):
     return OUT
 
 
+DEC = os.path.join(HERE, "dec")
+DEC_OUT = os.path.join(HERE, "libhmdec.so")
+DEC_SOURCES = ["params.cpp", "cabac.cpp", "slice_decoder.cpp", "decoder.cpp", "facade.cpp"]
+
+
+def build_decoder(force=False, verbose=False):
+    """libhm_amd/libhmdec.so: the host parser + libHMDecoder-compatible interface (plain C++, links libhmgpu.so)."""
+    gpu = build(force=False, verbose=verbose)
+    cxx = os.environ.get("CXX", "g++")
+    srcs = [os.path.join(DEC, f) for f in DEC_SOURCES]
+    deps = srcs + [os.path.join(DEC, f) for f in os.listdir(DEC) if f.endswith(".h")] + [
+        os.path.join(os.path.dirname(HERE), "include", "hmgpu.h"), os.path.join(os.path.dirname(HERE), "include", "hmdec.h"), gpu]
+    if force or _stale(DEC_OUT, deps):
+        cmd = [cxx, "-std=c++17", "-O2", "-fPIC", "-shared", "-Wall", "-o", DEC_OUT] + srcs + [
+            "-L" + HERE, "-lhmgpu", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath,/opt/rocm/lib"]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    return DEC_OUT
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
+    print(build_decoder(force="--force" in sys.argv, verbose=True))

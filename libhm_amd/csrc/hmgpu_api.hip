@@ -597,35 +597,17 @@ hmgpu_status hmgpu_picture_commit_received(hmgpu_ctx* c, hmgpu_pic pic) {
 
 void* hmgpu_stream(hmgpu_ctx* c) { return c ? (void*)c->stream : nullptr; }
 
-hmgpu_status hmgpu_decompress_slice(hmgpu_ctx* c, hmgpu_pic cur, int32_t slice_idx, const hmgpu_slice_params* sl,
-                                    const hmgpu_ctu_meta* m, const hmgpu_coeffs* co, int32_t first_ctu, int32_t num_ctus) {
-  if (!c || !valid_pic(c, cur) || !sl || !m || !co) return HMGPU_EINVAL;
-  if (slice_idx < 0 || slice_idx >= HMGPU_MAX_SLICES) return HMGPU_EINVAL;
-  if (first_ctu < 0 || num_ctus <= 0 || first_ctu + num_ctus > c->num_ctus) return HMGPU_EINVAL;
-  if (!m->depth || !m->part_size || !m->pred_mode || !m->qp || !m->tr_idx || !m->cbf[0] || !m->cbf[1] || !m->cbf[2] ||
-      !m->mv[0] || !m->mv[1] || !m->ref_idx[0] || !m->ref_idx[1] || !co->level[0] || !co->level[1] || !co->level[2])
-    return HMGPU_EINVAL;
+// slice table entry of one slice (validation, SliceDev, scaling lists): the part of a slice call that does not depend on CTUs
+static hmgpu_status register_slice(hmgpu_ctx* c, hmgpu_pic cur, int32_t slice_idx, const hmgpu_slice_params* sl) {
+  if (slice_idx < 0 || slice_idx >= HMGPU_MAX_SLICES || !sl) return HMGPU_EINVAL;
   if (sl->weighted_pred && (sl->wp_log2_denom[0] < 0 || sl->wp_log2_denom[0] > 7 || sl->wp_log2_denom[1] < 0 || sl->wp_log2_denom[1] > 7)) return HMGPU_EINVAL;
   Picture& p = c->pics[cur];
-  if (p.sao_applied) {                 // picture buffer decoded again without release/acquire: reconstruction planes again
-    p.sao_applied = false; p.dev.sao_applied = 0;
-    hmgpu_status st = push_final(c, cur);
-    if (st != HMGPU_OK) return st;
-  }
-  const size_t po = (size_t)first_ctu * c->parts, pn = (size_t)num_ctus * c->parts;
-  // tools outside the envelope: lossless / PCM CUs
-  const bool any_pcm = m->ipcm && memchr(m->ipcm + po, 1, pn) != nullptr;
-  const bool any_bypass = m->transquant_bypass && memchr(m->transquant_bypass + po, 1, pn) != nullptr;
-  if (any_pcm && (!co->pcm_sample[0] || !co->pcm_sample[1] || !co->pcm_sample[2] || !m->intra_dir[0])) return HMGPU_EINVAL;
-  if (any_pcm && (c->seq.pcm_bit_depth_luma < 1 || c->seq.pcm_bit_depth_luma > c->seq.bit_depth_luma ||
-                  c->seq.pcm_bit_depth_chroma < 1 || c->seq.pcm_bit_depth_chroma > c->seq.bit_depth_chroma)) return HMGPU_EINVAL;
   // reference pictures must be live device pictures
   for (int l = 0; l < 2; l++) {
     if (sl->num_ref_idx[l] < 0 || sl->num_ref_idx[l] > HMGPU_MAX_REF) return HMGPU_EINVAL;
     for (int i = 0; i < sl->num_ref_idx[l]; i++) if (!valid_pic(c, sl->ref_pic[l][i]) || sl->ref_pic[l][i] == cur) return HMGPU_EINVAL;
   }
   hipSetDevice(c->device);
-  // ---- slice table entry
   SliceDev sd;
   memset(&sd, 0, sizeof(sd));
   sd.slice_type = sl->slice_type; sd.cb_qp_offset = sl->cb_qp_offset; sd.cr_qp_offset = sl->cr_qp_offset;
@@ -645,7 +627,6 @@ hmgpu_status hmgpu_decompress_slice(hmgpu_ctx* c, hmgpu_pic cur, int32_t slice_i
   p.slices[slice_idx] = sd;
   p.max_slice = std::max(p.max_slice, (int)slice_idx);
   p.dev.lf_across_tiles = sl->lf_across_tiles;
-  p.dev.has_intra_dir = (m->intra_dir[0] && m->intra_dir[1]) ? 1 : 0;      // without the modes intra CUs are left untouched
   p.dev.sl_m = nullptr;
   if (sl->scaling_lists) {
     // xSetScalingListDec / processScalingListDec (TComTrQuant.cpp:2992-3012, 3092-3106) without the per-QP factor: m per position
@@ -665,9 +646,26 @@ hmgpu_status hmgpu_decompress_slice(hmgpu_ctx* c, hmgpu_pic cur, int32_t slice_i
     HIP_TRY(c, hipMemcpyAsync(p.sl_table, p.sl_host.data(), p.sl_host.size(), hipMemcpyHostToDevice, c->stream));
     p.dev.sl_m = p.sl_table;
   }
+  HIP_TRY(c, hipMemcpyAsync((void*)(p.dev.slices + slice_idx), &p.slices[slice_idx], sizeof(SliceDev), hipMemcpyHostToDevice, c->stream));
+  return HMGPU_OK;
+}
+
+// HM arrays of a CTU range to the device, then the reconstruction kernels over the range.  `slices` lists the slice table entries
+// whose reference pictures the range may read (their borders must be extended first); slice_idx is the one a missing
+// meta->slice_idx array stands for.
+static hmgpu_status stage_and_run(hmgpu_ctx* c, hmgpu_pic cur, int32_t slice_idx, const std::vector<int>& slices, bool any_wp,
+                                  const hmgpu_ctu_meta* m, const hmgpu_coeffs* co, int32_t first_ctu, int32_t num_ctus) {
+  Picture& p = c->pics[cur];
+  const size_t po = (size_t)first_ctu * c->parts, pn = (size_t)num_ctus * c->parts;
+  // lossless / PCM CUs need their own inputs
+  const bool any_pcm = m->ipcm && memchr(m->ipcm + po, 1, pn) != nullptr;
+  const bool any_bypass = m->transquant_bypass && memchr(m->transquant_bypass + po, 1, pn) != nullptr;
+  if (any_pcm && (!co->pcm_sample[0] || !co->pcm_sample[1] || !co->pcm_sample[2] || !m->intra_dir[0])) return HMGPU_EINVAL;
+  if (any_pcm && (c->seq.pcm_bit_depth_luma < 1 || c->seq.pcm_bit_depth_luma > c->seq.bit_depth_luma ||
+                  c->seq.pcm_bit_depth_chroma < 1 || c->seq.pcm_bit_depth_chroma > c->seq.bit_depth_chroma)) return HMGPU_EINVAL;
+  p.dev.has_intra_dir = (m->intra_dir[0] && m->intra_dir[1]) ? 1 : 0;      // without the modes intra CUs are left untouched
   {
     ProfScope ps(c, K_H2D);
-    HIP_TRY(c, hipMemcpyAsync((void*)(p.dev.slices + slice_idx), &p.slices[slice_idx], sizeof(SliceDev), hipMemcpyHostToDevice, c->stream));
     // ---- HM arrays of the CTU range (field-by-field, exactly the arrays TComDataCU owns)
 #define STAGE(dst, src, elem_bytes)                                                                                       \
     if (src) HIP_TRY(c, hipMemcpyAsync((char*)(dst) + po * (elem_bytes), (const char*)(src) + po * (elem_bytes), pn * (elem_bytes), \
@@ -718,15 +716,60 @@ hmgpu_status hmgpu_decompress_slice(hmgpu_ctx* c, hmgpu_pic cur, int32_t slice_i
                   return o.first_ctu < first_ctu + num_ctus && first_ctu < o.first_ctu + o.num_ctus; }), p.calls.end());
   // the caller's arrays are at hand: whether the range holds intra CUs at all decides if the intra kernel is launched
   const bool has_intra = p.dev.has_intra_dir && memchr(m->pred_mode + po, HMGPU_MODE_INTRA, pn) != nullptr;
-  SliceCall call = {first_ctu, num_ctus, slice_idx, has_intra, sl->weighted_pred != 0};
+  SliceCall call = {first_ctu, num_ctus, slice_idx, has_intra, any_wp};
   p.calls.push_back(call);
 
   Batch b; memset(&b, 0, sizeof(b));
   b.n = 1; b.pic[0] = cur; b.first_ctu[0] = first_ctu; b.num_ctus[0] = num_ctus;
   p.extended = false;
-  hmgpu_status st = ensure_refs_extended(c, b, p.calls.size() - 1);
+  for (int si : slices) {
+    const SliceDev& sd = p.slices[si];
+    for (int l = 0; l < 2; l++)
+      for (int r = 0; r < HMGPU_MAX_REF; r++)
+        if (sd.ref_pic[l][r] >= 0) { hmgpu_status st = ensure_extended(c, sd.ref_pic[l][r]); if (st != HMGPU_OK) return st; }
+  }
+  return run_recon(c, b, has_intra, any_wp);
+}
+
+static bool meta_complete(const hmgpu_ctu_meta* m, const hmgpu_coeffs* co) {
+  return m && co && m->depth && m->part_size && m->pred_mode && m->qp && m->tr_idx && m->cbf[0] && m->cbf[1] && m->cbf[2] && m->mv[0] &&
+         m->mv[1] && m->ref_idx[0] && m->ref_idx[1] && co->level[0] && co->level[1] && co->level[2];
+}
+
+static hmgpu_status reopen_picture(hmgpu_ctx* c, hmgpu_pic cur) {
+  Picture& p = c->pics[cur];
+  if (p.sao_applied) {                 // picture buffer decoded again without release/acquire: reconstruction planes again
+    p.sao_applied = false; p.dev.sao_applied = 0;
+    return push_final(c, cur);
+  }
+  return HMGPU_OK;
+}
+
+hmgpu_status hmgpu_decompress_slice(hmgpu_ctx* c, hmgpu_pic cur, int32_t slice_idx, const hmgpu_slice_params* sl,
+                                    const hmgpu_ctu_meta* m, const hmgpu_coeffs* co, int32_t first_ctu, int32_t num_ctus) {
+  if (!c || !valid_pic(c, cur) || !sl || !meta_complete(m, co)) return HMGPU_EINVAL;
+  if (first_ctu < 0 || num_ctus <= 0 || first_ctu + num_ctus > c->num_ctus) return HMGPU_EINVAL;
+  hmgpu_status st = reopen_picture(c, cur);
+  if (st == HMGPU_OK) st = register_slice(c, cur, slice_idx, sl);
   if (st != HMGPU_OK) return st;
-  return run_recon(c, b, has_intra, sl->weighted_pred != 0);
+  return stage_and_run(c, cur, slice_idx, std::vector<int>{slice_idx}, sl->weighted_pred != 0, m, co, first_ctu, num_ctus);
+}
+
+hmgpu_status hmgpu_decompress_picture(hmgpu_ctx* c, hmgpu_pic cur, int32_t num_slices, const hmgpu_slice_params* const* slices,
+                                      const hmgpu_ctu_meta* m, const hmgpu_coeffs* co) {
+  if (!c || !valid_pic(c, cur) || !slices || num_slices < 1 || num_slices > HMGPU_MAX_SLICES || !meta_complete(m, co)) return HMGPU_EINVAL;
+  if (num_slices > 1 && !m->slice_idx) return HMGPU_EINVAL;
+  if (m->slice_idx) for (int i = 0; i < c->num_ctus; i++) if (m->slice_idx[i] >= num_slices) return HMGPU_EINVAL;
+  hmgpu_status st = reopen_picture(c, cur);
+  std::vector<int> all;
+  bool any_wp = false;
+  for (int i = 0; i < num_slices && st == HMGPU_OK; i++) {
+    st = register_slice(c, cur, i, slices[i]);
+    all.push_back(i);
+    any_wp |= slices[i] && slices[i]->weighted_pred != 0;
+  }
+  if (st != HMGPU_OK) return st;
+  return stage_and_run(c, cur, 0, all, any_wp, m, co, 0, c->num_ctus);
 }
 
 hmgpu_status hmgpu_filter_picture_stages(hmgpu_ctx* c, hmgpu_pic cur, const hmgpu_pic_params* pp, const hmgpu_sao_param* sao,

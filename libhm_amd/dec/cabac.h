@@ -1,0 +1,122 @@
+// cabac.h -- CABAC parsing process of Rec. ITU-T H.265 9.3: arithmetic decoding engine (9.3.4.3), context variables and their
+// initialisation (9.3.2.2, Tables 9-5 ... 9-37).  HM counterpart: TDecBinCoderCABAC.cpp, ContextModel.cpp, ContextTables.h.
+// The engine is the specification's own formulation: a 9-bit offset register refilled bit by bit from a position counter, so the
+// places where the syntax goes back to plain bits (pcm_sample, byte_alignment after end_of_subset_one_bit) need no rewinding.
+#pragma once
+#include <cstdint>
+#include <cstring>
+
+#include "bitreader.h"
+
+namespace hmdec {
+
+// context variable ranges inside the flat table (ctxIdx offsets; counts as in 9.3.4.2)
+enum Ctx {
+  CTX_SAO_MERGE = 0,                        // 1
+  CTX_SAO_TYPE = CTX_SAO_MERGE + 1,         // 1
+  CTX_SPLIT_CU = CTX_SAO_TYPE + 1,          // 3
+  CTX_TQ_BYPASS = CTX_SPLIT_CU + 3,         // 1
+  CTX_SKIP = CTX_TQ_BYPASS + 1,             // 3
+  CTX_PRED_MODE = CTX_SKIP + 3,             // 1
+  CTX_PART_MODE = CTX_PRED_MODE + 1,        // 4
+  CTX_PREV_INTRA = CTX_PART_MODE + 4,       // 1
+  CTX_CHROMA_MODE = CTX_PREV_INTRA + 1,     // 1
+  CTX_ROOT_CBF = CTX_CHROMA_MODE + 1,       // 1
+  CTX_MERGE_FLAG = CTX_ROOT_CBF + 1,        // 1
+  CTX_MERGE_IDX = CTX_MERGE_FLAG + 1,       // 1
+  CTX_INTER_DIR = CTX_MERGE_IDX + 1,        // 5
+  CTX_REF_IDX = CTX_INTER_DIR + 5,          // 2
+  CTX_MVP = CTX_REF_IDX + 2,                // 1
+  CTX_SPLIT_TU = CTX_MVP + 1,               // 3
+  CTX_CBF_LUMA = CTX_SPLIT_TU + 3,          // 2
+  CTX_CBF_CHROMA = CTX_CBF_LUMA + 2,        // 4
+  CTX_MVD_GT0 = CTX_CBF_CHROMA + 4,         // 1
+  CTX_MVD_GT1 = CTX_MVD_GT0 + 1,            // 1
+  CTX_QP_DELTA = CTX_MVD_GT1 + 1,           // 2
+  CTX_TS_FLAG = CTX_QP_DELTA + 2,           // 2 (luma, chroma)
+  CTX_LAST_X = CTX_TS_FLAG + 2,             // 18
+  CTX_LAST_Y = CTX_LAST_X + 18,             // 18
+  CTX_CSBF = CTX_LAST_Y + 18,               // 4
+  CTX_SIG = CTX_CSBF + 4,                   // 42
+  CTX_GT1 = CTX_SIG + 42,                   // 24
+  CTX_GT2 = CTX_GT1 + 24,                   // 6
+  CTX_COUNT = CTX_GT2 + 6
+};
+
+struct ContextSet {
+  uint8_t s[CTX_COUNT];                     // (pStateIdx << 1) | valMps
+  void init(int init_type, int slice_qp);   // 9.3.2.2
+};
+
+class Cabac {
+ public:
+  void attach(const uint8_t* rbsp, size_t bytes) { p_ = rbsp; nbits_ = bytes * 8; }
+  size_t bit_pos() const { return pos_; }
+  // 9.3.2.5: initialisation of the arithmetic decoding engine at a byte-aligned position
+  void start(size_t bit_pos) {
+    pos_ = bit_pos;
+    range_ = 510;
+    offset_ = get(9);
+  }
+  int decision(uint8_t& ctx) {
+    const unsigned state = ctx >> 1, mps = ctx & 1;
+    const unsigned lps = kRangeLps[state][(range_ >> 6) & 3];
+    range_ -= lps;
+    int bin;
+    if (offset_ >= range_) {
+      offset_ -= range_;
+      range_ = lps;
+      bin = mps ^ 1;
+      ctx = (uint8_t)((kNextLps[state] << 1) | (state == 0 ? mps ^ 1 : mps));
+    } else {
+      bin = mps;
+      ctx = (uint8_t)((kNextMps[state] << 1) | mps);
+      if (range_ >= 256) return bin;
+    }
+    const int n = __builtin_clz(range_) - 23;       // shifts until bit 8 is set
+    range_ <<= n;
+    offset_ = (offset_ << n) | get(n);
+    return bin;
+  }
+  int bypass() {
+    offset_ = (offset_ << 1) | get(1);
+    if (offset_ >= range_) { offset_ -= range_; return 1; }
+    return 0;
+  }
+  unsigned bypass_bits(int n) {
+    unsigned v = 0;
+    while (n-- > 0) v = (v << 1) | (unsigned)bypass();
+    return v;
+  }
+  // 9.3.4.3.5; when the result is 1 the engine is finished: call finish_to_byte() before reading plain bits or restarting
+  int terminate() {
+    range_ -= 2;
+    if (offset_ >= range_) return 1;
+    if (range_ < 256) { range_ <<= 1; offset_ = (offset_ << 1) | get(1); }
+    return 0;
+  }
+  // After a terminating bin equal to 1 the engine has read exactly up to and including the 1 bit that rbsp_trailing_bits() /
+  // byte_alignment() start with (the encoder's flush, 9.3.4.5, writes it as its last bit; the first bit the encoder would have
+  // put out is suppressed, which is what makes the 9-bit window end there).  What follows are zero bits up to the byte boundary;
+  // pcm_sample data or the next sub-stream start at that boundary.
+  void finish_to_byte() {
+    if (pos_ == 0 || pos_ > nbits_ || !((p_[(pos_ - 1) >> 3] >> (7 - ((pos_ - 1) & 7))) & 1)) throw ParseError("CABAC: no stop bit behind a terminating bin");
+    while (pos_ & 7) if (get(1)) throw ParseError("CABAC: alignment bits are not zero");
+  }
+  unsigned plain_bits(int n) { return get(n); }     // pcm_sample_*: read_bits(n) between finish_to_byte() and start()
+
+ private:
+  unsigned get(int n) {
+    unsigned v = 0;
+    for (; n > 0; n--, pos_++) v = (v << 1) | (pos_ < nbits_ ? (p_[pos_ >> 3] >> (7 - (pos_ & 7))) & 1u : 0u);
+    if (pos_ > nbits_ + 64) throw ParseError("CABAC: read far past the end of the slice data");
+    return v;
+  }
+  const uint8_t* p_ = nullptr;
+  size_t nbits_ = 0, pos_ = 0;
+  unsigned range_ = 510, offset_ = 0;
+  static const uint8_t kRangeLps[64][4];
+  static const uint8_t kNextLps[64], kNextMps[64];
+};
+
+}  // namespace hmdec

@@ -1,0 +1,463 @@
+// decoder.cpp -- see decoder.h.  Clause numbers refer to Rec. ITU-T H.265.
+#include "decoder.h"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+
+#include "md5.h"
+
+namespace hmdec {
+
+static bool is_irap(int t) { return t >= NAL_BLA_W_LP && t <= NAL_RSV_IRAP_VCL23; }
+static bool is_idr(int t) { return t == NAL_IDR_W_RADL || t == NAL_IDR_N_LP; }
+static bool is_bla(int t) { return t >= NAL_BLA_W_LP && t <= NAL_BLA_N_LP; }
+static bool is_rasl(int t) { return t == NAL_RASL_N || t == NAL_RASL_R; }
+static bool is_radl(int t) { return t == NAL_RADL_N || t == NAL_RADL_R; }
+static bool is_sub_layer_non_ref(int t) { return t < 16 && (t & 1) == 0; }
+
+Decoder::Decoder() { memset(pending_hash_val_, 0, sizeof(pending_hash_val_)); }
+
+Decoder::~Decoder() {
+  if (gpu_) hmgpu_destroy(gpu_);
+}
+
+// ------------------------------------------------------------------------------------------------ NAL level
+bool Decoder::push(const uint8_t* d, size_t len, int max_tl, int* nal_type_out) {
+  if (len >= 3 && d[0] == 0 && d[1] == 0 && d[2] == 1) { d += 3; len -= 3; }
+  else if (len >= 4 && d[0] == 0 && d[1] == 0 && d[2] == 0 && d[3] == 1) { d += 4; len -= 4; }
+  if (len < 2) throw ParseError("NAL unit shorter than its header");
+  if (d[0] & 0x80) throw ParseError("forbidden_zero_bit is set");
+  const int type = (d[0] >> 1) & 0x3f, layer = ((d[0] & 1) << 5) | (d[1] >> 3), tid = (d[1] & 7) - 1;
+  if (nal_type_out) *nal_type_out = type;
+  if (tid < 0) throw ParseError("nuh_temporal_id_plus1 is zero");
+  if (layer != 0 || (max_tl >= 0 && tid > max_tl)) return false;
+  for (auto& p : pool_) p->lent = false;
+  if (type <= NAL_RASL_R || (type >= NAL_BLA_W_LP && type <= NAL_CRA)) {
+    if (len < 3) throw ParseError("slice NAL unit without payload");
+    if ((d[2] & 0x80) && cur_) {           // first_slice_segment_in_pic_flag while a picture is open: close it, unit comes again
+      finish_picture();
+      return true;
+    }
+    std::vector<uint8_t> rbsp = nal_to_rbsp(d + 2, len - 2);
+    BitReader br(rbsp.data(), rbsp.size());
+    SliceHeader sh;
+    parse_slice_header(br, type, tid, ps_, have_independent_ ? &last_independent_ : nullptr, sh);
+    decode_slice(rbsp, br, sh);
+    return false;
+  }
+  std::vector<uint8_t> rbsp = nal_to_rbsp(d + 2, len - 2);
+  BitReader br(rbsp.data(), rbsp.size());
+  switch (type) {
+    case NAL_VPS: { auto v = parse_vps(br); ps_.vps[v->id] = v; break; }
+    case NAL_SPS: { auto s = parse_sps(br); ps_.sps[s->id] = s; break; }
+    case NAL_PPS: { auto p = parse_pps(br); ps_.pps[p->id] = p; break; }
+    case NAL_PREFIX_SEI: parse_sei(rbsp, false); break;
+    case NAL_SUFFIX_SEI: parse_sei(rbsp, true); break;
+    case NAL_EOS:
+      finish_picture();
+      after_eos_ = true;
+      break;
+    default: break;                        // AUD, EOB, filler data, reserved and unspecified types carry nothing to decode
+  }
+  return false;
+}
+
+// D.2.1 sei_message(); only the decoded picture hash (D.2.19, payloadType 132) is of interest
+void Decoder::parse_sei(const std::vector<uint8_t>& rbsp, bool suffix) {
+  BitReader br(rbsp.data(), rbsp.size());
+  while (br.more_rbsp_data()) {
+    int type = 0, size = 0;
+    for (;;) { const int b = br.u(8); type += b; if (b != 255) break; }
+    for (;;) { const int b = br.u(8); size += b; if (b != 255) break; }
+    const size_t end = br.pos() + 8 * (size_t)size;
+    if (end > br.size_bits()) throw ParseError("SEI payload runs past the NAL unit");
+    if (suffix && type == 132 && size >= 1) {
+      const int hash_type = br.u(8);
+      const int bytes = hash_type == 0 ? 16 : hash_type == 1 ? 2 : hash_type == 2 ? 4 : 0;
+      if (bytes && size >= 1 + 3 * bytes) {
+        memset(pending_hash_val_, 0, sizeof(pending_hash_val_));
+        for (int c = 0; c < 3; c++) for (int i = 0; i < bytes; i++) pending_hash_val_[c][i] = (uint8_t)br.u(8);
+        pending_hash_method_ = hash_type + 1;
+        pending_hash_ = true;
+        if (cur_) {                        // the SEI follows the slices of the picture it describes
+          memcpy(cur_->sei_hash, pending_hash_val_, sizeof(pending_hash_val_));
+          cur_->sei_hash_method = pending_hash_method_;
+          pending_hash_ = false;
+        }
+      }
+    }
+    br.skip(end - br.pos());
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ picture level
+void Decoder::activate(const SliceHeader& sh) {
+  std::shared_ptr<Pps> pps = ps_.pps[sh.pps_id];
+  std::shared_ptr<Sps> sps = ps_.sps[pps->sps_id];
+  const bool new_seq = !sps_ || sps_->width != sps->width || sps_->height != sps->height || sps_->log2_ctb != sps->log2_ctb ||
+                       sps_->bit_depth_luma != sps->bit_depth_luma || sps_->bit_depth_chroma != sps->bit_depth_chroma || sps_->pcm != sps->pcm ||
+                       sps_->pcm_bit_depth_luma != sps->pcm_bit_depth_luma || sps_->pcm_bit_depth_chroma != sps->pcm_bit_depth_chroma ||
+                       sps_->pcm_loop_filter_disabled != sps->pcm_loop_filter_disabled || sps_->strong_intra_smoothing != sps->strong_intra_smoothing ||
+                       sps_->max_dec_pic_buffering[sps_->max_sub_layers - 1] != sps->max_dec_pic_buffering[sps->max_sub_layers - 1];
+  sps_ = sps;
+  pps_ = pps;
+  pps_->derive_tiles(*sps_);
+  if (!new_seq) return;
+  if (!is_irap(sh.nal_type)) throw ParseError("a new sequence parameter set is activated by a picture that is not an IRAP picture");
+  // a new coded video sequence with another geometry: the picture store starts over (pictures not yet output are dropped)
+  pool_.clear();
+  if (gpu_) { hmgpu_destroy(gpu_); gpu_ = nullptr; }
+  zscan_.init(sps_->log2_ctb);
+  memset(&seq_, 0, sizeof(seq_));
+  seq_.width = sps_->width;
+  seq_.height = sps_->height;
+  seq_.bit_depth_luma = sps_->bit_depth_luma;
+  seq_.bit_depth_chroma = sps_->bit_depth_chroma;
+  seq_.chroma_format = 1;
+  seq_.log2_ctu_size = sps_->log2_ctb;
+  seq_.max_pictures = std::min(20, sps_->max_dec_pic_buffering[sps_->max_sub_layers - 1] + 3);
+  seq_.pcm_loop_filter_disable = sps_->pcm && sps_->pcm_loop_filter_disabled;
+  seq_.strong_intra_smoothing = sps_->strong_intra_smoothing;
+  seq_.pcm_bit_depth_luma = sps_->pcm_bit_depth_luma;
+  seq_.pcm_bit_depth_chroma = sps_->pcm_bit_depth_chroma;
+  if (!parse_only_) {
+    const hmgpu_status st = hmgpu_create(&seq_, device_, &gpu_);
+    if (st != HMGPU_OK) throw std::runtime_error(std::string("hmgpu_create: ") + hmgpu_status_string(st));
+  }
+}
+
+PicData* Decoder::acquire_buffer() {
+  for (auto& p : pool_)
+    if (p.get() != cur_ && !p->is_reference && !p->needed_for_output && !p->lent) {
+      if (gpu_) hmgpu_sync(gpu_);          // the device may still be reading the arrays of the picture that lived here
+      return p.get();
+    }
+  if ((int)pool_.size() >= seq_.max_pictures) throw ParseError("decoded picture buffer overflow (more pictures held than the SPS allows)");
+  pool_.emplace_back(new PicData());
+  PicData* p = pool_.back().get();
+  p->allocate(*sps_, &zscan_);
+  if (gpu_) {
+    const hmgpu_status st = hmgpu_picture_acquire(gpu_, &p->handle);
+    if (st != HMGPU_OK) throw std::runtime_error(std::string("hmgpu_picture_acquire: ") + hmgpu_status_string(st));
+  }
+  return p;
+}
+
+// 8.3.1
+int Decoder::compute_poc(const SliceHeader& sh) {
+  if (is_idr(sh.nal_type)) return 0;
+  const int max_lsb = 1 << sps_->log2_max_poc_lsb;
+  int msb = 0;
+  if (!(is_irap(sh.nal_type) && no_rasl_output_)) {
+    const int prev_lsb = prev_tid0_poc_ & (max_lsb - 1), prev_msb = prev_tid0_poc_ - prev_lsb;
+    if (sh.poc_lsb < prev_lsb && prev_lsb - sh.poc_lsb >= max_lsb / 2) msb = prev_msb + max_lsb;
+    else if (sh.poc_lsb > prev_lsb && sh.poc_lsb - prev_lsb > max_lsb / 2) msb = prev_msb - max_lsb;
+    else msb = prev_msb;
+  }
+  return msb + sh.poc_lsb;
+}
+
+PicData* Decoder::find_ref(int poc, bool lsb_only, bool any_marking) {
+  const int mask = (1 << sps_->log2_max_poc_lsb) - 1;
+  for (auto& p : pool_) {
+    if (p.get() == cur_ || !p->decoded) continue;
+    if (!p->is_reference && !any_marking) continue;
+    if (lsb_only ? (p->poc & mask) == poc : p->poc == poc) return p.get();
+  }
+  return nullptr;
+}
+
+// 8.3.2 decoding process for the reference picture set
+void Decoder::apply_rps(const SliceHeader& sh) {
+  st_before_.clear();
+  st_after_.clear();
+  lt_curr_.clear();
+  if (is_irap(sh.nal_type) && no_rasl_output_)
+    for (auto& p : pool_) if (p.get() != cur_) p->is_reference = p->is_long_term = false;
+  if (is_idr(sh.nal_type)) return;
+  const int max_lsb = 1 << sps_->log2_max_poc_lsb;
+  std::vector<PicData*> keep;
+  // long-term pictures first: a picture named as long-term must not be picked up as short-term (8.3.2)
+  std::vector<PicData*> lt_all;
+  for (int i = 0; i < sh.num_long_term; i++) {
+    int poc = sh.lt_poc[i];
+    if (sh.lt_msb_present[i]) poc += cur_->poc - sh.lt_msb_cycle[i] * max_lsb - (cur_->poc & (max_lsb - 1));
+    PicData* p = find_ref(poc, !sh.lt_msb_present[i], false);
+    if (p) { keep.push_back(p); lt_all.push_back(p); }
+    if (sh.lt_used[i]) {
+      if (!p) throw ParseError("long-term reference picture is missing from the decoded picture buffer");
+      lt_curr_.push_back(p);
+    }
+  }
+  for (int i = 0; i < sh.rps.num_delta_pocs(); i++) {
+    const int poc = cur_->poc + sh.rps.delta_poc[i];
+    PicData* p = nullptr;
+    for (auto& q : pool_)
+      if (q.get() != cur_ && q->decoded && q->is_reference && !q->is_long_term && q->poc == poc && std::find(lt_all.begin(), lt_all.end(), q.get()) == lt_all.end()) p = q.get();
+    if (p) keep.push_back(p);
+    if (sh.rps.used[i]) {
+      if (!p) throw ParseError("short-term reference picture is missing from the decoded picture buffer");
+      (i < sh.rps.num_negative ? st_before_ : st_after_).push_back(p);
+    }
+  }
+  for (PicData* p : lt_all) p->is_long_term = true;
+  for (auto& p : pool_)
+    if (p.get() != cur_ && p->is_reference && std::find(keep.begin(), keep.end(), p.get()) == keep.end()) p->is_reference = p->is_long_term = false;
+}
+
+// 8.3.4 decoding process for reference picture lists construction
+void Decoder::build_ref_lists(const SliceHeader& sh, SliceInfo& si) {
+  for (int l = 0; l < 2; l++)
+    for (int i = 0; i < 16; i++) { si.ref_pics[l][i] = nullptr; si.ref_poc[l][i] = 0; si.ref_is_lt[l][i] = false; }
+  if (sh.type == SLICE_I) return;
+  const int total = (int)(st_before_.size() + st_after_.size() + lt_curr_.size());
+  if (total == 0) throw ParseError("P or B slice with an empty reference picture set");
+  for (int l = 0; l < (sh.type == SLICE_B ? 2 : 1); l++) {
+    const std::vector<PicData*>& a = l == 0 ? st_before_ : st_after_;
+    const std::vector<PicData*>& b = l == 0 ? st_after_ : st_before_;
+    std::vector<PicData*> temp;
+    std::vector<bool> lt;
+    const int n = std::max(sh.num_ref_idx[l], total);
+    while ((int)temp.size() < n) {
+      for (size_t i = 0; i < a.size() && (int)temp.size() < n; i++) { temp.push_back(a[i]); lt.push_back(false); }
+      for (size_t i = 0; i < b.size() && (int)temp.size() < n; i++) { temp.push_back(b[i]); lt.push_back(false); }
+      for (size_t i = 0; i < lt_curr_.size() && (int)temp.size() < n; i++) { temp.push_back(lt_curr_[i]); lt.push_back(true); }
+    }
+    for (int i = 0; i < sh.num_ref_idx[l]; i++) {
+      const int k = sh.list_mod_flag[l] ? sh.list_entry[l][i] : i;
+      si.ref_pics[l][i] = temp[k];
+      si.ref_poc[l][i] = temp[k]->poc;
+      si.ref_is_lt[l][i] = lt[k];
+    }
+  }
+}
+
+// the per-slice constants of include/hmgpu.h (TComSlice getters the hot path reads)
+void Decoder::build_slice_params(const SliceHeader& sh, SliceInfo& si) {
+  hmgpu_slice_params& p = si.params;
+  memset(&p, 0, sizeof(p));
+  si.type = sh.type;
+  si.header = sh;
+  p.slice_type = sh.type;
+  p.cb_qp_offset = pps_->cb_qp_offset + sh.cb_qp_offset;
+  p.cr_qp_offset = pps_->cr_qp_offset + sh.cr_qp_offset;
+  p.pps_cb_qp_offset = pps_->cb_qp_offset;
+  p.pps_cr_qp_offset = pps_->cr_qp_offset;
+  p.deblocking_disable = sh.deblocking_disabled;
+  p.beta_offset_div2 = sh.beta_offset_div2;
+  p.tc_offset_div2 = sh.tc_offset_div2;
+  p.lf_across_slices = sh.lf_across_slices;
+  p.weighted_pred = (sh.type == SLICE_P && pps_->weighted_pred) || (sh.type == SLICE_B && pps_->weighted_bipred);
+  p.lf_across_tiles = pps_->lf_across_tiles;
+  p.constrained_intra_pred = pps_->constrained_intra_pred;
+  for (int l = 0; l < 2; l++) {
+    p.num_ref_idx[l] = sh.num_ref_idx[l];
+    for (int i = 0; i < HMGPU_MAX_REF; i++) {
+      p.ref_pic[l][i] = i < sh.num_ref_idx[l] && si.ref_pics[l][i] ? si.ref_pics[l][i]->handle : HMGPU_NO_PIC;
+      p.ref_poc[l][i] = si.ref_poc[l][i];
+    }
+  }
+  if (p.weighted_pred) {                     // TComSlice::initWpScaling (TComSlice.cpp:1476-1510): offsets at the coding bit depth
+    p.wp_log2_denom[0] = sh.luma_log2_weight_denom;
+    p.wp_log2_denom[1] = sh.chroma_log2_weight_denom;
+    for (int l = 0; l < 2; l++)
+      for (int i = 0; i < sh.num_ref_idx[l]; i++) {
+        const PredWeight& w = sh.pw[l][i];
+        p.wp_weight[l][i][0] = (int16_t)w.luma_weight;
+        p.wp_offset[l][i][0] = (int16_t)(w.luma_offset << (sps_->bit_depth_luma - 8));
+        for (int c = 0; c < 2; c++) {
+          p.wp_weight[l][i][1 + c] = (int16_t)w.chroma_weight[c];
+          p.wp_offset[l][i][1 + c] = (int16_t)(w.chroma_offset[c] << (sps_->bit_depth_chroma - 8));
+        }
+      }
+  }
+  if (sps_->scaling_list_enabled) {           // TDecTop.cpp:651-668: PPS lists, else SPS lists (explicit or default)
+    const ScalingListSet& src = pps_->scaling_list_data_present ? pps_->scaling_lists : sps_->scaling_lists;
+    si.scaling_lists.reset(new hmgpu_scaling_lists);
+    memcpy(si.scaling_lists->coef, src.coef, sizeof(src.coef));
+    memcpy(si.scaling_lists->dc, src.dc, sizeof(src.dc));
+    p.scaling_lists = si.scaling_lists.get();
+  }
+}
+
+void Decoder::start_picture(const SliceHeader& sh) {
+  cur_ = acquire_buffer();
+  cur_->reset();
+  cur_->poc = sh.poc;
+  cur_->nal_type = sh.nal_type;
+  cur_->temporal_id = sh.temporal_id;
+  cur_->is_reference = true;                 // "used for short-term reference" until a later RPS says otherwise (8.3.1 end)
+  cur_->is_long_term = false;
+  cur_->pic_output = sh.pic_output && !(is_rasl(sh.nal_type) && skip_rasl_);
+  cur_->needed_for_output = false;
+  parse_state_ = PicParseState();
+  if (pending_hash_) pending_hash_ = false;  // a hash SEI ahead of its picture does not occur (suffix SEI)
+  apply_rps(sh);
+}
+
+void Decoder::decode_slice(const std::vector<uint8_t>& rbsp, BitReader& br, SliceHeader& sh) {
+  (void)br;
+  if (sh.first_slice_segment_in_pic) {
+    // 8.1: NoRaslOutputFlag of an IRAP picture: first picture, after an end of sequence, IDR or BLA
+    if (is_irap(sh.nal_type)) {
+      no_rasl_output_ = first_picture_ || after_eos_ || is_idr(sh.nal_type) || is_bla(sh.nal_type);
+      if (no_rasl_output_) skip_rasl_ = !is_idr(sh.nal_type);
+    } else if (first_picture_ || after_eos_) {
+      return;                                // nothing decodable before the first IRAP picture (TDecTop::isRandomAccessSkipPicture)
+    }
+    activate(sh);
+    sh.poc = compute_poc(sh);
+    if (is_irap(sh.nal_type) && no_rasl_output_) poc_cra_ = sh.poc;
+    if (is_rasl(sh.nal_type) && skip_rasl_ && sh.poc < poc_cra_) { have_independent_ = false; return; }   // associated IRAP starts the stream: skipped
+    if (!is_rasl(sh.nal_type) && !is_radl(sh.nal_type) && !is_irap(sh.nal_type) && sh.poc > poc_cra_) skip_rasl_ = false;
+    first_picture_ = false;
+    after_eos_ = false;
+    start_picture(sh);
+    if (sh.temporal_id == 0 && !is_rasl(sh.nal_type) && !is_radl(sh.nal_type) && !is_sub_layer_non_ref(sh.nal_type)) prev_tid0_poc_ = sh.poc;
+  } else {
+    if (!cur_) return;                       // slice of a picture that was skipped
+    sh.poc = cur_->poc;
+  }
+  if (!sh.dependent) {
+    last_independent_ = sh;
+    have_independent_ = true;
+    if (cur_->slices.size() >= HMGPU_MAX_SLICES) throw Unsupported("more slices in a picture than the device slice table holds");
+    cur_->slices.emplace_back(new SliceInfo());
+    SliceInfo& si = *cur_->slices.back();
+    si.first_ctb_ts = pps_->ctb_rs_to_ts[sh.segment_address];
+    build_ref_lists(sh, si);
+    build_slice_params(sh, si);
+  } else if (cur_->slices.empty()) {
+    throw ParseError("dependent slice segment at the start of a picture");
+  }
+  SliceDecoder sd(*sps_, *pps_, *cur_, parse_state_);
+  sd.decode(sh, (int)cur_->slices.size() - 1, rbsp.data(), rbsp.size());
+}
+
+void Decoder::finish_picture() {
+  if (!cur_) return;
+  PicData* p = cur_;
+  if (parse_state_.next_ctb_ts < p->num_ctbs) {
+    // slices were lost: HM conceals nothing either (TDecTop.cpp:560 "Warning: ... lost"); the missing CTUs stay as they are
+    fprintf(stderr, "hmdec: POC %d is incomplete (%d of %d CTUs)\n", p->poc, parse_state_.next_ctb_ts, p->num_ctbs);
+  }
+  if (gpu_) {
+    hmgpu_ctu_meta m;
+    memset(&m, 0, sizeof(m));
+    m.depth = p->depth.data(); m.part_size = p->part_size.data(); m.pred_mode = p->pred_mode.data(); m.qp = p->qp.data();
+    m.tr_idx = p->tr_idx.data();
+    for (int c = 0; c < 3; c++) { m.cbf[c] = p->cbf[c].data(); m.transform_skip[c] = p->ts[c].data(); }
+    for (int l = 0; l < 2; l++) { m.mv[l] = p->mv[l].data(); m.ref_idx[l] = p->ref_idx[l].data(); }
+    m.intra_dir[0] = p->intra_dir[0].data(); m.intra_dir[1] = p->intra_dir[1].data();
+    m.transquant_bypass = p->has_bypass ? p->bypass.data() : nullptr;
+    m.ipcm = p->has_pcm ? p->ipcm.data() : nullptr;
+    m.slice_idx = p->slice_idx.data();
+    m.tile_idx = p->tile_idx.data();
+    hmgpu_coeffs co;
+    memset(&co, 0, sizeof(co));
+    for (int c = 0; c < 3; c++) { co.level[c] = p->coeff[c].data(); co.pcm_sample[c] = p->has_pcm ? p->pcm[c].data() : nullptr; }
+    std::vector<const hmgpu_slice_params*> sl;
+    for (auto& s : p->slices) sl.push_back(&s->params);
+    hmgpu_status st = hmgpu_decompress_picture(gpu_, p->handle, (int32_t)sl.size(), sl.data(), &m, &co);
+    if (st != HMGPU_OK) throw std::runtime_error(std::string("hmgpu_decompress_picture: ") + hmgpu_status_string(st));
+    hmgpu_pic_params pp;
+    memset(&pp, 0, sizeof(pp));
+    pp.lf_across_tiles = pps_->lf_across_tiles;
+    pp.sao_enabled = sps_->sao;
+    st = hmgpu_filter_picture(gpu_, p->handle, &pp, sps_->sao ? p->sao.data() : nullptr);
+    if (st != HMGPU_OK) throw std::runtime_error(std::string("hmgpu_filter_picture: ") + hmgpu_status_string(st));
+  }
+  p->decoded = true;
+  p->filtered = true;
+  p->needed_for_output = p->pic_output;
+  cur_ = nullptr;
+  last_decoded_ = p;
+  pictures_decoded_++;
+  if (check_hash_ && p->sei_hash_method) check_hash(p);
+}
+
+bool Decoder::fetch_planes(PicData* pic) {
+  if (!gpu_ || !pic) return false;
+  if (pic->planes_valid) return true;
+  pic->plane[0].resize((size_t)pic->width * pic->height);
+  pic->plane[1].resize((size_t)pic->width * pic->height / 4);
+  pic->plane[2].resize((size_t)pic->width * pic->height / 4);
+  int16_t* planes[3] = {pic->plane[0].data(), pic->plane[1].data(), pic->plane[2].data()};
+  const int32_t strides[3] = {pic->width, pic->width / 2, pic->width / 2};
+  if (hmgpu_picture_download(gpu_, pic->handle, planes, strides) != HMGPU_OK) return false;
+  pic->planes_valid = true;
+  return true;
+}
+
+// TDecGop.cpp:199-262: the reconstruction against the decoded picture hash SEI
+void Decoder::check_hash(PicData* pic) {
+  if (!gpu_) return;
+  uint8_t got[3][16];
+  memset(got, 0, sizeof(got));
+  int len = 0;
+  if (pic->sei_hash_method == 1) {
+    if (!fetch_planes(pic)) return;
+    for (int c = 0; c < 3; c++) {
+      const int bd = c ? sps_->bit_depth_chroma : sps_->bit_depth_luma;
+      Md5 md5;
+      const std::vector<int16_t>& pl = pic->plane[c];
+      std::vector<uint8_t> bytes(pl.size() * (bd > 8 ? 2 : 1));
+      if (bd > 8) for (size_t i = 0; i < pl.size(); i++) { bytes[2 * i] = (uint8_t)pl[i]; bytes[2 * i + 1] = (uint8_t)(pl[i] >> 8); }
+      else for (size_t i = 0; i < pl.size(); i++) bytes[i] = (uint8_t)pl[i];
+      md5.update(bytes.data(), bytes.size());
+      md5.final(got[c]);
+    }
+    len = 16;
+  } else {
+    int32_t n = 0;
+    if (hmgpu_picture_hash(gpu_, pic->handle, pic->sei_hash_method, got, &n) != HMGPU_OK) return;
+    len = n;
+  }
+  bool ok = true;
+  for (int c = 0; c < 3; c++) if (memcmp(got[c], pic->sei_hash[c], len)) ok = false;
+  if (!ok) {
+    pic->hash_mismatch = true;
+    hash_mismatches_++;
+    fprintf(stderr, "hmdec: ***ERROR*** decoded picture hash mismatch, POC %d\n", pic->poc);
+  }
+}
+
+void Decoder::flush() { finish_picture(); }
+
+// ------------------------------------------------------------------------------------------------ output (libHM's rules)
+void Decoder::begin_output_scan(int max_tl) {
+  scan_.clear();
+  for (auto& p : pool_) if (p->decoded && p.get() != cur_) scan_.push_back(p.get());
+  std::sort(scan_.begin(), scan_.end(), [](const PicData* a, const PicData* b) { return a->poc < b->poc; });
+  scan_idx_ = 0;
+  num_not_displayed_ = dpb_fullness_ = 0;
+  if (!sps_) return;
+  const int layers = sps_->max_sub_layers;
+  const int t = (max_tl == -1 || max_tl >= layers) ? layers - 1 : max_tl;
+  num_reorder_ = sps_->num_reorder_pics[t];
+  max_dec_buffering_ = sps_->max_dec_pic_buffering[t];            // HM stores sps_max_dec_pic_buffering_minus1 + 1 too (TDecCAVLC.cpp parseSPS)
+  for (PicData* p : scan_) {
+    if (p->needed_for_output && p->poc > last_display_poc) { num_not_displayed_++; dpb_fullness_++; }
+    else if (p->is_reference) dpb_fullness_++;
+  }
+}
+
+PicData* Decoder::next_output(bool flush_all) {
+  while (scan_idx_ < scan_.size()) {
+    PicData* p = scan_[scan_idx_];
+    if ((flush_all && p->needed_for_output) ||
+        (p->needed_for_output && p->poc > last_display_poc && (num_not_displayed_ > num_reorder_ || dpb_fullness_ > max_dec_buffering_))) {
+      if (!flush_all) num_not_displayed_--;
+      if (!p->is_reference) dpb_fullness_--;
+      last_display_poc = p->poc;
+      p->needed_for_output = false;
+      p->lent = true;
+      return p;
+    }
+    scan_idx_++;
+  }
+  return nullptr;
+}
+
+}  // namespace hmdec

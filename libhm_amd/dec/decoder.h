@@ -1,0 +1,86 @@
+// decoder.h -- the host half of an HEVC decoder around the device path: NAL units in, finished pictures out.
+// Parsing (parameter sets, slice headers, CABAC slice data), picture order count (8.3.1), reference picture sets (8.3.2), reference
+// picture lists (8.3.4) and the output order stay on the host; every sample is produced by libhmgpu through the two drop-in calls.
+// HM counterpart: TDecTop.cpp (decode / xActivateParameterSets / xDecodeSlice / executeLoopFilters), TComSlice.cpp (setRefPicList,
+// applyReferencePictureSet), TDecGop.cpp, SEIread.cpp (decoded picture hash).
+#pragma once
+#include <deque>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "picture.h"
+#include "slice_decoder.h"
+
+namespace hmdec {
+
+class Decoder {
+ public:
+  Decoder();
+  ~Decoder();
+  // configuration (before the first NAL unit)
+  void set_parse_only(bool v) { parse_only_ = v; }        // no device: metadata only (host-side tests)
+  void set_check_hash(bool v) { check_hash_ = v; }
+  void set_device(int ordinal) { device_ = ordinal; }
+  // One NAL unit (with or without a start code).  Returns true when the unit starts a new picture while the previous one was still
+  // open: that picture has then been finished and the SAME unit must be pushed again (libHM's bNewPicture protocol).
+  bool push(const uint8_t* data, size_t len, int max_temporal_layer, int* nal_type_out);
+  void finish_picture();                                  // TDecTop::executeLoopFilters
+  void flush();                                           // end of stream / EOS: everything still waiting becomes output
+  // output: libHM's rules (libHMDecoder.cpp:248-339)
+  void begin_output_scan(int max_temporal_layer);
+  PicData* next_output(bool flush_all);
+  const Sps* active_sps() const { return sps_.get(); }
+  PicData* last_decoded() const { return last_decoded_; }
+  int hash_mismatches() const { return hash_mismatches_; }
+  int pictures_decoded() const { return pictures_decoded_; }
+  const std::string& last_error() const { return last_error_; }
+  void set_error(const std::string& s) { last_error_ = s; }
+  bool fetch_planes(PicData* pic);                        // device -> host planes of a finished picture (no-op when parse-only)
+  int last_display_poc = -(1 << 30);
+
+ private:
+  void activate(const SliceHeader& sh);
+  void start_picture(const SliceHeader& sh);
+  void decode_slice(const std::vector<uint8_t>& rbsp, BitReader& br, SliceHeader& sh);
+  int compute_poc(const SliceHeader& sh);
+  void apply_rps(const SliceHeader& sh);
+  void build_ref_lists(const SliceHeader& sh, SliceInfo& si);
+  void build_slice_params(const SliceHeader& sh, SliceInfo& si);
+  void parse_sei(const std::vector<uint8_t>& rbsp, bool suffix);
+  void check_hash(PicData* pic);
+  PicData* acquire_buffer();
+  PicData* find_ref(int poc, bool lsb_only, bool any_marking);
+
+  ParamSets ps_;
+  std::shared_ptr<Sps> sps_;
+  std::shared_ptr<Pps> pps_;
+  ZScan zscan_;
+  hmgpu_ctx* gpu_ = nullptr;
+  hmgpu_seq_params seq_{};
+  std::vector<std::unique_ptr<PicData>> pool_;            // DPB + free buffers
+  PicData* cur_ = nullptr;
+  PicData* last_decoded_ = nullptr;
+  PicParseState parse_state_;
+  SliceHeader last_independent_;
+  bool have_independent_ = false;
+  // 8.3.1 / 8.3.2 state
+  int prev_tid0_poc_ = 0;
+  bool first_picture_ = true, after_eos_ = false, no_rasl_output_ = false;
+  int poc_cra_ = 0;
+  bool skip_rasl_ = false;
+  std::vector<PicData*> st_before_, st_after_, lt_curr_;
+  // pending SEI
+  bool pending_hash_ = false;
+  int pending_hash_method_ = 0;
+  uint8_t pending_hash_val_[3][16];
+  // output scan state
+  int num_not_displayed_ = 0, dpb_fullness_ = 0, num_reorder_ = 0, max_dec_buffering_ = 0;
+  size_t scan_idx_ = 0;
+  std::vector<PicData*> scan_;
+  bool parse_only_ = false, check_hash_ = true;
+  int device_ = 0, hash_mismatches_ = 0, pictures_decoded_ = 0;
+  std::string last_error_;
+};
+
+}  // namespace hmdec

@@ -1,0 +1,118 @@
+// picture.h -- what the parser leaves behind for one picture: HM's per-CTU TComDataCU arrays (4x4 partitions in z-scan order inside
+// each CTU, TComDataCU.h:86-157), coefficient levels in HM's TU layout, SAO parameters as parsed, and the slice table.  These are
+// exactly the arrays hmgpu_decompress_slice / hmgpu_filter_picture take (include/hmgpu.h), so nothing is converted on the way.
+#pragma once
+#include <cstdint>
+#include <cstring>
+#include <memory>
+#include <vector>
+
+#include "../../include/hmgpu.h"
+#include "params.h"
+
+namespace hmdec {
+
+struct ZScan {                       // raster (4x4 units inside a CTU) <-> HM z-scan order (g_auiRasterToZscan / g_auiZscanToRaster)
+  int log2_ctb = 0, n4 = 0;          // n4: 4x4 units per CTU side
+  std::vector<uint16_t> r2z, z2r;
+  void init(int log2_ctb_size) {
+    log2_ctb = log2_ctb_size;
+    n4 = 1 << (log2_ctb - 2);
+    r2z.assign(n4 * n4, 0);
+    z2r.assign(n4 * n4, 0);
+    for (int y = 0; y < n4; y++)
+      for (int x = 0; x < n4; x++) {
+        int z = 0;
+        for (int b = 0; b < log2_ctb - 2; b++) z |= (((x >> b) & 1) << (2 * b)) | (((y >> b) & 1) << (2 * b + 1));
+        r2z[y * n4 + x] = (uint16_t)z;
+        z2r[z] = (uint16_t)(y * n4 + x);
+      }
+  }
+};
+
+struct PicData;
+struct SliceInfo {                   // one slice (independent segment + its dependent segments)
+  PicData* ref_pics[2][16];
+  hmgpu_slice_params params;
+  std::unique_ptr<hmgpu_scaling_lists> scaling_lists;
+  int type = SLICE_I;
+  int ref_poc[2][16];                // POC and marking of every reference at the time the slice was decoded (TMVP of later pictures)
+  bool ref_is_lt[2][16];
+  int first_ctb_ts = 0, num_ctbs = 0;
+  SliceHeader header;
+};
+
+struct PicData {
+  // geometry
+  int width = 0, height = 0, log2_ctb = 0, ctbs_w = 0, ctbs_h = 0, num_ctbs = 0, parts = 0;
+  const ZScan* zs = nullptr;
+  // per partition, [num_ctbs][parts]
+  std::vector<uint8_t> depth, tr_idx, cbf[3], ts[3], intra_dir[2], bypass, ipcm, skip, merge, merge_idx, inter_dir;
+  std::vector<int8_t> part_size, pred_mode, qp, ref_idx[2];
+  std::vector<int16_t> mv[2];        // {hor, ver}
+  // per CTB
+  std::vector<uint16_t> slice_idx, tile_idx;
+  std::vector<int32_t> slice_addr;   // SliceAddrRs of the slice that decoded the CTB, -1 = not (yet) decoded
+  // levels / PCM samples in HM's layout
+  std::vector<int16_t> coeff[3], pcm[3];
+  std::vector<hmgpu_sao_param> sao;  // [num_ctbs][3]
+  std::vector<std::unique_ptr<SliceInfo>> slices;
+  // picture state (8.3)
+  int poc = 0, nal_type = 0, temporal_id = 0;
+  bool is_reference = false, is_long_term = false, needed_for_output = false, pic_output = true, decoded = false, filtered = false;
+  bool has_pcm = false, has_bypass = false, lent = false;     // lent: handed to the application by the last output scan
+  hmgpu_pic handle = HMGPU_NO_PIC;
+  // output side
+  bool planes_valid = false;
+  std::vector<int16_t> plane[3];
+  uint8_t sei_hash[3][16];
+  int sei_hash_method = 0;           // 0 = none, 1 = MD5, 2 = CRC, 3 = checksum
+  bool hash_mismatch = false;
+
+  void allocate(const Sps& sps, const ZScan* z) {
+    width = sps.width; height = sps.height; log2_ctb = sps.log2_ctb;
+    ctbs_w = sps.pic_w_ctbs(); ctbs_h = sps.pic_h_ctbs(); num_ctbs = ctbs_w * ctbs_h;
+    parts = 1 << (2 * log2_ctb - 4);
+    zs = z;
+    const size_t n = (size_t)num_ctbs * parts;
+    for (auto* v : {&depth, &tr_idx, &cbf[0], &cbf[1], &cbf[2], &ts[0], &ts[1], &ts[2], &intra_dir[0], &intra_dir[1], &bypass, &ipcm, &skip, &merge, &merge_idx, &inter_dir}) v->assign(n, 0);
+    for (auto* v : {&part_size, &pred_mode, &qp, &ref_idx[0], &ref_idx[1]}) v->assign(n, 0);
+    mv[0].assign(2 * n, 0);
+    mv[1].assign(2 * n, 0);
+    slice_idx.assign(num_ctbs, 0);
+    tile_idx.assign(num_ctbs, 0);
+    slice_addr.assign(num_ctbs, -1);
+    const size_t luma = (size_t)num_ctbs << (2 * log2_ctb);
+    coeff[0].assign(luma, 0);
+    coeff[1].assign(luma / 4, 0);
+    coeff[2].assign(luma / 4, 0);
+    if (sps.pcm) { pcm[0].assign(luma, 0); pcm[1].assign(luma / 4, 0); pcm[2].assign(luma / 4, 0); }
+    sao.assign((size_t)num_ctbs * 3, hmgpu_sao_param{});
+  }
+  // a new picture in the same buffers: the state HM's TComDataCU::initCtu leaves (TComDataCU.cpp:420-470)
+  void reset() {
+    std::fill(depth.begin(), depth.end(), 0);
+    std::fill(tr_idx.begin(), tr_idx.end(), 0);
+    for (int c = 0; c < 3; c++) { std::fill(cbf[c].begin(), cbf[c].end(), 0); std::fill(ts[c].begin(), ts[c].end(), 0); std::fill(coeff[c].begin(), coeff[c].end(), 0); }
+    std::fill(intra_dir[0].begin(), intra_dir[0].end(), 1);
+    std::fill(intra_dir[1].begin(), intra_dir[1].end(), 0);
+    for (auto* v : {&bypass, &ipcm, &skip, &merge, &merge_idx, &inter_dir}) std::fill(v->begin(), v->end(), 0);
+    std::fill(part_size.begin(), part_size.end(), (int8_t)HMGPU_SIZE_NONE);
+    std::fill(pred_mode.begin(), pred_mode.end(), (int8_t)2);       // HM's NUMBER_OF_PREDICTION_MODES: nothing decoded here
+    std::fill(qp.begin(), qp.end(), 0);
+    for (int l = 0; l < 2; l++) { std::fill(ref_idx[l].begin(), ref_idx[l].end(), (int8_t)-1); std::fill(mv[l].begin(), mv[l].end(), 0); }
+    std::fill(slice_idx.begin(), slice_idx.end(), 0);
+    std::fill(slice_addr.begin(), slice_addr.end(), -1);
+    std::fill(sao.begin(), sao.end(), hmgpu_sao_param{});
+    slices.clear();
+    has_pcm = has_bypass = decoded = filtered = planes_valid = hash_mismatch = false;
+    sei_hash_method = 0;
+  }
+  size_t part_at(int x, int y) const {      // partition index of the 4x4 block covering luma sample (x, y)
+    const int mask = (1 << log2_ctb) - 1;
+    return (size_t)((y >> log2_ctb) * ctbs_w + (x >> log2_ctb)) * parts + zs->r2z[((y & mask) >> 2) * zs->n4 + ((x & mask) >> 2)];
+  }
+  int ctb_at(int x, int y) const { return (y >> log2_ctb) * ctbs_w + (x >> log2_ctb); }
+};
+
+}  // namespace hmdec

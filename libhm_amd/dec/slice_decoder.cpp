@@ -1,0 +1,880 @@
+// slice_decoder.cpp -- see slice_decoder.h.  Clause numbers refer to Rec. ITU-T H.265.
+#include "slice_decoder.h"
+
+#include <algorithm>
+#include <cstdlib>
+
+namespace hmdec {
+
+namespace {
+enum { MODE_INTER = HMGPU_MODE_INTER, MODE_INTRA = HMGPU_MODE_INTRA };
+enum { PART_2Nx2N = 0, PART_2NxN, PART_Nx2N, PART_NxN, PART_2NxnU, PART_2NxnD, PART_nLx2N, PART_nRx2N };
+enum { PRED_L0 = 0, PRED_L1 = 1, PRED_BI = 2 };
+const int kDmChroma = 36;            // HM's DM_CHROMA_IDX: "same as luma", kept symbolic in m_puhIntraDir[chroma]
+
+// 6.5.3 - 6.5.5: scan orders for sub-block grids / positions inside a 4x4 sub-block; pos = y * blk + x
+struct ScanTables {
+  uint8_t order[4][3][64];           // [log2 blk][scanIdx][i] -> pos
+  uint8_t index[4][3][64];           // inverse
+  ScanTables() {
+    for (int l = 0; l < 4; l++) {
+      const int blk = 1 << l;
+      int i = 0, x = 0, y = 0;
+      for (;;) {
+        while (y >= 0) {
+          if (x < blk && y < blk) order[l][0][i++] = (uint8_t)(y * blk + x);
+          y--;
+          x++;
+        }
+        y = x;
+        x = 0;
+        if (i >= blk * blk) break;
+      }
+      for (int k = 0; k < blk * blk; k++) {
+        order[l][1][k] = (uint8_t)k;                                   // horizontal: raster
+        order[l][2][k] = (uint8_t)((k % blk) * blk + k / blk);         // vertical: column by column
+      }
+      for (int s = 0; s < 3; s++) for (int k = 0; k < blk * blk; k++) index[l][s][order[l][s][k]] = (uint8_t)k;
+    }
+  }
+};
+const ScanTables kScan;
+const uint8_t kSigCtx4x4[16] = {0, 1, 4, 5, 2, 3, 4, 5, 6, 6, 8, 8, 7, 7, 8, 8};      // 9.3.4.2.5 ctxIdxMap (index = (yC << 2) + xC)
+
+inline int clip3(int lo, int hi, int v) { return v < lo ? lo : v > hi ? hi : v; }
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------ slice segment level
+void SliceDecoder::init_contexts() {
+  int init_type = 0;
+  if (sh_->type == SLICE_P) init_type = sh_->cabac_init_flag ? 2 : 1;
+  else if (sh_->type == SLICE_B) init_type = sh_->cabac_init_flag ? 1 : 2;
+  ctx_.init(init_type, sh_->qp);
+}
+
+bool SliceDecoder::decode(const SliceHeader& sh, int slice_idx, const uint8_t* rbsp, size_t bytes) {
+  sh_ = &sh;
+  slice_idx_ = slice_idx;
+  slice_ = pic_.slices[slice_idx].get();
+  cabac_.attach(rbsp, bytes);
+  no_backward_pred_ = true;
+  for (int l = 0; l < 2; l++)
+    for (int i = 0; i < sh.num_ref_idx[l]; i++) if (slice_->ref_poc[l][i] > pic_.poc) no_backward_pred_ = false;
+  const int W = pic_.ctbs_w;
+  ctb_ts_ = pps_.ctb_rs_to_ts[sh.segment_address];
+  if (ctb_ts_ != st_.next_ctb_ts) throw ParseError("slice segment does not continue where the previous one ended");
+  if (!sh.dependent) st_.last_qp = sh.qp;           // first quantisation group in a slice: qPY_PREV = SliceQpY (8.6.1)
+  cabac_.start(sh.data_bit_offset);
+  bool first = true, done = false;
+  while (!done) {
+    ctb_rs_ = pps_.ctb_ts_to_rs[ctb_ts_];
+    const int cx = ctb_rs_ % W, cy = ctb_rs_ / W;
+    const bool tile_first = ctb_ts_ == 0 || pps_.tile_id[ctb_ts_] != pps_.tile_id[ctb_ts_ - 1];
+    const bool row_first = pps_.entropy_coding_sync && (cx == 0 || pps_.tile_id[ctb_ts_] != pps_.tile_id[pps_.ctb_rs_to_ts[ctb_rs_ - 1]]);
+    // 9.3.1: which context variables the CTU starts from
+    if (tile_first) {
+      init_contexts();
+      st_.last_qp = sh.qp;
+    } else if (row_first) {
+      const int x0 = cx << sps_.log2_ctb, y0 = cy << sps_.log2_ctb;
+      pic_.slice_addr[ctb_rs_] = sh.slice_address;          // the availability test below looks at the current CTB too
+      if (st_.wpp_valid && available(x0, y0, x0 + sps_.ctb_size(), y0 - sps_.ctb_size())) ctx_ = st_.wpp;
+      else init_contexts();
+      st_.last_qp = sh.qp;
+    } else if (first) {
+      if (sh.dependent) {
+        if (!st_.have_end_of_segment) throw ParseError("dependent slice segment without stored context variables");
+        ctx_ = st_.end_of_segment;
+      } else {
+        init_contexts();
+      }
+    }
+    first = false;
+    ctu(ctb_rs_);
+    if (pps_.entropy_coding_sync) {                         // 9.3.2.4: storage after the second CTB of a row of the tile
+      int col_start = 0;
+      for (int v : pps_.col_bd) if (v <= cx) col_start = v;
+      if (cx == col_start + 1) { st_.wpp = ctx_; st_.wpp_valid = true; }
+    }
+    const int end = cabac_.terminate();                     // end_of_slice_segment_flag
+    ctb_ts_++;
+    if (end) {
+      if (pps_.dependent_slice_segments_enabled) { st_.end_of_segment = ctx_; st_.have_end_of_segment = true; }
+      done = true;
+    } else {
+      if (ctb_ts_ >= pic_.num_ctbs) throw ParseError("slice data runs past the last CTB of the picture");
+      const int next_rs = pps_.ctb_ts_to_rs[ctb_ts_];
+      const bool new_tile = pps_.tiles_enabled && pps_.tile_id[ctb_ts_] != pps_.tile_id[ctb_ts_ - 1];
+      const bool new_row = pps_.entropy_coding_sync && (next_rs % W == 0 || pps_.tile_id[ctb_ts_] != pps_.tile_id[pps_.ctb_rs_to_ts[next_rs - 1]]);
+      if (new_tile || new_row) {
+        if (!cabac_.terminate()) throw ParseError("end_of_subset_one_bit is not 1");
+        cabac_.finish_to_byte();
+        cabac_.start(cabac_.bit_pos());
+      }
+    }
+  }
+  st_.next_ctb_ts = ctb_ts_;
+  slice_->num_ctbs += 0;
+  return ctb_ts_ >= pic_.num_ctbs;
+}
+
+void SliceDecoder::ctu(int rs) {
+  const int x0 = (rs % pic_.ctbs_w) << sps_.log2_ctb, y0 = (rs / pic_.ctbs_w) << sps_.log2_ctb;
+  pic_.slice_addr[rs] = sh_->slice_address;
+  pic_.slice_idx[rs] = (uint16_t)slice_idx_;
+  pic_.tile_idx[rs] = (uint16_t)pps_.tile_id[ctb_ts_];
+  if (sh_->sao_luma || sh_->sao_chroma) sao_syntax(rs);
+  coding_quadtree(x0, y0, sps_.log2_ctb, 0);
+}
+
+// 7.3.8.3 sao(); filled the way HM's parser leaves SAOBlkParam (TDecSbac.cpp:1708-1848): merge resolution happens on the device side
+void SliceDecoder::sao_syntax(int rs) {
+  const int rx = rs % pic_.ctbs_w, ry = rs / pic_.ctbs_w;
+  hmgpu_sao_param* prm = &pic_.sao[(size_t)rs * 3];
+  const bool enabled[3] = {sh_->sao_luma, sh_->sao_chroma, sh_->sao_chroma};
+  bool merge_left = false, merge_up = false;
+  if (rx > 0) {
+    const bool in_slice = pic_.slice_addr[rs - 1] == sh_->slice_address;
+    const bool in_tile = pps_.tile_id[ctb_ts_] == pps_.tile_id[pps_.ctb_rs_to_ts[rs - 1]];
+    if (in_slice && in_tile) merge_left = cabac_.decision(ctx_.s[CTX_SAO_MERGE]);
+  }
+  if (ry > 0 && !merge_left) {
+    const bool in_slice = pic_.slice_addr[rs - pic_.ctbs_w] == sh_->slice_address;
+    const bool in_tile = pps_.tile_id[ctb_ts_] == pps_.tile_id[pps_.ctb_rs_to_ts[rs - pic_.ctbs_w]];
+    if (in_slice && in_tile) merge_up = cabac_.decision(ctx_.s[CTX_SAO_MERGE]);
+  }
+  if (merge_left || merge_up) {
+    for (int c = 0; c < 3; c++) {
+      prm[c].mode_idc = enabled[c] ? HMGPU_SAO_MERGE : HMGPU_SAO_OFF;
+      prm[c].type_idc = merge_left ? HMGPU_SAO_MERGE_LEFT : HMGPU_SAO_MERGE_ABOVE;
+    }
+    return;
+  }
+  for (int c = 0; c < 3; c++) {
+    hmgpu_sao_param& p = prm[c];
+    p = hmgpu_sao_param{};
+    if (!enabled[c]) continue;
+    if (c < 2) {
+      int type = 0;                                   // sao_type_idx_*: TR cMax 2, first bin context coded
+      if (cabac_.decision(ctx_.s[CTX_SAO_TYPE])) type = cabac_.bypass() ? 2 : 1;
+      if (type == 0) continue;
+      p.mode_idc = HMGPU_SAO_NEW;
+      p.type_idc = type == 1 ? HMGPU_SAO_BO : HMGPU_SAO_EO_0;
+    } else {
+      p.mode_idc = prm[1].mode_idc;
+      p.type_idc = prm[1].type_idc;
+      if (p.mode_idc != HMGPU_SAO_NEW) continue;
+    }
+    const int bd = c ? sps_.bit_depth_chroma : sps_.bit_depth_luma;
+    const int cmax = (1 << (std::min(bd, 10) - 5)) - 1;
+    int off[4];
+    for (int i = 0; i < 4; i++) {
+      int v = 0;
+      while (v < cmax && cabac_.bypass()) v++;
+      off[i] = v;
+    }
+    if (p.type_idc == HMGPU_SAO_BO) {
+      for (int i = 0; i < 4; i++) if (off[i] && cabac_.bypass()) off[i] = -off[i];
+      p.type_aux_info = cabac_.bypass_bits(5);
+      for (int i = 0; i < 4; i++) p.offset[(p.type_aux_info + i) & 31] = off[i];
+    } else {
+      if (c == 0) p.type_idc = HMGPU_SAO_EO_0 + cabac_.bypass_bits(2);
+      else if (c == 1) p.type_idc = HMGPU_SAO_EO_0 + cabac_.bypass_bits(2);
+      else p.type_idc = prm[1].type_idc;
+      p.offset[0] = off[0];
+      p.offset[1] = off[1];
+      p.offset[2] = 0;
+      p.offset[3] = -off[2];
+      p.offset[4] = -off[3];
+    }
+  }
+}
+
+// 6.4.1 z-scan order availability of the block at (xn, yn) for the block at (xc, yc)
+bool SliceDecoder::available(int xc, int yc, int xn, int yn) const {
+  if (xn < 0 || yn < 0 || xn >= pic_.width || yn >= pic_.height) return false;
+  const int cn = pic_.ctb_at(xn, yn), cc = pic_.ctb_at(xc, yc);
+  if (pic_.slice_addr[cn] != sh_->slice_address) return false;                 // other slice, or not decoded yet
+  if (cn != cc) {
+    if (pps_.tile_id[pps_.ctb_rs_to_ts[cn]] != pps_.tile_id[pps_.ctb_rs_to_ts[cc]]) return false;
+    return pps_.ctb_rs_to_ts[cn] < pps_.ctb_rs_to_ts[cc];
+  }
+  const int mask = (1 << sps_.log2_ctb) - 1, n4 = pic_.zs->n4;
+  const int zn = pic_.zs->r2z[((yn & mask) >> 2) * n4 + ((xn & mask) >> 2)], zc = pic_.zs->r2z[((yc & mask) >> 2) * n4 + ((xc & mask) >> 2)];
+  return zn <= zc;
+}
+
+void SliceDecoder::coding_quadtree(int x0, int y0, int log2, int depth) {
+  const int size = 1 << log2;
+  bool split;
+  if (x0 + size <= pic_.width && y0 + size <= pic_.height && log2 > sps_.log2_min_cb) {
+    int inc = 0;
+    if (available(x0, y0, x0 - 1, y0) && pic_.depth[pic_.part_at(x0 - 1, y0)] > depth) inc++;
+    if (available(x0, y0, x0, y0 - 1) && pic_.depth[pic_.part_at(x0, y0 - 1)] > depth) inc++;
+    split = cabac_.decision(ctx_.s[CTX_SPLIT_CU + inc]);
+  } else {
+    split = log2 > sps_.log2_min_cb;
+  }
+  if (pps_.cu_qp_delta_enabled && log2 >= sps_.log2_ctb - pps_.diff_cu_qp_delta_depth) {
+    is_cu_qp_delta_coded_ = false;
+    cu_qp_delta_val_ = 0;
+    start_quant_group(x0, y0);
+  }
+  if (split) {
+    const int h = size >> 1;
+    coding_quadtree(x0, y0, log2 - 1, depth + 1);
+    if (x0 + h < pic_.width) coding_quadtree(x0 + h, y0, log2 - 1, depth + 1);
+    if (y0 + h < pic_.height) coding_quadtree(x0, y0 + h, log2 - 1, depth + 1);
+    if (x0 + h < pic_.width && y0 + h < pic_.height) coding_quadtree(x0 + h, y0 + h, log2 - 1, depth + 1);
+  } else {
+    coding_unit(x0, y0, log2, depth);
+  }
+}
+
+// 8.6.1: qPY_PRED of the quantisation group starting at (x0, y0)
+void SliceDecoder::start_quant_group(int x0, int y0) {
+  qg_x_ = x0;
+  qg_y_ = y0;
+  const int mask = (1 << sps_.log2_ctb) - 1;
+  const int a = (x0 & mask) ? pic_.qp[pic_.part_at(x0 - 1, y0)] : st_.last_qp;
+  const int b = (y0 & mask) ? pic_.qp[pic_.part_at(x0, y0 - 1)] : st_.last_qp;
+  qg_pred_ = (a + b + 1) >> 1;
+}
+
+int SliceDecoder::cu_qp() const {
+  if (!pps_.cu_qp_delta_enabled) return sh_->qp;
+  const int off = 6 * (sps_.bit_depth_luma - 8);
+  return ((qg_pred_ + cu_qp_delta_val_ + 52 + 2 * off) % (52 + off)) - off;
+}
+
+// 7.3.8.14 cu_qp_delta_abs / cu_qp_delta_sign_flag
+void SliceDecoder::qp_delta() {
+  int v = 0;
+  if (cabac_.decision(ctx_.s[CTX_QP_DELTA])) {
+    v = 1;
+    while (v < 5 && cabac_.decision(ctx_.s[CTX_QP_DELTA + 1])) v++;
+    if (v == 5) {                                     // EG0 suffix
+      int k = 0;
+      unsigned s = 0;
+      while (cabac_.bypass()) { s += 1u << k; if (++k > 16) throw ParseError("cu_qp_delta_abs too large"); }
+      if (k) s += cabac_.bypass_bits(k);
+      v += (int)s;
+    }
+  }
+  if (v && cabac_.bypass()) v = -v;
+  const int off = 6 * (sps_.bit_depth_luma - 8);
+  if (v < -(26 + off / 2) || v > 25 + off / 2) throw ParseError("CuQpDeltaVal out of range");
+  cu_qp_delta_val_ = v;
+  is_cu_qp_delta_coded_ = true;
+}
+
+// ------------------------------------------------------------------------------------------------ coding unit
+void SliceDecoder::coding_unit(int x0, int y0, int log2, int depth) {
+  const int size = 1 << log2, nparts = 1 << (2 * (log2 - 2));
+  const size_t base = pic_.part_at(x0, y0);
+  cu_x_ = x0; cu_y_ = y0; cu_log2_ = log2;
+  cu_bypass_ = pps_.transquant_bypass_enabled && cabac_.decision(ctx_.s[CTX_TQ_BYPASS]);
+  bool skip = false;
+  if (sh_->type != SLICE_I) {
+    int inc = 0;
+    if (available(x0, y0, x0 - 1, y0) && pic_.skip[pic_.part_at(x0 - 1, y0)]) inc++;
+    if (available(x0, y0, x0, y0 - 1) && pic_.skip[pic_.part_at(x0, y0 - 1)]) inc++;
+    skip = cabac_.decision(ctx_.s[CTX_SKIP + inc]);
+  }
+  fill_z(pic_.depth, base, nparts, (uint8_t)depth);
+  fill_z(pic_.skip, base, nparts, (uint8_t)skip);
+  if (cu_bypass_) { fill_z(pic_.bypass, base, nparts, (uint8_t)1); pic_.has_bypass = true; }
+  int part_mode = PART_2Nx2N;
+  bool pcm = false;
+  if (skip) {
+    cu_pred_mode_ = MODE_INTER;
+    fill_z(pic_.pred_mode, base, nparts, (int8_t)MODE_INTER);
+    fill_z(pic_.part_size, base, nparts, (int8_t)PART_2Nx2N);
+    prediction_unit(x0, y0, size, x0, y0, size, size, 0, PART_2Nx2N, depth, true);
+  } else {
+    cu_pred_mode_ = MODE_INTRA;
+    if (sh_->type != SLICE_I) cu_pred_mode_ = cabac_.decision(ctx_.s[CTX_PRED_MODE]) ? MODE_INTRA : MODE_INTER;
+    if (cu_pred_mode_ == MODE_INTRA) {
+      if (log2 == sps_.log2_min_cb) part_mode = cabac_.decision(ctx_.s[CTX_PART_MODE]) ? PART_2Nx2N : PART_NxN;
+    } else {                                                               // 9.3.3.6 binarisation of part_mode
+      if (cabac_.decision(ctx_.s[CTX_PART_MODE])) {
+        part_mode = PART_2Nx2N;
+      } else if (log2 == sps_.log2_min_cb) {
+        if (log2 == 3) part_mode = cabac_.decision(ctx_.s[CTX_PART_MODE + 1]) ? PART_2NxN : PART_Nx2N;
+        else if (cabac_.decision(ctx_.s[CTX_PART_MODE + 1])) part_mode = PART_2NxN;
+        else part_mode = cabac_.decision(ctx_.s[CTX_PART_MODE + 2]) ? PART_Nx2N : PART_NxN;
+      } else if (!sps_.amp) {
+        part_mode = cabac_.decision(ctx_.s[CTX_PART_MODE + 1]) ? PART_2NxN : PART_Nx2N;
+      } else {
+        const bool hor = cabac_.decision(ctx_.s[CTX_PART_MODE + 1]);
+        if (cabac_.decision(ctx_.s[CTX_PART_MODE + 3])) part_mode = hor ? PART_2NxN : PART_Nx2N;
+        else if (cabac_.bypass()) part_mode = hor ? PART_2NxnD : PART_nRx2N;
+        else part_mode = hor ? PART_2NxnU : PART_nLx2N;
+      }
+    }
+    fill_z(pic_.pred_mode, base, nparts, (int8_t)cu_pred_mode_);
+    fill_z(pic_.part_size, base, nparts, (int8_t)part_mode);
+    if (cu_pred_mode_ == MODE_INTRA) {
+      if (part_mode == PART_2Nx2N && sps_.pcm && log2 >= sps_.log2_min_pcm_cb && log2 <= sps_.log2_max_pcm_cb) pcm = cabac_.terminate();
+      if (pcm) {
+        cabac_.finish_to_byte();                   // pcm_alignment_zero_bits
+        pcm_sample(x0, y0, log2);
+        cabac_.start(cabac_.bit_pos());
+        fill_z(pic_.ipcm, base, nparts, (uint8_t)1);
+        pic_.has_pcm = true;
+      } else {
+        intra_modes(x0, y0, log2, part_mode == PART_NxN);
+      }
+    } else {
+      const int h = size >> 1, q = size >> 2;
+      switch (part_mode) {
+        case PART_2Nx2N: prediction_unit(x0, y0, size, x0, y0, size, size, 0, part_mode, depth, false); break;
+        case PART_2NxN:
+          prediction_unit(x0, y0, size, x0, y0, size, h, 0, part_mode, depth, false);
+          prediction_unit(x0, y0, size, x0, y0 + h, size, h, 1, part_mode, depth, false);
+          break;
+        case PART_Nx2N:
+          prediction_unit(x0, y0, size, x0, y0, h, size, 0, part_mode, depth, false);
+          prediction_unit(x0, y0, size, x0 + h, y0, h, size, 1, part_mode, depth, false);
+          break;
+        case PART_2NxnU:
+          prediction_unit(x0, y0, size, x0, y0, size, q, 0, part_mode, depth, false);
+          prediction_unit(x0, y0, size, x0, y0 + q, size, size - q, 1, part_mode, depth, false);
+          break;
+        case PART_2NxnD:
+          prediction_unit(x0, y0, size, x0, y0, size, size - q, 0, part_mode, depth, false);
+          prediction_unit(x0, y0, size, x0, y0 + size - q, size, q, 1, part_mode, depth, false);
+          break;
+        case PART_nLx2N:
+          prediction_unit(x0, y0, size, x0, y0, q, size, 0, part_mode, depth, false);
+          prediction_unit(x0, y0, size, x0 + q, y0, size - q, size, 1, part_mode, depth, false);
+          break;
+        case PART_nRx2N:
+          prediction_unit(x0, y0, size, x0, y0, size - q, size, 0, part_mode, depth, false);
+          prediction_unit(x0, y0, size, x0 + size - q, y0, q, size, 1, part_mode, depth, false);
+          break;
+        default:
+          prediction_unit(x0, y0, size, x0, y0, h, h, 0, part_mode, depth, false);
+          prediction_unit(x0, y0, size, x0 + h, y0, h, h, 1, part_mode, depth, false);
+          prediction_unit(x0, y0, size, x0, y0 + h, h, h, 2, part_mode, depth, false);
+          prediction_unit(x0, y0, size, x0 + h, y0 + h, h, h, 3, part_mode, depth, false);
+          break;
+      }
+    }
+    if (!pcm) {
+      bool root_cbf = true;
+      if (cu_pred_mode_ != MODE_INTRA && !(part_mode == PART_2Nx2N && pic_.merge[base])) root_cbf = cabac_.decision(ctx_.s[CTX_ROOT_CBF]);
+      if (root_cbf) transform_tree(x0, y0, x0, y0, log2, 0, 0, log2, false, false);
+    }
+  }
+  const int qp = cu_qp();
+  fill_z(pic_.qp, base, nparts, (int8_t)qp);
+  st_.last_qp = qp;
+}
+
+// 7.3.8.7 pcm_sample()
+void SliceDecoder::pcm_sample(int x0, int y0, int log2) {
+  const int size = 1 << log2;
+  const size_t ctb = pic_.ctb_at(x0, y0), z = pic_.part_at(x0, y0) - ctb * pic_.parts;
+  int16_t* y = &pic_.pcm[0][(ctb << (2 * sps_.log2_ctb)) + 16 * z];
+  for (int i = 0; i < size * size; i++) y[i] = (int16_t)cabac_.plain_bits(sps_.pcm_bit_depth_luma);
+  for (int c = 1; c < 3; c++) {
+    int16_t* d = &pic_.pcm[c][(ctb << (2 * sps_.log2_ctb - 2)) + 4 * z];
+    for (int i = 0; i < size * size / 4; i++) d[i] = (int16_t)cabac_.plain_bits(sps_.pcm_bit_depth_chroma);
+  }
+}
+
+// 7.3.8.5 (intra part of coding_unit) + 8.4.2 / 8.4.3
+void SliceDecoder::intra_modes(int x0, int y0, int log2, bool nxn) {
+  const int n = nxn ? 4 : 1, pb = (1 << log2) >> (nxn ? 1 : 0);
+  bool prev[4];
+  for (int i = 0; i < n; i++) prev[i] = cabac_.decision(ctx_.s[CTX_PREV_INTRA]);
+  for (int i = 0; i < n; i++) {
+    int mpm_idx = 0, rem = 0;
+    if (prev[i]) { if (cabac_.bypass()) mpm_idx = cabac_.bypass() ? 2 : 1; }
+    else rem = cabac_.bypass_bits(5);
+    const int x = x0 + (i & 1) * pb, y = y0 + (i >> 1) * pb;
+    auto cand = [&](int xn, int yn, bool above) {
+      if (!available(x, y, xn, yn)) return 1;
+      const size_t p = pic_.part_at(xn, yn);
+      if (pic_.pred_mode[p] != MODE_INTRA || pic_.ipcm[p]) return 1;
+      if (above && yn < ((y >> sps_.log2_ctb) << sps_.log2_ctb)) return 1;
+      return (int)pic_.intra_dir[0][p];
+    };
+    const int a = cand(x - 1, y, false), b = cand(x, y - 1, true);
+    int c[3];
+    if (a == b) {
+      if (a < 2) { c[0] = 0; c[1] = 1; c[2] = 26; }
+      else { c[0] = a; c[1] = 2 + ((a + 29) % 32); c[2] = 2 + ((a - 2 + 1) % 32); }
+    } else {
+      c[0] = a; c[1] = b;
+      c[2] = (a != 0 && b != 0) ? 0 : (a != 1 && b != 1) ? 1 : 26;
+    }
+    int mode;
+    if (prev[i]) {
+      mode = c[mpm_idx];
+    } else {
+      if (c[0] > c[1]) std::swap(c[0], c[1]);
+      if (c[0] > c[2]) std::swap(c[0], c[2]);
+      if (c[1] > c[2]) std::swap(c[1], c[2]);
+      mode = rem;
+      for (int k = 0; k < 3; k++) if (mode >= c[k]) mode++;
+    }
+    intra_luma_[i] = mode;
+    for (int yy = y; yy < y + pb; yy += 4) for (int xx = x; xx < x + pb; xx += 4) pic_.intra_dir[0][pic_.part_at(xx, yy)] = (uint8_t)mode;
+  }
+  int chroma = 4;
+  if (cabac_.decision(ctx_.s[CTX_CHROMA_MODE])) chroma = cabac_.bypass_bits(2);
+  int stored = kDmChroma;
+  intra_chroma_ = intra_luma_[0];
+  if (chroma != 4) {
+    static const int kModes[4] = {0, 26, 10, 1};
+    intra_chroma_ = kModes[chroma] == intra_luma_[0] ? 34 : kModes[chroma];
+    stored = intra_chroma_;
+  }
+  const size_t base = pic_.part_at(x0, y0);
+  fill_z(pic_.intra_dir[1], base, 1 << (2 * (log2 - 2)), (uint8_t)stored);
+}
+
+// ------------------------------------------------------------------------------------------------ prediction unit
+SliceDecoder::Motion SliceDecoder::motion_at(int x, int y) const {
+  const size_t p = pic_.part_at(x, y);
+  Motion m;
+  for (int l = 0; l < 2; l++) {
+    m.ref[l] = pic_.ref_idx[l][p];
+    m.mv[l].x = pic_.mv[l][2 * p];
+    m.mv[l].y = pic_.mv[l][2 * p + 1];
+  }
+  return m;
+}
+
+void SliceDecoder::set_motion(int x0, int y0, int w, int h, const Motion& m) {
+  for (int y = y0; y < y0 + h; y += 4)
+    for (int x = x0; x < x0 + w; x += 4) {
+      const size_t p = pic_.part_at(x, y);
+      for (int l = 0; l < 2; l++) {
+        pic_.ref_idx[l][p] = m.ref[l];
+        pic_.mv[l][2 * p] = m.ref[l] >= 0 ? m.mv[l].x : 0;
+        pic_.mv[l][2 * p + 1] = m.ref[l] >= 0 ? m.mv[l].y : 0;
+      }
+    }
+}
+
+// 6.4.2 availability of a neighbouring prediction block (also false for intra neighbours)
+bool SliceDecoder::pu_available(int xcb, int ycb, int ncbs, int xpb, int ypb, int w, int h, int part_idx, int xn, int yn) const {
+  bool ok;
+  const bool same_cb = xcb <= xn && ycb <= yn && xcb + ncbs > xn && ycb + ncbs > yn;
+  if (!same_cb) ok = available(xpb, ypb, xn, yn);
+  else ok = !((w << 1) == ncbs && (h << 1) == ncbs && part_idx == 1 && ycb + h <= yn && xcb + w > xn);
+  if (ok && pic_.pred_mode[pic_.part_at(xn, yn)] != MODE_INTER) ok = false;
+  return ok;
+}
+
+SliceDecoder::Mv SliceDecoder::scale_mv(Mv mv, int tb, int td) {
+  td = clip3(-128, 127, td);
+  tb = clip3(-128, 127, tb);
+  const int tx = (16384 + (std::abs(td) >> 1)) / td;
+  const int f = clip3(-4096, 4095, (tb * tx + 32) >> 6);
+  auto one = [f](int v) {
+    const int p = f * v;
+    return (int16_t)clip3(-32768, 32767, (p < 0 ? -1 : 1) * ((std::abs(p) + 127) >> 8));
+  };
+  Mv r;
+  r.x = one(mv.x);
+  r.y = one(mv.y);
+  return r;
+}
+
+// 8.5.3.2.9: motion of the collocated block covering (xcol, ycol) (already on the 16x16 grid) for list `list`, reference `ref_idx`
+bool SliceDecoder::col_mv(int xcol, int ycol, int list, int ref_idx, Mv& out) const {
+  const PicData* col = slice_->ref_pics[(sh_->type == SLICE_B && !sh_->collocated_from_l0) ? 1 : 0][sh_->collocated_ref_idx];
+  if (!col) return false;
+  const size_t p = col->part_at(xcol, ycol);
+  if (col->pred_mode[p] != MODE_INTER) return false;
+  int lc;
+  if (col->ref_idx[0][p] < 0) lc = 1;
+  else if (col->ref_idx[1][p] < 0) lc = 0;
+  else lc = no_backward_pred_ ? list : (sh_->collocated_from_l0 ? 1 : 0);
+  const int ref_col = col->ref_idx[lc][p];
+  if (ref_col < 0) return false;
+  const SliceInfo& cs = *col->slices[col->slice_idx[col->ctb_at(xcol, ycol)]];
+  const bool cur_lt = slice_->ref_is_lt[list][ref_idx], col_lt = cs.ref_is_lt[lc][ref_col];
+  if (cur_lt != col_lt) return false;
+  Mv mv;
+  mv.x = col->mv[lc][2 * p];
+  mv.y = col->mv[lc][2 * p + 1];
+  const int col_diff = col->poc - cs.ref_poc[lc][ref_col], cur_diff = pic_.poc - slice_->ref_poc[list][ref_idx];
+  if (cur_lt || col_diff == cur_diff || col_diff == 0) out = mv;
+  else out = scale_mv(mv, cur_diff, col_diff);
+  return true;
+}
+
+// 8.5.3.2.8 temporal luma motion vector prediction
+bool SliceDecoder::temporal_mv(int xpb, int ypb, int w, int h, int list, int ref_idx, Mv& out) const {
+  if (!sh_->temporal_mvp) return false;
+  const int xbr = xpb + w, ybr = ypb + h;
+  if ((ypb >> sps_.log2_ctb) == (ybr >> sps_.log2_ctb) && ybr < pic_.height && xbr < pic_.width)
+    if (col_mv((xbr >> 4) << 4, (ybr >> 4) << 4, list, ref_idx, out)) return true;
+  const int xc = xpb + (w >> 1), yc = ypb + (h >> 1);
+  return col_mv((xc >> 4) << 4, (yc >> 4) << 4, list, ref_idx, out);
+}
+
+// 8.5.3.2.2 - 8.5.3.2.5 merge mode
+void SliceDecoder::merge_candidates(int xcb, int ycb, int ncbs, int xpb, int ypb, int w, int h, int part_idx, int part_mode, int merge_idx, Motion& out) {
+  const int ow = w, oh = h;
+  if (pps_.log2_par_mrg_level > 2 && ncbs == 8) { xpb = xcb; ypb = ycb; w = h = ncbs; part_idx = 0; part_mode = PART_2Nx2N; }
+  const int L = pps_.log2_par_mrg_level, maxc = sh_->max_num_merge_cand;
+  Motion cand[6];
+  int n = 0;
+  auto usable = [&](int xn, int yn) {
+    if ((xpb >> L) == (xn >> L) && (ypb >> L) == (yn >> L)) return false;
+    return pu_available(xcb, ycb, ncbs, xpb, ypb, w, h, part_idx, xn, yn);
+  };
+  bool av_a1 = false, av_b1 = false;
+  Motion a1, b1;
+  int spatial = 0;
+  if (!((part_mode == PART_Nx2N || part_mode == PART_nLx2N || part_mode == PART_nRx2N) && part_idx == 1) && usable(xpb - 1, ypb + h - 1)) {
+    a1 = motion_at(xpb - 1, ypb + h - 1);
+    av_a1 = true;
+    cand[n++] = a1;
+    spatial++;
+  }
+  if (!((part_mode == PART_2NxN || part_mode == PART_2NxnU || part_mode == PART_2NxnD) && part_idx == 1) && usable(xpb + w - 1, ypb - 1)) {
+    b1 = motion_at(xpb + w - 1, ypb - 1);
+    av_b1 = true;                            // stays "available" for the comparisons below even when it duplicates A1 (HM: isAvailableB1)
+    if (!(av_a1 && b1.same(a1))) { cand[n++] = b1; spatial++; }
+  }
+  if (usable(xpb + w, ypb - 1)) {
+    const Motion b0 = motion_at(xpb + w, ypb - 1);
+    if (!(av_b1 && b0.same(b1))) { cand[n++] = b0; spatial++; }
+  }
+  if (usable(xpb - 1, ypb + h)) {
+    const Motion a0 = motion_at(xpb - 1, ypb + h);
+    if (!(av_a1 && a0.same(a1))) { cand[n++] = a0; spatial++; }
+  }
+  if (spatial != 4 && usable(xpb - 1, ypb - 1)) {
+    const Motion b2 = motion_at(xpb - 1, ypb - 1);
+    if (!(av_a1 && b2.same(a1)) && !(av_b1 && b2.same(b1))) cand[n++] = b2;
+  }
+  if (n < maxc && sh_->temporal_mvp) {
+    Motion c;
+    Mv mv;
+    bool any = false;
+    if (temporal_mv(xpb, ypb, w, h, 0, 0, mv)) { c.mv[0] = mv; c.ref[0] = 0; any = true; }
+    if (sh_->type == SLICE_B && temporal_mv(xpb, ypb, w, h, 1, 0, mv)) { c.mv[1] = mv; c.ref[1] = 0; any = true; }
+    if (any) cand[n++] = c;
+  }
+  if (n > maxc) n = maxc;
+  if (sh_->type == SLICE_B && n > 1 && n < maxc) {                      // 8.5.3.2.4 combined bi-predictive candidates
+    static const uint8_t l0c[12] = {0, 1, 0, 2, 1, 2, 0, 3, 1, 3, 2, 3}, l1c[12] = {1, 0, 2, 0, 2, 1, 3, 0, 3, 1, 3, 2};
+    const int orig = n;
+    for (int k = 0; k < orig * (orig - 1) && n < maxc; k++) {
+      const Motion &p0 = cand[l0c[k]], &p1 = cand[l1c[k]];
+      if (p0.ref[0] >= 0 && p1.ref[1] >= 0 && (slice_->ref_poc[0][p0.ref[0]] != slice_->ref_poc[1][p1.ref[1]] || !(p0.mv[0] == p1.mv[1]))) {
+        Motion c;
+        c.mv[0] = p0.mv[0]; c.ref[0] = p0.ref[0];
+        c.mv[1] = p1.mv[1]; c.ref[1] = p1.ref[1];
+        cand[n++] = c;
+      }
+    }
+  }
+  const int num_ref = sh_->type == SLICE_P ? sh_->num_ref_idx[0] : std::min(sh_->num_ref_idx[0], sh_->num_ref_idx[1]);
+  for (int zero = 0; n < maxc; zero++) {                                // 8.5.3.2.5 zero candidates
+    Motion c;
+    c.ref[0] = (int8_t)(zero < num_ref ? zero : 0);
+    if (sh_->type == SLICE_B) c.ref[1] = c.ref[0];
+    cand[n++] = c;
+  }
+  out = cand[merge_idx];
+  if (out.ref[0] >= 0 && out.ref[1] >= 0 && ow + oh == 12) { out.ref[1] = -1; out.mv[1] = Mv(); }
+}
+
+// 8.5.3.2.6 / 8.5.3.2.7 luma motion vector prediction
+SliceDecoder::Mv SliceDecoder::amvp(int xcb, int ycb, int ncbs, int xpb, int ypb, int w, int h, int part_idx, int list, int ref_idx, int mvp_flag) {
+  const int X = list, Y = 1 - list;
+  const int target_poc = slice_->ref_poc[X][ref_idx];
+  const bool target_lt = slice_->ref_is_lt[X][ref_idx];
+  auto same_poc = [&](const Motion& m, Mv& mv) {          // first pass: a motion vector pointing at the very same picture
+    if (m.ref[X] >= 0 && slice_->ref_poc[X][m.ref[X]] == target_poc) { mv = m.mv[X]; return true; }
+    if (m.ref[Y] >= 0 && slice_->ref_poc[Y][m.ref[Y]] == target_poc) { mv = m.mv[Y]; return true; }
+    return false;
+  };
+  auto scaled = [&](const Motion& m, Mv& mv) {            // second pass: any motion vector of the same kind of reference, scaled
+    for (int l : {X, Y}) {
+      if (m.ref[l] < 0) continue;
+      const bool lt = slice_->ref_is_lt[l][m.ref[l]];
+      if (lt != target_lt) continue;
+      mv = m.mv[l];
+      const int nb_poc = slice_->ref_poc[l][m.ref[l]];
+      if (!lt && nb_poc != target_poc) mv = scale_mv(mv, pic_.poc - target_poc, pic_.poc - nb_poc);
+      return true;
+    }
+    return false;
+  };
+  const int ax[2] = {xpb - 1, xpb - 1}, ay[2] = {ypb + h, ypb + h - 1};
+  const int bx[3] = {xpb + w, xpb + w - 1, xpb - 1}, by[3] = {ypb - 1, ypb - 1, ypb - 1};
+  bool av_a[2], av_b[3];
+  for (int k = 0; k < 2; k++) av_a[k] = pu_available(xcb, ycb, ncbs, xpb, ypb, w, h, part_idx, ax[k], ay[k]);
+  for (int k = 0; k < 3; k++) av_b[k] = pu_available(xcb, ycb, ncbs, xpb, ypb, w, h, part_idx, bx[k], by[k]);
+  const bool is_scaled = av_a[0] || av_a[1];
+  bool have_a = false, have_b = false;
+  Mv mva, mvb;
+  for (int k = 0; k < 2 && !have_a; k++) if (av_a[k]) have_a = same_poc(motion_at(ax[k], ay[k]), mva);
+  for (int k = 0; k < 2 && !have_a; k++) if (av_a[k]) have_a = scaled(motion_at(ax[k], ay[k]), mva);
+  for (int k = 0; k < 3 && !have_b; k++) if (av_b[k]) have_b = same_poc(motion_at(bx[k], by[k]), mvb);
+  if (!is_scaled) {
+    if (have_b) { mva = mvb; have_a = true; }
+    have_b = false;
+    for (int k = 0; k < 3 && !have_b; k++) if (av_b[k]) have_b = scaled(motion_at(bx[k], by[k]), mvb);
+  }
+  Mv list2[3];
+  int n = 0;
+  if (have_a) list2[n++] = mva;
+  if (have_b && !(have_a && mva == mvb)) list2[n++] = mvb;
+  if (n < 2) {
+    Mv col;
+    if (temporal_mv(xpb, ypb, w, h, X, ref_idx, col)) list2[n++] = col;
+  }
+  while (n < 2) list2[n++] = Mv();
+  return list2[mvp_flag];
+}
+
+void SliceDecoder::prediction_unit(int xcb, int ycb, int ncbs, int x0, int y0, int w, int h, int part_idx, int part_mode, int depth, bool skip) {
+  const bool merge = skip || cabac_.decision(ctx_.s[CTX_MERGE_FLAG]);
+  Motion m;
+  int merge_idx = 0, inter_dir = 0;
+  if (merge) {
+    if (sh_->max_num_merge_cand > 1 && cabac_.decision(ctx_.s[CTX_MERGE_IDX])) {
+      merge_idx = 1;
+      while (merge_idx < sh_->max_num_merge_cand - 1 && cabac_.bypass()) merge_idx++;
+    }
+    merge_candidates(xcb, ycb, ncbs, x0, y0, w, h, part_idx, part_mode, merge_idx, m);
+  } else {
+    int dir = PRED_L0;
+    if (sh_->type == SLICE_B) {
+      if (w + h != 12 && cabac_.decision(ctx_.s[CTX_INTER_DIR + depth])) dir = PRED_BI;
+      else dir = cabac_.decision(ctx_.s[CTX_INTER_DIR + 4]) ? PRED_L1 : PRED_L0;
+    }
+    auto mvd_coding = [&](int& dx, int& dy) {                           // 7.3.8.9
+      const bool g0x = cabac_.decision(ctx_.s[CTX_MVD_GT0]), g0y = cabac_.decision(ctx_.s[CTX_MVD_GT0]);
+      const bool g1x = g0x && cabac_.decision(ctx_.s[CTX_MVD_GT1]), g1y = g0y && cabac_.decision(ctx_.s[CTX_MVD_GT1]);
+      auto rest = [&](bool g0, bool g1) {
+        if (!g0) return 0;
+        int a = 1;
+        if (g1) {                                                       // abs_mvd_minus2: EG1
+          int k = 1;
+          unsigned s = 0;
+          while (cabac_.bypass()) { s += 1u << k; if (++k > 16) throw ParseError("abs_mvd_minus2 too large"); }
+          s += cabac_.bypass_bits(k);
+          a = 2 + (int)s;
+        }
+        return cabac_.bypass() ? -a : a;
+      };
+      dx = rest(g0x, g1x);
+      dy = rest(g0y, g1y);
+    };
+    for (int l = 0; l < 2; l++) {
+      if (dir == (l == 0 ? PRED_L1 : PRED_L0)) continue;
+      int ref = 0;
+      const int cmax = sh_->num_ref_idx[l] - 1;
+      while (ref < cmax) {
+        const int bit = ref < 2 ? cabac_.decision(ctx_.s[CTX_REF_IDX + ref]) : cabac_.bypass();
+        if (!bit) break;
+        ref++;
+      }
+      int dx = 0, dy = 0;
+      if (!(l == 1 && sh_->mvd_l1_zero && dir == PRED_BI)) mvd_coding(dx, dy);
+      const int mvp_flag = cabac_.decision(ctx_.s[CTX_MVP]);
+      const Mv p = amvp(xcb, ycb, ncbs, x0, y0, w, h, part_idx, l, ref, mvp_flag);
+      m.ref[l] = (int8_t)ref;
+      m.mv[l].x = (int16_t)(p.x + dx);
+      m.mv[l].y = (int16_t)(p.y + dy);
+    }
+  }
+  inter_dir = (m.ref[0] >= 0 ? 1 : 0) | (m.ref[1] >= 0 ? 2 : 0);
+  set_motion(x0, y0, w, h, m);
+  for (int y = y0; y < y0 + h; y += 4)
+    for (int x = x0; x < x0 + w; x += 4) {
+      const size_t p = pic_.part_at(x, y);
+      pic_.merge[p] = merge;
+      pic_.merge_idx[p] = (uint8_t)merge_idx;
+      pic_.inter_dir[p] = (uint8_t)inter_dir;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ transform tree
+void SliceDecoder::transform_tree(int x0, int y0, int xbase, int ybase, int log2, int tr_depth, int blk, int cu_log2, bool parent_cb, bool parent_cr) {
+  const size_t base = pic_.part_at(x0, y0);
+  const int nparts = 1 << (2 * (log2 - 2));
+  const int8_t part_mode = pic_.part_size[base];
+  const bool intra_split = cu_pred_mode_ == MODE_INTRA && part_mode == PART_NxN;
+  const int max_depth = cu_pred_mode_ == MODE_INTRA ? sps_.max_th_depth_intra + (intra_split ? 1 : 0) : sps_.max_th_depth_inter;
+  bool split;
+  if (log2 <= sps_.log2_max_tb && log2 > sps_.log2_min_tb && tr_depth < max_depth && !(intra_split && tr_depth == 0)) {
+    split = cabac_.decision(ctx_.s[CTX_SPLIT_TU + 5 - log2]);
+  } else {
+    const bool inter_split = sps_.max_th_depth_inter == 0 && cu_pred_mode_ == MODE_INTER && part_mode != PART_2Nx2N && tr_depth == 0;
+    split = log2 > sps_.log2_max_tb || (intra_split && tr_depth == 0) || inter_split;
+  }
+  bool cbf_cb = parent_cb, cbf_cr = parent_cr;          // 4x4 luma blocks: the chroma flags of the parent stand
+  if (log2 > 2) {
+    cbf_cb = (tr_depth == 0 || parent_cb) && cabac_.decision(ctx_.s[CTX_CBF_CHROMA + tr_depth]);
+    cbf_cr = (tr_depth == 0 || parent_cr) && cabac_.decision(ctx_.s[CTX_CBF_CHROMA + tr_depth]);
+  }
+  if (cbf_cb) for (int i = 0; i < nparts; i++) pic_.cbf[1][base + i] |= (uint8_t)(1 << tr_depth);
+  if (cbf_cr) for (int i = 0; i < nparts; i++) pic_.cbf[2][base + i] |= (uint8_t)(1 << tr_depth);
+  if (split) {
+    const int h = 1 << (log2 - 1);
+    transform_tree(x0, y0, x0, y0, log2 - 1, tr_depth + 1, 0, cu_log2, cbf_cb, cbf_cr);
+    transform_tree(x0 + h, y0, x0, y0, log2 - 1, tr_depth + 1, 1, cu_log2, cbf_cb, cbf_cr);
+    transform_tree(x0, y0 + h, x0, y0, log2 - 1, tr_depth + 1, 2, cu_log2, cbf_cb, cbf_cr);
+    transform_tree(x0 + h, y0 + h, x0, y0, log2 - 1, tr_depth + 1, 3, cu_log2, cbf_cb, cbf_cr);
+    uint8_t any = 0;
+    for (int i = 0; i < nparts; i++) any |= pic_.cbf[0][base + i];
+    if ((any >> (tr_depth + 1)) & 1) for (int i = 0; i < nparts; i++) pic_.cbf[0][base + i] |= (uint8_t)(1 << tr_depth);
+    return;
+  }
+  bool cbf_luma = true;
+  if (cu_pred_mode_ == MODE_INTRA || tr_depth != 0 || cbf_cb || cbf_cr) cbf_luma = cabac_.decision(ctx_.s[CTX_CBF_LUMA + (tr_depth == 0 ? 1 : 0)]);
+  fill_z(pic_.tr_idx, base, nparts, (uint8_t)tr_depth);
+  if (cbf_luma) for (int i = 0; i < nparts; i++) pic_.cbf[0][base + i] |= (uint8_t)(1 << tr_depth);
+  if (cbf_luma || cbf_cb || cbf_cr) {                   // 7.3.8.10 transform_unit()
+    if (pps_.cu_qp_delta_enabled && !is_cu_qp_delta_coded_) qp_delta();
+    if (cbf_luma) residual_coding(x0, y0, log2, 0);
+    if (log2 > 2) {
+      if (cbf_cb) residual_coding(x0, y0, log2 - 1, 1);
+      if (cbf_cr) residual_coding(x0, y0, log2 - 1, 2);
+    } else if (blk == 3) {
+      if (cbf_cb) residual_coding(xbase, ybase, 2, 1);
+      if (cbf_cr) residual_coding(xbase, ybase, 2, 2);
+    }
+  }
+}
+
+// 7.3.8.11 residual_coding(); (x0, y0) in luma samples, log2 = size of the block in samples of component c
+void SliceDecoder::residual_coding(int x0, int y0, int log2, int c) {
+  const int size = 1 << log2;
+  const size_t part = pic_.part_at(x0, y0), ctb = pic_.ctb_at(x0, y0), z = part - ctb * pic_.parts;
+  int16_t* dst = c == 0 ? &pic_.coeff[0][(ctb << (2 * sps_.log2_ctb)) + 16 * z] : &pic_.coeff[c][(ctb << (2 * sps_.log2_ctb - 2)) + 4 * z];
+  if (pps_.transform_skip_enabled && !cu_bypass_ && log2 == 2 && cabac_.decision(ctx_.s[CTX_TS_FLAG + (c ? 1 : 0)])) {
+    const int span = c ? 2 : 1;                          // a 4x4 chroma block lies over 2x2 luma partitions
+    for (int y = 0; y < span; y++) for (int x = 0; x < span; x++) pic_.ts[c][pic_.part_at(x0 + 4 * x, y0 + 4 * y)] = 1;
+  }
+  // last significant coefficient position (9.3.4.2.3)
+  int ctx_off, ctx_shift;
+  if (c == 0) { ctx_off = 3 * (log2 - 2) + ((log2 - 1) >> 2); ctx_shift = (log2 + 1) >> 2; }
+  else { ctx_off = 15; ctx_shift = log2 - 2; }
+  const int cmax = (log2 << 1) - 1;
+  int px = 0, py = 0;
+  while (px < cmax && cabac_.decision(ctx_.s[CTX_LAST_X + ctx_off + (px >> ctx_shift)])) px++;
+  while (py < cmax && cabac_.decision(ctx_.s[CTX_LAST_Y + ctx_off + (py >> ctx_shift)])) py++;
+  int lx = px, ly = py;
+  if (px > 3) { const int nb = (px >> 1) - 1; lx = (1 << nb) * (2 + (px & 1)) + (int)cabac_.bypass_bits(nb); }
+  if (py > 3) { const int nb = (py >> 1) - 1; ly = (1 << nb) * (2 + (py & 1)) + (int)cabac_.bypass_bits(nb); }
+  int scan_idx = 0;
+  if (cu_pred_mode_ == MODE_INTRA && (log2 == 2 || (log2 == 3 && c == 0))) {
+    const int mode = c == 0 ? pic_.intra_dir[0][part] : intra_chroma_;
+    if (mode >= 6 && mode <= 14) scan_idx = 2;
+    else if (mode >= 22 && mode <= 30) scan_idx = 1;
+  }
+  if (scan_idx == 2) std::swap(lx, ly);
+  if (lx >= size || ly >= size) throw ParseError("last significant coefficient outside the transform block");
+  const int sb_log2 = log2 - 2, sbw = 1 << sb_log2;
+  const uint8_t* sb_order = kScan.order[sb_log2][scan_idx];
+  const uint8_t* in_order = kScan.order[2][scan_idx];
+  const int last_sb = kScan.index[sb_log2][scan_idx][(ly >> 2) * sbw + (lx >> 2)];
+  const int last_pos = kScan.index[2][scan_idx][(ly & 3) * 4 + (lx & 3)];
+  uint8_t csbf[9][9] = {{0}};
+  int prev_c1 = 1;
+  bool first_sb = true;
+  const bool sdh = pps_.sign_data_hiding && !cu_bypass_;
+  for (int i = last_sb; i >= 0; i--) {
+    const int xs = sb_order[i] % sbw, ys = sb_order[i] / sbw;
+    const int right = csbf[ys][xs + 1], below = csbf[ys + 1][xs];
+    bool coded = true, infer_dc = false;
+    if (i < last_sb && i > 0) {
+      coded = cabac_.decision(ctx_.s[CTX_CSBF + ((right | below) ? 1 : 0) + (c ? 2 : 0)]);
+      infer_dc = true;
+    }
+    csbf[ys][xs] = coded;
+    if (!coded) continue;
+    // significance map (9.3.4.2.5)
+    int pos[16], nsig = 0;
+    int n = 15;
+    if (i == last_sb) { pos[nsig++] = last_pos; n = last_pos - 1; }
+    const int prev_csbf = right | (below << 1);
+    for (; n >= 0; n--) {
+      const int xp = in_order[n] & 3, yp = in_order[n] >> 2;
+      bool sig;
+      if (n > 0 || !infer_dc) {
+        int sc;
+        if (log2 == 2) {
+          sc = kSigCtx4x4[(yp << 2) + xp];
+        } else if (n == 0 && i == 0) {
+          sc = 0;
+        } else {
+          switch (prev_csbf) {
+            case 0: sc = (xp + yp == 0) ? 2 : (xp + yp < 3) ? 1 : 0; break;
+            case 1: sc = (yp == 0) ? 2 : (yp == 1) ? 1 : 0; break;
+            case 2: sc = (xp == 0) ? 2 : (xp == 1) ? 1 : 0; break;
+            default: sc = 2; break;
+          }
+          if (c == 0) {
+            if (i > 0) sc += 3;
+            sc += log2 == 3 ? (scan_idx == 0 ? 9 : 15) : 21;
+          } else {
+            sc += log2 == 3 ? 9 : 12;
+          }
+        }
+        sig = cabac_.decision(ctx_.s[CTX_SIG + (c ? 27 : 0) + sc]);
+        if (sig) infer_dc = false;
+      } else {
+        sig = true;                                      // the only coefficient a coded sub-block can still have
+      }
+      if (sig) pos[nsig++] = n;
+    }
+    if (nsig == 0) continue;
+    // greater-than-1 / greater-than-2 flags (9.3.4.2.6, 9.3.4.2.7)
+    int ctx_set = (i == 0 || c > 0) ? 0 : 2;
+    if (!first_sb && prev_c1 == 0) ctx_set++;
+    first_sb = false;
+    int c1 = 1, first_g1 = -1;
+    uint8_t g1[16] = {0};
+    const int ng1 = nsig < 8 ? nsig : 8;
+    for (int k = 0; k < ng1; k++) {
+      g1[k] = (uint8_t)cabac_.decision(ctx_.s[CTX_GT1 + (c ? 16 : 0) + ctx_set * 4 + c1]);
+      if (g1[k]) { c1 = 0; if (first_g1 < 0) first_g1 = k; }
+      else if (c1 > 0 && c1 < 3) c1++;
+    }
+    prev_c1 = c1;
+    int g2 = 0;
+    if (first_g1 >= 0) g2 = cabac_.decision(ctx_.s[CTX_GT2 + (c ? 4 : 0) + ctx_set]);
+    const bool hidden = sdh && pos[0] - pos[nsig - 1] > 3;
+    const int nsign = nsig - (hidden ? 1 : 0);
+    const unsigned signs = cabac_.bypass_bits(nsign) << (16 - nsign);
+    int rice = 0, sum = 0;
+    for (int k = 0; k < nsig; k++) {
+      int level = 1 + g1[k] + (k == first_g1 ? g2 : 0);
+      const int thresh = k < 8 ? (k == first_g1 ? 3 : 2) : 1;
+      if (level == thresh) {
+        int prefix = 0;
+        while (prefix < 32 && cabac_.bypass()) prefix++;
+        if (prefix == 32) throw ParseError("coeff_abs_level_remaining prefix too long");
+        int rem;
+        if (prefix <= 3) rem = (prefix << rice) + (int)cabac_.bypass_bits(rice);
+        else rem = (((1 << (prefix - 3)) + 3 - 1) << rice) + (int)cabac_.bypass_bits(prefix - 3 + rice);
+        level += rem;
+        if (level > 3 * (1 << rice)) rice = std::min(rice + 1, 4);
+      }
+      sum += level;
+      bool neg;
+      if (k < nsign) neg = (signs >> (15 - k)) & 1;
+      else neg = sum & 1;
+      const int v = neg ? -level : level;
+      const int xc = (xs << 2) + (in_order[pos[k]] & 3), yc = (ys << 2) + (in_order[pos[k]] >> 2);
+      dst[yc * size + xc] = (int16_t)clip3(-32768, 32767, v);
+    }
+  }
+}
+
+}  // namespace hmdec

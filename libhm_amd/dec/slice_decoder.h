@@ -1,0 +1,83 @@
+// slice_decoder.h -- slice_segment_data() of Rec. ITU-T H.265 7.3.8 parsed into HM's per-CTU arrays (picture.h), together with the
+// decoding processes that feed on parsed data only: QP derivation (8.6.1), intra mode derivation (8.4.2, 8.4.3) and motion vector
+// prediction (8.5.3.2: merge, AMVP, temporal candidates).  HM counterpart: TDecSlice.cpp, TDecCu.cpp:142-372, TDecEntropy.cpp,
+// TDecSbac.cpp, TComDataCU.cpp (getInterMergeCandidates :2400-2710, fillMvpCand :2790-3000, xGetColMVP :3240-3330).
+#pragma once
+#include "cabac.h"
+#include "picture.h"
+
+namespace hmdec {
+
+struct PicParseState {               // carried from one slice segment of a picture to the next
+  ContextSet end_of_segment;         // 9.3.2.4 storage for dependent slice segments
+  bool have_end_of_segment = false;
+  int last_qp = 0;                   // qPY_PREV
+  int next_ctb_ts = 0;
+  ContextSet wpp;                    // 9.3.2.4 storage after the second CTB of a row (entropy_coding_sync)
+  bool wpp_valid = false;
+};
+
+class SliceDecoder {
+ public:
+  SliceDecoder(const Sps& sps, const Pps& pps, PicData& pic, PicParseState& st) : sps_(sps), pps_(pps), pic_(pic), st_(st) {}
+  // parses one slice segment; `slice` is the entry of pic.slices it belongs to.  Returns true when the picture is complete.
+  bool decode(const SliceHeader& sh, int slice_idx, const uint8_t* rbsp, size_t bytes);
+
+ private:
+  struct Mv { int16_t x = 0, y = 0; bool operator==(const Mv& o) const { return x == o.x && y == o.y; } };
+  struct Motion {
+    Mv mv[2];
+    int8_t ref[2] = {-1, -1};
+    bool same(const Motion& o) const {
+      if (ref[0] != o.ref[0] || ref[1] != o.ref[1]) return false;
+      for (int l = 0; l < 2; l++) if (ref[l] >= 0 && !(mv[l] == o.mv[l])) return false;
+      return true;
+    }
+  };
+  void init_contexts();
+  void ctu(int rs);
+  void sao_syntax(int rs);
+  void coding_quadtree(int x0, int y0, int log2, int depth);
+  void coding_unit(int x0, int y0, int log2, int depth);
+  void pcm_sample(int x0, int y0, int log2);
+  void prediction_unit(int xcb, int ycb, int ncbs, int x0, int y0, int w, int h, int part_idx, int part_mode, int depth, bool skip);
+  void intra_modes(int x0, int y0, int log2, bool nxn);
+  void transform_tree(int x0, int y0, int xbase, int ybase, int log2, int tr_depth, int blk, int cu_log2, bool parent_cbf_cb, bool parent_cbf_cr);
+  void residual_coding(int x0, int y0, int log2, int c);
+  void qp_delta();
+  void start_quant_group(int x0, int y0);
+  int cu_qp() const;
+  // neighbourhood
+  bool available(int xc, int yc, int xn, int yn) const;
+  bool pu_available(int xcb, int ycb, int ncbs, int xpb, int ypb, int w, int h, int part_idx, int xn, int yn) const;
+  Motion motion_at(int x, int y) const;
+  void set_motion(int x0, int y0, int w, int h, const Motion& m);
+  void merge_candidates(int xcb, int ycb, int ncbs, int xpb, int ypb, int w, int h, int part_idx, int part_mode, int merge_idx, Motion& out);
+  Mv amvp(int xcb, int ycb, int ncbs, int xpb, int ypb, int w, int h, int part_idx, int list, int ref_idx, int mvp_flag);
+  bool temporal_mv(int xpb, int ypb, int w, int h, int list, int ref_idx, Mv& out) const;
+  bool col_mv(int xcol, int ycol, int list, int ref_idx, Mv& out) const;
+  static Mv scale_mv(Mv mv, int tb, int td);
+  void fill(std::vector<uint8_t>& a, int x0, int y0, int log2, uint8_t v);
+  template <class T> void fill_z(std::vector<T>& a, size_t first, int count, T v) { std::fill(a.begin() + first, a.begin() + first + count, v); }
+
+  const Sps& sps_;
+  const Pps& pps_;
+  PicData& pic_;
+  PicParseState& st_;
+  const SliceHeader* sh_ = nullptr;
+  SliceInfo* slice_ = nullptr;
+  Cabac cabac_;
+  ContextSet ctx_;
+  int slice_idx_ = 0, ctb_rs_ = 0, ctb_ts_ = 0;
+  // quantisation group state (7.3.8.4, 8.6.1)
+  bool is_cu_qp_delta_coded_ = false;
+  int cu_qp_delta_val_ = 0, qg_pred_ = 0, qg_x_ = 0, qg_y_ = 0;
+  bool first_qg_in_unit_ = true;     // first quantisation group of the slice / tile / WPP row
+  // current CU
+  int cu_pred_mode_ = 0, cu_x_ = 0, cu_y_ = 0, cu_log2_ = 0;
+  bool cu_bypass_ = false;
+  int intra_luma_[4] = {0}, intra_chroma_ = 0;
+  bool no_backward_pred_ = false;
+};
+
+}  // namespace hmdec

@@ -1,0 +1,130 @@
+"""Host parser (libhmdec.so) against HM: every fixture stream is an HM-encoded bitstream together with what HM's
+own parser left behind for each picture (per-CTU TComDataCU arrays, coefficient levels, SAO parameters, slice constants, dumped by
+oracle/ref_harness.cpp).  The parser runs without a device (parse-only) and must reproduce all of it, array for array."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from libhm_amd import abi, hmdec
+from tests import golden_util as gu
+
+ARRAYS = [("depth", "depth"), ("part_size", "part_size"), ("pred_mode", "pred_mode"), ("qp", "qp"), ("tr_idx", "tr_idx"),
+          ("cbf0", "cbf_y"), ("cbf1", "cbf_u"), ("cbf2", "cbf_v"), ("ts0", "ts_y"), ("ts1", "ts_u"), ("ts2", "ts_v"),
+          ("intra_dir0", "intra_dir_l"), ("intra_dir1", "intra_dir_c"), ("ref_idx0", "ref_idx0"), ("ref_idx1", "ref_idx1"),
+          ("mv0", "mv0"), ("mv1", "mv1"), ("bypass", "bypass"), ("ipcm", "ipcm")]
+
+
+def _decode(name, **kw):
+    z = gu.load("stream_" + name)
+    got = []
+    with hmdec.Decoder(parse_only=True, **kw) as d:
+        def on_decoded(p):
+            arrays = {n: p.array(n) for n, _ in ARRAYS}
+            for n in ("skip", "merge", "coeff0", "coeff1", "coeff2", "sao", "slice_idx", "tile_idx", "pcm0", "pcm1", "pcm2"):
+                arrays[n] = p.array(n)
+            got.append(dict(poc=p.poc, arrays=arrays, slices=[p.slice_params(i) for i in range(p.num_slices())], hash=p.hash_sei()))
+        outputs = []
+        d.decode_stream(z["bitstream"], on_decoded=on_decoded, on_output=lambda p: outputs.append(p.poc))
+    return z, got, outputs
+
+
+@pytest.mark.parametrize("name", gu.STREAMS)
+def test_parser_reproduces_hm_metadata(name):
+    z, got, outputs = _decode(name)
+    pics = gu.stream_pictures(name)
+    assert len(got) == len(pics)
+    for g, p in zip(got, pics):
+        assert g["poc"] == p.poc                                                 # decoding order and POC (8.3.1)
+        decoded = p.meta_np["part_size"].reshape(-1) != abi.SIZE_NONE           # partitions inside the picture
+        k = "pic%02d_" % p.index
+        for mine, theirs in ARRAYS:
+            a, b = g["arrays"][mine], p.meta_np[theirs].reshape(-1)
+            if mine.startswith("mv"):
+                a, b = a.reshape(-1, 2), p.meta_np[theirs].reshape(-1, 2)
+            assert np.array_equal(a[decoded], b[decoded]), "%s pic %d: %s" % (name, p.index, mine)
+        assert np.array_equal(g["arrays"]["skip"][decoded], z[k + "meta_skip"].reshape(-1)[decoded])
+        inter = decoded & (p.meta_np["pred_mode"].reshape(-1) == abi.MODE_INTER)
+        assert np.array_equal(g["arrays"]["merge"][inter], z[k + "meta_merge"].reshape(-1)[inter])
+        for c in range(3):
+            assert np.array_equal(g["arrays"]["coeff%d" % c], z[k + "coeff%d" % c].reshape(-1)), "%s pic %d: levels %d" % (name, p.index, c)
+        assert np.array_equal(g["arrays"]["slice_idx"], p.meta_np["slice_idx"])
+        if "tile_idx" in p.meta_np:
+            assert np.array_equal(g["arrays"]["tile_idx"], p.meta_np["tile_idx"])
+        if (k + "pcm0") in z.files and p.meta_np["ipcm"].any():
+            ipcm = p.meta_np["ipcm"].reshape(p.num_ctus, -1)
+            for c in range(3):
+                per = 16 >> (2 if c else 0)
+                mask = np.repeat(ipcm, per, axis=1).reshape(-1).astype(bool)          # HM layout: 16 (4) samples per partition
+                assert np.array_equal(g["arrays"]["pcm%d" % c][mask], z[k + "pcm%d" % c].reshape(-1)[mask])
+
+
+@pytest.mark.parametrize("name", gu.STREAMS)
+def test_parser_reproduces_hm_sao_and_slice_constants(name):
+    z, got, outputs = _decode(name)
+    pics = gu.stream_pictures(name)
+    for g, p in zip(got, pics):
+        sao = g["arrays"]["sao"].reshape(p.num_ctus, 3, 35)
+        want = p.sao_raw
+        assert np.array_equal(sao[:, :, 0], want[:, :, 0]), "SAO mode, pic %d" % p.index
+        on = want[:, :, 0] != 0
+        assert np.array_equal(sao[:, :, 1][on], want[:, :, 1][on])                          # EO class / BO / merge direction
+        new = want[:, :, 0] == 1
+        bo = new & (want[:, :, 1] == 4)
+        assert np.array_equal(sao[:, :, 2][bo], want[:, :, 2][bo])                          # band position
+        assert np.array_equal(sao[bo][:, 3:], want[bo][:, 3:])
+        eo = new & (want[:, :, 1] < 4)
+        assert np.array_equal(sao[eo][:, 3:8], want[eo][:, 3:8])
+        assert len(g["slices"]) == len(p.slices)
+        for (mine, lists), theirs in zip(g["slices"], p.slices):
+            for f in ("slice_type", "cb_qp_offset", "cr_qp_offset", "pps_cb_qp_offset", "pps_cr_qp_offset", "deblocking_disable",
+                      "lf_across_slices", "weighted_pred", "lf_across_tiles", "constrained_intra_pred"):
+                assert getattr(mine, f) == getattr(theirs, f), "%s pic %d: %s" % (name, p.index, f)
+            if not theirs.deblocking_disable:
+                assert (mine.beta_offset_div2, mine.tc_offset_div2) == (theirs.beta_offset_div2, theirs.tc_offset_div2)
+            for l in range(2):
+                assert mine.num_ref_idx[l] == theirs.num_ref_idx[l]
+                for i in range(mine.num_ref_idx[l]):
+                    assert mine.ref_poc[l][i] == theirs.ref_poc[l][i]
+            if theirs.weighted_pred:
+                assert list(mine.wp_log2_denom) == list(theirs.wp_log2_denom)
+                for l in range(2):
+                    for i in range(mine.num_ref_idx[l]):
+                        assert list(mine.wp_weight[l][i]) == list(theirs.wp_weight[l][i]), (l, i)
+                        assert list(mine.wp_offset[l][i]) == list(theirs.wp_offset[l][i]), (l, i)
+            assert bool(mine.scaling_lists) == (p.scaling_lists is not None)
+            if p.scaling_lists is not None:
+                for sz in range(4):
+                    for l in range(6):
+                        if sz == 3 and l % 3:
+                            continue                                                          # 32x32 chroma: not used in 4:2:0
+                        n = 16 if sz == 0 else 64
+                        assert list(lists.coef[sz][l][:n]) == list(p.scaling_lists.coef[sz][l][:n]), (sz, l)
+                        if sz >= 2:
+                            assert lists.dc[sz][l] == p.scaling_lists.dc[sz][l]
+
+
+@pytest.mark.parametrize("name", ["ra_main10_208x120", "ldp_main8_416x240", "ra_wp_main8_208x120"])
+def test_output_order_and_hash_sei(name):
+    """pictures leave in increasing POC order (libHMDecoder.h:183-187), all of them, and the decoded-picture-hash SEI of every
+    picture is the MD5 HM computed for its own reconstruction (the fixtures were encoded with SEIDecodedPictureHash=1)"""
+    z, got, outputs = _decode(name)
+    pics = gu.stream_pictures(name)
+    assert outputs == sorted(p.poc for p in pics)
+    for g, p in zip(got, pics):
+        method, digest = g["hash"]
+        assert method == 1 and digest == p.md5
+
+
+def test_split_nal_units_and_version():
+    assert hmdec.lib().libHMDec_get_version() == b"16.0"
+    units = hmdec.split_nal_units(b"\x00\x00\x00\x01\x40\x01\xaa\x00\x00\x01\x42\x01\xbb\xcc\x00\x00\x00\x01\x44\x01")
+    assert units == [b"\x40\x01\xaa", b"\x42\x01\xbb\xcc", b"\x44\x01"]
+
+
+def test_errors_are_reported_not_fatal():
+    with hmdec.Decoder(parse_only=True) as d:
+        with pytest.raises(RuntimeError):
+            d.push(b"\x80\x01\x00\x00", False)             # forbidden_zero_bit
+        with pytest.raises(RuntimeError):
+            d.push(b"\x02\x01\x80\x00\x00", False)          # a slice before any parameter set
