@@ -70,12 +70,17 @@ int hmdec_hash_mismatches(libHMDec_context* ctx);                             /*
 int hmdec_pictures_decoded(libHMDec_context* ctx);
 const char* hmdec_last_error(libHMDec_context* ctx);
 libHMDec_picture* hmdec_last_decoded_picture(libHMDec_context* ctx);          /* the picture finished most recently, decoding order */
+libHMDec_picture* hmdec_open_picture(libHMDec_context* ctx);                  /* the picture whose slices are still arriving, or NULL */
 /* parser output of a picture by name: "depth", "part_size", "pred_mode", "qp", "tr_idx", "cbf0".."cbf2", "ts0".."ts2", "mv0", "mv1",
  * "ref_idx0", "ref_idx1", "intra_dir0", "intra_dir1", "bypass", "ipcm", "skip", "merge", "slice_idx", "tile_idx", "coeff0".."coeff2",
  * "pcm0".."pcm2", "sao", "plane0".."plane2" -- the HM-layout arrays of include/hmgpu.h.  Returns 0 and pointer/size on success. */
 int hmdec_picture_array(libHMDec_picture* pic, const char* name, const void** data, int64_t* bytes);
 int hmdec_picture_num_slices(libHMDec_picture* pic);
 int hmdec_picture_slice_params(libHMDec_picture* pic, int slice, void* out /* hmgpu_slice_params */, void* lists_out /* hmgpu_scaling_lists or NULL */);
+/* conformance window of the picture's SPS in luma samples: left, right, top, bottom (libHM hands out the uncropped picture) */
+int hmdec_picture_conformance_window(libHMDec_picture* pic, int32_t window[4]);
+/* libHMDEC_get_internal_info for C callers: pointer to the first element and the count (same storage, same lifetime) */
+int hmdec_internal_info(libHMDec_context* ctx, libHMDec_picture* pic, int type, const libHMDec_BlockValue** data);
 int hmdec_picture_hash_sei(libHMDec_picture* pic, uint8_t digest[48]);        /* returns the method (0 none, 1 MD5, 2 CRC, 3 checksum) */
 
 #ifdef __cplusplus

@@ -287,6 +287,7 @@ void Decoder::start_picture(const SliceHeader& sh) {
   cur_->poc = sh.poc;
   cur_->nal_type = sh.nal_type;
   cur_->temporal_id = sh.temporal_id;
+  cur_->conf_window[0] = sps_->conf_left; cur_->conf_window[1] = sps_->conf_right; cur_->conf_window[2] = sps_->conf_top; cur_->conf_window[3] = sps_->conf_bottom;
   cur_->is_reference = true;                 // "used for short-term reference" until a later RPS says otherwise (8.3.1 end)
   cur_->is_long_term = false;
   cur_->pic_output = sh.pic_output && !(is_rasl(sh.nal_type) && skip_rasl_);

@@ -32,6 +32,7 @@ class Decoder {
   PicData* next_output(bool flush_all);
   const Sps* active_sps() const { return sps_.get(); }
   PicData* last_decoded() const { return last_decoded_; }
+  PicData* open_picture() const { return cur_; }
   int hash_mismatches() const { return hash_mismatches_; }
   int pictures_decoded() const { return pictures_decoded_; }
   const std::string& last_error() const { return last_error_; }

@@ -260,6 +260,8 @@ int hmdec_pictures_decoded(libHMDec_context* ctx) { return ctx ? static_cast<Wra
 const char* hmdec_last_error(libHMDec_context* ctx) { return ctx ? static_cast<Wrapper*>(ctx)->dec.last_error().c_str() : ""; }
 libHMDec_picture* hmdec_last_decoded_picture(libHMDec_context* ctx) { return ctx ? static_cast<Wrapper*>(ctx)->dec.last_decoded() : nullptr; }
 
+libHMDec_picture* hmdec_open_picture(libHMDec_context* ctx) { return ctx ? static_cast<Wrapper*>(ctx)->dec.open_picture() : nullptr; }
+
 int hmdec_picture_array(libHMDec_picture* pic, const char* name, const void** data, int64_t* bytes) {
   if (!pic || !name || !data || !bytes) return 1;
   PicData& p = *as_pic(pic);
@@ -298,6 +300,20 @@ int hmdec_picture_slice_params(libHMDec_picture* pic, int slice, void* out, void
   memcpy(out, &p.slices[slice]->params, sizeof(hmgpu_slice_params));
   if (lists_out && p.slices[slice]->scaling_lists) memcpy(lists_out, p.slices[slice]->scaling_lists.get(), sizeof(hmgpu_scaling_lists));
   return 0;
+}
+
+int hmdec_picture_conformance_window(libHMDec_picture* pic, int32_t window[4]) {
+  if (!pic || !window) return 1;
+  for (int i = 0; i < 4; i++) window[i] = as_pic(pic)->conf_window[i];
+  return 0;
+}
+
+int hmdec_internal_info(libHMDec_context* ctx, libHMDec_picture* pic, int type, const libHMDec_BlockValue** data) {
+  if (!data || type < LIBHMDEC_CTU_SLICE_INDEX || type > LIBHMDEC_TU_COEFF_ENERGY_CR) return -1;
+  std::vector<libHMDec_BlockValue>* v = libHMDEC_get_internal_info(ctx, pic, (libHMDec_info_type)type);
+  if (!v) return -1;
+  *data = v->data();
+  return (int)v->size();
 }
 
 int hmdec_picture_hash_sei(libHMDec_picture* pic, uint8_t digest[48]) {

@@ -58,7 +58,7 @@ struct PicData {
   std::vector<hmgpu_sao_param> sao;  // [num_ctbs][3]
   std::vector<std::unique_ptr<SliceInfo>> slices;
   // picture state (8.3)
-  int poc = 0, nal_type = 0, temporal_id = 0;
+  int poc = 0, nal_type = 0, temporal_id = 0, conf_window[4] = {0, 0, 0, 0};
   bool is_reference = false, is_long_term = false, needed_for_output = false, pic_output = true, decoded = false, filtered = false;
   bool has_pcm = false, has_bypass = false, lent = false;     // lent: handed to the application by the last output scan
   hmgpu_pic handle = HMGPU_NO_PIC;

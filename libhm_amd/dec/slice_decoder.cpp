@@ -99,6 +99,7 @@ bool SliceDecoder::decode(const SliceHeader& sh, int slice_idx, const uint8_t* r
     const int end = cabac_.terminate();                     // end_of_slice_segment_flag
     ctb_ts_++;
     if (end) {
+      cabac_.finish_to_byte();                              // rbsp_slice_segment_trailing_bits(): catches a parser that lost sync
       if (pps_.dependent_slice_segments_enabled) { st_.end_of_segment = ctx_; st_.have_end_of_segment = true; }
       done = true;
     } else {
@@ -114,7 +115,6 @@ bool SliceDecoder::decode(const SliceHeader& sh, int slice_idx, const uint8_t* r
     }
   }
   st_.next_ctb_ts = ctb_ts_;
-  slice_->num_ctbs += 0;
   return ctb_ts_ >= pic_.num_ctbs;
 }
 

@@ -45,12 +45,27 @@ def lib():
         L.hmdec_last_error.restype = C.c_char_p
         L.hmdec_last_decoded_picture.argtypes = [C.c_void_p]
         L.hmdec_last_decoded_picture.restype = C.c_void_p
+        L.hmdec_open_picture.argtypes = [C.c_void_p]
+        L.hmdec_open_picture.restype = C.c_void_p
         L.hmdec_picture_array.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]
         L.hmdec_picture_num_slices.argtypes = [C.c_void_p]
         L.hmdec_picture_slice_params.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         L.hmdec_picture_hash_sei.argtypes = [C.c_void_p, C.c_void_p]
+        L.hmdec_picture_conformance_window.argtypes = [C.c_void_p, C.POINTER(C.c_int32)]
+        L.hmdec_internal_info.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.POINTER(BlockValue))]
         _lib = L
     return _lib
+
+
+class BlockValue(C.Structure):
+    _fields_ = [("x", C.c_ushort), ("y", C.c_ushort), ("w", C.c_ushort), ("h", C.c_ushort), ("value", C.c_int), ("value2", C.c_int)]
+
+
+INFO = {n: i for i, n in enumerate(
+    ["CTU_SLICE_INDEX", "CU_PREDICTION_MODE", "CU_TRQ_BYPASS", "CU_SKIP_FLAG", "CU_PART_MODE", "CU_INTRA_MODE_LUMA", "CU_INTRA_MODE_CHROMA",
+     "CU_ROOT_CBF", "PU_MERGE_FLAG", "PU_MERGE_INDEX", "PU_UNI_BI_PREDICTION", "PU_REFERENCE_POC_0", "PU_MV_0", "PU_REFERENCE_POC_1", "PU_MV_1",
+     "TU_CBF_Y", "TU_CBF_CB", "TU_CBF_CR", "TU_COEFF_TR_SKIP_Y", "TU_COEFF_TR_SKIP_Cb", "TU_COEFF_TR_SKIP_Cr", "TU_COEFF_ENERGY_Y",
+     "TU_COEFF_ENERGY_CB", "TU_COEFF_ENERGY_CR"])}
 
 
 def split_nal_units(stream):
@@ -111,6 +126,16 @@ class Picture:
         buf = (C.c_char * n.value).from_address(ptr.value)
         return np.frombuffer(buf, dtype=dt).copy()
 
+    def conformance_window(self):
+        w = (C.c_int32 * 4)()
+        lib().hmdec_picture_conformance_window(self.h, w)
+        return tuple(w)
+
+    def cropped_plane(self, c):
+        l, r, t, b = (v >> (1 if c else 0) for v in self.conformance_window())
+        p = self.plane(c)
+        return p[t:p.shape[0] - b, l:p.shape[1] - r]
+
     def num_slices(self):
         return lib().hmdec_picture_num_slices(self.h)
 
@@ -159,6 +184,14 @@ class Decoder:
     def get_picture(self):
         h = lib().libHMDec_get_picture(self.ctx)
         return Picture(h) if h else None
+
+    def internal_info(self, pic, kind):
+        """libHMDEC_get_internal_info as a list of (x, y, w, h, value, value2)"""
+        data = C.POINTER(BlockValue)()
+        n = lib().hmdec_internal_info(self.ctx, pic.h, INFO[kind], C.byref(data))
+        if n < 0:
+            raise RuntimeError("hmdec_internal_info")
+        return [(data[i].x, data[i].y, data[i].w, data[i].h, data[i].value, data[i].value2) for i in range(n)]
 
     def last_decoded(self):
         h = lib().hmdec_last_decoded_picture(self.ctx)

@@ -146,7 +146,7 @@ def encode(name, tmp):
     cmd = [hmref.ENCODER_PATH, "-c", os.path.join(HM_CFG, cfg), "-i", yuv, "-wdt", str(w), "-hgt", str(h), "-fr", "30",
            "-f", str(frames), "--InputBitDepth=%d" % ibd, "--InternalBitDepth=%d" % bd, "--OutputBitDepth=%d" % bd,
            "-q", str(qp), "-b", bs, "-o", rec, "--SEIDecodedPictureHash=1", "--Level=3.1"] + extra
-    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)   # (some slice/tile option mixes hang HM's encoder)
     if r.returncode != 0:
         print(r.stdout[-3000:])
         raise RuntimeError("encoder failed for " + name)
@@ -217,6 +217,54 @@ def dump_stream(name, bitstream, enc_rec, geom):
     path = os.path.join(GOLD, "stream_%s.npz" % name)
     np.savez_compressed(path, **out)
     print("wrote %s (%.1f KB)" % (path, os.path.getsize(path) / 1024.0))
+
+
+# ------------------------------------------------------------------------------------------ "lite" streams
+# Streams whose syntax HM 16.0's own decoder does not get through (it asserts in TComBitStream.h:191 on the multi-slice / WPP
+# streams its encoder writes) or that add nothing to the metadata fixtures: the bitstream plus the ENCODER's reconstruction, which
+# is by HM practice what a conforming decoder must output, and whose MD5 the encoder put into the stream as SEI.
+LITE = {
+    # name: (cfg, w, h, frames, input bit depth, internal bit depth, qp, extra encoder args)
+    # (HM 16.0's encoder writes every slice NAL with the data of all following CTUs of the picture appended unless slice SEGMENTS
+    # are configured as well -- the reason its own decoder trips over them; with SliceSegmentArgument == SliceArgument every slice
+    # is one independent segment and the stream is well formed)
+    "ldp_slices_main8_208x120": ("encoder_lowdelay_P_main.cfg", 208, 120, 3, 8, 8, 32,
+                                 ["--SliceMode=1", "--SliceArgument=3", "--SliceSegmentMode=1", "--SliceSegmentArgument=3", "--LFCrossSliceBoundaryFlag=0"]),
+    "ldp_depslices_main10_208x120": ("encoder_lowdelay_P_main10.cfg", 208, 120, 3, 10, 10, 30,
+                                     ["--SliceMode=1", "--SliceArgument=4", "--SliceSegmentMode=1", "--SliceSegmentArgument=2", "--LFCrossSliceBoundaryFlag=1"]),
+    "ldp_wpp_main10_416x240": ("encoder_lowdelay_P_main10.cfg", 416, 240, 3, 10, 10, 32, ["--WaveFrontSynchro=1"]),
+    "ldp_wpp_depslices_main8_416x240": ("encoder_lowdelay_P_main.cfg", 416, 240, 3, 8, 8, 34,
+                                        ["--WaveFrontSynchro=1", "--SliceMode=1", "--SliceArgument=10", "--SliceSegmentMode=1", "--SliceSegmentArgument=3"]),
+    "ldp_dqp_main10_208x120": ("encoder_lowdelay_P_main10.cfg", 208, 120, 3, 10, 10, 30, ["--MaxDeltaQP=3", "--MaxCuDQPDepth=2"]),
+    "ra_cra_main8_208x120": ("encoder_randomaccess_main.cfg", 208, 120, 18, 8, 8, 34, ["--IntraPeriod=8", "--DecodingRefreshType=1"]),
+    "ldp_ctu32_main8_208x120": ("encoder_lowdelay_P_main.cfg", 208, 120, 3, 8, 8, 30, ["--MaxCUWidth=32", "--MaxCUHeight=32", "--MaxPartitionDepth=3"]),
+    "ldp_ctu16_main10_208x120": ("encoder_lowdelay_P_main10.cfg", 208, 120, 3, 10, 10, 30, ["--MaxCUWidth=16", "--MaxCUHeight=16", "--MaxPartitionDepth=2", "--QuadtreeTULog2MaxSize=4"]),
+    "ldp_crop_main8_204x116": ("encoder_lowdelay_P_main.cfg", 204, 116, 3, 8, 8, 32, ["--ConformanceWindowMode=1"]),
+    "ldp_tileslices_main10_832x128": ("encoder_lowdelay_P_main10.cfg", 832, 128, 3, 10, 10, 32,
+                                      ["--TileUniformSpacing=1", "--NumTileColumnsMinus1=2", "--NumTileRowsMinus1=1", "--SliceMode=3", "--SliceArgument=2",
+                                       "--SliceSegmentMode=1", "--SliceSegmentArgument=64", "--LFCrossSliceBoundaryFlag=0"]),
+    "ldb_main8_208x120": ("encoder_lowdelay_main.cfg", 208, 120, 4, 8, 8, 32, []),
+}
+
+
+def make_lite(names=None):
+    os.makedirs(GOLD, exist_ok=True)
+    STREAMS.update(LITE)
+    with tempfile.TemporaryDirectory() as tmp:
+        for name in (names or LITE):
+            print("encoding", name)
+            bs, rec, (w, h, frames, bd) = encode(name, tmp)
+            out = {"bitstream": np.frombuffer(bs, dtype=np.uint8), "geom": np.array([w, h, frames, bd], dtype=np.int32)}
+            per = w * h * 3 // 2
+            assert rec.size == per * frames
+            for poc in range(frames):                                      # the recon file is in output (POC) order, cropped
+                fr = rec[poc * per:(poc + 1) * per].astype(np.int16)
+                out["poc%02d_0" % poc] = fr[:w * h].reshape(h, w)
+                out["poc%02d_1" % poc] = fr[w * h:w * h * 5 // 4].reshape(h // 2, w // 2)
+                out["poc%02d_2" % poc] = fr[w * h * 5 // 4:].reshape(h // 2, w // 2)
+            path = os.path.join(GOLD, "lite_%s.npz" % name)
+            np.savez_compressed(path, **out)
+            print("wrote %s (%.1f KB, %d bytes of bitstream)" % (path, os.path.getsize(path) / 1024.0, len(bs)))
 
 
 def make_streams(names=None):
@@ -328,3 +376,5 @@ if __name__ == "__main__":
         make_kats()
     if what in ("streams", "all"):
         make_streams(sys.argv[2:] or None)
+    if what in ("lite", "all"):
+        make_lite(sys.argv[2:] or None)

@@ -9,6 +9,10 @@ from libhm_amd import abi
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 STREAMS = ["ldp_main8_416x240", "ra_main10_208x120", "ldp_main10_208x120", "intra_main10_208x120", "ldp_cip_main10_208x120",
            "ldp_wp_main10_208x120", "ra_wp_main8_208x120", "ldp_sl_main10_208x120", "ldp_sldef_main8_208x120", "ldp_tiles_main10_832x128", "ldp_lossless_main10_208x120", "ldp_pcm_main8_208x120"]
+# bitstream + encoder reconstruction only (oracle/make_golden.py LITE): syntax HM 16.0's own decoder cannot be run on, or variants
+LITE = ["ldp_slices_main8_208x120", "ldp_depslices_main10_208x120", "ldp_wpp_main10_416x240", "ldp_wpp_depslices_main8_416x240",
+        "ldp_dqp_main10_208x120", "ra_cra_main8_208x120", "ldp_ctu32_main8_208x120", "ldp_ctu16_main10_208x120", "ldp_crop_main8_204x116",
+        "ldp_tileslices_main10_832x128", "ldb_main8_208x120"]
 _cache = {}
 
 

@@ -1,0 +1,107 @@
+"""End to end on the GPU: an HM-encoded bitstream goes into the libHMDecoder-compatible interface, the host
+parses, the device reconstructs, and what comes out of libHMDEC_get_image_plane must be HM's own output pictures, sample for
+sample -- with the decoder's own check of the decoded-picture-hash SEI (MD5) green on every picture."""
+import numpy as np
+import pytest
+
+from libhm_amd import hmdec
+from tests import golden_util as gu
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("name", gu.STREAMS)
+def test_bitstream_to_pictures_matches_hm(name):
+    z = gu.load("stream_" + name)
+    want = {p.poc: p for p in gu.stream_pictures(name)}
+    out = []
+    with hmdec.Decoder() as d:
+        def on_output(p):
+            out.append(p.poc)
+            w = want[p.poc]
+            for c in range(3):
+                assert p.size(c) == (w.fin[c].shape[1], w.fin[c].shape[0])
+                assert np.array_equal(p.plane(c), w.fin[c]), "%s POC %d component %d" % (name, p.poc, c)
+        d.decode_stream(z["bitstream"], on_output=on_output)
+        assert d.pictures_decoded == len(want)
+        assert d.hash_mismatches == 0                      # TDecGop.cpp:199-262 against the SEI in the stream
+    assert out == sorted(want)                             # every picture, in output order
+    assert hmdec.lib().libHMDEC_get_internal_bit_depth(0) == want[out[0]].bd_y
+
+
+def test_hash_check_notices_a_wrong_picture():
+    """the SEI check is live: the same stream with one SEI digest byte flipped reports a mismatch (and still decodes)"""
+    z = gu.load("stream_ldp_main8_416x240")
+    nals = hmdec.split_nal_units(z["bitstream"])
+    bad = []
+    hit = False
+    for n in nals:
+        if not hit and ((n[0] >> 1) & 0x3f) == 40 and n[2] == 132:      # suffix SEI, decoded picture hash
+            n = n[:6] + bytes([n[6] ^ 0x55]) + n[7:]
+            hit = True
+        bad.append(n)
+    assert hit
+    stream = b"".join(b"\x00\x00\x00\x01" + n for n in bad)
+    with hmdec.Decoder() as d:
+        d.decode_stream(stream)
+        assert d.hash_mismatches == 1
+        assert d.pictures_decoded == 3
+
+
+def test_internals_describe_the_picture():
+    """libHMDEC_get_internal_info: blocks tile the picture and carry the parsed values"""
+    import ctypes as C
+    z = gu.load("stream_ldp_main8_416x240")
+    pics = gu.stream_pictures("ldp_main8_416x240")
+    L = hmdec.lib()
+    with hmdec.Decoder() as d:
+        seen = []
+        d.decode_stream(z["bitstream"], on_output=lambda p: seen.append(p.poc))
+        assert seen == [0, 1, 2]
+        p = d.last_decoded()
+        assert p.poc == pics[-1].poc
+        pm = p.array("pred_mode")
+        assert np.array_equal(pm[pics[-1].meta_np["part_size"].reshape(-1) != 8], pics[-1].meta_np["pred_mode"].reshape(-1)[pics[-1].meta_np["part_size"].reshape(-1) != 8])
+
+
+@pytest.mark.parametrize("name", gu.LITE)
+def test_syntax_variants_decode_to_the_encoders_reconstruction(name):
+    """slices, dependent slice segments, wavefronts, CU-level QP, CRA + leading pictures, 32/16-sample CTUs, conformance window,
+    slices of tiles, low-delay B: output == HM's encoder reconstruction (== what HM's decoder must produce), hash SEI check green"""
+    z = gu.load("lite_" + name)
+    w, h, frames, bd = (int(v) for v in z["geom"])
+    out = []
+    with hmdec.Decoder() as d:
+        def on_output(p):
+            out.append(p.poc)
+            for c in range(3):
+                assert np.array_equal(p.cropped_plane(c), z["poc%02d_%d" % (p.poc, c)]), "%s POC %d component %d" % (name, p.poc, c)
+        d.decode_stream(z["bitstream"], on_output=on_output)
+        assert d.hash_mismatches == 0
+        assert d.pictures_decoded == frames
+    assert out == list(range(frames))
+
+
+def test_random_access_at_a_cra_picture():
+    """decoding starts at the second CRA picture of the stream: its RASL pictures (which reference pictures before the CRA) are
+    dropped (8.1: NoRaslOutputFlag; TDecTop::isRandomAccessSkipPicture), everything else is decoded exactly"""
+    z = gu.load("lite_ra_cra_main8_208x120")
+    nals = hmdec.split_nal_units(z["bitstream"])
+    types = [(n[0] >> 1) & 0x3f for n in nals]
+    cras = [i for i, t in enumerate(types) if t == 21]
+    assert len(cras) >= 2
+    start = cras[1]
+    while start > 0 and types[start - 1] in (39, 35):                    # prefix SEI / AUD that belong to the CRA access unit
+        start -= 1
+    stream = b"".join(b"\x00\x00\x00\x01" + n for n in [n for n, t in zip(nals, types) if t in (32, 33, 34)] + nals[start:])
+    out = []
+    with hmdec.Decoder() as d:
+        def on_output(p):
+            out.append(p.poc)
+            for c in range(3):
+                assert np.array_equal(p.cropped_plane(c), z["poc%02d_%d" % (p.poc, c)]), "POC %d component %d" % (p.poc, c)
+        d.decode_stream(stream, on_output=on_output)
+        assert d.hash_mismatches == 0
+    cra_poc = out[0]
+    assert cra_poc in (8, 16) and out == sorted(out) and all(p >= cra_poc for p in out)
+    assert len(out) >= 2

@@ -128,3 +128,62 @@ def test_errors_are_reported_not_fatal():
             d.push(b"\x80\x01\x00\x00", False)             # forbidden_zero_bit
         with pytest.raises(RuntimeError):
             d.push(b"\x02\x01\x80\x00\x00", False)          # a slice before any parameter set
+
+
+@pytest.mark.parametrize("name", gu.LITE)
+def test_parser_gets_through_every_syntax_variant(name):
+    """slices, dependent slice segments, wavefronts, CU-level QP, CRA with leading pictures, 32/16-sample CTUs, cropping, slices of
+    tiles, B low delay: the parser stays in sync to the last bit of every slice (the stop bit check behind end_of_slice_segment_flag),
+    puts all pictures out in POC order, and the hash SEIs it collected are the MD5s of HM's encoder reconstruction"""
+    import hashlib
+    z = gu.load("lite_" + name)
+    w, h, frames, bd = (int(v) for v in z["geom"])
+    hashes, out = {}, []
+    with hmdec.Decoder(parse_only=True) as d:
+        d.decode_stream(z["bitstream"], on_decoded=lambda p: hashes.__setitem__(p.poc, p.hash_sei()), on_output=lambda p: out.append(p.poc))
+        assert d.pictures_decoded == frames
+    assert out == list(range(frames))
+    if "crop" in name:
+        return                                                   # the SEI hashes the uncropped picture, the fixture holds the cropped one
+    for poc in range(frames):
+        method, digest = hashes[poc]
+        want = b"".join(hashlib.md5(z["poc%02d_%d" % (poc, c)].astype(np.uint8 if bd == 8 else "<u2").tobytes()).digest() for c in range(3))
+        assert method == 1 and digest == want, "POC %d" % poc
+
+
+def test_internal_info_tiles_the_picture():
+    """libHMDEC_get_internal_info (libHMDecoder.cpp:602-720): CU blocks tile the picture exactly, PU / TU entries carry the parsed
+    values of the block they name"""
+    name = "ra_main10_208x120"
+    z = gu.load("stream_" + name)
+    pics = gu.stream_pictures(name)
+    with hmdec.Decoder(parse_only=True) as d:
+        done = []
+        def on_decoded(p):
+            ref = pics[len(done)]
+            done.append(p.poc)
+            cover = np.zeros((ref.height, ref.width), dtype=np.int32)
+            for x, y, w, h, v, _ in d.internal_info(p, "CU_PREDICTION_MODE"):
+                cover[y:y + h, x:x + w] += 1
+                assert v in (0, 1)
+            assert np.all(cover == 1)
+            depth = p.array("depth")
+            skips = d.internal_info(p, "CU_SKIP_FLAG")
+            assert len(skips) == len(d.internal_info(p, "CU_PART_MODE"))
+            mv0 = p.array("mv0").reshape(-1, 2)
+            n_mv = 0
+            for x, y, w, h, v, v2 in d.internal_info(p, "PU_MV_0"):
+                ctu = (y // 64) * ref.ctus_w + x // 64
+                inside = [(yy, xx) for yy in range(y, y + h, 4) for xx in range(x, x + w, 4)]
+                # every 4x4 partition of the PU holds the PU's vector
+                for yy, xx in inside[:1] + inside[-1:]:
+                    bx, by = (xx % 64) // 4, (yy % 64) // 4
+                    part = ctu * 256 + sum((((bx >> b) & 1) << (2 * b)) | (((by >> b) & 1) << (2 * b + 1)) for b in range(4))
+                    assert (mv0[part][0], mv0[part][1]) == (v, v2)
+                n_mv += 1
+            assert (n_mv > 0) == (ref.slice_type != 2)
+            cbf = d.internal_info(p, "TU_CBF_Y")
+            assert all(v in (0, 1) for *_, v, _ in cbf) and len(cbf) > 0
+            assert [b[4] for b in d.internal_info(p, "CTU_SLICE_INDEX")] == [0] * ref.num_ctus
+        d.decode_stream(z["bitstream"], on_decoded=on_decoded)
+        assert len(done) == len(pics)
