@@ -82,10 +82,12 @@ def main():
     ap.add_argument("--width", type=int, default=3840)
     ap.add_argument("--height", type=int, default=2160)
     ap.add_argument("--bi", type=int, default=0, help="1: B pictures (bi-prediction) instead of P")
-    ap.add_argument("--workload", default="full", choices=("full", "idct", "mc", "mc_bi", "filter", "intra", "gop"))
+    ap.add_argument("--workload", default="full", choices=("full", "idct", "mc", "mc_bi", "filter", "intra", "gop", "decode"))
+    ap.add_argument("--stream", default=None, help="decode workload: Annex B file (default tests/golden/bench_ldp_main10_3840x2160.bin)")
     ap.add_argument("--mode-probs", default=None, help="experiment: CTU partition probabilities 64x64,32x32,16x16,8x8,AMP (comma separated)")
     ap.add_argument("--intra-frac", type=float, default=None, help="experiment: fraction of CUs that are intra (with intra modes: reconstructed on the GPU)")
     ap.add_argument("--cbf-prob", type=float, default=None, help="experiment: probability that a TU is coded")
+    ap.add_argument("--streams", type=int, default=1, choices=(1, 2), help="2: the batch runs as two half-batches on two HIP streams (kernels of different kinds overlap)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-steps", type=int, default=5)
     args = ap.parse_args()
@@ -101,6 +103,8 @@ def main():
 
     if args.workload == "gop":
         return gop_main(args, hdist, dist, rank, world, local_rank, copy_gbps)
+    if args.workload == "decode":
+        return decode_main(args, hdist, dist, rank, world, local_rank)
     w, h, bd = args.width, args.height, 10
     nb = args.batch
     wl = args.workload
@@ -151,6 +155,7 @@ def main():
     t_stage = time.time() - t_stage
 
     ALL = stages
+    ctx.set_streams(args.streams)
     for _ in range(args.warmup):
         ctx.replay(pics, ALL, 1)
     # barrier + sync on both sides, MAX over ranks (libhm_amd/dist.py)
@@ -207,7 +212,7 @@ def main():
                                     {"full": "prep+MC+dequant/IT/recon+deblock+SAO", "idct": "prep+MC+dequant/IT/recon, 32x32 luma / 16x16 chroma TUs, stress levels",
                                      "mc": "prep+MC+dequant/IT/recon", "mc_bi": "prep+MC+dequant/IT/recon",
                                      "intra": "all-intra pictures: prep+intra prediction/dequant/IT/recon (CTU-row wavefront)+deblock+SAO", "filter": "prep+MC+dequant/IT/recon+deblock+SAO, 25% intra CUs (Bs 2 edges)"}[wl], nb),
-                       "sub_benchmark": wl,
+                       "sub_benchmark": wl, "streams": args.streams,
                        "pictures_per_step": nb, "parallelism": "frame-parallel, 1 process per GPU, no data-path collective"},
             "roofline": roof, "kernels": kernels, "device_ms_per_step_sum_of_kernels": round(dev_ms, 4),
             "hbm_GBps_whole_step_algorithmic": round(sum(sum(b[k] for k in kernels) for b in [bytes_pp[i % 2] for i in range(nb)])
@@ -271,6 +276,96 @@ def gop_main(args, hdist, dist, rank, world, local_rank, copy_gbps):
             out["hbm_copy_GBps_measured"] = copy_gbps
         print(json.dumps(out), flush=True)
     ctx.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def decode_main(args, hdist, dist, rank, world, local_rank):
+    """SURVEY 8 f-2 sub-benchmark: a whole decoder.  An HM-encoded Annex B stream goes through libhmdec (host parser + device
+    reconstruction) exactly as a libHM client would drive it; a step is one pass over the stream, every rank decodes its own copy
+    (replicas).  Verified by the stream's own decoded-picture-hash SEI in an untimed pass; the timed passes run with the check off
+    (as the HM baseline does) but hand every picture to the "application" (device -> host planes), as libHMDec_get_picture does."""
+    import subprocess
+    from libhm_amd import hmdec
+    here = os.path.dirname(os.path.abspath(__file__))
+    path = args.stream or os.path.join(here, "tests", "golden", "bench_ldp_main10_3840x2160.bin")
+    data = open(path, "rb").read()
+    nals = hmdec.split_nal_units(data)
+    info = {}
+
+    def drain(d, state):
+        while True:
+            p = d.get_picture()
+            if p is None:
+                return
+            w, h = p.size(0)
+            state["pixels"] += w * h
+            state["pictures"] += 1
+            info["size"] = (w, h)
+
+    def feed(d, state, last):
+        """one pass of the stream through an existing decoder (libHM's loop); the next pass's IDR flushes what is still held"""
+        for i, nal in enumerate(nals):
+            eof = last and i == len(nals) - 1
+            while True:
+                new_pic, check = d.push(nal, eof)
+                if check:
+                    drain(d, state)
+                if not new_pic:
+                    break
+
+    # verification pass (MD5 of every picture against the SEI of the stream)
+    state = {"pixels": 0, "pictures": 0}
+    with hmdec.Decoder(device=local_rank, check_hash=True) as d:
+        feed(d, state, True)
+        npic, pixels, bad = d.pictures_decoded, state["pixels"], d.hash_mismatches
+    if bad or npic == 0 or state["pictures"] != npic:
+        raise SystemExit("decode: %d of %d pictures disagree with their hash SEI (%d output)" % (bad, npic, state["pictures"]))
+    # timed: ONE decoder (device context, picture buffers) fed the stream args.steps times, as a player looping a clip would
+    d = hmdec.Decoder(device=local_rank, check_hash=False)
+    state = {"pixels": 0, "pictures": 0}
+    for _ in range(max(1, args.warmup)):
+        feed(d, state, False)
+    state = {"pixels": 0, "pictures": 0}
+
+    def steps():
+        for k in range(args.steps):
+            feed(d, state, k == args.steps - 1)
+    elapsed = hdist.timed_region(dist, steps, lambda: None, device=("cuda:%d" % local_rank) if dist is not None else None)
+    d.close()
+    # the warm-up passes leave pictures in the decoder that the first timed pass puts out: count what actually came out
+    pixels_timed, pictures_timed = state["pixels"], state["pictures"]
+    # host parsing alone (no device work): what bounds the decoder today
+    t0 = time.perf_counter()
+    with hmdec.Decoder(parse_only=True) as d:
+        d.decode_stream(data)
+    t_parse = time.perf_counter() - t0
+    if rank == 0:
+        w, h = info["size"]
+        out = {
+            "metric": "decoded Mpixels/s (luma), whole decoder: Annex B stream -> pictures at the application", "unit": "Mpixels/s",
+            "value": round(world * pixels_timed / elapsed / 1e6, 1), "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "int16 samples / int32 accumulate", "data": "synthetic clip encoded by HM 16.0 (%s, %d bytes, %d pictures)" % (os.path.basename(path), len(data), npic),
+            "config": {"workload": "%dx%d HM-encoded stream through libhmdec: host CABAC parsing (1 thread) + device reconstruction + "
+                                   "picture download, %d NAL units" % (w, h, len(nals)),
+                       "sub_benchmark": "decode", "pictures_per_step": npic, "parallelism": "replicas, 1 process per GPU"},
+            "fps": round(world * pictures_timed / elapsed, 2),
+            "host_parse_only_Mpixels_s": round(pixels / t_parse / 1e6, 1),
+            "host_parse_only_Mbit_s": round(len(data) * 8 / t_parse / 1e6, 1),
+            "hash_sei_verified_pictures": npic,
+            "roofline": None,        # host-bound (CABAC parsing); the device kernels are measured by the default workload
+        }
+        ref_dec = os.path.join(here, "oracle", "_ref", "TAppDecoder")
+        if not args.no_cpu_baseline and os.path.exists(ref_dec):
+            best = 1e9
+            for _ in range(2):
+                t0 = time.perf_counter()
+                subprocess.run([ref_dec, "-b", path, "--SEIDecodedPictureHash=0"], check=True, stdout=subprocess.DEVNULL)
+                best = min(best, time.perf_counter() - t0)
+            out["cpu_baseline"] = {"value": round(pixels / best / 1e6, 2), "unit": "Mpixels/s", "cores": 1, "kind": "reference",
+                                   "sample": "HM 16.0 TAppDecoder (oracle/_ref, -O3) on the same stream, hash check off, no output file, best of 2: %.2f s" % best}
+        print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
 

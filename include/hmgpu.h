@@ -157,6 +157,12 @@ int32_t      hmgpu_last_device_error(const hmgpu_ctx* ctx);        /* hipError_t
 const char*  hmgpu_status_string(hmgpu_status s);
 hmgpu_status hmgpu_sync(hmgpu_ctx* ctx);                           /* wait for everything enqueued so far */
 
+/* Page-locked host memory for the caller's arrays (metadata, levels, SAO parameters, download targets): staging from it is a true
+ * asynchronous DMA at full link speed, from ordinary memory the runtime copies through a bounce buffer while the caller waits.
+ * Returns NULL when no device memory manager is available (no GPU): use malloc then. */
+void* hmgpu_host_alloc(size_t bytes);
+void  hmgpu_host_free(void* p);
+
 /* geometry helpers (TComPicSym::create, TComPicSym.cpp:73-92) */
 int32_t hmgpu_num_ctus(const hmgpu_seq_params* seq);
 int32_t hmgpu_parts_per_ctu(const hmgpu_seq_params* seq);
@@ -254,6 +260,11 @@ hmgpu_status hmgpu_replay(hmgpu_ctx* ctx, hmgpu_pic cur, int32_t stages /* 8 = r
 /* the same for `n` mutually independent pictures at once (<= 16): every kernel is launched once for the whole batch
  * (one grid z-slice per picture) -- the frame-parallel mode used for throughput measurements */
 hmgpu_status hmgpu_replay_batch(hmgpu_ctx* ctx, const hmgpu_pic* pics, int32_t n, int32_t stages, int32_t iters);
+
+/* Lanes of hmgpu_replay_batch: 1 (default) = one stream, kernel after kernel; 2 = the batch is cut in two halves that run on two
+ * streams, so that kernels of different kinds overlap (more pictures per second, per-kernel times no longer separable; profiling
+ * forces one lane). */
+hmgpu_status hmgpu_set_streams(hmgpu_ctx* ctx, int32_t n);
 
 #define HMGPU_NUM_KERNELS 12
 typedef struct hmgpu_stats {

@@ -70,6 +70,7 @@ def lib():
         L.hmgpu_picture_release.argtypes = [C.c_void_p, C.c_int32]
         L.hmgpu_picture_upload.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_int32)]
         L.hmgpu_picture_download.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_int32)]
+        L.hmgpu_set_streams.argtypes = [C.c_void_p, C.c_int32]
         L.hmgpu_picture_download_packed.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_int32)] + [C.c_int32] * 5
         L.hmgpu_picture_hash.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.POINTER(C.c_int32)]
         L.hmgpu_picture_device_region.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]
@@ -148,6 +149,10 @@ class Context:
         strides = (C.c_int32 * 3)(*[p.shape[1] for p in planes])
         self._chk(lib().hmgpu_picture_download(self._h, pic, ptrs, strides), "hmgpu_picture_download")
         return planes
+
+    def set_streams(self, n):
+        """lanes of replay(): 1 = serial kernels, 2 = two half-batches on two streams"""
+        self._chk(lib().hmgpu_set_streams(self._h, n), "hmgpu_set_streams")
 
     def download_packed(self, pic, bytes_per_sample, crop=(0, 0, 0, 0)):
         """the picture as 8- or 16-bit planes cropped by (left, right, top, bottom) luma samples"""

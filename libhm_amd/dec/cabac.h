@@ -50,11 +50,14 @@ struct ContextSet {
 
 class Cabac {
  public:
-  void attach(const uint8_t* rbsp, size_t bytes) { p_ = rbsp; nbits_ = bytes * 8; }
-  size_t bit_pos() const { return pos_; }
+  void attach(const uint8_t* rbsp, size_t bytes) { p_ = rbsp; nbytes_ = bytes; }
+  size_t bit_pos() const { return next_byte_ * 8 - avail_; }
   // 9.3.2.5: initialisation of the arithmetic decoding engine at a byte-aligned position
   void start(size_t bit_pos) {
-    pos_ = bit_pos;
+    next_byte_ = bit_pos >> 3;
+    avail_ = 0;
+    res_ = 0;
+    if (bit_pos & 7) get((int)(bit_pos & 7));
     range_ = 510;
     offset_ = get(9);
   }
@@ -83,9 +86,19 @@ class Cabac {
     if (offset_ >= range_) { offset_ -= range_; return 1; }
     return 0;
   }
+  // n bypass bins at once (n <= 16): with offset < range before, the n bins are the quotient of (offset << n | new bits) by range
   unsigned bypass_bits(int n) {
+    if (n <= 0) return 0;
+    if (n == 1) return (unsigned)bypass();
     unsigned v = 0;
-    while (n-- > 0) v = (v << 1) | (unsigned)bypass();
+    while (n > 0) {
+      const int k = n > 16 ? 16 : n;
+      const unsigned long long wide = ((unsigned long long)offset_ << k) | get(k);
+      const unsigned q = (unsigned)(wide / range_);
+      offset_ = (unsigned)(wide - (unsigned long long)q * range_);
+      v = (v << k) | q;
+      n -= k;
+    }
     return v;
   }
   // 9.3.4.3.5; when the result is 1 the engine is finished: call finish_to_byte() before reading plain bits or restarting
@@ -100,20 +113,30 @@ class Cabac {
   // put out is suppressed, which is what makes the 9-bit window end there).  What follows are zero bits up to the byte boundary;
   // pcm_sample data or the next sub-stream start at that boundary.
   void finish_to_byte() {
-    if (pos_ == 0 || pos_ > nbits_ || !((p_[(pos_ - 1) >> 3] >> (7 - ((pos_ - 1) & 7))) & 1)) throw ParseError("CABAC: no stop bit behind a terminating bin");
-    while (pos_ & 7) if (get(1)) throw ParseError("CABAC: alignment bits are not zero");
+    const size_t pos = bit_pos();
+    if (pos == 0 || pos > nbytes_ * 8 || !((p_[(pos - 1) >> 3] >> (7 - ((pos - 1) & 7))) & 1)) throw ParseError("CABAC: no stop bit behind a terminating bin");
+    while (bit_pos() & 7) if (get(1)) throw ParseError("CABAC: alignment bits are not zero");
   }
   unsigned plain_bits(int n) { return get(n); }     // pcm_sample_*: read_bits(n) between finish_to_byte() and start()
 
  private:
-  unsigned get(int n) {
-    unsigned v = 0;
-    for (; n > 0; n--, pos_++) v = (v << 1) | (pos_ < nbits_ ? (p_[pos_ >> 3] >> (7 - (pos_ & 7))) & 1u : 0u);
-    if (pos_ > nbits_ + 64) throw ParseError("CABAC: read far past the end of the slice data");
-    return v;
+  unsigned get(int n) {                               // n <= 25; bits behind the end of the data read as zero
+    if (n == 0) return 0;
+    if (avail_ < n) {
+      while (avail_ <= 56) {
+        res_ = (res_ << 8) | (next_byte_ < nbytes_ ? p_[next_byte_] : 0u);
+        next_byte_++;
+        avail_ += 8;
+      }
+      if (next_byte_ > nbytes_ + 24) throw ParseError("CABAC: read far past the end of the slice data");
+    }
+    avail_ -= n;
+    return (unsigned)(res_ >> avail_) & ((1u << n) - 1);
   }
   const uint8_t* p_ = nullptr;
-  size_t nbits_ = 0, pos_ = 0;
+  size_t nbytes_ = 0, next_byte_ = 0;
+  uint64_t res_ = 0;
+  int avail_ = 0;
   unsigned range_ = 510, offset_ = 0;
   static const uint8_t kRangeLps[64][4];
   static const uint8_t kNextLps[64], kNextMps[64];

@@ -3,11 +3,34 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <new>
 
 #include "md5.h"
 
 namespace hmdec {
+
+// ---- host memory for the picture arrays: page-locked through libhmgpu when a device is in use, malloc otherwise.  A 64-byte
+// header in front of every block remembers which of the two it came from.
+namespace {
+thread_local bool tl_pinned = false;
+}
+void host_alloc_use_pinned(bool on) { tl_pinned = on; }
+void* host_alloc(size_t bytes) {
+  uint8_t* base = nullptr;
+  bool pinned = false;
+  if (tl_pinned) { base = static_cast<uint8_t*>(hmgpu_host_alloc(bytes + 64)); pinned = base != nullptr; }
+  if (!base) base = static_cast<uint8_t*>(malloc(bytes + 64));
+  if (!base) throw std::bad_alloc();
+  base[0] = pinned ? 1 : 0;
+  return base + 64;
+}
+void host_free(void* p) {
+  if (!p) return;
+  uint8_t* base = static_cast<uint8_t*>(p) - 64;
+  if (base[0]) hmgpu_host_free(base); else free(base);
+}
 
 static bool is_irap(int t) { return t >= NAL_BLA_W_LP && t <= NAL_RSV_IRAP_VCL23; }
 static bool is_idr(int t) { return t == NAL_IDR_W_RADL || t == NAL_IDR_N_LP; }
@@ -19,6 +42,12 @@ static bool is_sub_layer_non_ref(int t) { return t < 16 && (t & 1) == 0; }
 Decoder::Decoder() { memset(pending_hash_val_, 0, sizeof(pending_hash_val_)); }
 
 Decoder::~Decoder() {
+  if (gpu_ && getenv("HMDEC_STATS")) {          // tuning aid: device time per kernel class over the life of the decoder
+    hmgpu_stats st;
+    if (hmgpu_get_stats(gpu_, &st, 0) == HMGPU_OK)
+      for (int k = 0; k < HMGPU_NUM_KERNELS; k++)
+        if (st.kernel_launches[k]) fprintf(stderr, "hmdec: %-14s %8.3f ms in %llu launches\n", hmgpu_kernel_name(k), st.kernel_ms[k], (unsigned long long)st.kernel_launches[k]);
+  }
   if (gpu_) hmgpu_destroy(gpu_);
 }
 
@@ -124,19 +153,26 @@ void Decoder::activate(const SliceHeader& sh) {
   if (!parse_only_) {
     const hmgpu_status st = hmgpu_create(&seq_, device_, &gpu_);
     if (st != HMGPU_OK) throw std::runtime_error(std::string("hmgpu_create: ") + hmgpu_status_string(st));
+    if (getenv("HMDEC_STATS")) hmgpu_set_profiling(gpu_, 1);
   }
 }
 
 PicData* Decoder::acquire_buffer() {
   for (auto& p : pool_)
     if (p.get() != cur_ && !p->is_reference && !p->needed_for_output && !p->lent) {
-      if (gpu_) hmgpu_sync(gpu_);          // the device may still be reading the arrays of the picture that lived here
+      if (gpu_ && p->submit_seq > synced_seq_) {          // the device may still be reading the arrays of the picture that lived here
+        hmgpu_sync(gpu_);
+        synced_seq_ = submitted_seq_;
+      }
       return p.get();
     }
   if ((int)pool_.size() >= seq_.max_pictures) throw ParseError("decoded picture buffer overflow (more pictures held than the SPS allows)");
   pool_.emplace_back(new PicData());
   PicData* p = pool_.back().get();
+  host_alloc_use_pinned(gpu_ != nullptr);
   p->allocate(*sps_, &zscan_);
+  if (gpu_) for (int c = 0; c < 3; c++) p->plane[c].resize((size_t)(p->width >> (c ? 1 : 0)) * (p->height >> (c ? 1 : 0)));
+  host_alloc_use_pinned(false);
   if (gpu_) {
     const hmgpu_status st = hmgpu_picture_acquire(gpu_, &p->handle);
     if (st != HMGPU_OK) throw std::runtime_error(std::string("hmgpu_picture_acquire: ") + hmgpu_status_string(st));
@@ -368,6 +404,7 @@ void Decoder::finish_picture() {
     pp.sao_enabled = sps_->sao;
     st = hmgpu_filter_picture(gpu_, p->handle, &pp, sps_->sao ? p->sao.data() : nullptr);
     if (st != HMGPU_OK) throw std::runtime_error(std::string("hmgpu_filter_picture: ") + hmgpu_status_string(st));
+    p->submit_seq = ++submitted_seq_;
   }
   p->decoded = true;
   p->filtered = true;
@@ -386,7 +423,9 @@ bool Decoder::fetch_planes(PicData* pic) {
   pic->plane[2].resize((size_t)pic->width * pic->height / 4);
   int16_t* planes[3] = {pic->plane[0].data(), pic->plane[1].data(), pic->plane[2].data()};
   const int32_t strides[3] = {pic->width, pic->width / 2, pic->width / 2};
+  const uint64_t seq = submitted_seq_;
   if (hmgpu_picture_download(gpu_, pic->handle, planes, strides) != HMGPU_OK) return false;
+  synced_seq_ = seq;                         // a download returns after everything enqueued before it
   pic->planes_valid = true;
   return true;
 }
@@ -402,7 +441,7 @@ void Decoder::check_hash(PicData* pic) {
     for (int c = 0; c < 3; c++) {
       const int bd = c ? sps_->bit_depth_chroma : sps_->bit_depth_luma;
       Md5 md5;
-      const std::vector<int16_t>& pl = pic->plane[c];
+      const HostVec<int16_t>& pl = pic->plane[c];
       std::vector<uint8_t> bytes(pl.size() * (bd > 8 ? 2 : 1));
       if (bd > 8) for (size_t i = 0; i < pl.size(); i++) { bytes[2 * i] = (uint8_t)pl[i]; bytes[2 * i + 1] = (uint8_t)(pl[i] >> 8); }
       else for (size_t i = 0; i < pl.size(); i++) bytes[i] = (uint8_t)pl[i];

@@ -81,6 +81,7 @@ class Decoder {
   std::vector<PicData*> scan_;
   bool parse_only_ = false, check_hash_ = true;
   int device_ = 0, hash_mismatches_ = 0, pictures_decoded_ = 0;
+  uint64_t submitted_seq_ = 0, synced_seq_ = 0;            // device submissions / the last one known to have completed
   std::string last_error_;
 };
 

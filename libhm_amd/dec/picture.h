@@ -12,6 +12,22 @@
 
 namespace hmdec {
 
+// The arrays the device reads (and the planes it writes) live in page-locked memory when a device is in use: hmgpu stages them with
+// asynchronous DMA while the parser goes on with the next picture.  The switch is per thread and read at allocation time.
+void* host_alloc(size_t bytes);
+void host_free(void* p);
+void host_alloc_use_pinned(bool on);
+template <class T> struct HostAlloc {
+  using value_type = T;
+  HostAlloc() = default;
+  template <class U> HostAlloc(const HostAlloc<U>&) {}
+  T* allocate(size_t n) { return static_cast<T*>(host_alloc(n * sizeof(T))); }
+  void deallocate(T* p, size_t) { host_free(p); }
+  template <class U> bool operator==(const HostAlloc<U>&) const { return true; }
+  template <class U> bool operator!=(const HostAlloc<U>&) const { return false; }
+};
+template <class T> using HostVec = std::vector<T, HostAlloc<T>>;
+
 struct ZScan {                       // raster (4x4 units inside a CTU) <-> HM z-scan order (g_auiRasterToZscan / g_auiZscanToRaster)
   int log2_ctb = 0, n4 = 0;          // n4: 4x4 units per CTU side
   std::vector<uint16_t> r2z, z2r;
@@ -47,24 +63,25 @@ struct PicData {
   int width = 0, height = 0, log2_ctb = 0, ctbs_w = 0, ctbs_h = 0, num_ctbs = 0, parts = 0;
   const ZScan* zs = nullptr;
   // per partition, [num_ctbs][parts]
-  std::vector<uint8_t> depth, tr_idx, cbf[3], ts[3], intra_dir[2], bypass, ipcm, skip, merge, merge_idx, inter_dir;
-  std::vector<int8_t> part_size, pred_mode, qp, ref_idx[2];
-  std::vector<int16_t> mv[2];        // {hor, ver}
+  HostVec<uint8_t> depth, tr_idx, cbf[3], ts[3], intra_dir[2], bypass, ipcm, skip, merge, merge_idx, inter_dir;
+  HostVec<int8_t> part_size, pred_mode, qp, ref_idx[2];
+  HostVec<int16_t> mv[2];        // {hor, ver}
   // per CTB
-  std::vector<uint16_t> slice_idx, tile_idx;
+  HostVec<uint16_t> slice_idx, tile_idx;
   std::vector<int32_t> slice_addr;   // SliceAddrRs of the slice that decoded the CTB, -1 = not (yet) decoded
   // levels / PCM samples in HM's layout
-  std::vector<int16_t> coeff[3], pcm[3];
-  std::vector<hmgpu_sao_param> sao;  // [num_ctbs][3]
+  HostVec<int16_t> coeff[3], pcm[3];
+  HostVec<hmgpu_sao_param> sao;      // [num_ctbs][3]
   std::vector<std::unique_ptr<SliceInfo>> slices;
   // picture state (8.3)
   int poc = 0, nal_type = 0, temporal_id = 0, conf_window[4] = {0, 0, 0, 0};
   bool is_reference = false, is_long_term = false, needed_for_output = false, pic_output = true, decoded = false, filtered = false;
   bool has_pcm = false, has_bypass = false, lent = false;     // lent: handed to the application by the last output scan
   hmgpu_pic handle = HMGPU_NO_PIC;
+  uint64_t submit_seq = 0;           // device submission that last read these arrays
   // output side
   bool planes_valid = false;
-  std::vector<int16_t> plane[3];
+  HostVec<int16_t> plane[3];
   uint8_t sei_hash[3][16];
   int sei_hash_method = 0;           // 0 = none, 1 = MD5, 2 = CRC, 3 = checksum
   bool hash_mismatch = false;

@@ -40,6 +40,11 @@ struct ScanTables {
 };
 const ScanTables kScan;
 const uint8_t kSigCtx4x4[16] = {0, 1, 4, 5, 2, 3, 4, 5, 6, 6, 8, 8, 7, 7, 8, 8};      // 9.3.4.2.5 ctxIdxMap (index = (yC << 2) + xC)
+// 9.3.4.2.5, blocks larger than 4x4: sigCtx by the coded flags of the right / below sub-blocks and the position (yP << 2) + xP
+const uint8_t kSigCtxPattern[4][16] = {{2, 1, 1, 0, 1, 1, 0, 0, 1, 0, 0, 0, 0, 0, 0, 0},
+                                       {2, 2, 2, 2, 1, 1, 1, 1, 0, 0, 0, 0, 0, 0, 0, 0},
+                                       {2, 1, 0, 0, 2, 1, 0, 0, 2, 1, 0, 0, 2, 1, 0, 0},
+                                       {2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2}};
 
 inline int clip3(int lo, int hi, int v) { return v < lo ? lo : v > hi ? hi : v; }
 }  // namespace
@@ -803,30 +808,20 @@ void SliceDecoder::residual_coding(int x0, int y0, int log2, int c) {
     int n = 15;
     if (i == last_sb) { pos[nsig++] = last_pos; n = last_pos - 1; }
     const int prev_csbf = right | (below << 1);
+    // context offset shared by all positions of the sub-block (position (0,0) of the block is the exception: context 0)
+    int sig_base;
+    const uint8_t* sig_tab;
+    if (log2 == 2) { sig_tab = kSigCtx4x4; sig_base = c ? 27 : 0; }
+    else {
+      sig_tab = kSigCtxPattern[prev_csbf];
+      if (c == 0) sig_base = (i > 0 ? 3 : 0) + (log2 == 3 ? (scan_idx == 0 ? 9 : 15) : 21);
+      else sig_base = 27 + (log2 == 3 ? 9 : 12);
+    }
     for (; n >= 0; n--) {
-      const int xp = in_order[n] & 3, yp = in_order[n] >> 2;
       bool sig;
       if (n > 0 || !infer_dc) {
-        int sc;
-        if (log2 == 2) {
-          sc = kSigCtx4x4[(yp << 2) + xp];
-        } else if (n == 0 && i == 0) {
-          sc = 0;
-        } else {
-          switch (prev_csbf) {
-            case 0: sc = (xp + yp == 0) ? 2 : (xp + yp < 3) ? 1 : 0; break;
-            case 1: sc = (yp == 0) ? 2 : (yp == 1) ? 1 : 0; break;
-            case 2: sc = (xp == 0) ? 2 : (xp == 1) ? 1 : 0; break;
-            default: sc = 2; break;
-          }
-          if (c == 0) {
-            if (i > 0) sc += 3;
-            sc += log2 == 3 ? (scan_idx == 0 ? 9 : 15) : 21;
-          } else {
-            sc += log2 == 3 ? 9 : 12;
-          }
-        }
-        sig = cabac_.decision(ctx_.s[CTX_SIG + (c ? 27 : 0) + sc]);
+        const int sc = (n == 0 && i == 0 && log2 > 2) ? (c ? 27 : 0) : sig_base + sig_tab[in_order[n]];
+        sig = cabac_.decision(ctx_.s[CTX_SIG + sc]);
         if (sig) infer_dc = false;
       } else {
         sig = true;                                      // the only coefficient a coded sub-block can still have

@@ -57,8 +57,7 @@ class SliceDecoder {
   bool temporal_mv(int xpb, int ypb, int w, int h, int list, int ref_idx, Mv& out) const;
   bool col_mv(int xcol, int ycol, int list, int ref_idx, Mv& out) const;
   static Mv scale_mv(Mv mv, int tb, int td);
-  void fill(std::vector<uint8_t>& a, int x0, int y0, int log2, uint8_t v);
-  template <class T> void fill_z(std::vector<T>& a, size_t first, int count, T v) { std::fill(a.begin() + first, a.begin() + first + count, v); }
+  template <class V, class T> void fill_z(V& a, size_t first, int count, T v) { std::fill(a.begin() + first, a.begin() + first + count, v); }
 
   const Sps& sps_;
   const Pps& pps_;

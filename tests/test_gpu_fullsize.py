@@ -147,6 +147,15 @@ def test_properties_at_2160p():
         a, b = ctx.download(hc), ctx.download(hd)
         assert gu.hm_md5(a, [bd] * 3) == digest_single
         assert gu.hm_md5(b, [bd] * 3) == digest_single
+        # (4) the same batch as two lanes on two streams (hmgpu_set_streams): the pictures do not change
+        ctx.set_streams(2)
+        ctx.replay([hc, hd], 15, 3)
+        a, b = ctx.download(hc), ctx.download(hd)
+        assert gu.hm_md5(a, [bd] * 3) == digest_single
+        assert gu.hm_md5(b, [bd] * 3) == digest_single
+        ctx.set_streams(1)
+        with pytest.raises(libhm_amd.HmgpuError):
+            ctx.set_streams(3)
 
 
 def test_unsupported_tools_are_refused():
