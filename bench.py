@@ -78,7 +78,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=8, help="independent pictures per step (<= 16)")
+    ap.add_argument("--batch", type=int, default=16, help="independent pictures per step (<= 16)")
     ap.add_argument("--width", type=int, default=3840)
     ap.add_argument("--height", type=int, default=2160)
     ap.add_argument("--bi", type=int, default=0, help="1: B pictures (bi-prediction) instead of P")
@@ -194,7 +194,7 @@ def main():
         # counters cannot be read from inside the process, so the figure is only reported for the workload it was taken on
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if wl == "full" and nb == 8 and not args.bi and (w, h) == (3840, 2160) and os.path.exists(tpath):
+        if wl == "full" and nb == 16 and args.streams == 1 and not args.bi and (w, h) == (3840, 2160) and os.path.exists(tpath):
             traffic = json.load(open(tpath))["kernels"].get(dom, {}).get("traffic_bytes")
         roof = {"kernel": dom, "bound": "hbm", "achieved": kernels[dom]["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": kernels[dom]["frac"], "traffic": traffic,

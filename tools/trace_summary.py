@@ -6,7 +6,7 @@ import collections
 import csv
 import sys
 
-batch = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+batch = int(sys.argv[2]) if len(sys.argv) > 2 else 16
 d = collections.defaultdict(list)
 rows = [r for r in csv.DictReader(open(sys.argv[1])) if r["Kernel_Name"].startswith(("hmgpu::", "void hmgpu::"))]
 t0 = min(int(r["Start_Timestamp"]) for r in rows if "k_prep" in r["Kernel_Name"] and int(r["Grid_Size_Z"]) == batch * int(r["Workgroup_Size_Z"]))
