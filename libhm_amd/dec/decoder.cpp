@@ -301,10 +301,10 @@ void Decoder::build_slice_params(const SliceHeader& sh, SliceInfo& si) {
       for (int i = 0; i < sh.num_ref_idx[l]; i++) {
         const PredWeight& w = sh.pw[l][i];
         p.wp_weight[l][i][0] = (int16_t)w.luma_weight;
-        p.wp_offset[l][i][0] = (int16_t)(w.luma_offset << (sps_->bit_depth_luma - 8));
+        p.wp_offset[l][i][0] = (int16_t)(w.luma_offset * (1 << (sps_->bit_depth_luma - 8)));
         for (int c = 0; c < 2; c++) {
           p.wp_weight[l][i][1 + c] = (int16_t)w.chroma_weight[c];
-          p.wp_offset[l][i][1 + c] = (int16_t)(w.chroma_offset[c] << (sps_->bit_depth_chroma - 8));
+          p.wp_offset[l][i][1 + c] = (int16_t)(w.chroma_offset[c] * (1 << (sps_->bit_depth_chroma - 8)));
         }
       }
   }

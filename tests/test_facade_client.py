@@ -46,6 +46,36 @@ def test_cxx_client_links_and_runs(tmp_path, reference_header):
     assert all(int(l.split()[-1]) > 0 for l in lines[1:])
 
 
+def test_corrupted_streams_never_crash(tmp_path):
+    """robustness of the host parser: bit flips, overwritten bytes, deletions and insertions anywhere in HM-encoded streams end in a
+    decoded stream or in an error code from libHMDec_push_nal_unit (client exit code 4) -- never in a crash or a hang"""
+    import random
+    exe = _build(tmp_path, False)
+    rng = random.Random(20261003)
+    names = ["stream_ldp_main8_416x240", "stream_ra_main10_208x120", "lite_ldp_wpp_depslices_main8_416x240", "lite_ldp_tileslices_main10_832x128",
+             "stream_ldp_pcm_main8_208x120", "lite_ra_cra_main8_208x120", "stream_ldp_wp_main10_208x120", "stream_ldp_sl_main10_208x120"]
+    outcomes = {0: 0, 4: 0}
+    for it in range(120):
+        b = bytearray(bytes(gu.load(rng.choice(names))["bitstream"]))
+        mode = rng.randrange(4)
+        for _ in range(rng.randrange(1, 6)):
+            pos = rng.randrange(4, len(b))
+            if mode == 0:
+                b[pos] ^= 1 << rng.randrange(8)
+            elif mode == 1:
+                b[pos] = rng.randrange(256)
+            elif mode == 2:
+                del b[pos:pos + rng.randrange(1, 40)]
+            else:
+                b[pos:pos] = bytes(rng.randrange(256) for _ in range(rng.randrange(1, 8)))
+        f = tmp_path / "fuzz.bin"
+        f.write_bytes(bytes(b))
+        r = subprocess.run([exe, str(f), "parse-only"], stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=60)
+        assert r.returncode in (0, 4), "iteration %d: exit code %d\n%s" % (it, r.returncode, r.stderr[-400:])
+        outcomes[r.returncode] += 1
+    assert outcomes[0] > 0 and outcomes[4] > 0          # both ends of the spectrum were exercised
+
+
 @pytest.mark.gpu
 def test_cxx_client_on_the_gpu(tmp_path):
     exe = _build(tmp_path, False)
