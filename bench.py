@@ -88,6 +88,7 @@ def main():
     ap.add_argument("--intra-frac", type=float, default=None, help="experiment: fraction of CUs that are intra (with intra modes: reconstructed on the GPU)")
     ap.add_argument("--cbf-prob", type=float, default=None, help="experiment: probability that a TU is coded")
     ap.add_argument("--streams", type=int, default=1, choices=(1, 2), help="2: the batch runs as two half-batches on two HIP streams (kernels of different kinds overlap)")
+    ap.add_argument("--threads", type=int, default=4, help="decode workload: parser threads of libhmdec (1 = all on the calling thread)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-steps", type=int, default=5)
     args = ap.parse_args()
@@ -316,13 +317,13 @@ def decode_main(args, hdist, dist, rank, world, local_rank):
 
     # verification pass (MD5 of every picture against the SEI of the stream)
     state = {"pixels": 0, "pictures": 0}
-    with hmdec.Decoder(device=local_rank, check_hash=True) as d:
+    with hmdec.Decoder(device=local_rank, check_hash=True, threads=args.threads) as d:
         feed(d, state, True)
         npic, pixels, bad = d.pictures_decoded, state["pixels"], d.hash_mismatches
     if bad or npic == 0 or state["pictures"] != npic:
         raise SystemExit("decode: %d of %d pictures disagree with their hash SEI (%d output)" % (bad, npic, state["pictures"]))
     # timed: ONE decoder (device context, picture buffers) fed the stream args.steps times, as a player looping a clip would
-    d = hmdec.Decoder(device=local_rank, check_hash=False)
+    d = hmdec.Decoder(device=local_rank, check_hash=False, threads=args.threads)
     state = {"pixels": 0, "pictures": 0}
     for _ in range(max(1, args.warmup)):
         feed(d, state, False)
@@ -337,7 +338,7 @@ def decode_main(args, hdist, dist, rank, world, local_rank):
     pixels_timed, pictures_timed = state["pixels"], state["pictures"]
     # host parsing alone (no device work): what bounds the decoder today
     t0 = time.perf_counter()
-    with hmdec.Decoder(parse_only=True) as d:
+    with hmdec.Decoder(parse_only=True, threads=args.threads) as d:
         d.decode_stream(data)
     t_parse = time.perf_counter() - t0
     if rank == 0:
@@ -347,9 +348,9 @@ def decode_main(args, hdist, dist, rank, world, local_rank):
             "value": round(world * pixels_timed / elapsed / 1e6, 1), "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "int16 samples / int32 accumulate", "data": "synthetic clip encoded by HM 16.0 (%s, %d bytes, %d pictures)" % (os.path.basename(path), len(data), npic),
-            "config": {"workload": "%dx%d HM-encoded stream through libhmdec: host CABAC parsing (1 thread) + device reconstruction + "
-                                   "picture download, %d NAL units" % (w, h, len(nals)),
-                       "sub_benchmark": "decode", "pictures_per_step": npic, "parallelism": "replicas, 1 process per GPU"},
+            "config": {"workload": "%dx%d HM-encoded stream through libhmdec: host CABAC parsing (%d parser thread%s) + device reconstruction + "
+                                   "picture download, %d NAL units" % (w, h, args.threads, "" if args.threads == 1 else "s, frame-parallel", len(nals)),
+                       "sub_benchmark": "decode", "parser_threads": args.threads, "pictures_per_step": npic, "parallelism": "replicas, 1 process per GPU"},
             "fps": round(world * pictures_timed / elapsed, 2),
             "host_parse_only_Mpixels_s": round(pixels / t_parse / 1e6, 1),
             "host_parse_only_Mbit_s": round(len(data) * 8 / t_parse / 1e6, 1),

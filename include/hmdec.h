@@ -65,6 +65,9 @@ libHMDec_error libHMDEC_clear_internal_info(libHMDec_context* decCtx);        /*
 
 /* ---------------------------------------------------------------------------------------------- this library's own additions */
 void hmdec_set_device(libHMDec_context* ctx, int device_ordinal);             /* GPU to decode on (default 0); before the first NAL unit */
+/* parser threads (1..16, default 1): slice data of several pictures is parsed concurrently (frame-parallel, a picture at most one
+ * CTB row behind the picture it takes temporal motion vectors from); pictures come out in the same order, later.  Before the first NAL unit. */
+void hmdec_set_threads(libHMDec_context* ctx, int n);
 void hmdec_set_parse_only(libHMDec_context* ctx, int on);                     /* no device work: parser output only (planes unavailable) */
 int hmdec_hash_mismatches(libHMDec_context* ctx);                             /* pictures whose reconstruction disagreed with the hash SEI */
 int hmdec_pictures_decoded(libHMDec_context* ctx);

@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
 #include <new>
 
 #include "md5.h"
@@ -42,6 +43,12 @@ static bool is_sub_layer_non_ref(int t) { return t < 16 && (t & 1) == 0; }
 Decoder::Decoder() { memset(pending_hash_val_, 0, sizeof(pending_hash_val_)); }
 
 Decoder::~Decoder() {
+  if (!workers_.empty()) {
+    { std::lock_guard<std::mutex> lk(mu_); stop_ = true; }
+    cv_work_.notify_all();
+    cv_progress_.notify_all();
+    for (std::thread& t : workers_) t.join();
+  }
   if (gpu_ && getenv("HMDEC_STATS")) {          // tuning aid: device time per kernel class over the life of the decoder
     hmgpu_stats st;
     if (hmgpu_get_stats(gpu_, &st, 0) == HMGPU_OK)
@@ -62,10 +69,13 @@ bool Decoder::push(const uint8_t* d, size_t len, int max_tl, int* nal_type_out) 
   if (tid < 0) throw ParseError("nuh_temporal_id_plus1 is zero");
   if (layer != 0 || (max_tl >= 0 && tid > max_tl)) return false;
   for (auto& p : pool_) p->lent = false;
+  max_tl_ = max_tl;
+  if (threaded()) retire_ready(false);
   if (type <= NAL_RASL_R || (type >= NAL_BLA_W_LP && type <= NAL_CRA)) {
     if (len < 3) throw ParseError("slice NAL unit without payload");
     if ((d[2] & 0x80) && cur_) {           // first_slice_segment_in_pic_flag while a picture is open: close it, unit comes again
-      finish_picture();
+      if (threaded()) { close_current(); retire_ready(false); }      // (its parser thread may still be busy: nobody waits here)
+      else finish_picture();
       return true;
     }
     std::vector<uint8_t> rbsp = nal_to_rbsp(d + 2, len - 2);
@@ -129,9 +139,16 @@ void Decoder::activate(const SliceHeader& sh) {
                        sps_->pcm_bit_depth_luma != sps->pcm_bit_depth_luma || sps_->pcm_bit_depth_chroma != sps->pcm_bit_depth_chroma ||
                        sps_->pcm_loop_filter_disabled != sps->pcm_loop_filter_disabled || sps_->strong_intra_smoothing != sps->strong_intra_smoothing ||
                        sps_->max_dec_pic_buffering[sps_->max_sub_layers - 1] != sps->max_dec_pic_buffering[sps->max_sub_layers - 1];
+  if (new_seq && threaded()) { close_current(); retire_ready(true); }      // nothing of the old sequence may still be in flight
   sps_ = sps;
   pps_ = pps;
-  pps_->derive_tiles(*sps_);
+  // (a PPS object is shared with the parser threads of earlier pictures: its tables are derived once per picture geometry)
+  if (pps_->derived_w != sps_->pic_w_ctbs() || pps_->derived_h != sps_->pic_h_ctbs()) {
+    if (threaded()) { close_current(); retire_ready(true); }
+    pps_->derive_tiles(*sps_);
+    pps_->derived_w = sps_->pic_w_ctbs();
+    pps_->derived_h = sps_->pic_h_ctbs();
+  }
   if (!new_seq) return;
   if (!is_irap(sh.nal_type)) throw ParseError("a new sequence parameter set is activated by a picture that is not an IRAP picture");
   // a new coded video sequence with another geometry: the picture store starts over (pictures not yet output are dropped)
@@ -145,7 +162,7 @@ void Decoder::activate(const SliceHeader& sh) {
   seq_.bit_depth_chroma = sps_->bit_depth_chroma;
   seq_.chroma_format = 1;
   seq_.log2_ctu_size = sps_->log2_ctb;
-  seq_.max_pictures = std::min(20, sps_->max_dec_pic_buffering[sps_->max_sub_layers - 1] + 3);
+  seq_.max_pictures = std::min(40, sps_->max_dec_pic_buffering[sps_->max_sub_layers - 1] + 3 + (threaded() ? threads_ + 1 : 0));
   seq_.pcm_loop_filter_disable = sps_->pcm && sps_->pcm_loop_filter_disabled;
   seq_.strong_intra_smoothing = sps_->strong_intra_smoothing;
   seq_.pcm_bit_depth_luma = sps_->pcm_bit_depth_luma;
@@ -158,8 +175,17 @@ void Decoder::activate(const SliceHeader& sh) {
 }
 
 PicData* Decoder::acquire_buffer() {
+  for (int attempt = 0; threaded() && attempt < 64; attempt++) {
+    bool free_one = (int)pool_.size() < seq_.max_pictures;
+    for (auto& p : pool_)
+      if (p.get() != cur_ && !p->is_reference && !p->needed_for_output && !p->lent && !p->in_flight && p->users.load() == 0) free_one = true;
+    if (free_one || inflight_.empty()) break;
+    // every buffer is held by a picture still in flight: wait for the oldest one, hand it on, look again
+    { std::unique_lock<std::mutex> lk(mu_); PicData* head = inflight_.front()->pic; cv_progress_.wait(lk, [&] { return head->parse_done.load(); }); }
+    retire_ready(false);
+  }
   for (auto& p : pool_)
-    if (p.get() != cur_ && !p->is_reference && !p->needed_for_output && !p->lent) {
+    if (p.get() != cur_ && !p->is_reference && !p->needed_for_output && !p->lent && !p->in_flight && p->users.load() == 0) {
       if (gpu_ && p->submit_seq > synced_seq_) {          // the device may still be reading the arrays of the picture that lived here
         hmgpu_sync(gpu_);
         synced_seq_ = submitted_seq_;
@@ -197,7 +223,7 @@ int Decoder::compute_poc(const SliceHeader& sh) {
 PicData* Decoder::find_ref(int poc, bool lsb_only, bool any_marking) {
   const int mask = (1 << sps_->log2_max_poc_lsb) - 1;
   for (auto& p : pool_) {
-    if (p.get() == cur_ || !p->decoded) continue;
+    if (p.get() == cur_ || !(p->decoded || p->in_flight)) continue;
     if (!p->is_reference && !any_marking) continue;
     if (lsb_only ? (p->poc & mask) == poc : p->poc == poc) return p.get();
   }
@@ -230,7 +256,7 @@ void Decoder::apply_rps(const SliceHeader& sh) {
     const int poc = cur_->poc + sh.rps.delta_poc[i];
     PicData* p = nullptr;
     for (auto& q : pool_)
-      if (q.get() != cur_ && q->decoded && q->is_reference && !q->is_long_term && q->poc == poc && std::find(lt_all.begin(), lt_all.end(), q.get()) == lt_all.end()) p = q.get();
+      if (q.get() != cur_ && (q->decoded || q->in_flight) && q->is_reference && !q->is_long_term && q->poc == poc && std::find(lt_all.begin(), lt_all.end(), q.get()) == lt_all.end()) p = q.get();
     if (p) keep.push_back(p);
     if (sh.rps.used[i]) {
       if (!p) throw ParseError("short-term reference picture is missing from the decoded picture buffer");
@@ -323,6 +349,8 @@ void Decoder::start_picture(const SliceHeader& sh) {
   cur_->poc = sh.poc;
   cur_->nal_type = sh.nal_type;
   cur_->temporal_id = sh.temporal_id;
+  cur_->sao_enabled = sps_->sao;
+  cur_->lf_across_tiles = pps_->lf_across_tiles;
   cur_->conf_window[0] = sps_->conf_left; cur_->conf_window[1] = sps_->conf_right; cur_->conf_window[2] = sps_->conf_top; cur_->conf_window[3] = sps_->conf_bottom;
   cur_->is_reference = true;                 // "used for short-term reference" until a later RPS says otherwise (8.3.1 end)
   cur_->is_long_term = false;
@@ -331,6 +359,30 @@ void Decoder::start_picture(const SliceHeader& sh) {
   parse_state_ = PicParseState();
   if (pending_hash_) pending_hash_ = false;  // a hash SEI ahead of its picture does not occur (suffix SEI)
   apply_rps(sh);
+  if (threaded()) {
+    // at most threads_ pictures are parsed at once: wait for one of them before opening another
+    for (;;) {
+      int busy = 0;
+      for (auto& t : inflight_) if (!t->pic->parse_done.load()) busy++;
+      if (busy < threads_) break;
+      std::unique_lock<std::mutex> lk(mu_);
+      cv_progress_.wait(lk, [&] { for (auto& t : inflight_) if (t->pic->parse_done.load()) return true; return false; });
+      lk.unlock();
+      retire_ready(false);
+    }
+    cur_->rows_done.store(0);
+    cur_->parse_done.store(false);
+    cur_->in_flight = true;
+    std::unique_ptr<PicTask> t(new PicTask());
+    t->pic = cur_;
+    cur_task_ = t.get();
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      inflight_.push_back(std::move(t));
+      runnable_.push_back(cur_task_);
+    }
+    cv_work_.notify_all();
+  }
 }
 
 void Decoder::decode_slice(const std::vector<uint8_t>& rbsp, BitReader& br, SliceHeader& sh) {
@@ -368,17 +420,164 @@ void Decoder::decode_slice(const std::vector<uint8_t>& rbsp, BitReader& br, Slic
   } else if (cur_->slices.empty()) {
     throw ParseError("dependent slice segment at the start of a picture");
   }
-  SliceDecoder sd(*sps_, *pps_, *cur_, parse_state_);
-  sd.decode(sh, (int)cur_->slices.size() - 1, rbsp.data(), rbsp.size());
+  if (!threaded()) {
+    SliceDecoder sd(*sps_, *pps_, *cur_, parse_state_);
+    sd.decode(sh, (int)cur_->slices.size() - 1, rbsp.data(), rbsp.size());
+    return;
+  }
+  // the parser thread of this picture reads the motion data of its reference pictures: they stay until it is done
+  const SliceInfo& si = *cur_->slices.back();
+  for (int l = 0; l < 2; l++)
+    for (int i = 0; i < 16; i++) {
+      PicData* r = si.ref_pics[l][i];
+      if (r && std::find(cur_task_->held.begin(), cur_task_->held.end(), r) == cur_task_->held.end()) { r->users.fetch_add(1); cur_task_->held.push_back(r); }
+    }
+  SliceJob job;
+  job.sh = sh;
+  job.slice_idx = (int)cur_->slices.size() - 1;
+  job.rbsp = rbsp;
+  job.sps = sps_;
+  job.pps = pps_;
+  { std::lock_guard<std::mutex> lk(mu_); cur_task_->jobs.push_back(std::move(job)); }
+  cv_work_.notify_all();
+}
+
+// ------------------------------------------------------------------------------------------------ frame-parallel parsing
+void Decoder::set_threads(int n) {
+  if (n < 1) n = 1;
+  if (n > 16) n = 16;
+  if (!workers_.empty() || cur_ || !pool_.empty()) return;          // only before decoding starts
+  threads_ = n;
+  if (n == 1) return;
+  hooks_.self = this;
+  hooks_.wait_rows = &Decoder::hook_wait_rows;
+  hooks_.rows_done = &Decoder::hook_rows_done;
+  for (int i = 0; i < n; i++) workers_.emplace_back([this] { worker_main(); });
+}
+
+void Decoder::hook_wait_rows(void* self, const PicData* pic, int rows) {
+  Decoder* d = static_cast<Decoder*>(self);
+  std::unique_lock<std::mutex> lk(d->mu_);
+  d->cv_progress_.wait(lk, [&] { return d->stop_ || pic->rows_done.load(std::memory_order_acquire) >= rows; });
+}
+
+void Decoder::hook_rows_done(void* self, PicData* pic, int rows) {
+  Decoder* d = static_cast<Decoder*>(self);
+  { std::lock_guard<std::mutex> lk(d->mu_); pic->rows_done.store(rows, std::memory_order_release); }
+  d->cv_progress_.notify_all();
+}
+
+// a parser thread: takes a picture and parses its slice segments in the order they arrive, until the picture is closed
+void Decoder::worker_main() {
+  for (;;) {
+    PicTask* t;
+    {
+      std::unique_lock<std::mutex> lk(mu_);
+      cv_work_.wait(lk, [&] { return stop_ || !runnable_.empty(); });
+      if (stop_) return;
+      t = runnable_.front();
+      runnable_.pop_front();
+    }
+    for (;;) {
+      SliceJob job;
+      {
+        std::unique_lock<std::mutex> lk(mu_);
+        cv_work_.wait(lk, [&] { return stop_ || !t->jobs.empty() || t->closed; });
+        if (stop_) return;
+        if (t->jobs.empty()) break;
+        job = std::move(t->jobs.front());
+        t->jobs.pop_front();
+      }
+      if (!t->error.empty()) continue;                     // the picture is already lost: drain its jobs
+      if (getenv("HMDEC_TRACE")) { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); fprintf(stderr, "%ld.%06ld begin POC %d slice %d\n", ts.tv_sec % 1000, ts.tv_nsec / 1000, t->pic->poc, job.slice_idx); }
+      try {
+        SliceDecoder sd(*job.sps, *job.pps, *t->pic, t->state, &hooks_);
+        sd.decode(job.sh, job.slice_idx, job.rbsp.data(), job.rbsp.size());
+      } catch (const std::exception& e) {
+        std::lock_guard<std::mutex> lk(mu_);
+        t->error = e.what();
+      }
+      if (getenv("HMDEC_TRACE")) { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); fprintf(stderr, "%ld.%06ld end   POC %d\n", ts.tv_sec % 1000, ts.tv_nsec / 1000, t->pic->poc); }
+    }
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      t->pic->rows_done.store(t->pic->ctbs_h, std::memory_order_release);
+      t->pic->parse_done.store(true, std::memory_order_release);
+    }
+    cv_progress_.notify_all();
+  }
+}
+
+void Decoder::close_current() {
+  if (!cur_task_) return;
+  { std::lock_guard<std::mutex> lk(mu_); cur_task_->closed = true; }
+  cv_work_.notify_all();
+  cur_task_ = nullptr;
+  cur_ = nullptr;
+}
+
+// pictures whose parsing is complete leave the pipeline in decoding order: device work, hash check, output decision
+void Decoder::retire_ready(bool wait_all) {
+  while (!inflight_.empty()) {
+    PicTask* t = inflight_.front().get();
+    if (t == cur_task_) break;                             // still open: more slices may come
+    if (!t->pic->parse_done.load(std::memory_order_acquire)) {
+      if (!wait_all) break;
+      std::unique_lock<std::mutex> lk(mu_);
+      cv_progress_.wait(lk, [&] { return t->pic->parse_done.load(std::memory_order_acquire); });
+    }
+    PicData* p = t->pic;
+    const std::string error = t->error;
+    const int parsed = t->state.next_ctb_ts;
+    for (PicData* r : t->held) r->users.fetch_sub(1);
+    p->in_flight = false;
+    inflight_.pop_front();
+    if (!error.empty()) {                                  // the slice data could not be parsed: the picture is dropped
+      p->is_reference = p->is_long_term = false;
+      p->needed_for_output = false;
+      p->decoded = false;
+      throw ParseError(error);
+    }
+    submit_picture(p, parsed);
+    begin_output_scan(max_tl_);
+    while (PicData* o = next_output(false)) out_queue_.push_back(o);
+  }
+}
+
+void Decoder::queue_flush() {
+  retire_ready(true);
+  begin_output_scan(max_tl_);
+  while (PicData* o = next_output(true)) out_queue_.push_back(o);
+  last_display_poc = -(1 << 30);
+}
+
+PicData* Decoder::pop_output() {
+  if (out_queue_.empty()) return nullptr;
+  PicData* p = out_queue_.front();
+  out_queue_.pop_front();
+  p->lent = true;
+  return p;
 }
 
 void Decoder::finish_picture() {
+  if (threaded()) {                          // close the open picture and wait for everything in flight
+    close_current();
+    retire_ready(true);
+    return;
+  }
   if (!cur_) return;
   PicData* p = cur_;
-  if (parse_state_.next_ctb_ts < p->num_ctbs) {
+  cur_ = nullptr;
+  submit_picture(p, parse_state_.next_ctb_ts);
+}
+
+void Decoder::submit_picture(PicData* p, int parsed_ctbs) {
+  if (parsed_ctbs < p->num_ctbs) {
     // slices were lost: HM conceals nothing either (TDecTop.cpp:560 "Warning: ... lost"); the missing CTUs stay as they are
-    fprintf(stderr, "hmdec: POC %d is incomplete (%d of %d CTUs)\n", p->poc, parse_state_.next_ctb_ts, p->num_ctbs);
+    fprintf(stderr, "hmdec: POC %d is incomplete (%d of %d CTUs)\n", p->poc, parsed_ctbs, p->num_ctbs);
   }
+  p->rows_done.store(p->ctbs_h, std::memory_order_release);
+  for (int rs = 0; rs < p->num_ctbs; rs++) if (p->slice_addr[rs] < 0) p->reset_ctu(rs);     // CTUs no slice delivered
   if (gpu_) {
     hmgpu_ctu_meta m;
     memset(&m, 0, sizeof(m));
@@ -400,16 +599,15 @@ void Decoder::finish_picture() {
     if (st != HMGPU_OK) throw std::runtime_error(std::string("hmgpu_decompress_picture: ") + hmgpu_status_string(st));
     hmgpu_pic_params pp;
     memset(&pp, 0, sizeof(pp));
-    pp.lf_across_tiles = pps_->lf_across_tiles;
-    pp.sao_enabled = sps_->sao;
-    st = hmgpu_filter_picture(gpu_, p->handle, &pp, sps_->sao ? p->sao.data() : nullptr);
+    pp.lf_across_tiles = p->lf_across_tiles;
+    pp.sao_enabled = p->sao_enabled;
+    st = hmgpu_filter_picture(gpu_, p->handle, &pp, p->sao_enabled ? p->sao.data() : nullptr);
     if (st != HMGPU_OK) throw std::runtime_error(std::string("hmgpu_filter_picture: ") + hmgpu_status_string(st));
     p->submit_seq = ++submitted_seq_;
   }
   p->decoded = true;
   p->filtered = true;
   p->needed_for_output = p->pic_output;
-  cur_ = nullptr;
   last_decoded_ = p;
   pictures_decoded_++;
   if (check_hash_ && p->sei_hash_method) check_hash(p);

@@ -4,9 +4,12 @@
 // HM counterpart: TDecTop.cpp (decode / xActivateParameterSets / xDecodeSlice / executeLoopFilters), TComSlice.cpp (setRefPicList,
 // applyReferencePictureSet), TDecGop.cpp, SEIread.cpp (decoded picture hash).
 #pragma once
+#include <condition_variable>
 #include <deque>
 #include <memory>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "picture.h"
@@ -22,6 +25,14 @@ class Decoder {
   void set_parse_only(bool v) { parse_only_ = v; }        // no device: metadata only (host-side tests)
   void set_check_hash(bool v) { check_hash_ = v; }
   void set_device(int ordinal) { device_ = ordinal; }
+  // Parser threads (frame-parallel parsing): 1 = everything on the caller's thread (default).  With n > 1 the slice data of up to n
+  // pictures is parsed concurrently, a picture running at most one CTB row behind the picture it takes temporal motion vectors
+  // from; pictures are handed to the device, checked and put out in decoding order all the same, only later.
+  void set_threads(int n);
+  bool threaded() const { return threads_ > 1; }
+  void retire_ready(bool wait_all);                       // threaded: finished pictures go to the device and to the output queue
+  void queue_flush();                                     // threaded: everything decoded and still waiting becomes output
+  PicData* pop_output();
   // One NAL unit (with or without a start code).  Returns true when the unit starts a new picture while the previous one was still
   // open: that picture has then been finished and the SAME unit must be pushed again (libHM's bNewPicture protocol).
   bool push(const uint8_t* data, size_t len, int max_temporal_layer, int* nal_type_out);
@@ -50,6 +61,11 @@ class Decoder {
   void build_slice_params(const SliceHeader& sh, SliceInfo& si);
   void parse_sei(const std::vector<uint8_t>& rbsp, bool suffix);
   void check_hash(PicData* pic);
+  void submit_picture(PicData* pic, int parsed_ctbs);     // device work + marks of a completely parsed picture
+  void close_current();
+  void worker_main();
+  static void hook_wait_rows(void* self, const PicData* pic, int rows);
+  static void hook_rows_done(void* self, PicData* pic, int rows);
   PicData* acquire_buffer();
   PicData* find_ref(int poc, bool lsb_only, bool any_marking);
 
@@ -83,6 +99,26 @@ class Decoder {
   int device_ = 0, hash_mismatches_ = 0, pictures_decoded_ = 0;
   uint64_t submitted_seq_ = 0, synced_seq_ = 0;            // device submissions / the last one known to have completed
   std::string last_error_;
+  // ---- frame-parallel parsing
+  struct SliceJob { SliceHeader sh; int slice_idx = 0; std::vector<uint8_t> rbsp; std::shared_ptr<Sps> sps; std::shared_ptr<Pps> pps; };
+  struct PicTask {
+    PicData* pic = nullptr;
+    std::deque<SliceJob> jobs;
+    bool closed = false;                                  // no more slices will come
+    PicParseState state;
+    std::vector<PicData*> held;                           // reference pictures kept alive for the parser thread
+    std::string error;
+  };
+  int threads_ = 1, max_tl_ = -1;
+  std::vector<std::thread> workers_;
+  std::mutex mu_;
+  std::condition_variable cv_work_, cv_progress_;
+  std::deque<std::unique_ptr<PicTask>> inflight_;         // decoding order
+  std::deque<PicTask*> runnable_;
+  PicTask* cur_task_ = nullptr;
+  bool stop_ = false;
+  ProgressHooks hooks_;
+  std::deque<PicData*> out_queue_;
 };
 
 }  // namespace hmdec

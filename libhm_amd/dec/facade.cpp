@@ -3,6 +3,7 @@
 // and :450-720 (internals), re-stated on this decoder's own data structures.
 #include "../../include/hmdec.h"
 
+#include <cstdlib>
 #include <cstring>
 #include <string>
 
@@ -27,7 +28,11 @@ extern "C" {
 const char* libHMDec_get_version(void) { return "16.0"; }
 
 libHMDec_context* libHMDec_new_decoder(void) {
-  try { return new Wrapper(); } catch (...) { return nullptr; }
+  try {
+    Wrapper* w = new Wrapper();
+    if (const char* e = getenv("HMDEC_THREADS")) w->dec.set_threads(atoi(e));      // lets an unmodified libHM client use parser threads
+    return w;
+  } catch (...) { return nullptr; }
 }
 
 libHMDec_error libHMDec_free_decoder(libHMDec_context* ctx) {
@@ -71,6 +76,19 @@ libHMDec_error libHMDec_push_nal_unit(libHMDec_context* ctx, const void* data8, 
     return LIBHMDEC_ERROR;
   }
   if (const Sps* sps = w->dec.active_sps()) { g_bit_depth[0] = sps->bit_depth_luma; g_bit_depth[1] = sps->bit_depth_chroma; }
+  if (w->dec.threaded()) {
+    // parser threads: pictures reach the output queue as they leave the pipeline (in decoding order, with the same output rule);
+    // the points where libHM flushes -- a new IDR / BLA picture, the end of the stream -- first wait for the pipeline to drain
+    try {
+      const bool irap = nal_type == NAL_IDR_W_RADL || nal_type == NAL_IDR_N_LP || nal_type == NAL_BLA_N_LP || nal_type == NAL_BLA_W_RADL || nal_type == NAL_BLA_W_LP;
+      if ((bNewPicture && irap) || eof || nal_type == NAL_EOS) w->dec.queue_flush();
+    } catch (const std::exception& e) {
+      w->dec.set_error(e.what());
+      return LIBHMDEC_ERROR_READ_ERROR;
+    }
+    checkOutputPictures = true;
+    return LIBHMDEC_OK;
+  }
   w->flush_output = false;
   const bool irap_flush = nal_type == NAL_IDR_W_RADL || nal_type == NAL_IDR_N_LP || nal_type == NAL_BLA_N_LP || nal_type == NAL_BLA_W_RADL || nal_type == NAL_BLA_W_LP;
   if (bNewPicture && irap_flush) { checkOutputPictures = true; w->flush_output = true; }
@@ -85,6 +103,11 @@ libHMDec_error libHMDec_push_nal_unit(libHMDec_context* ctx, const void* data8, 
 libHMDec_picture* libHMDec_get_picture(libHMDec_context* ctx) {
   Wrapper* w = static_cast<Wrapper*>(ctx);
   if (!w) return nullptr;
+  if (w->dec.threaded()) {
+    PicData* q = w->dec.pop_output();
+    if (q) w->dec.fetch_planes(q);
+    return q;
+  }
   PicData* p = w->dec.next_output(w->flush_output);
   if (!p) {
     if (w->flush_output) { w->dec.last_display_poc = -(1 << 30); w->flush_output = false; }
@@ -254,6 +277,7 @@ libHMDec_error libHMDEC_clear_internal_info(libHMDec_context* ctx) {
 
 // ------------------------------------------------------------------------------------------------ this library's own additions
 void hmdec_set_device(libHMDec_context* ctx, int ordinal) { if (ctx) static_cast<Wrapper*>(ctx)->dec.set_device(ordinal); }
+void hmdec_set_threads(libHMDec_context* ctx, int n) { if (ctx) static_cast<Wrapper*>(ctx)->dec.set_threads(n); }
 void hmdec_set_parse_only(libHMDec_context* ctx, int on) { if (ctx) static_cast<Wrapper*>(ctx)->dec.set_parse_only(on != 0); }
 int hmdec_hash_mismatches(libHMDec_context* ctx) { return ctx ? static_cast<Wrapper*>(ctx)->dec.hash_mismatches() : -1; }
 int hmdec_pictures_decoded(libHMDec_context* ctx) { return ctx ? static_cast<Wrapper*>(ctx)->dec.pictures_decoded() : -1; }

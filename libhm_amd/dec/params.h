@@ -75,6 +75,7 @@ struct Pps {
   int log2_par_mrg_level = 2;
   // derived once the SPS is known (6.5.1)
   std::vector<int> col_bd, row_bd, ctb_rs_to_ts, ctb_ts_to_rs, tile_id;     // tile_id indexed by TS address
+  int derived_w = -1, derived_h = -1;      // picture size in CTBs the tables above were derived for
   void derive_tiles(const Sps& sps);
 };
 

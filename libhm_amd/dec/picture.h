@@ -2,6 +2,7 @@
 // each CTU, TComDataCU.h:86-157), coefficient levels in HM's TU layout, SAO parameters as parsed, and the slice table.  These are
 // exactly the arrays hmgpu_decompress_slice / hmgpu_filter_picture take (include/hmgpu.h), so nothing is converted on the way.
 #pragma once
+#include <atomic>
 #include <cstdint>
 #include <cstring>
 #include <memory>
@@ -77,6 +78,12 @@ struct PicData {
   int poc = 0, nal_type = 0, temporal_id = 0, conf_window[4] = {0, 0, 0, 0};
   bool is_reference = false, is_long_term = false, needed_for_output = false, pic_output = true, decoded = false, filtered = false;
   bool has_pcm = false, has_bypass = false, lent = false;     // lent: handed to the application by the last output scan
+  // frame-parallel parsing (decoder.cpp): progress of the parser thread that owns the picture, and who still reads its arrays
+  std::atomic<int> rows_done{0};     // CTB rows whose motion data is final (temporal MV prediction of later pictures waits on it)
+  std::atomic<bool> parse_done{true};
+  std::atomic<int> users{0};         // pictures in flight that predict from this one
+  bool in_flight = false;
+  bool sao_enabled = false, lf_across_tiles = true;   // of the parameter sets the picture was decoded with
   hmgpu_pic handle = HMGPU_NO_PIC;
   uint64_t submit_seq = 0;           // device submission that last read these arrays
   // output side
@@ -106,24 +113,37 @@ struct PicData {
     if (sps.pcm) { pcm[0].assign(luma, 0); pcm[1].assign(luma / 4, 0); pcm[2].assign(luma / 4, 0); }
     sao.assign((size_t)num_ctbs * 3, hmgpu_sao_param{});
   }
-  // a new picture in the same buffers: the state HM's TComDataCU::initCtu leaves (TComDataCU.cpp:420-470)
+  // a new picture in the same buffers.  Only the per-CTB bookkeeping is cleared here; the arrays of a CTU are brought to the
+  // state HM's TComDataCU::initCtu leaves (TComDataCU.cpp:420-470) by reset_ctu() when the parser reaches the CTU -- on the
+  // parser's thread, right before it writes them
   void reset() {
-    std::fill(depth.begin(), depth.end(), 0);
-    std::fill(tr_idx.begin(), tr_idx.end(), 0);
-    for (int c = 0; c < 3; c++) { std::fill(cbf[c].begin(), cbf[c].end(), 0); std::fill(ts[c].begin(), ts[c].end(), 0); std::fill(coeff[c].begin(), coeff[c].end(), 0); }
-    std::fill(intra_dir[0].begin(), intra_dir[0].end(), 1);
-    std::fill(intra_dir[1].begin(), intra_dir[1].end(), 0);
-    for (auto* v : {&bypass, &ipcm, &skip, &merge, &merge_idx, &inter_dir}) std::fill(v->begin(), v->end(), 0);
-    std::fill(part_size.begin(), part_size.end(), (int8_t)HMGPU_SIZE_NONE);
-    std::fill(pred_mode.begin(), pred_mode.end(), (int8_t)2);       // HM's NUMBER_OF_PREDICTION_MODES: nothing decoded here
-    std::fill(qp.begin(), qp.end(), 0);
-    for (int l = 0; l < 2; l++) { std::fill(ref_idx[l].begin(), ref_idx[l].end(), (int8_t)-1); std::fill(mv[l].begin(), mv[l].end(), 0); }
     std::fill(slice_idx.begin(), slice_idx.end(), 0);
     std::fill(slice_addr.begin(), slice_addr.end(), -1);
-    std::fill(sao.begin(), sao.end(), hmgpu_sao_param{});
     slices.clear();
+    slices.reserve(HMGPU_MAX_SLICES);   // entries are added while a parser thread reads earlier ones: the storage must not move
     has_pcm = has_bypass = decoded = filtered = planes_valid = hash_mismatch = false;
     sei_hash_method = 0;
+  }
+  void reset_ctu(int rs) {
+    const size_t first = (size_t)rs * parts;
+    auto fill = [&](auto& v, auto value) { std::fill(v.begin() + first, v.begin() + first + parts, value); };
+    fill(depth, (uint8_t)0);
+    fill(tr_idx, (uint8_t)0);
+    for (int c = 0; c < 3; c++) { fill(cbf[c], (uint8_t)0); fill(ts[c], (uint8_t)0); }
+    fill(intra_dir[0], (uint8_t)1);
+    fill(intra_dir[1], (uint8_t)0);
+    fill(bypass, (uint8_t)0); fill(ipcm, (uint8_t)0); fill(skip, (uint8_t)0); fill(merge, (uint8_t)0); fill(merge_idx, (uint8_t)0); fill(inter_dir, (uint8_t)0);
+    fill(part_size, (int8_t)HMGPU_SIZE_NONE);
+    fill(pred_mode, (int8_t)2);          // HM's NUMBER_OF_PREDICTION_MODES: nothing decoded here
+    fill(qp, (int8_t)0);
+    for (int l = 0; l < 2; l++) {
+      fill(ref_idx[l], (int8_t)-1);
+      std::fill(mv[l].begin() + 2 * first, mv[l].begin() + 2 * (first + parts), (int16_t)0);
+    }
+    const size_t luma = (size_t)1 << (2 * log2_ctb);
+    std::fill(coeff[0].begin() + rs * luma, coeff[0].begin() + (rs + 1) * luma, (int16_t)0);
+    for (int c = 1; c < 3; c++) std::fill(coeff[c].begin() + rs * (luma / 4), coeff[c].begin() + (rs + 1) * (luma / 4), (int16_t)0);
+    for (int c = 0; c < 3; c++) sao[(size_t)rs * 3 + c] = hmgpu_sao_param{};
   }
   size_t part_at(int x, int y) const {      // partition index of the 4x4 block covering luma sample (x, y)
     const int mask = (1 << log2_ctb) - 1;

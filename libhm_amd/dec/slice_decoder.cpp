@@ -101,6 +101,10 @@ bool SliceDecoder::decode(const SliceHeader& sh, int slice_idx, const uint8_t* r
       for (int v : pps_.col_bd) if (v <= cx) col_start = v;
       if (cx == col_start + 1) { st_.wpp = ctx_; st_.wpp_valid = true; }
     }
+    if (!pps_.tiles_enabled && cx == W - 1) {               // a CTB row is complete: later pictures may take motion vectors from it
+      if (hooks_ && hooks_->rows_done) hooks_->rows_done(hooks_->self, &pic_, cy + 1);
+      else pic_.rows_done.store(cy + 1, std::memory_order_release);
+    }
     const int end = cabac_.terminate();                     // end_of_slice_segment_flag
     ctb_ts_++;
     if (end) {
@@ -125,6 +129,7 @@ bool SliceDecoder::decode(const SliceHeader& sh, int slice_idx, const uint8_t* r
 
 void SliceDecoder::ctu(int rs) {
   const int x0 = (rs % pic_.ctbs_w) << sps_.log2_ctb, y0 = (rs / pic_.ctbs_w) << sps_.log2_ctb;
+  pic_.reset_ctu(rs);
   pic_.slice_addr[rs] = sh_->slice_address;
   pic_.slice_idx[rs] = (uint16_t)slice_idx_;
   pic_.tile_idx[rs] = (uint16_t)pps_.tile_id[ctb_ts_];
@@ -494,6 +499,8 @@ SliceDecoder::Mv SliceDecoder::scale_mv(Mv mv, int tb, int td) {
 bool SliceDecoder::col_mv(int xcol, int ycol, int list, int ref_idx, Mv& out) const {
   const PicData* col = slice_->ref_pics[(sh_->type == SLICE_B && !sh_->collocated_from_l0) ? 1 : 0][sh_->collocated_ref_idx];
   if (!col) return false;
+  if (hooks_ && hooks_->wait_rows && col->rows_done.load(std::memory_order_acquire) <= (ycol >> sps_.log2_ctb))
+    hooks_->wait_rows(hooks_->self, col, (ycol >> sps_.log2_ctb) + 1);      // the collocated picture is still being parsed
   const size_t p = col->part_at(xcol, ycol);
   if (col->pred_mode[p] != MODE_INTER) return false;
   int lc;

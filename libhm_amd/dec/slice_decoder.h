@@ -8,6 +8,13 @@
 
 namespace hmdec {
 
+// how a parser thread learns that rows of another picture are final (set by the decoder; null = never wait)
+struct ProgressHooks {
+  void (*wait_rows)(void* self, const PicData* pic, int rows) = nullptr;
+  void (*rows_done)(void* self, PicData* pic, int rows) = nullptr;
+  void* self = nullptr;
+};
+
 struct PicParseState {               // carried from one slice segment of a picture to the next
   ContextSet end_of_segment;         // 9.3.2.4 storage for dependent slice segments
   bool have_end_of_segment = false;
@@ -19,7 +26,8 @@ struct PicParseState {               // carried from one slice segment of a pict
 
 class SliceDecoder {
  public:
-  SliceDecoder(const Sps& sps, const Pps& pps, PicData& pic, PicParseState& st) : sps_(sps), pps_(pps), pic_(pic), st_(st) {}
+  SliceDecoder(const Sps& sps, const Pps& pps, PicData& pic, PicParseState& st, const ProgressHooks* hooks = nullptr)
+      : sps_(sps), pps_(pps), pic_(pic), st_(st), hooks_(hooks) {}
   // parses one slice segment; `slice` is the entry of pic.slices it belongs to.  Returns true when the picture is complete.
   bool decode(const SliceHeader& sh, int slice_idx, const uint8_t* rbsp, size_t bytes);
 
@@ -63,6 +71,7 @@ class SliceDecoder {
   const Pps& pps_;
   PicData& pic_;
   PicParseState& st_;
+  const ProgressHooks* hooks_ = nullptr;
   const SliceHeader* sh_ = nullptr;
   SliceInfo* slice_ = nullptr;
   Cabac cabac_;

@@ -39,6 +39,7 @@ def lib():
         L.libHMDEC_get_internal_bit_depth.argtypes = [C.c_int]
         L.hmdec_set_device.argtypes = [C.c_void_p, C.c_int]
         L.hmdec_set_parse_only.argtypes = [C.c_void_p, C.c_int]
+        L.hmdec_set_threads.argtypes = [C.c_void_p, C.c_int]
         L.hmdec_hash_mismatches.argtypes = [C.c_void_p]
         L.hmdec_pictures_decoded.argtypes = [C.c_void_p]
         L.hmdec_last_error.argtypes = [C.c_void_p]
@@ -152,12 +153,13 @@ class Picture:
 
 
 class Decoder:
-    def __init__(self, parse_only=False, device=0, check_hash=True, max_temporal_layer=-1):
+    def __init__(self, parse_only=False, device=0, check_hash=True, max_temporal_layer=-1, threads=1):
         self.ctx = lib().libHMDec_new_decoder()
         if not self.ctx:
             raise MemoryError("libHMDec_new_decoder")
         lib().hmdec_set_parse_only(self.ctx, 1 if parse_only else 0)
         lib().hmdec_set_device(self.ctx, device)
+        lib().hmdec_set_threads(self.ctx, threads)
         lib().libHMDec_set_SEI_Check(self.ctx, check_hash)
         lib().libHMDec_set_max_temporal_layer(self.ctx, max_temporal_layer)
 

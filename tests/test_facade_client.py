@@ -70,7 +70,8 @@ def test_corrupted_streams_never_crash(tmp_path):
                 b[pos:pos] = bytes(rng.randrange(256) for _ in range(rng.randrange(1, 8)))
         f = tmp_path / "fuzz.bin"
         f.write_bytes(bytes(b))
-        r = subprocess.run([exe, str(f), "parse-only"], stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=60)
+        env = dict(os.environ, HMDEC_THREADS="3") if it % 2 else dict(os.environ)      # every other one with parser threads
+        r = subprocess.run([exe, str(f), "parse-only"], stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=60, env=env)
         assert r.returncode in (0, 4), "iteration %d: exit code %d\n%s" % (it, r.returncode, r.stderr[-400:])
         outcomes[r.returncode] += 1
     assert outcomes[0] > 0 and outcomes[4] > 0          # both ends of the spectrum were exercised

@@ -10,12 +10,13 @@ from tests import golden_util as gu
 pytestmark = pytest.mark.gpu
 
 
+@pytest.mark.parametrize("threads", [1, 4])
 @pytest.mark.parametrize("name", gu.STREAMS)
-def test_bitstream_to_pictures_matches_hm(name):
+def test_bitstream_to_pictures_matches_hm(name, threads):
     z = gu.load("stream_" + name)
     want = {p.poc: p for p in gu.stream_pictures(name)}
     out = []
-    with hmdec.Decoder() as d:
+    with hmdec.Decoder(threads=threads) as d:
         def on_output(p):
             out.append(p.poc)
             w = want[p.poc]
@@ -64,14 +65,15 @@ def test_internals_describe_the_picture():
         assert np.array_equal(pm[pics[-1].meta_np["part_size"].reshape(-1) != 8], pics[-1].meta_np["pred_mode"].reshape(-1)[pics[-1].meta_np["part_size"].reshape(-1) != 8])
 
 
+@pytest.mark.parametrize("threads", [1, 3])
 @pytest.mark.parametrize("name", gu.LITE)
-def test_syntax_variants_decode_to_the_encoders_reconstruction(name):
+def test_syntax_variants_decode_to_the_encoders_reconstruction(name, threads):
     """slices, dependent slice segments, wavefronts, CU-level QP, CRA + leading pictures, 32/16-sample CTUs, conformance window,
     slices of tiles, low-delay B: output == HM's encoder reconstruction (== what HM's decoder must produce), hash SEI check green"""
     z = gu.load("lite_" + name)
     w, h, frames, bd = (int(v) for v in z["geom"])
     out = []
-    with hmdec.Decoder() as d:
+    with hmdec.Decoder(threads=threads) as d:
         def on_output(p):
             out.append(p.poc)
             for c in range(3):

@@ -16,22 +16,27 @@ ARRAYS = [("depth", "depth"), ("part_size", "part_size"), ("pred_mode", "pred_mo
 
 
 def _decode(name, **kw):
+    """everything the parser produced, per picture in HM's decoding order (the fixture's order).  The arrays are taken when a picture
+    is put out: that works the same with parser threads, where pictures leave the pipeline in bursts."""
     z = gu.load("stream_" + name)
-    got = []
+    by_poc, outputs = {}, []
     with hmdec.Decoder(parse_only=True, **kw) as d:
-        def on_decoded(p):
+        def on_output(p):
             arrays = {n: p.array(n) for n, _ in ARRAYS}
             for n in ("skip", "merge", "coeff0", "coeff1", "coeff2", "sao", "slice_idx", "tile_idx", "pcm0", "pcm1", "pcm2"):
                 arrays[n] = p.array(n)
-            got.append(dict(poc=p.poc, arrays=arrays, slices=[p.slice_params(i) for i in range(p.num_slices())], hash=p.hash_sei()))
-        outputs = []
-        d.decode_stream(z["bitstream"], on_decoded=on_decoded, on_output=lambda p: outputs.append(p.poc))
-    return z, got, outputs
+            by_poc[p.poc] = dict(poc=p.poc, arrays=arrays, slices=[p.slice_params(i) for i in range(p.num_slices())], hash=p.hash_sei())
+            outputs.append(p.poc)
+        d.decode_stream(z["bitstream"], on_output=on_output)
+    order = [int(z["pic%02d_info" % i][4]) for i in range(int(z["num_pics"][0]))]
+    assert sorted(order) == sorted(by_poc), (order, sorted(by_poc))
+    return z, [by_poc[poc] for poc in order], outputs
 
 
+@pytest.mark.parametrize("threads", [1, 4])
 @pytest.mark.parametrize("name", gu.STREAMS)
-def test_parser_reproduces_hm_metadata(name):
-    z, got, outputs = _decode(name)
+def test_parser_reproduces_hm_metadata(name, threads):
+    z, got, outputs = _decode(name, threads=threads)
     pics = gu.stream_pictures(name)
     assert len(got) == len(pics)
     for g, p in zip(got, pics):
@@ -130,8 +135,9 @@ def test_errors_are_reported_not_fatal():
             d.push(b"\x02\x01\x80\x00\x00", False)          # a slice before any parameter set
 
 
+@pytest.mark.parametrize("threads", [1, 3])
 @pytest.mark.parametrize("name", gu.LITE)
-def test_parser_gets_through_every_syntax_variant(name):
+def test_parser_gets_through_every_syntax_variant(name, threads):
     """slices, dependent slice segments, wavefronts, CU-level QP, CRA with leading pictures, 32/16-sample CTUs, cropping, slices of
     tiles, B low delay: the parser stays in sync to the last bit of every slice (the stop bit check behind end_of_slice_segment_flag),
     puts all pictures out in POC order, and the hash SEIs it collected are the MD5s of HM's encoder reconstruction"""
@@ -139,8 +145,8 @@ def test_parser_gets_through_every_syntax_variant(name):
     z = gu.load("lite_" + name)
     w, h, frames, bd = (int(v) for v in z["geom"])
     hashes, out = {}, []
-    with hmdec.Decoder(parse_only=True) as d:
-        d.decode_stream(z["bitstream"], on_decoded=lambda p: hashes.__setitem__(p.poc, p.hash_sei()), on_output=lambda p: out.append(p.poc))
+    with hmdec.Decoder(parse_only=True, threads=threads) as d:
+        d.decode_stream(z["bitstream"], on_output=lambda p: (hashes.__setitem__(p.poc, p.hash_sei()), out.append(p.poc)))
         assert d.pictures_decoded == frames
     assert out == list(range(frames))
     if "crop" in name:
