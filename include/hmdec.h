@@ -80,6 +80,10 @@ libHMDec_picture* hmdec_open_picture(libHMDec_context* ctx);                  /*
 int hmdec_picture_array(libHMDec_picture* pic, const char* name, const void** data, int64_t* bytes);
 int hmdec_picture_num_slices(libHMDec_picture* pic);
 int hmdec_picture_slice_params(libHMDec_picture* pic, int slice, void* out /* hmgpu_slice_params */, void* lists_out /* hmgpu_scaling_lists or NULL */);
+/* geometry and sequence-level constants of a picture: width, height, log2 CTB size, bit depth luma, bit depth chroma, PCM bit depth
+ * luma, PCM bit depth chroma, pcm_loop_filter_disabled (and PCM enabled), strong_intra_smoothing, SAO enabled, loop filter across
+ * tiles, number of CTBs -- what hmgpu_seq_params / hmgpu_pic_params are filled from */
+int hmdec_picture_geometry(libHMDec_picture* pic, int32_t out[12]);
 /* conformance window of the picture's SPS in luma samples: left, right, top, bottom (libHM hands out the uncropped picture) */
 int hmdec_picture_conformance_window(libHMDec_picture* pic, int32_t window[4]);
 /* libHMDEC_get_internal_info for C callers: pointer to the first element and the count (same storage, same lifetime) */

@@ -350,6 +350,10 @@ void Decoder::start_picture(const SliceHeader& sh) {
   cur_->nal_type = sh.nal_type;
   cur_->temporal_id = sh.temporal_id;
   cur_->sao_enabled = sps_->sao;
+  cur_->bit_depth[0] = sps_->bit_depth_luma; cur_->bit_depth[1] = sps_->bit_depth_chroma;
+  cur_->pcm_bit_depth[0] = sps_->pcm_bit_depth_luma; cur_->pcm_bit_depth[1] = sps_->pcm_bit_depth_chroma;
+  cur_->pcm_lf_disable = sps_->pcm && sps_->pcm_loop_filter_disabled;
+  cur_->strong_intra = sps_->strong_intra_smoothing;
   cur_->lf_across_tiles = pps_->lf_across_tiles;
   cur_->conf_window[0] = sps_->conf_left; cur_->conf_window[1] = sps_->conf_right; cur_->conf_window[2] = sps_->conf_top; cur_->conf_window[3] = sps_->conf_bottom;
   cur_->is_reference = true;                 // "used for short-term reference" until a later RPS says otherwise (8.3.1 end)

@@ -326,6 +326,15 @@ int hmdec_picture_slice_params(libHMDec_picture* pic, int slice, void* out, void
   return 0;
 }
 
+int hmdec_picture_geometry(libHMDec_picture* pic, int32_t out[12]) {
+  if (!pic || !out) return 1;
+  const PicData& p = *as_pic(pic);
+  const int32_t v[12] = {p.width, p.height, p.log2_ctb, p.bit_depth[0], p.bit_depth[1], p.pcm_bit_depth[0], p.pcm_bit_depth[1],
+                         p.pcm_lf_disable, p.strong_intra, p.sao_enabled, p.lf_across_tiles, p.num_ctbs};
+  memcpy(out, v, sizeof(v));
+  return 0;
+}
+
 int hmdec_picture_conformance_window(libHMDec_picture* pic, int32_t window[4]) {
   if (!pic || !window) return 1;
   for (int i = 0; i < 4; i++) window[i] = as_pic(pic)->conf_window[i];

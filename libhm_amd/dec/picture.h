@@ -84,6 +84,8 @@ struct PicData {
   std::atomic<int> users{0};         // pictures in flight that predict from this one
   bool in_flight = false;
   bool sao_enabled = false, lf_across_tiles = true;   // of the parameter sets the picture was decoded with
+  int bit_depth[2] = {8, 8}, pcm_bit_depth[2] = {8, 8};
+  bool pcm_lf_disable = false, strong_intra = false;
   hmgpu_pic handle = HMGPU_NO_PIC;
   uint64_t submit_seq = 0;           // device submission that last read these arrays
   // output side

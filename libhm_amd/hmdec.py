@@ -52,6 +52,7 @@ def lib():
         L.hmdec_picture_num_slices.argtypes = [C.c_void_p]
         L.hmdec_picture_slice_params.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         L.hmdec_picture_hash_sei.argtypes = [C.c_void_p, C.c_void_p]
+        L.hmdec_picture_geometry.argtypes = [C.c_void_p, C.POINTER(C.c_int32)]
         L.hmdec_picture_conformance_window.argtypes = [C.c_void_p, C.POINTER(C.c_int32)]
         L.hmdec_internal_info.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.POINTER(BlockValue))]
         _lib = L
@@ -126,6 +127,12 @@ class Picture:
             return np.zeros(0, dtype=dt)
         buf = (C.c_char * n.value).from_address(ptr.value)
         return np.frombuffer(buf, dtype=dt).copy()
+
+    def geometry(self):
+        g = (C.c_int32 * 12)()
+        lib().hmdec_picture_geometry(self.h, g)
+        keys = ("width", "height", "log2_ctb", "bd_y", "bd_c", "pcm_bd_y", "pcm_bd_c", "pcm_lf_disable", "strong_intra", "sao", "lf_across_tiles", "num_ctbs")
+        return dict(zip(keys, (int(v) for v in g)))
 
     def conformance_window(self):
         w = (C.c_int32 * 4)()
