@@ -33,6 +33,22 @@ def test_library_exports_every_declared_symbol(built_lib):
     assert not missing, missing
 
 
+def test_decoder_library_exports_every_declared_symbol(built_lib):
+    """libhmdec.so: everything include/hmdec.h declares -- the libHMDecoder-compatible names and this library's own additions"""
+    from libhm_amd import build
+    dec = build.build_decoder()
+    text = open(os.path.join(ROOT, "include", "hmdec.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    names = sorted(set(re.findall(r"\b((?:libHMDec_|libHMDEC_|hmdec_)[A-Za-z0-9_]+)\s*\(", text)))
+    assert len(names) >= 28, names
+    out = subprocess.check_output(["nm", "-D", "--defined-only", dec], text=True)
+    exported = set(line.split()[-1] for line in out.splitlines() if " T " in line)
+    missing = [n for n in names if n not in exported]
+    assert not missing, missing
+    # and nothing of the test infrastructure is linked in
+    assert "oracle" not in subprocess.check_output(["ldd", dec], text=True)
+
+
 def test_struct_sizes_match_the_header(built_lib, tmp_path):
     from libhm_amd import abi
     src = tmp_path / "sz.c"
