@@ -43,8 +43,11 @@ enum Ctx {
   CTX_COUNT = CTX_GT2 + 6
 };
 
+// (a context variable is 7 bits; it is kept in 16 so that stores to it cannot alias the engine's registers -- unsigned char may
+// alias anything, which would force the compiler to reload range and offset after every bin)
+typedef uint16_t ctx_t;
 struct ContextSet {
-  uint8_t s[CTX_COUNT];                     // (pStateIdx << 1) | valMps
+  ctx_t s[CTX_COUNT];                       // (pStateIdx << 1) | valMps
   void init(int init_type, int slice_qp);   // 9.3.2.2
 };
 
@@ -61,7 +64,7 @@ class Cabac {
     range_ = 510;
     offset_ = get(9);
   }
-  int decision(uint8_t& ctx) {
+  int decision(ctx_t& ctx) {
     const unsigned state = ctx >> 1, mps = ctx & 1;
     const unsigned lps = kRangeLps[state][(range_ >> 6) & 3];
     range_ -= lps;
@@ -70,10 +73,10 @@ class Cabac {
       offset_ -= range_;
       range_ = lps;
       bin = mps ^ 1;
-      ctx = (uint8_t)((kNextLps[state] << 1) | (state == 0 ? mps ^ 1 : mps));
+      ctx = (ctx_t)((kNextLps[state] << 1) | (state == 0 ? mps ^ 1 : mps));
     } else {
       bin = mps;
-      ctx = (uint8_t)((kNextMps[state] << 1) | mps);
+      ctx = (ctx_t)((kNextMps[state] << 1) | mps);
       if (range_ >= 256) return bin;
     }
     const int n = __builtin_clz(range_) - 23;       // shifts until bit 8 is set
@@ -123,10 +126,18 @@ class Cabac {
   unsigned get(int n) {                               // n <= 25; bits behind the end of the data read as zero
     if (n == 0) return 0;
     if (avail_ < n) {
-      while (avail_ <= 56) {
-        res_ = (res_ << 8) | (next_byte_ < nbytes_ ? p_[next_byte_] : 0u);
-        next_byte_++;
-        avail_ += 8;
+      if (avail_ <= 32 && next_byte_ + 4 <= nbytes_) {
+        uint32_t w;
+        memcpy(&w, p_ + next_byte_, 4);
+        res_ = (res_ << 32) | __builtin_bswap32(w);
+        next_byte_ += 4;
+        avail_ += 32;
+      } else {
+        while (avail_ <= 56) {
+          res_ = (res_ << 8) | (next_byte_ < nbytes_ ? p_[next_byte_] : 0u);
+          next_byte_++;
+          avail_ += 8;
+        }
       }
       if (next_byte_ > nbytes_ + 24) throw ParseError("CABAC: read far past the end of the slice data");
     }

@@ -796,7 +796,7 @@ void SliceDecoder::residual_coding(int x0, int y0, int log2, int c) {
   const uint8_t* in_order = kScan.order[2][scan_idx];
   const int last_sb = kScan.index[sb_log2][scan_idx][(ly >> 2) * sbw + (lx >> 2)];
   const int last_pos = kScan.index[2][scan_idx][(ly & 3) * 4 + (lx & 3)];
-  uint8_t csbf[9][9] = {{0}};
+  int csbf[9][9] = {{0}};
   int prev_c1 = 1;
   bool first_sb = true;
   const bool sdh = pps_.sign_data_hiding && !cu_bypass_;
@@ -841,10 +841,10 @@ void SliceDecoder::residual_coding(int x0, int y0, int log2, int c) {
     if (!first_sb && prev_c1 == 0) ctx_set++;
     first_sb = false;
     int c1 = 1, first_g1 = -1;
-    uint8_t g1[16] = {0};
+    int g1[16] = {0};
     const int ng1 = nsig < 8 ? nsig : 8;
     for (int k = 0; k < ng1; k++) {
-      g1[k] = (uint8_t)cabac_.decision(ctx_.s[CTX_GT1 + (c ? 16 : 0) + ctx_set * 4 + c1]);
+      g1[k] = cabac_.decision(ctx_.s[CTX_GT1 + (c ? 16 : 0) + ctx_set * 4 + c1]);
       if (g1[k]) { c1 = 0; if (first_g1 < 0) first_g1 = k; }
       else if (c1 > 0 && c1 < 3) c1++;
     }
