@@ -17,8 +17,8 @@ STREAMS = {
     # name: (cfg, w, h, frames, bit depth, qp, extra)
     "bench_ldp_main10_3840x2160": ("encoder_lowdelay_P_main10.cfg", 3840, 2160, 5, 10, 32, []),
     "bench_ra_main10_1920x1080": ("encoder_randomaccess_main10.cfg", 1920, 1080, 9, 10, 32, ["--IntraPeriod=8"]),
-    # a longer clip with the usual proportion of intra data (one I picture, 32 P pictures): what parser threads are for
-    "bench_ldp_main10_1920x1080_33": ("encoder_lowdelay_P_main10.cfg", 1920, 1080, 33, 10, 32, []),
+    # a longer low-delay clip: one I picture and 16 small P pictures (the synthetic scene is nearly static)
+    "bench_ldp_main10_1920x1080_17": ("encoder_lowdelay_P_main10.cfg", 1920, 1080, 17, 10, 32, []),
 }
 
 
