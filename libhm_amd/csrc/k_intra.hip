@@ -60,17 +60,22 @@ struct IntraLds {
   __attribute__((aligned(4))) int16_t top[132];
   // the CTU's TComDataCU arrays, fetched once with one dword per lane and array (the walk over CUs and TUs is a serial chain:
   // every byte it had to wait for from global memory would cost a round trip)
+  // the CTU's coefficient levels of this component (HM layout), staged while the block still waits for its neighbours: the
+  // serial TU chain would otherwise pay one trip to HBM per coded TU (the levels are read exactly once: never a cache hit)
+  __attribute__((aligned(16))) int16_t lev[64 * 64];
   __attribute__((aligned(4))) uint8_t m_depth[256], m_part[256], m_pred[256], m_tr[256], m_qp[256], m_cbf[256], m_ts[256], m_dir[256], m_dirl[256], m_byp[256], m_pcm[256];
 };
 
 struct TuCtx {
   int comp, ctu, z_tu, log2n, mode, cbf, skip, bypass, x0, y0, qp_cu;     // x0, y0: component samples
-  int cip, cqo, slice, tile;                                      // per-CTU constants: constrained intra pred, chroma QP offset, slice / tile index
+  int cip, cqo, slice, tile, nb_same;                             // per-CTU constants: constrained intra pred, chroma QP offset, slice / tile index, neighbours in the same slice and tile
   int cx0, cy0;                                                   // CTU origin in component samples
 };
 
 // availability of the 4x4 luma partition at luma sample (px, py) as intra reference of the TU at (ctu, z_tu)
-__device__ inline bool intra_avail(const PicDev& P, int ctu, int z_tu, int px, int py, bool cip, int slice, int tile) {
+// nb_same: bit k set = neighbouring CTU k (0 left, 1 above-left, 2 above, 3 above-right) lies in the same slice and tile, worked out
+// once per CTU; m_pred: the CTU's own prediction modes in LDS (constrained intra prediction)
+__device__ inline bool intra_avail(const PicDev& P, int ctu, int z_tu, int px, int py, bool cip, unsigned nb_same, const uint8_t* m_pred) {
   if (px < 0 || py < 0 || px >= P.width || py >= P.height) return false;
   const int ctu_mask = (1 << P.log2ctu) - 1;
   const int nctu = (py >> P.log2ctu) * P.ctus_w + (px >> P.log2ctu);
@@ -78,11 +83,13 @@ __device__ inline bool intra_avail(const PicDev& P, int ctu, int z_tu, int px, i
   int nz = 0;
 #pragma unroll
   for (int k = 0; k < 4; k++) nz |= (((bx >> k) & 1) << (2 * k)) | (((by >> k) & 1) << (2 * k + 1));
-  if (nctu == ctu) { if (nz >= z_tu) return false; }
-  else {
-    if (nctu > ctu) return false;
-    if (ldg(P.slice_idx + nctu) != slice || ldg(P.tile_idx + nctu) != tile) return false;
+  if (nctu == ctu) {
+    if (nz >= z_tu) return false;
+    return !cip || m_pred[nz] == HMGPU_MODE_INTRA;
   }
+  if (nctu > ctu) return false;
+  const int k = nctu == ctu - 1 ? 0 : nctu == ctu - P.ctus_w - 1 ? 1 : nctu == ctu - P.ctus_w ? 2 : 3;
+  if (!((nb_same >> k) & 1)) return false;
   if (cip && ldg(P.pred_mode + (size_t)nctu * P.parts + nz) != HMGPU_MODE_INTRA) return false;
   return true;
 }
@@ -114,11 +121,11 @@ __device__ inline void intra_tu(const PicDev& P, const TuCtx& t, IntraLds& L) {
 #pragma unroll
   for (int i = 0; i < N / 2; i++) lv[i] = 0;
   if (t.cbf && active) {
-    const int16_t* lev = P.coef[comp] + (size_t)t.ctu * ((size_t)(1 << (2 * P.log2ctu)) >> (comp ? 2 : 0)) + (comp ? 4 : 16) * t.z_tu + n * N;
-    if constexpr (N == 4) { const u32x2 a = ldg2(lev); lv[0] = a.x; lv[1] = a.y; }
+    const int16_t* lev = &L.lev[(comp ? 4 : 16) * t.z_tu + n * N];          // staged by k_intra before the wait for the neighbours
+    if constexpr (N == 4) { const u32x2 a = *reinterpret_cast<const u32x2*>(lev); lv[0] = a.x; lv[1] = a.y; }
     else {
 #pragma unroll
-      for (int i = 0; i < N / 8; i++) { const u32x4 a = ldg4(lev + i * 8); lv[4 * i] = a.x; lv[4 * i + 1] = a.y; lv[4 * i + 2] = a.z; lv[4 * i + 3] = a.w; }
+      for (int i = 0; i < N / 8; i++) { const u32x4 a = *reinterpret_cast<const u32x4*>(lev + i * 8); lv[4 * i] = a.x; lv[4 * i + 1] = a.y; lv[4 * i + 2] = a.z; lv[4 * i + 3] = a.w; }
     }
   }
 
@@ -129,7 +136,7 @@ __device__ inline void intra_tu(const PicDev& P, const TuCtx& t, IntraLds& L) {
     if (lane < 2 * U) { px = lx - 4; py = ly + 4 * (2 * U - 1 - lane); }
     else if (lane == 2 * U) { px = lx - 4; py = ly - 4; }
     else { px = lx + 4 * (lane - 2 * U - 1); py = ly - 4; }
-    av = intra_avail(P, t.ctu, t.z_tu, px, py, cip, t.slice, t.tile);
+    av = intra_avail(P, t.ctu, t.z_tu, px, py, cip, (unsigned)t.nb_same, L.m_pred);
   }
   const unsigned long long am = __builtin_amdgcn_ballot_w64(av);
   for (int i = lane; i < total; i += 64) {
@@ -307,6 +314,16 @@ __device__ inline void intra_ctu(const PicDev& P, int comp, int ctu, IntraLds& L
   const int slice = ldg(P.slice_idx + ctu), tile = ldg(P.tile_idx + ctu);
   const SliceDev& sd = P.slices[slice];
   const int cip = ldg(&sd.constrained_intra_pred);
+  // which of the four neighbouring CTUs an intra reference may come from (same slice, same tile): once per CTU
+  int nb_same = 0;
+  {
+    const int cx = ctu % P.ctus_w, cy = ctu / P.ctus_w;
+    const int nbc[4] = {cx > 0 ? ctu - 1 : -1, (cx > 0 && cy > 0) ? ctu - P.ctus_w - 1 : -1, cy > 0 ? ctu - P.ctus_w : -1,
+                        (cy > 0 && cx + 1 < P.ctus_w) ? ctu - P.ctus_w + 1 : -1};
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+      if (nbc[k] >= 0 && ldg(P.slice_idx + nbc[k]) == slice && ldg(P.tile_idx + nbc[k]) == tile) nb_same |= 1 << k;
+  }
   const int cqo = comp == 1 ? ldg(&sd.cb_qp_offset) : comp == 2 ? ldg(&sd.cr_qp_offset) : 0;
   wave_lds_sync();
   int z = 0;
@@ -344,7 +361,7 @@ __device__ inline void intra_ctu(const PicDev& P, int comp, int ctu, IntraLds& L
       const int tr = L.m_tr[zc];
       const int log2tu = log2cu - tr;
       TuCtx t;
-      t.comp = comp; t.ctu = ctu; t.z_tu = zc; t.qp_cu = qp_cu; t.cip = cip; t.cqo = cqo; t.slice = slice; t.tile = tile;
+      t.comp = comp; t.ctu = ctu; t.z_tu = zc; t.qp_cu = qp_cu; t.cip = cip; t.cqo = cqo; t.slice = slice; t.tile = tile; t.nb_same = nb_same;
       t.cx0 = ctu_x >> cs; t.cy0 = ctu_y >> cs;
       t.x0 = (ctu_x + 4 * zscan_x(zc)) >> cs; t.y0 = (ctu_y + 4 * zscan_y(zc)) >> cs;
       bool run = true;
@@ -400,6 +417,12 @@ __global__ void __launch_bounds__(64) k_intra(const PicDev* __restrict__ pics, B
     left = __builtin_amdgcn_ballot_w64(l) != 0; right = __builtin_amdgcn_ballot_w64(r) != 0;
     top = __builtin_amdgcn_ballot_w64(t) != 0; bottom = __builtin_amdgcn_ballot_w64(bm) != 0;
   };
+  // the levels of this CTU do not depend on anybody: on their way into LDS while the neighbours finish
+  {
+    const int n_lev = (1 << (2 * P.log2ctu)) >> (comp ? 2 : 0);
+    const int16_t* src = P.coef[comp] + (size_t)ctu * n_lev;
+    for (int i = lane * 8; i < n_lev; i += 64 * 8) *reinterpret_cast<u32x4*>(&L.lev[i]) = ldg4(src + i);
+  }
   unsigned my_l, my_r, my_t, my_b;
   border_mask(ctu, my_l, my_r, my_t, my_b);
 #pragma unroll
@@ -416,6 +439,7 @@ __global__ void __launch_bounds__(64) k_intra(const PicDev* __restrict__ pics, B
     while (__hip_atomic_load(done + n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) __builtin_amdgcn_s_sleep(64);
   }
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  wave_lds_sync();
   intra_ctu(P, comp, ctu, L);
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
   if (lane == 0) __hip_atomic_store(done + ctu, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);

@@ -96,9 +96,9 @@ class Cabac {
     unsigned v = 0;
     while (n > 0) {
       const int k = n > 16 ? 16 : n;
-      const unsigned long long wide = ((unsigned long long)offset_ << k) | get(k);
-      const unsigned q = (unsigned)(wide / range_);
-      offset_ = (unsigned)(wide - (unsigned long long)q * range_);
+      const unsigned wide = (offset_ << k) | get(k);          // offset < range <= 510: 25 bits at most
+      const unsigned q = wide / range_;
+      offset_ = wide - q * range_;
       v = (v << k) | q;
       n -= k;
     }

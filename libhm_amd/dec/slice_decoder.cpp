@@ -765,10 +765,11 @@ void SliceDecoder::transform_tree(int x0, int y0, int xbase, int ybase, int log2
 
 // 7.3.8.11 residual_coding(); (x0, y0) in luma samples, log2 = size of the block in samples of component c
 void SliceDecoder::residual_coding(int x0, int y0, int log2, int c) {
+  Cabac eng = cabac_;                    // the engine's registers stay in CPU registers for the whole block (written back at the end)
   const int size = 1 << log2;
   const size_t part = pic_.part_at(x0, y0), ctb = pic_.ctb_at(x0, y0), z = part - ctb * pic_.parts;
   int16_t* dst = c == 0 ? &pic_.coeff[0][(ctb << (2 * sps_.log2_ctb)) + 16 * z] : &pic_.coeff[c][(ctb << (2 * sps_.log2_ctb - 2)) + 4 * z];
-  if (pps_.transform_skip_enabled && !cu_bypass_ && log2 == 2 && cabac_.decision(ctx_.s[CTX_TS_FLAG + (c ? 1 : 0)])) {
+  if (pps_.transform_skip_enabled && !cu_bypass_ && log2 == 2 && eng.decision(ctx_.s[CTX_TS_FLAG + (c ? 1 : 0)])) {
     const int span = c ? 2 : 1;                          // a 4x4 chroma block lies over 2x2 luma partitions
     for (int y = 0; y < span; y++) for (int x = 0; x < span; x++) pic_.ts[c][pic_.part_at(x0 + 4 * x, y0 + 4 * y)] = 1;
   }
@@ -778,11 +779,11 @@ void SliceDecoder::residual_coding(int x0, int y0, int log2, int c) {
   else { ctx_off = 15; ctx_shift = log2 - 2; }
   const int cmax = (log2 << 1) - 1;
   int px = 0, py = 0;
-  while (px < cmax && cabac_.decision(ctx_.s[CTX_LAST_X + ctx_off + (px >> ctx_shift)])) px++;
-  while (py < cmax && cabac_.decision(ctx_.s[CTX_LAST_Y + ctx_off + (py >> ctx_shift)])) py++;
+  while (px < cmax && eng.decision(ctx_.s[CTX_LAST_X + ctx_off + (px >> ctx_shift)])) px++;
+  while (py < cmax && eng.decision(ctx_.s[CTX_LAST_Y + ctx_off + (py >> ctx_shift)])) py++;
   int lx = px, ly = py;
-  if (px > 3) { const int nb = (px >> 1) - 1; lx = (1 << nb) * (2 + (px & 1)) + (int)cabac_.bypass_bits(nb); }
-  if (py > 3) { const int nb = (py >> 1) - 1; ly = (1 << nb) * (2 + (py & 1)) + (int)cabac_.bypass_bits(nb); }
+  if (px > 3) { const int nb = (px >> 1) - 1; lx = (1 << nb) * (2 + (px & 1)) + (int)eng.bypass_bits(nb); }
+  if (py > 3) { const int nb = (py >> 1) - 1; ly = (1 << nb) * (2 + (py & 1)) + (int)eng.bypass_bits(nb); }
   int scan_idx = 0;
   if (cu_pred_mode_ == MODE_INTRA && (log2 == 2 || (log2 == 3 && c == 0))) {
     const int mode = c == 0 ? pic_.intra_dir[0][part] : intra_chroma_;
@@ -805,7 +806,7 @@ void SliceDecoder::residual_coding(int x0, int y0, int log2, int c) {
     const int right = csbf[ys][xs + 1], below = csbf[ys + 1][xs];
     bool coded = true, infer_dc = false;
     if (i < last_sb && i > 0) {
-      coded = cabac_.decision(ctx_.s[CTX_CSBF + ((right | below) ? 1 : 0) + (c ? 2 : 0)]);
+      coded = eng.decision(ctx_.s[CTX_CSBF + ((right | below) ? 1 : 0) + (c ? 2 : 0)]);
       infer_dc = true;
     }
     csbf[ys][xs] = coded;
@@ -828,7 +829,7 @@ void SliceDecoder::residual_coding(int x0, int y0, int log2, int c) {
       bool sig;
       if (n > 0 || !infer_dc) {
         const int sc = (n == 0 && i == 0 && log2 > 2) ? (c ? 27 : 0) : sig_base + sig_tab[in_order[n]];
-        sig = cabac_.decision(ctx_.s[CTX_SIG + sc]);
+        sig = eng.decision(ctx_.s[CTX_SIG + sc]);
         if (sig) infer_dc = false;
       } else {
         sig = true;                                      // the only coefficient a coded sub-block can still have
@@ -844,27 +845,27 @@ void SliceDecoder::residual_coding(int x0, int y0, int log2, int c) {
     int g1[16] = {0};
     const int ng1 = nsig < 8 ? nsig : 8;
     for (int k = 0; k < ng1; k++) {
-      g1[k] = cabac_.decision(ctx_.s[CTX_GT1 + (c ? 16 : 0) + ctx_set * 4 + c1]);
+      g1[k] = eng.decision(ctx_.s[CTX_GT1 + (c ? 16 : 0) + ctx_set * 4 + c1]);
       if (g1[k]) { c1 = 0; if (first_g1 < 0) first_g1 = k; }
       else if (c1 > 0 && c1 < 3) c1++;
     }
     prev_c1 = c1;
     int g2 = 0;
-    if (first_g1 >= 0) g2 = cabac_.decision(ctx_.s[CTX_GT2 + (c ? 4 : 0) + ctx_set]);
+    if (first_g1 >= 0) g2 = eng.decision(ctx_.s[CTX_GT2 + (c ? 4 : 0) + ctx_set]);
     const bool hidden = sdh && pos[0] - pos[nsig - 1] > 3;
     const int nsign = nsig - (hidden ? 1 : 0);
-    const unsigned signs = cabac_.bypass_bits(nsign) << (16 - nsign);
+    const unsigned signs = eng.bypass_bits(nsign) << (16 - nsign);
     int rice = 0, sum = 0;
     for (int k = 0; k < nsig; k++) {
       int level = 1 + g1[k] + (k == first_g1 ? g2 : 0);
       const int thresh = k < 8 ? (k == first_g1 ? 3 : 2) : 1;
       if (level == thresh) {
         int prefix = 0;
-        while (prefix < 32 && cabac_.bypass()) prefix++;
+        while (prefix < 32 && eng.bypass()) prefix++;
         if (prefix == 32) throw ParseError("coeff_abs_level_remaining prefix too long");
         int rem;
-        if (prefix <= 3) rem = (prefix << rice) + (int)cabac_.bypass_bits(rice);
-        else rem = (((1 << (prefix - 3)) + 3 - 1) << rice) + (int)cabac_.bypass_bits(prefix - 3 + rice);
+        if (prefix <= 3) rem = (prefix << rice) + (int)eng.bypass_bits(rice);
+        else rem = (((1 << (prefix - 3)) + 3 - 1) << rice) + (int)eng.bypass_bits(prefix - 3 + rice);
         level += rem;
         if (level > 3 * (1 << rice)) rice = std::min(rice + 1, 4);
       }
@@ -877,6 +878,7 @@ void SliceDecoder::residual_coding(int x0, int y0, int log2, int c) {
       dst[yc * size + xc] = (int16_t)clip3(-32768, 32767, v);
     }
   }
+  cabac_ = eng;
 }
 
 }  // namespace hmdec
