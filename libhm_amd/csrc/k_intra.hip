@@ -370,7 +370,7 @@ __device__ inline void intra_ctu(const PicDev& P, int comp, int ctu, IntraLds& L
       else { t.log2n = 2; run = (zc & 3) == 0; }            // four 4x4 luma TUs share one 4x4 chroma TU, with the first of them (TComTU.cpp:141-171)
       if (run) {
         int mode = L.m_dir[zc];
-        if (comp && mode == 36) mode = L.m_dirl[zc & ~3];                              // DM_CHROMA_IDX (TDecCu.cpp:523-524)
+        if (comp && mode == 36) mode = L.m_dirl[z];      // DM_CHROMA_IDX (TDecCu.cpp:523-524): the luma mode of the CU's first partition (z: the CU's origin)
         t.mode = mode;
         t.cbf = (L.m_cbf[zc] >> tr) & 1;
         t.skip = L.m_ts[zc];

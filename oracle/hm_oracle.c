@@ -792,7 +792,12 @@ static void intra_tu(cu_ctx* c, int comp, int z_tu, int log2n, int cbf_depth, in
   int16_t* dst = c->cur->plane[comp] + (size_t)y0 * g->w[comp] + x0;
   const int maxv = (1 << g->bd[comp]) - 1;
   int x, y;
-  if (comp != 0 && mode == 36) mode = g->m->intra_dir[0][(size_t)a * g->parts + (z_tu & ~3)];   /* DM_CHROMA_IDX: TDecCu.cpp:523-524 */
+  if (comp != 0 && mode == 36) {   /* DM_CHROMA_IDX: TDecCu.cpp:523-524 with getChromasCorrespondingPULumaIdx (TComChromaFormat.h:129-132):
+                                      the luma mode of the first partition of the minimum-size CU -- intra NxN only exists at that size,
+                                      every other CU carries one mode throughout, so "first partition of the CU" names the same mode */
+    const int cu_parts = g->parts >> (2 * g->m->depth[(size_t)a * g->parts + z_tu]);
+    mode = g->m->intra_dir[0][(size_t)a * g->parts + (z_tu & ~(cu_parts - 1))];
+  }
   intra_ref_line(c, comp, z_tu, n, x0, y0, line);
   intra_smooth(g, comp, mode, n, log2n, line, fl);
   intra_predict(comp, g->bd[comp], mode, n, log2n, fl, pred);

@@ -244,6 +244,21 @@ LITE = {
                                       ["--TileUniformSpacing=1", "--NumTileColumnsMinus1=2", "--NumTileRowsMinus1=1", "--SliceMode=3", "--SliceArgument=2",
                                        "--SliceSegmentMode=1", "--SliceSegmentArgument=64", "--LFCrossSliceBoundaryFlag=0"]),
     "ldb_main8_208x120": ("encoder_lowdelay_main.cfg", 208, 120, 4, 8, 8, 32, []),
+    # non-zero PPS chroma QP offsets (chroma dequantisation and chroma deblocking QP), VUI in the SPS, access unit delimiters,
+    # cabac_init_flag in use, three merge candidates
+    "ldp_cqp_vui_main10_208x120": ("encoder_lowdelay_P_main10.cfg", 208, 120, 4, 10, 10, 30,
+                                   ["--CbQpOffset=4", "--CrQpOffset=-3", "--VuiParametersPresent=1", "--AspectRatioInfoPresent=1", "--AspectRatioIdc=255",
+                                    "--SarWidth=4", "--SarHeight=3", "--AccessUnitDelimiter=1", "--CabacInitPresent=1", "--MaxNumMergeCand=3"]),
+    # the loop-filter combinations the fused kernel does not serve: no SAO (deblocking only), no deblocking (SAO only), neither
+    "ldp_nosao_main10_208x120": ("encoder_lowdelay_P_main10.cfg", 208, 120, 3, 10, 10, 32, ["--SAO=0"]),
+    "ldp_nodbk_main8_208x120": ("encoder_lowdelay_P_main.cfg", 208, 120, 3, 8, 8, 32, ["--LoopFilterDisable=1"]),
+    "ldp_nofilters_main8_208x120": ("encoder_lowdelay_P_main.cfg", 208, 120, 3, 8, 8, 32, ["--SAO=0", "--LoopFilterDisable=1"]),
+    # no temporal motion vector prediction; 16x16 minimum CUs with 8x8 minimum transform blocks and a deeper transform tree
+    "ra_notmvp_main8_208x120": ("encoder_randomaccess_main.cfg", 208, 120, 9, 8, 8, 32, ["--IntraPeriod=8", "--TMVPMode=0"]),
+    "ldp_mincu16_main10_208x112": ("encoder_lowdelay_P_main10.cfg", 208, 112, 3, 10, 10, 28,
+                                   ["--MaxPartitionDepth=3", "--QuadtreeTULog2MinSize=3", "--QuadtreeTUMaxDepthInter=2", "--QuadtreeTUMaxDepthIntra=2"]),
+    # fine quantisation, intra only: transform skip and sign data hiding at work on every 4x4 block
+    "intra_qp12_main8_208x120": ("encoder_intra_main.cfg", 208, 120, 2, 8, 8, 12, []),
 }
 
 

@@ -12,7 +12,9 @@ STREAMS = ["ldp_main8_416x240", "ra_main10_208x120", "ldp_main10_208x120", "intr
 # bitstream + encoder reconstruction only (oracle/make_golden.py LITE): syntax HM 16.0's own decoder cannot be run on, or variants
 LITE = ["ldp_slices_main8_208x120", "ldp_depslices_main10_208x120", "ldp_wpp_main10_416x240", "ldp_wpp_depslices_main8_416x240",
         "ldp_dqp_main10_208x120", "ra_cra_main8_208x120", "ldp_ctu32_main8_208x120", "ldp_ctu16_main10_208x120", "ldp_crop_main8_204x116",
-        "ldp_tileslices_main10_832x128", "ldb_main8_208x120"]
+        "ldp_tileslices_main10_832x128", "ldb_main8_208x120", "ldp_cqp_vui_main10_208x120", "ldp_nosao_main10_208x120",
+        "ldp_nodbk_main8_208x120", "ldp_nofilters_main8_208x120", "ra_notmvp_main8_208x120", "ldp_mincu16_main10_208x112",
+        "intra_qp12_main8_208x120"]
 _cache = {}
 
 

@@ -34,9 +34,7 @@ def _parsed_pictures(stream):
     return pics
 
 
-@pytest.mark.parametrize("name", ["ldp_slices_main8_208x120", "ldp_depslices_main10_208x120", "ldp_wpp_depslices_main8_416x240",
-                                  "ldp_dqp_main10_208x120", "ldp_ctu32_main8_208x120", "ldp_ctu16_main10_208x120", "ldp_crop_main8_204x116",
-                                  "ldp_tileslices_main10_832x128", "ldb_main8_208x120", "ra_cra_main8_208x120"])
+@pytest.mark.parametrize("name", gu.LITE)
 def test_oracle_reconstructs_the_encoders_pictures(oracle, name):
     z = gu.load("lite_" + name)
     pics = _parsed_pictures(z["bitstream"])
