@@ -143,6 +143,13 @@ def encode(name, tmp):
         slf = os.path.join(tmp, name + "_sl.txt")
         write_scaling_list_file(slf)
         extra = [e.replace("@SLFILE@", slf) for e in extra]
+    cfg_lines = [e[4:] for e in extra if e.startswith("cfg:")]          # options that only parse from a configuration file (arrays)
+    extra = [e for e in extra if not e.startswith("cfg:")]
+    if cfg_lines:
+        xcfg = os.path.join(tmp, name + "_extra.cfg")
+        with open(xcfg, "w") as f:
+            f.write("\n".join(cfg_lines) + "\n")
+        extra = ["-c", xcfg] + extra
     cmd = [hmref.ENCODER_PATH, "-c", os.path.join(HM_CFG, cfg), "-i", yuv, "-wdt", str(w), "-hgt", str(h), "-fr", "30",
            "-f", str(frames), "--InputBitDepth=%d" % ibd, "--InternalBitDepth=%d" % bd, "--OutputBitDepth=%d" % bd,
            "-q", str(qp), "-b", bs, "-o", rec, "--SEIDecodedPictureHash=1", "--Level=3.1"] + extra
@@ -259,6 +266,19 @@ LITE = {
                                    ["--MaxPartitionDepth=3", "--QuadtreeTULog2MinSize=3", "--QuadtreeTUMaxDepthInter=2", "--QuadtreeTUMaxDepthIntra=2"]),
     # fine quantisation, intra only: transform skip and sign data hiding at work on every 4x4 block
     "intra_qp12_main8_208x120": ("encoder_intra_main.cfg", 208, 120, 2, 8, 8, 12, []),
+    # parsing / derivation rules that only certain parameter values reach
+    "ra_parmrg4_main8_208x120": ("encoder_randomaccess_main.cfg", 208, 120, 5, 8, 8, 32, ["--IntraPeriod=8", "--Log2ParallelMergeLevel=4"]),
+    "ldp_tudepth1_main10_208x120": ("encoder_lowdelay_P_main10.cfg", 208, 120, 3, 10, 10, 30, ["--QuadtreeTUMaxDepthInter=1", "--QuadtreeTUMaxDepthIntra=1"]),
+    "ldp_maxtb16_noamp_main8_208x120": ("encoder_lowdelay_P_main.cfg", 208, 120, 3, 8, 8, 30, ["--QuadtreeTULog2MaxSize=4", "--AMP=0"]),
+    "ldp_nots_nosdh_main10_208x120": ("encoder_lowdelay_P_main10.cfg", 208, 120, 3, 10, 10, 26, ["--TransformSkip=0", "--SignHideFlag=0"]),
+    "ldp_ctu32_mincu16_main8_224x128": ("encoder_lowdelay_P_main.cfg", 224, 128, 3, 8, 8, 30, ["--MaxCUWidth=32", "--MaxCUHeight=32", "--MaxPartitionDepth=2"]),
+    "ldp_qpneg_main10_208x120": ("encoder_lowdelay_P_main10.cfg", 208, 120, 2, 10, 10, -8, []),
+    "ldp_qp48_main8_208x120": ("encoder_lowdelay_P_main.cfg", 208, 120, 4, 8, 8, 48, []),
+    "ldp_slicedbk_main10_208x120": ("encoder_lowdelay_P_main10.cfg", 208, 120, 3, 10, 10, 34,
+                                    ["--DeblockingFilterControlPresent=1", "--LoopFilterOffsetInPPS=0", "--LoopFilterBetaOffset_div2=-3", "--LoopFilterTcOffset_div2=4"]),
+    "ldp_qgctu_main8_208x120": ("encoder_lowdelay_P_main.cfg", 208, 120, 3, 8, 8, 30, ["--MaxDeltaQP=2", "--MaxCuDQPDepth=0"]),
+    "ldp_tilesexp_main10_832x192": ("encoder_lowdelay_P_main10.cfg", 832, 192, 2, 10, 10, 34,
+                                    ["--TileUniformSpacing=0", "--NumTileColumnsMinus1=2", "--TileColumnWidthArray=4,5", "--NumTileRowsMinus1=1", "--TileRowHeightArray=1", "--LFCrossTileBoundaryFlag=1"]),
 }
 
 
