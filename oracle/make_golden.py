@@ -159,7 +159,8 @@ def encode(name, tmp):
         raise RuntimeError("encoder failed for " + name)
     with open(bs, "rb") as f:
         data = f.read()
-    recdata = np.fromfile(rec, dtype=np.uint8 if bd == 8 else "<u2")
+    # (the reconstruction file has 16-bit samples as soon as either component has more than 8 bits)
+    recdata = np.fromfile(rec, dtype="<u2" if os.path.getsize(rec) == w * h * 3 * frames else np.uint8)
     return data, recdata, (w, h, frames, bd)
 
 
@@ -277,6 +278,9 @@ LITE = {
     "ldp_slicedbk_main10_208x120": ("encoder_lowdelay_P_main10.cfg", 208, 120, 3, 10, 10, 34,
                                     ["--DeblockingFilterControlPresent=1", "--LoopFilterOffsetInPPS=0", "--LoopFilterBetaOffset_div2=-3", "--LoopFilterTcOffset_div2=4"]),
     "ldp_qgctu_main8_208x120": ("encoder_lowdelay_P_main.cfg", 208, 120, 3, 8, 8, 30, ["--MaxDeltaQP=2", "--MaxCuDQPDepth=0"]),
+    # different bit depths for luma and chroma (10 / 8 and 8 / 10), extreme chroma QP offsets
+    "ldp_bd10_8_208x120": ("encoder_lowdelay_P_main10.cfg", 208, 120, 3, 8, 10, 30, ["--InternalBitDepthC=8", "--CbQpOffset=-12", "--CrQpOffset=12"]),
+    "ldp_bd8_10_208x120": ("encoder_lowdelay_P_main10.cfg", 208, 120, 3, 8, 8, 30, ["--InternalBitDepthC=10", "--CbQpOffset=12", "--CrQpOffset=-12"]),
     "ldp_tilesexp_main10_832x192": ("encoder_lowdelay_P_main10.cfg", 832, 192, 2, 10, 10, 34,
                                     ["--TileUniformSpacing=0", "--NumTileColumnsMinus1=2", "--TileColumnWidthArray=4,5", "--NumTileRowsMinus1=1", "--TileRowHeightArray=1", "--LFCrossTileBoundaryFlag=1"]),
 }
