@@ -107,3 +107,23 @@ def test_random_access_at_a_cra_picture():
     cra_poc = out[0]
     assert cra_poc in (8, 16) and out == sorted(out) and all(p >= cra_poc for p in out)
     assert len(out) >= 2
+
+
+@pytest.mark.parametrize("max_layer", [0, 1, 2])
+def test_temporal_sub_layers_can_be_dropped(max_layer):
+    """libHMDec_set_max_temporal_layer (libHMDecoder.h:133-139): NAL units above the layer are ignored; what remains decodes to
+    exactly the same pictures, because a picture never references a higher temporal layer"""
+    name = "ra_main10_208x120"
+    z = gu.load("stream_" + name)
+    want = {p.poc: p for p in gu.stream_pictures(name)}
+    layer = {int(z["pic%02d_info" % i][4]): int(z["pic%02d_info" % i][14]) for i in range(int(z["num_pics"][0]))}
+    out = []
+    with hmdec.Decoder(max_temporal_layer=max_layer) as d:
+        def on_output(p):
+            out.append(p.poc)
+            for c in range(3):
+                assert np.array_equal(p.plane(c), want[p.poc].fin[c]), "POC %d component %d" % (p.poc, c)
+        d.decode_stream(z["bitstream"], on_output=on_output)
+        assert d.hash_mismatches == 0
+    assert out == sorted(poc for poc, t in layer.items() if t <= max_layer)
+    assert 0 < len(out) < len(want) or max_layer >= max(layer.values())
