@@ -406,7 +406,13 @@ void Decoder::decode_slice(const std::vector<uint8_t>& rbsp, BitReader& br, Slic
     if (!is_rasl(sh.nal_type) && !is_radl(sh.nal_type) && !is_irap(sh.nal_type) && sh.poc > poc_cra_) skip_rasl_ = false;
     first_picture_ = false;
     after_eos_ = false;
-    start_picture(sh);
+    try {
+      start_picture(sh);
+    } catch (...) {                        // e.g. a reference picture is missing: the picture is not decoded at all
+      if (cur_ && !cur_task_) { cur_->is_reference = cur_->is_long_term = cur_->needed_for_output = cur_->in_flight = false; cur_ = nullptr; }
+      else if (cur_task_) close_current();
+      throw;
+    }
     if (sh.temporal_id == 0 && !is_rasl(sh.nal_type) && !is_radl(sh.nal_type) && !is_sub_layer_non_ref(sh.nal_type)) prev_tid0_poc_ = sh.poc;
   } else {
     if (!cur_) return;                       // slice of a picture that was skipped
@@ -419,8 +425,14 @@ void Decoder::decode_slice(const std::vector<uint8_t>& rbsp, BitReader& br, Slic
     cur_->slices.emplace_back(new SliceInfo());
     SliceInfo& si = *cur_->slices.back();
     si.first_ctb_ts = pps_->ctb_rs_to_ts[sh.segment_address];
-    build_ref_lists(sh, si);
-    build_slice_params(sh, si);
+    try {
+      build_ref_lists(sh, si);
+      build_slice_params(sh, si);
+    } catch (...) {
+      cur_->slices.pop_back();             // the slice is not decoded; whatever the picture already holds stays
+      have_independent_ = false;
+      throw;
+    }
   } else if (cur_->slices.empty()) {
     throw ParseError("dependent slice segment at the start of a picture");
   }
@@ -513,9 +525,12 @@ void Decoder::worker_main() {
 }
 
 void Decoder::close_current() {
-  if (!cur_task_) return;
-  { std::lock_guard<std::mutex> lk(mu_); cur_task_->closed = true; }
-  cv_work_.notify_all();
+  if (cur_task_) {
+    { std::lock_guard<std::mutex> lk(mu_); cur_task_->closed = true; }
+    cv_work_.notify_all();
+  } else if (cur_) {                       // a picture that never got a parser thread (its first slice failed): dropped
+    cur_->is_reference = cur_->is_long_term = cur_->needed_for_output = cur_->in_flight = false;
+  }
   cur_task_ = nullptr;
   cur_ = nullptr;
 }
@@ -576,6 +591,13 @@ void Decoder::finish_picture() {
 }
 
 void Decoder::submit_picture(PicData* p, int parsed_ctbs) {
+  if (p->slices.empty()) {                 // no slice of the picture could be decoded: there is nothing to reconstruct or to show
+    p->is_reference = p->is_long_term = p->needed_for_output = false;
+    p->decoded = false;
+    p->rows_done.store(p->ctbs_h, std::memory_order_release);
+    fprintf(stderr, "hmdec: POC %d dropped (no decodable slice)\n", p->poc);
+    return;
+  }
   if (parsed_ctbs < p->num_ctbs) {
     // slices were lost: HM conceals nothing either (TDecTop.cpp:560 "Warning: ... lost"); the missing CTUs stay as they are
     fprintf(stderr, "hmdec: POC %d is incomplete (%d of %d CTUs)\n", p->poc, parsed_ctbs, p->num_ctbs);

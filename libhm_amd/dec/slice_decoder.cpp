@@ -58,6 +58,23 @@ void SliceDecoder::init_contexts() {
 }
 
 bool SliceDecoder::decode(const SliceHeader& sh, int slice_idx, const uint8_t* rbsp, size_t bytes) {
+  const int first_ts = pps_.ctb_rs_to_ts[sh.segment_address];
+  ctb_ts_ = first_ts;
+  try {
+    return decode_segment(sh, slice_idx, rbsp, bytes);
+  } catch (...) {
+    // a segment that cannot be parsed leaves nothing behind: its CTUs go back to "never decoded", so that a half-written CTU
+    // never reaches the device (HM asserts in this situation; here the picture goes on without the segment)
+    for (int ts = first_ts; ts <= ctb_ts_ && ts < pic_.num_ctbs; ts++) {
+      const int rs = pps_.ctb_ts_to_rs[ts];
+      pic_.reset_ctu(rs);
+      pic_.slice_addr[rs] = -1;
+    }
+    throw;
+  }
+}
+
+bool SliceDecoder::decode_segment(const SliceHeader& sh, int slice_idx, const uint8_t* rbsp, size_t bytes) {
   sh_ = &sh;
   slice_idx_ = slice_idx;
   slice_ = pic_.slices[slice_idx].get();
@@ -509,7 +526,9 @@ bool SliceDecoder::col_mv(int xcol, int ycol, int list, int ref_idx, Mv& out) co
   else lc = no_backward_pred_ ? list : (sh_->collocated_from_l0 ? 1 : 0);
   const int ref_col = col->ref_idx[lc][p];
   if (ref_col < 0) return false;
-  const SliceInfo& cs = *col->slices[col->slice_idx[col->ctb_at(xcol, ycol)]];
+  const size_t cslice = col->slice_idx[col->ctb_at(xcol, ycol)];
+  if (cslice >= col->slices.size()) return false;          // (a damaged collocated picture)
+  const SliceInfo& cs = *col->slices[cslice];
   const bool cur_lt = slice_->ref_is_lt[list][ref_idx], col_lt = cs.ref_is_lt[lc][ref_col];
   if (cur_lt != col_lt) return false;
   Mv mv;

@@ -42,6 +42,7 @@ class SliceDecoder {
       return true;
     }
   };
+  bool decode_segment(const SliceHeader& sh, int slice_idx, const uint8_t* rbsp, size_t bytes);
   void init_contexts();
   void ctu(int rs);
   void sao_syntax(int rs);

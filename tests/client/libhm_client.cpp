@@ -38,13 +38,19 @@ int main(int argc, char** argv) {
   const bool parse_only = argc > 2;
   if (parse_only) hmdec_set_parse_only(dec, 1);
   printf("version %s\n", libHMDec_get_version());
+  const bool keep_going = getenv("HMDEC_CLIENT_KEEP_GOING") != nullptr;
+  int errors = 0;
   const auto nals = split(data);
   for (size_t i = 0; i < nals.size(); i++) {
     const bool eof = i + 1 == nals.size();
     bool again = true;
     while (again) {
       bool new_picture = false, check_output = false;
-      if (libHMDec_push_nal_unit(dec, nals[i].data(), (int)nals[i].size(), eof, new_picture, check_output) != LIBHMDEC_OK) return 4;
+      if (libHMDec_push_nal_unit(dec, nals[i].data(), (int)nals[i].size(), eof, new_picture, check_output) != LIBHMDEC_OK) {
+        if (!keep_going) return 4;
+        errors++;                      // robustness runs: drop the unit, go on with the next one
+        new_picture = false;
+      }
       if (check_output)
         while (libHMDec_picture* pic = libHMDec_get_picture(dec)) {
           short* y = libHMDEC_get_image_plane(pic, LIBHMDEC_LUMA);
@@ -59,5 +65,6 @@ int main(int argc, char** argv) {
     }
   }
   libHMDEC_clear_internal_info(dec);
-  return libHMDec_free_decoder(dec) == LIBHMDEC_OK ? 0 : 5;
+  if (libHMDec_free_decoder(dec) != LIBHMDEC_OK) return 5;
+  return errors ? 4 : 0;
 }

@@ -71,6 +71,8 @@ def test_corrupted_streams_never_crash(tmp_path):
         f = tmp_path / "fuzz.bin"
         f.write_bytes(bytes(b))
         env = dict(os.environ, HMDEC_THREADS="3") if it % 2 else dict(os.environ)      # every other one with parser threads
+        if it % 3 == 0:
+            env["HMDEC_CLIENT_KEEP_GOING"] = "1"                                       # ... and some going on after the first error
         r = subprocess.run([exe, str(f), "parse-only"], stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=60, env=env)
         assert r.returncode in (0, 4), "iteration %d: exit code %d\n%s" % (it, r.returncode, r.stderr[-400:])
         outcomes[r.returncode] += 1
