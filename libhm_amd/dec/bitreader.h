@@ -17,12 +17,14 @@ struct Unsupported : std::runtime_error {
 };
 
 // NAL payload (after the two header bytes) -> RBSP: 0x000003 -> 0x0000
-inline std::vector<uint8_t> nal_to_rbsp(const uint8_t* p, size_t n) {
+// `removed` (optional): payload positions of the emulation prevention bytes that were dropped -- entry point offsets in the slice
+// header count them (7.4.7.1), positions in the RBSP do not
+inline std::vector<uint8_t> nal_to_rbsp(const uint8_t* p, size_t n, std::vector<size_t>* removed = nullptr) {
   std::vector<uint8_t> out;
   out.reserve(n);
   int zeros = 0;
   for (size_t i = 0; i < n; i++) {
-    if (zeros >= 2 && p[i] == 3) { zeros = 0; continue; }
+    if (zeros >= 2 && p[i] == 3) { zeros = 0; if (removed) removed->push_back(i); continue; }
     out.push_back(p[i]);
     zeros = p[i] == 0 ? zeros + 1 : 0;
   }

@@ -78,11 +78,12 @@ bool Decoder::push(const uint8_t* d, size_t len, int max_tl, int* nal_type_out) 
       else finish_picture();
       return true;
     }
-    std::vector<uint8_t> rbsp = nal_to_rbsp(d + 2, len - 2);
+    std::vector<size_t> epb;
+    std::vector<uint8_t> rbsp = nal_to_rbsp(d + 2, len - 2, &epb);
     BitReader br(rbsp.data(), rbsp.size());
     SliceHeader sh;
     parse_slice_header(br, type, tid, ps_, have_independent_ ? &last_independent_ : nullptr, sh);
-    decode_slice(rbsp, br, sh);
+    decode_slice(rbsp, br, sh, epb);
     return false;
   }
   std::vector<uint8_t> rbsp = nal_to_rbsp(d + 2, len - 2);
@@ -389,7 +390,7 @@ void Decoder::start_picture(const SliceHeader& sh) {
   }
 }
 
-void Decoder::decode_slice(const std::vector<uint8_t>& rbsp, BitReader& br, SliceHeader& sh) {
+void Decoder::decode_slice(const std::vector<uint8_t>& rbsp, BitReader& br, SliceHeader& sh, const std::vector<size_t>& epb) {
   (void)br;
   if (sh.first_slice_segment_in_pic) {
     // 8.1: NoRaslOutputFlag of an IRAP picture: first picture, after an end of sequence, IDR or BLA
@@ -454,6 +455,27 @@ void Decoder::decode_slice(const std::vector<uint8_t>& rbsp, BitReader& br, Slic
   job.rbsp = rbsp;
   job.sps = sps_;
   job.pps = pps_;
+  // a wavefront-coded picture in one slice segment with one entry point per CTB row: its rows can be parsed side by side
+  const int rows = cur_->ctbs_h, W = cur_->ctbs_w;
+  if (pps_->entropy_coding_sync && !pps_->tiles_enabled && !sh.dependent && sh.segment_address == 0 && rows > 1 &&
+      (int)sh.entry_points.size() == rows - 1) {
+    auto w = std::make_shared<WppShared>();
+    w->init(rows, W);
+    // entry points count bytes of the NAL unit, emulation prevention bytes included; positions in the RBSP do not (7.4.7.1)
+    const size_t rbsp_start = sh.data_bit_offset / 8;
+    size_t nal_pos = rbsp_start;
+    for (size_t i = 0; i < epb.size(); i++) if (epb[i] - i <= rbsp_start) nal_pos = rbsp_start + i + 1;
+    bool ok = true;
+    for (int r = 0; r < rows; r++) {
+      size_t removed = 0;
+      while (removed < epb.size() && epb[removed] < nal_pos) removed++;
+      const size_t pos = nal_pos - removed;
+      if (pos >= rbsp.size()) { ok = false; break; }
+      w->row_bit_pos[r] = pos * 8;
+      if (r + 1 < rows) nal_pos += sh.entry_points[r];
+    }
+    if (ok) job.wpp = w;
+  }
   { std::lock_guard<std::mutex> lk(mu_); cur_task_->jobs.push_back(std::move(job)); }
   cv_work_.notify_all();
 }
@@ -486,14 +508,16 @@ void Decoder::hook_rows_done(void* self, PicData* pic, int rows) {
 // a parser thread: takes a picture and parses its slice segments in the order they arrive, until the picture is closed
 void Decoder::worker_main() {
   for (;;) {
-    PicTask* t;
+    PicTask* t = nullptr;
+    WppSession help;
     {
       std::unique_lock<std::mutex> lk(mu_);
-      cv_work_.wait(lk, [&] { return stop_ || !runnable_.empty(); });
+      cv_work_.wait(lk, [&] { return stop_ || !runnable_.empty() || !wpp_sessions_.empty(); });
       if (stop_) return;
-      t = runnable_.front();
-      runnable_.pop_front();
+      if (!wpp_sessions_.empty()) help = wpp_sessions_.front();        // rows of a picture in progress come before a new picture
+      else { t = runnable_.front(); runnable_.pop_front(); }
     }
+    if (help.job) { run_wpp_rows(*help.job, help.task); continue; }
     for (;;) {
       SliceJob job;
       {
@@ -505,6 +529,23 @@ void Decoder::worker_main() {
         t->jobs.pop_front();
       }
       if (!t->error.empty()) continue;                     // the picture is already lost: drain its jobs
+      if (job.wpp) {
+        // open the rows to the other parser threads, take part, and wait until the last row is done
+        auto shared_job = std::make_shared<SliceJob>(job);
+        { std::lock_guard<std::mutex> lk(mu_); { WppSession ses; ses.job = shared_job; ses.task = t; wpp_sessions_.push_back(ses); } }
+        cv_work_.notify_all();
+        run_wpp_rows(*shared_job, t);
+        {
+          std::unique_lock<std::mutex> lk(shared_job->wpp->mu);
+          shared_job->wpp->cv.wait(lk, [&] { return shared_job->wpp->rows_finished.load() >= shared_job->wpp->rows; });
+        }
+        {
+          std::lock_guard<std::mutex> lk(mu_);
+          if (shared_job->wpp->failed.load()) t->error = shared_job->wpp->error.empty() ? "wavefront row could not be parsed" : shared_job->wpp->error;
+          else t->state.next_ctb_ts = t->pic->num_ctbs;
+        }
+        continue;
+      }
       if (getenv("HMDEC_TRACE")) { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); fprintf(stderr, "%ld.%06ld begin POC %d slice %d\n", ts.tv_sec % 1000, ts.tv_nsec / 1000, t->pic->poc, job.slice_idx); }
       try {
         SliceDecoder sd(*job.sps, *job.pps, *t->pic, t->state, &hooks_);
@@ -521,6 +562,25 @@ void Decoder::worker_main() {
       t->pic->parse_done.store(true, std::memory_order_release);
     }
     cv_progress_.notify_all();
+  }
+}
+
+void Decoder::run_wpp_rows(const SliceJob& job, PicTask* t) {
+  WppShared& w = *job.wpp;
+  for (;;) {
+    const int row = w.next_row.fetch_add(1);
+    if (row >= w.rows) break;
+    if (row == w.rows - 1) {                               // the last row is claimed: nothing left to offer to other threads
+      std::lock_guard<std::mutex> lk(mu_);
+      for (auto it = wpp_sessions_.begin(); it != wpp_sessions_.end(); ++it)
+        if (it->job->wpp.get() == &w) { wpp_sessions_.erase(it); break; }
+    }
+    if (getenv("HMDEC_TRACE")) { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); fprintf(stderr, "%ld.%06ld POC %d row %d begins\n", ts.tv_sec % 1000, ts.tv_nsec / 1000, t->pic->poc, row); }
+    PicParseState st;
+    SliceDecoder sd(*job.sps, *job.pps, *t->pic, st, &hooks_);
+    sd.decode_wpp_row(job.sh, job.slice_idx, job.rbsp.data(), job.rbsp.size(), row, w);
+    { std::lock_guard<std::mutex> lk(w.mu); w.rows_finished.fetch_add(1); }
+    w.cv.notify_all();
   }
 }
 

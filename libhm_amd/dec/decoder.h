@@ -54,7 +54,7 @@ class Decoder {
  private:
   void activate(const SliceHeader& sh);
   void start_picture(const SliceHeader& sh);
-  void decode_slice(const std::vector<uint8_t>& rbsp, BitReader& br, SliceHeader& sh);
+  void decode_slice(const std::vector<uint8_t>& rbsp, BitReader& br, SliceHeader& sh, const std::vector<size_t>& epb);
   int compute_poc(const SliceHeader& sh);
   void apply_rps(const SliceHeader& sh);
   void build_ref_lists(const SliceHeader& sh, SliceInfo& si);
@@ -100,7 +100,11 @@ class Decoder {
   uint64_t submitted_seq_ = 0, synced_seq_ = 0;            // device submissions / the last one known to have completed
   std::string last_error_;
   // ---- frame-parallel parsing
-  struct SliceJob { SliceHeader sh; int slice_idx = 0; std::vector<uint8_t> rbsp; std::shared_ptr<Sps> sps; std::shared_ptr<Pps> pps; };
+  struct SliceJob {
+    SliceHeader sh; int slice_idx = 0; std::vector<uint8_t> rbsp; std::shared_ptr<Sps> sps; std::shared_ptr<Pps> pps;
+    std::shared_ptr<WppShared> wpp;                       // set: the segment is a whole wavefront-coded picture, parsed row-parallel
+  };
+
   struct PicTask {
     PicData* pic = nullptr;
     std::deque<SliceJob> jobs;
@@ -109,12 +113,15 @@ class Decoder {
     std::vector<PicData*> held;                           // reference pictures kept alive for the parser thread
     std::string error;
   };
+  struct WppSession { std::shared_ptr<SliceJob> job; PicTask* task = nullptr; };
+  void run_wpp_rows(const SliceJob& job, PicTask* t);     // claims and parses rows of a wavefront picture until none is left
   int threads_ = 1, max_tl_ = -1;
   std::vector<std::thread> workers_;
   std::mutex mu_;
   std::condition_variable cv_work_, cv_progress_;
   std::deque<std::unique_ptr<PicTask>> inflight_;         // decoding order
   std::deque<PicTask*> runnable_;
+  std::deque<WppSession> wpp_sessions_;                    // wavefront pictures with rows nobody has claimed yet
   PicTask* cur_task_ = nullptr;
   bool stop_ = false;
   ProgressHooks hooks_;

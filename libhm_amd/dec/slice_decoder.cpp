@@ -144,6 +144,57 @@ bool SliceDecoder::decode_segment(const SliceHeader& sh, int slice_idx, const ui
   return ctb_ts_ >= pic_.num_ctbs;
 }
 
+void SliceDecoder::decode_wpp_row(const SliceHeader& sh, int slice_idx, const uint8_t* rbsp, size_t bytes, int row, WppShared& w) {
+  sh_ = &sh;
+  slice_idx_ = slice_idx;
+  slice_ = pic_.slices[slice_idx].get();
+  cabac_.attach(rbsp, bytes);
+  no_backward_pred_ = true;
+  for (int l = 0; l < 2; l++)
+    for (int i = 0; i < sh.num_ref_idx[l]; i++) if (slice_->ref_poc[l][i] > pic_.poc) no_backward_pred_ = false;
+  const int W = w.width;
+  int cx = 0;
+  try {
+    if (row > 0) w.wait(row - 1, std::min(2, W));
+    if (w.failed.load()) throw ParseError("a row above could not be parsed");
+    // 9.3.1: the first CTB of a row starts from the variables stored after the second CTB of the row above, if that CTB is
+    // available (same slice, picture wider than one CTB); otherwise from the initial values
+    if (row > 0 && W > 1) ctx_ = w.ctx_after2[row - 1];
+    else init_contexts();
+    st_.last_qp = sh.qp;                                      // first quantisation group of a CTB row (8.6.1)
+    cabac_.start(w.row_bit_pos[row]);
+    for (cx = 0; cx < W; cx++) {
+      if (row > 0) w.wait(row - 1, std::min(cx + 2, W));      // the CTB above and to the right must be complete
+      if (w.failed.load()) throw ParseError("a row above could not be parsed");
+      ctb_rs_ = ctb_ts_ = row * W + cx;
+      ctu(ctb_rs_);
+      if (cx == 1) w.ctx_after2[row] = ctx_;
+      if (cx == W - 1) {
+        if (hooks_ && hooks_->rows_done) hooks_->rows_done(hooks_->self, &pic_, row + 1);
+        else pic_.rows_done.store(row + 1, std::memory_order_release);
+      }
+      const int end = cabac_.terminate();                     // end_of_slice_segment_flag
+      const bool last = row == w.rows - 1 && cx == W - 1;
+      if ((end != 0) != last) throw ParseError("end_of_slice_segment_flag does not match the picture's last CTB");
+      if (cx == W - 1) {
+        if (!last && !cabac_.terminate()) throw ParseError("end_of_subset_one_bit is not 1");
+        cabac_.finish_to_byte();
+      }
+      w.publish(row, cx + 1);
+    }
+  } catch (const std::exception& e) {
+    { std::lock_guard<std::mutex> lk(w.mu); if (w.error.empty()) w.error = e.what(); }
+    w.failed.store(true);
+    for (int x = cx; x < W; x++) {                           // what this row did not finish goes back to "never decoded"
+      const int rs = row * W + x;
+      pic_.reset_ctu(rs);
+      pic_.slice_addr[rs] = -1;
+    }
+    if (hooks_ && hooks_->rows_done) hooks_->rows_done(hooks_->self, &pic_, row + 1);
+    w.publish(row, W);                                        // nobody below waits for this row any longer
+  }
+}
+
 void SliceDecoder::ctu(int rs) {
   const int x0 = (rs % pic_.ctbs_w) << sps_.log2_ctb, y0 = (rs / pic_.ctbs_w) << sps_.log2_ctb;
   pic_.reset_ctu(rs);

@@ -3,6 +3,10 @@
 // prediction (8.5.3.2: merge, AMVP, temporal candidates).  HM counterpart: TDecSlice.cpp, TDecCu.cpp:142-372, TDecEntropy.cpp,
 // TDecSbac.cpp, TComDataCU.cpp (getInterMergeCandidates :2400-2710, fillMvpCand :2790-3000, xGetColMVP :3240-3330).
 #pragma once
+#include <condition_variable>
+#include <mutex>
+#include <string>
+
 #include "cabac.h"
 #include "picture.h"
 
@@ -24,12 +28,46 @@ struct PicParseState {               // carried from one slice segment of a pict
   bool wpp_valid = false;
 };
 
+// Wavefront parallel processing inside one picture (entropy_coding_sync_enabled_flag, one slice segment, no tiles): every CTB row
+// is a sub-stream of its own that starts from the context variables the row above had after its second CTB, so rows can be parsed
+// by different threads, each at least two CTBs behind the row above (9.3.1, 9.3.2.4).  Rows are claimed in increasing order from
+// `next_row`; whoever claims a row parses it, so a row only ever waits for rows that are being parsed or are finished.
+struct WppShared {
+  int rows = 0, width = 0;
+  std::vector<size_t> row_bit_pos;                 // where the sub-stream of each row starts in the RBSP
+  std::vector<ContextSet> ctx_after2;              // context variables after the second CTB of each row
+  std::unique_ptr<std::atomic<int>[]> progress;    // CTBs of each row that are finished
+  std::atomic<int> next_row{0}, rows_finished{0};
+  std::atomic<bool> failed{false};
+  std::mutex mu;
+  std::condition_variable cv;
+  std::string error;
+  void init(int r, int w) {
+    rows = r; width = w;
+    row_bit_pos.assign(r, 0);
+    ctx_after2.resize(r);
+    progress.reset(new std::atomic<int>[r]);
+    for (int i = 0; i < r; i++) progress[i].store(0);
+  }
+  void publish(int row, int done) {
+    { std::lock_guard<std::mutex> lk(mu); progress[row].store(done, std::memory_order_release); }
+    cv.notify_all();
+  }
+  void wait(int row, int need) {
+    if (progress[row].load(std::memory_order_acquire) >= need) return;
+    std::unique_lock<std::mutex> lk(mu);
+    cv.wait(lk, [&] { return progress[row].load(std::memory_order_acquire) >= need; });
+  }
+};
+
 class SliceDecoder {
  public:
   SliceDecoder(const Sps& sps, const Pps& pps, PicData& pic, PicParseState& st, const ProgressHooks* hooks = nullptr)
       : sps_(sps), pps_(pps), pic_(pic), st_(st), hooks_(hooks) {}
   // parses one slice segment; `slice` is the entry of pic.slices it belongs to.  Returns true when the picture is complete.
   bool decode(const SliceHeader& sh, int slice_idx, const uint8_t* rbsp, size_t bytes);
+  // one CTB row of a wavefront-coded picture (see WppShared); every row has its own SliceDecoder and PicParseState
+  void decode_wpp_row(const SliceHeader& sh, int slice_idx, const uint8_t* rbsp, size_t bytes, int row, WppShared& w);
 
  private:
   struct Mv { int16_t x = 0, y = 0; bool operator==(const Mv& o) const { return x == o.x && y == o.y; } };

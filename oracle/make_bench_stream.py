@@ -16,6 +16,9 @@ OUT = os.path.join(os.path.dirname(HERE), "tests", "golden")
 STREAMS = {
     # name: (cfg, w, h, frames, bit depth, qp, extra)
     "bench_ldp_main10_3840x2160": ("encoder_lowdelay_P_main10.cfg", 3840, 2160, 5, 10, 32, []),
+    # the same clip with wavefront parallel processing (one sub-stream per CTB row, entry points in the slice header): what x265-style
+    # 4K streams look like, and what lets the parser work on several rows of one picture at once
+    "bench_ldp_wpp_main10_3840x2160": ("encoder_lowdelay_P_main10.cfg", 3840, 2160, 5, 10, 32, ["--WaveFrontSynchro=1"]),
     "bench_ra_main10_1920x1080": ("encoder_randomaccess_main10.cfg", 1920, 1080, 9, 10, 32, ["--IntraPeriod=8"]),
     # a longer low-delay clip: one I picture and 16 small P pictures (the synthetic scene is nearly static)
     "bench_ldp_main10_1920x1080_17": ("encoder_lowdelay_P_main10.cfg", 1920, 1080, 17, 10, 32, []),
