@@ -83,12 +83,12 @@ def main():
     ap.add_argument("--height", type=int, default=2160)
     ap.add_argument("--bi", type=int, default=0, help="1: B pictures (bi-prediction) instead of P")
     ap.add_argument("--workload", default="full", choices=("full", "idct", "mc", "mc_bi", "filter", "intra", "gop", "decode"))
-    ap.add_argument("--stream", default=None, help="decode workload: Annex B file (default tests/golden/bench_ldp_main10_3840x2160.bin)")
+    ap.add_argument("--stream", default=None, help="decode workload: Annex B file (default tests/golden/bench_ldp_wpp_main10_3840x2160.bin: 2160p with wavefronts)")
     ap.add_argument("--mode-probs", default=None, help="experiment: CTU partition probabilities 64x64,32x32,16x16,8x8,AMP (comma separated)")
     ap.add_argument("--intra-frac", type=float, default=None, help="experiment: fraction of CUs that are intra (with intra modes: reconstructed on the GPU)")
     ap.add_argument("--cbf-prob", type=float, default=None, help="experiment: probability that a TU is coded")
     ap.add_argument("--streams", type=int, default=1, choices=(1, 2), help="2: the batch runs as two half-batches on two HIP streams (kernels of different kinds overlap)")
-    ap.add_argument("--threads", type=int, default=4, help="decode workload: parser threads of libhmdec (1 = all on the calling thread)")
+    ap.add_argument("--threads", type=int, default=8, help="decode workload: parser threads of libhmdec (1 = all on the calling thread)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-steps", type=int, default=5)
     args = ap.parse_args()
@@ -289,7 +289,7 @@ def decode_main(args, hdist, dist, rank, world, local_rank):
     import subprocess
     from libhm_amd import hmdec
     here = os.path.dirname(os.path.abspath(__file__))
-    path = args.stream or os.path.join(here, "tests", "golden", "bench_ldp_main10_3840x2160.bin")
+    path = args.stream or os.path.join(here, "tests", "golden", "bench_ldp_wpp_main10_3840x2160.bin")
     data = open(path, "rb").read()
     nals = hmdec.split_nal_units(data)
     info = {}

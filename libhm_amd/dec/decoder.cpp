@@ -71,12 +71,24 @@ bool Decoder::push(const uint8_t* d, size_t len, int max_tl, int* nal_type_out) 
   for (auto& p : pool_) p->lent = false;
   max_tl_ = max_tl;
   if (threaded()) retire_ready(false);
+  if (repush_pending_) {                   // the unit that was answered with "new picture" comes again, as the protocol demands
+    repush_pending_ = false;
+    if (len == repush_len_ && memcmp(d, repush_head_, std::min<size_t>(len, sizeof(repush_head_))) == 0) return false;
+  }
+  bool taken_early = false;
   if (type <= NAL_RASL_R || (type >= NAL_BLA_W_LP && type <= NAL_CRA)) {
     if (len < 3) throw ParseError("slice NAL unit without payload");
     if ((d[2] & 0x80) && cur_) {           // first_slice_segment_in_pic_flag while a picture is open: close it, unit comes again
-      if (threaded()) { close_current(); retire_ready(false); }      // (its parser thread may still be busy: nobody waits here)
-      else finish_picture();
-      return true;
+      if (!threaded()) { finish_picture(); return true; }
+      // Parser threads: the finished picture is closed (its thread may still be busy: nobody waits here) and the new unit is taken
+      // in at once, so that its parsing overlaps whatever the caller does before repeating it -- typically fetching output
+      // pictures, which waits for the device.  The answer is still "new picture"; the repetition is skipped above.
+      close_current();
+      retire_ready(false);
+      taken_early = true;
+      repush_len_ = len;
+      memset(repush_head_, 0, sizeof(repush_head_));
+      memcpy(repush_head_, d, std::min<size_t>(len, sizeof(repush_head_)));
     }
     std::vector<size_t> epb;
     std::vector<uint8_t> rbsp = nal_to_rbsp(d + 2, len - 2, &epb);
@@ -84,6 +96,7 @@ bool Decoder::push(const uint8_t* d, size_t len, int max_tl, int* nal_type_out) 
     SliceHeader sh;
     parse_slice_header(br, type, tid, ps_, have_independent_ ? &last_independent_ : nullptr, sh);
     decode_slice(rbsp, br, sh, epb);
+    if (taken_early) { repush_pending_ = true; return true; }
     return false;
   }
   std::vector<uint8_t> rbsp = nal_to_rbsp(d + 2, len - 2);

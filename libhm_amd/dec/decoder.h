@@ -126,6 +126,10 @@ class Decoder {
   bool stop_ = false;
   ProgressHooks hooks_;
   std::deque<PicData*> out_queue_;
+  // a unit that opened a new picture has been taken in already (threaded mode): its repetition by the caller is recognised and skipped
+  bool repush_pending_ = false;
+  size_t repush_len_ = 0;
+  uint8_t repush_head_[24] = {0};
 };
 
 }  // namespace hmdec

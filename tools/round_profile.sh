@@ -15,9 +15,9 @@ python3 bench.py --workload intra --steps 5 --warmup 1 --profile-steps 2 --no-cp
 python3 bench.py --workload gop --steps 10 > $out/bench_gop.json 2> $out/bench_gop.err
 python3 bench.py --streams 2 --no-cpu-baseline > $out/bench_full_2lanes.json 2> $out/bench_full_2lanes.err
 python3 bench.py --batch 8 --no-cpu-baseline > $out/bench_full_batch8.json 2> $out/bench_full_batch8.err
-python3 bench.py --workload decode --steps 3 --warmup 1 > $out/bench_decode_2160p.json 2> $out/bench_decode_2160p.err
+python3 bench.py --workload decode --stream tests/golden/bench_ldp_main10_3840x2160.bin --steps 3 --warmup 1 > $out/bench_decode_2160p.json 2> $out/bench_decode_2160p.err
 python3 bench.py --workload decode --stream tests/golden/bench_ra_main10_1920x1080.bin --steps 5 --warmup 2 > $out/bench_decode_1080p.json 2> $out/bench_decode_1080p.err
-python3 bench.py --workload decode --stream tests/golden/bench_ldp_wpp_main10_3840x2160.bin --steps 3 --warmup 1 --threads 8 > $out/bench_decode_2160p_wpp.json 2> $out/bench_decode_2160p_wpp.err
+python3 bench.py --workload decode --steps 3 --warmup 1 > $out/bench_decode_2160p_wpp.json 2> $out/bench_decode_2160p_wpp.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline > $out/stats.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -- python3 bench.py --steps 2 --warmup 1 --profile-steps 1 --no-cpu-baseline > $out/pmc_fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/pmc_write -- python3 bench.py --steps 2 --warmup 1 --profile-steps 1 --no-cpu-baseline > $out/pmc_write.log 2>&1
