@@ -6,6 +6,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <ctime>
+#include <pthread.h>
 #include <new>
 
 #include "md5.h"
@@ -470,22 +471,26 @@ void Decoder::decode_slice(const std::vector<uint8_t>& rbsp, BitReader& br, Slic
   job.pps = pps_;
   // a wavefront-coded picture in one slice segment with one entry point per CTB row: its rows can be parsed side by side
   const int rows = cur_->ctbs_h, W = cur_->ctbs_w;
-  if (pps_->entropy_coding_sync && !pps_->tiles_enabled && !sh.dependent && sh.segment_address == 0 && rows > 1 &&
-      (int)sh.entry_points.size() == rows - 1) {
+  const int num_tiles = pps_->num_tile_cols * pps_->num_tile_rows;
+  const bool by_rows = pps_->entropy_coding_sync && !pps_->tiles_enabled && rows > 1 && (int)sh.entry_points.size() == rows - 1;
+  const bool by_tiles = pps_->tiles_enabled && !pps_->entropy_coding_sync && num_tiles > 1 && (int)sh.entry_points.size() == num_tiles - 1;
+  if ((by_rows || by_tiles) && !sh.dependent && sh.segment_address == 0) {
     auto w = std::make_shared<WppShared>();
-    w->init(rows, W);
+    const int units = by_rows ? rows : num_tiles;              // sub-streams: CTB rows, or tiles (which depend on nothing)
+    w->init(units, W);
+    w->tiles = by_tiles;
     // entry points count bytes of the NAL unit, emulation prevention bytes included; positions in the RBSP do not (7.4.7.1)
     const size_t rbsp_start = sh.data_bit_offset / 8;
     size_t nal_pos = rbsp_start;
     for (size_t i = 0; i < epb.size(); i++) if (epb[i] - i <= rbsp_start) nal_pos = rbsp_start + i + 1;
     bool ok = true;
-    for (int r = 0; r < rows; r++) {
+    for (int r = 0; r < units; r++) {
       size_t removed = 0;
       while (removed < epb.size() && epb[removed] < nal_pos) removed++;
       const size_t pos = nal_pos - removed;
       if (pos >= rbsp.size()) { ok = false; break; }
       w->row_bit_pos[r] = pos * 8;
-      if (r + 1 < rows) nal_pos += sh.entry_points[r];
+      if (r + 1 < units) nal_pos += sh.entry_points[r];
     }
     if (ok) job.wpp = w;
   }
@@ -588,10 +593,11 @@ void Decoder::run_wpp_rows(const SliceJob& job, PicTask* t) {
       for (auto it = wpp_sessions_.begin(); it != wpp_sessions_.end(); ++it)
         if (it->job->wpp.get() == &w) { wpp_sessions_.erase(it); break; }
     }
-    if (getenv("HMDEC_TRACE")) { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); fprintf(stderr, "%ld.%06ld POC %d row %d begins\n", ts.tv_sec % 1000, ts.tv_nsec / 1000, t->pic->poc, row); }
+    if (getenv("HMDEC_TRACE")) { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); fprintf(stderr, "%ld.%06ld POC %d unit %d begins (thread %lx)\n", ts.tv_sec % 1000, ts.tv_nsec / 1000, t->pic->poc, row, (unsigned long)pthread_self() & 0xffffff); }
     PicParseState st;
     SliceDecoder sd(*job.sps, *job.pps, *t->pic, st, &hooks_);
-    sd.decode_wpp_row(job.sh, job.slice_idx, job.rbsp.data(), job.rbsp.size(), row, w);
+    if (w.tiles) sd.decode_tile(job.sh, job.slice_idx, job.rbsp.data(), job.rbsp.size(), row, w);
+    else sd.decode_wpp_row(job.sh, job.slice_idx, job.rbsp.data(), job.rbsp.size(), row, w);
     { std::lock_guard<std::mutex> lk(w.mu); w.rows_finished.fetch_add(1); }
     w.cv.notify_all();
   }

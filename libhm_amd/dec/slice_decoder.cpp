@@ -195,6 +195,45 @@ void SliceDecoder::decode_wpp_row(const SliceHeader& sh, int slice_idx, const ui
   }
 }
 
+void SliceDecoder::decode_tile(const SliceHeader& sh, int slice_idx, const uint8_t* rbsp, size_t bytes, int tile, WppShared& w) {
+  sh_ = &sh;
+  slice_idx_ = slice_idx;
+  slice_ = pic_.slices[slice_idx].get();
+  cabac_.attach(rbsp, bytes);
+  no_backward_pred_ = true;
+  for (int l = 0; l < 2; l++)
+    for (int i = 0; i < sh.num_ref_idx[l]; i++) if (slice_->ref_poc[l][i] > pic_.poc) no_backward_pred_ = false;
+  int first_ts = -1, last_ts = -1;                            // the tile's CTBs are consecutive in tile scan (6.5.1)
+  for (int ts = 0; ts < pic_.num_ctbs; ts++) if (pps_.tile_id[ts] == tile) { if (first_ts < 0) first_ts = ts; last_ts = ts; }
+  int ts = first_ts;
+  try {
+    if (first_ts < 0) throw ParseError("tile without CTBs");
+    init_contexts();
+    st_.last_qp = sh.qp;                                      // first quantisation group of a tile (8.6.1)
+    cabac_.start(w.row_bit_pos[tile]);
+    for (ts = first_ts; ts <= last_ts; ts++) {
+      ctb_ts_ = ts;
+      ctb_rs_ = pps_.ctb_ts_to_rs[ts];
+      ctu(ctb_rs_);
+      const int end = cabac_.terminate();                     // end_of_slice_segment_flag
+      const bool last = ts == pic_.num_ctbs - 1;
+      if ((end != 0) != last) throw ParseError("end_of_slice_segment_flag does not match the picture's last CTB");
+      if (ts == last_ts) {
+        if (!last && !cabac_.terminate()) throw ParseError("end_of_subset_one_bit is not 1");
+        cabac_.finish_to_byte();
+      }
+    }
+  } catch (const std::exception& e) {
+    { std::lock_guard<std::mutex> lk(w.mu); if (w.error.empty()) w.error = e.what(); }
+    w.failed.store(true);
+    for (int t2 = std::max(ts, first_ts); t2 >= 0 && t2 <= last_ts; t2++) {
+      const int rs = pps_.ctb_ts_to_rs[t2];
+      pic_.reset_ctu(rs);
+      pic_.slice_addr[rs] = -1;
+    }
+  }
+}
+
 void SliceDecoder::ctu(int rs) {
   const int x0 = (rs % pic_.ctbs_w) << sps_.log2_ctb, y0 = (rs / pic_.ctbs_w) << sps_.log2_ctb;
   pic_.reset_ctu(rs);
@@ -212,14 +251,12 @@ void SliceDecoder::sao_syntax(int rs) {
   const bool enabled[3] = {sh_->sao_luma, sh_->sao_chroma, sh_->sao_chroma};
   bool merge_left = false, merge_up = false;
   if (rx > 0) {
-    const bool in_slice = pic_.slice_addr[rs - 1] == sh_->slice_address;
     const bool in_tile = pps_.tile_id[ctb_ts_] == pps_.tile_id[pps_.ctb_rs_to_ts[rs - 1]];
-    if (in_slice && in_tile) merge_left = cabac_.decision(ctx_.s[CTX_SAO_MERGE]);
+    if (in_tile && pic_.slice_addr[rs - 1] == sh_->slice_address) merge_left = cabac_.decision(ctx_.s[CTX_SAO_MERGE]);
   }
   if (ry > 0 && !merge_left) {
-    const bool in_slice = pic_.slice_addr[rs - pic_.ctbs_w] == sh_->slice_address;
     const bool in_tile = pps_.tile_id[ctb_ts_] == pps_.tile_id[pps_.ctb_rs_to_ts[rs - pic_.ctbs_w]];
-    if (in_slice && in_tile) merge_up = cabac_.decision(ctx_.s[CTX_SAO_MERGE]);
+    if (in_tile && pic_.slice_addr[rs - pic_.ctbs_w] == sh_->slice_address) merge_up = cabac_.decision(ctx_.s[CTX_SAO_MERGE]);
   }
   if (merge_left || merge_up) {
     for (int c = 0; c < 3; c++) {
@@ -272,11 +309,10 @@ void SliceDecoder::sao_syntax(int rs) {
 bool SliceDecoder::available(int xc, int yc, int xn, int yn) const {
   if (xn < 0 || yn < 0 || xn >= pic_.width || yn >= pic_.height) return false;
   const int cn = pic_.ctb_at(xn, yn), cc = pic_.ctb_at(xc, yc);
+  // (the tile test comes first: tiles may be parsed by different threads, and nothing of another tile is to be looked at)
+  if (cn != cc && pps_.tile_id[pps_.ctb_rs_to_ts[cn]] != pps_.tile_id[pps_.ctb_rs_to_ts[cc]]) return false;
   if (pic_.slice_addr[cn] != sh_->slice_address) return false;                 // other slice, or not decoded yet
-  if (cn != cc) {
-    if (pps_.tile_id[pps_.ctb_rs_to_ts[cn]] != pps_.tile_id[pps_.ctb_rs_to_ts[cc]]) return false;
-    return pps_.ctb_rs_to_ts[cn] < pps_.ctb_rs_to_ts[cc];
-  }
+  if (cn != cc) return pps_.ctb_rs_to_ts[cn] < pps_.ctb_rs_to_ts[cc];
   const int mask = (1 << sps_.log2_ctb) - 1, n4 = pic_.zs->n4;
   const int zn = pic_.zs->r2z[((yn & mask) >> 2) * n4 + ((xn & mask) >> 2)], zc = pic_.zs->r2z[((yc & mask) >> 2) * n4 + ((xc & mask) >> 2)];
   return zn <= zc;

@@ -33,7 +33,8 @@ struct PicParseState {               // carried from one slice segment of a pict
 // by different threads, each at least two CTBs behind the row above (9.3.1, 9.3.2.4).  Rows are claimed in increasing order from
 // `next_row`; whoever claims a row parses it, so a row only ever waits for rows that are being parsed or are finished.
 struct WppShared {
-  int rows = 0, width = 0;
+  int rows = 0, width = 0;                         // units: CTB rows of `width` CTBs, or (tiles = true) the picture's tiles
+  bool tiles = false;
   std::vector<size_t> row_bit_pos;                 // where the sub-stream of each row starts in the RBSP
   std::vector<ContextSet> ctx_after2;              // context variables after the second CTB of each row
   std::unique_ptr<std::atomic<int>[]> progress;    // CTBs of each row that are finished
@@ -68,6 +69,8 @@ class SliceDecoder {
   bool decode(const SliceHeader& sh, int slice_idx, const uint8_t* rbsp, size_t bytes);
   // one CTB row of a wavefront-coded picture (see WppShared); every row has its own SliceDecoder and PicParseState
   void decode_wpp_row(const SliceHeader& sh, int slice_idx, const uint8_t* rbsp, size_t bytes, int row, WppShared& w);
+  // one tile of a picture coded as one slice segment with an entry point per tile: tiles depend on nothing but themselves
+  void decode_tile(const SliceHeader& sh, int slice_idx, const uint8_t* rbsp, size_t bytes, int tile, WppShared& w);
 
  private:
   struct Mv { int16_t x = 0, y = 0; bool operator==(const Mv& o) const { return x == o.x && y == o.y; } };
