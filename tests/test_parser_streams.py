@@ -196,3 +196,26 @@ def test_internal_info_tiles_the_picture():
             assert [b[4] for b in d.internal_info(p, "CTU_SLICE_INDEX")] == [0] * ref.num_ctus
         d.decode_stream(z["bitstream"], on_decoded=on_decoded)
         assert len(done) == len(pics)
+
+
+@pytest.mark.parametrize("stream, threads", [("bench_ldp_wpp_main10_3840x2160.bin", 8), ("bench_ra_main10_1920x1080.bin", 5)])
+def test_parser_threads_change_nothing_at_full_size(stream, threads):
+    """frame-parallel and row-parallel parsing against the single-threaded parser on full-size HM-encoded clips (2160p with wavefronts:
+    34 CTB rows per picture shared among the threads; 1080p random access: pictures overlapping): every array of every picture equal"""
+    import os
+    data = open(os.path.join(gu.GOLD, stream), "rb").read()
+    names = [n for n, _ in ARRAYS] + ["skip", "merge", "coeff0", "coeff1", "coeff2", "sao", "slice_idx"]
+
+    def run(t):
+        out = {}
+        with hmdec.Decoder(parse_only=True, threads=t) as d:
+            def on_output(p):
+                import zlib
+                out[p.poc] = {n: zlib.crc32(p.array(n).tobytes()) for n in names}
+                out[p.poc]["hash"] = p.hash_sei()
+            d.decode_stream(data, on_output=on_output)
+        return out
+    a, b = run(1), run(threads)
+    assert sorted(a) == sorted(b) and len(a) >= 5
+    for poc in a:
+        assert a[poc] == b[poc], "POC %d: %s" % (poc, [n for n in a[poc] if a[poc][n] != b[poc][n]])
