@@ -127,3 +127,18 @@ def test_temporal_sub_layers_can_be_dropped(max_layer):
         assert d.hash_mismatches == 0
     assert out == sorted(poc for poc, t in layer.items() if t <= max_layer)
     assert 0 < len(out) < len(want) or max_layer >= max(layer.values())
+
+
+@pytest.mark.parametrize("stream, pictures, threads", [("bench_ldp_wpp_main10_3840x2160.bin", 5, 8), ("bench_ldp_main10_3840x2160.bin", 5, 1),
+                                                       ("bench_ra_main10_1920x1080.bin", 9, 4), ("bench_ldp_main10_1920x1080_17.bin", 17, 3)])
+def test_full_size_streams_verify_against_their_hash_sei(stream, pictures, threads):
+    """2160p and 1080p HM-encoded clips: every picture's MD5 (computed from the planes that come back from the device) equals the
+    decoded-picture-hash SEI HM's encoder put into the stream -- the reference's own end-to-end check (TDecGop.cpp:199-262)"""
+    import os
+    data = open(os.path.join(gu.GOLD, stream), "rb").read()
+    out = []
+    with hmdec.Decoder(threads=threads) as d:
+        d.decode_stream(data, on_output=lambda p: out.append(p.poc))
+        assert d.pictures_decoded == pictures
+        assert d.hash_mismatches == 0
+    assert out == sorted(out) and len(out) == pictures
