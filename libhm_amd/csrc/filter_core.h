@@ -33,63 +33,108 @@ __device__ inline int boundary_strength(const BlkInfo& p, const BlkInfo& q, bool
   return 1;
 }
 
-// one line across a luma edge: s[0..7] = p3 p2 p1 p0 q0 q1 q2 q3   (xPelFilterLuma, :800-859)
-__device__ inline void filter_luma_line(int (&s)[8], int tc, bool strong, int thr_cut, bool filt_p, bool filt_q, int maxv) {
-  const int m0 = s[0], m1 = s[1], m2 = s[2], m3 = s[3], m4 = s[4], m5 = s[5], m6 = s[6], m7 = s[7];
-  if (strong) {
-    s[3] = clip3(m3 - 2 * tc, m3 + 2 * tc, (m1 + 2 * m2 + 2 * m3 + 2 * m4 + m5 + 4) >> 3);
-    s[4] = clip3(m4 - 2 * tc, m4 + 2 * tc, (m2 + 2 * m3 + 2 * m4 + 2 * m5 + m6 + 4) >> 3);
-    s[2] = clip3(m2 - 2 * tc, m2 + 2 * tc, (m1 + m2 + m3 + m4 + 2) >> 2);
-    s[5] = clip3(m5 - 2 * tc, m5 + 2 * tc, (m3 + m4 + m5 + m6 + 2) >> 2);
-    s[1] = clip3(m1 - 2 * tc, m1 + 2 * tc, (2 * m0 + 3 * m1 + m2 + m3 + m4 + 4) >> 3);
-    s[6] = clip3(m6 - 2 * tc, m6 + 2 * tc, (m3 + m4 + m5 + 3 * m6 + 2 * m7 + 4) >> 3);
-  } else {
-    int delta = (9 * (m4 - m3) - 3 * (m5 - m2) + 8) >> 4;
-    if (abs(delta) < thr_cut) {
-      const int tc2 = tc >> 1;
-      delta = clip3(-tc, tc, delta);
-      s[3] = clip3(0, maxv, m3 + delta);
-      s[4] = clip3(0, maxv, m4 - delta);
-      if (filt_p) s[2] = clip3(0, maxv, m2 + clip3(-tc2, tc2, (((m1 + m3 + 1) >> 1) - m2 + delta) >> 1));
-      if (filt_q) s[5] = clip3(0, maxv, m5 + clip3(-tc2, tc2, (((m6 + m4 + 1) >> 1) - m5 - delta) >> 1));
-    }
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+__device__ inline s16x2 as_s16x2(uint32_t v) { return __builtin_bit_cast(s16x2, v); }
+__device__ inline u16x2 as_u16x2(uint32_t v) { return __builtin_bit_cast(u16x2, v); }
+__device__ inline uint32_t as_u32(s16x2 v) { return __builtin_bit_cast(uint32_t, v); }
+__device__ inline uint32_t as_u32(u16x2 v) { return __builtin_bit_cast(uint32_t, v); }
+__device__ inline s16x2 splat(int v) { return (s16x2){(short)v, (short)v}; }
+__device__ inline u16x2 usplat(int v) { return (u16x2){(unsigned short)v, (unsigned short)v}; }
+__device__ inline s16x2 pk_clip(s16x2 lo, s16x2 hi, s16x2 v) { return __builtin_elementwise_min(__builtin_elementwise_max(v, lo), hi); }
+
+// Two lines across a luma edge at once (xPelFilterLuma, :800-859): s[k] holds sample k (p3 p2 p1 p0 q0 q1 q2 q3) of the two
+// lines in its 16-bit halves.  Samples are at most 10 bits wide (hmgpu_set_sequence refuses more), so every intermediate of
+// the HM formulas -- the largest is 9*(q0-p0) - 3*(q1-p1) + 8, |.| <= 12284 -- is exact in 16 bits.
+__device__ inline void filter_luma_pair_strong(uint32_t (&s)[8], int tc) {
+  const u16x2 m0 = as_u16x2(s[0]), m1 = as_u16x2(s[1]), m2 = as_u16x2(s[2]), m3 = as_u16x2(s[3]);
+  const u16x2 m4 = as_u16x2(s[4]), m5 = as_u16x2(s[5]), m6 = as_u16x2(s[6]), m7 = as_u16x2(s[7]);
+  const s16x2 t2 = splat(2 * tc);
+  const u16x2 s23 = m2 + m3, s34 = m3 + m4, s45 = m4 + m5;
+  const u16x2 n3 = (m1 + s23 + s23 + m4 + m4 + m5 + usplat(4)) >> 3;
+  const u16x2 n4 = (m2 + s34 + s34 + m5 + m5 + m6 + usplat(4)) >> 3;
+  const u16x2 n2 = (m1 + s23 + m4 + usplat(2)) >> 2;
+  const u16x2 n5 = (s34 + m5 + m6 + usplat(2)) >> 2;
+  const u16x2 n1 = (m0 + m0 + m1 + m1 + m1 + s23 + m4 + usplat(4)) >> 3;
+  const u16x2 n6 = (s34 + m5 + m6 + m6 + m6 + m7 + m7 + usplat(4)) >> 3;
+  (void)s45;
+  auto lim = [&](u16x2 m, u16x2 n) { const s16x2 c = as_s16x2(as_u32(m)); return as_u32(pk_clip(c - t2, c + t2, as_s16x2(as_u32(n)))); };
+  s[1] = lim(m1, n1); s[2] = lim(m2, n2); s[3] = lim(m3, n3);
+  s[4] = lim(m4, n4); s[5] = lim(m5, n5); s[6] = lim(m6, n6);
+}
+__device__ inline void filter_luma_pair_weak(uint32_t (&s)[8], int tc, int thr_cut, bool filt_p, bool filt_q, int maxv) {
+  const s16x2 m1 = as_s16x2(s[1]), m2 = as_s16x2(s[2]), m3 = as_s16x2(s[3]), m4 = as_s16x2(s[4]), m5 = as_s16x2(s[5]), m6 = as_s16x2(s[6]);
+  const s16x2 zero = splat(0), mx = splat(maxv), tcv = splat(tc), tc2 = splat(tc >> 1);
+  s16x2 delta = ((m4 - m3) * splat(9) - (m5 - m2) * splat(3) + splat(8)) >> 4;
+  // 0xffff in the halves whose line is filtered (|delta| < thr_cut): the sign of |delta| - thr_cut
+  const uint32_t on = as_u32((__builtin_elementwise_max(delta, -delta) - splat(thr_cut)) >> 15);
+  delta = pk_clip(-tcv, tcv, delta);
+  const uint32_t n3 = as_u32(pk_clip(zero, mx, m3 + delta)), n4 = as_u32(pk_clip(zero, mx, m4 - delta));
+  s[3] = (n3 & on) | (s[3] & ~on);
+  s[4] = (n4 & on) | (s[4] & ~on);
+  if (filt_p) {
+    const s16x2 d1 = pk_clip(-tc2, tc2, ((((m1 + m3 + splat(1)) >> 1) - m2 + delta) >> 1));
+    s[2] = (as_u32(pk_clip(zero, mx, m2 + d1)) & on) | (s[2] & ~on);
+  }
+  if (filt_q) {
+    const s16x2 d2 = pk_clip(-tc2, tc2, ((((m6 + m4 + splat(1)) >> 1) - m5 - delta) >> 1));
+    s[5] = (as_u32(pk_clip(zero, mx, m5 + d2)) & on) | (s[5] & ~on);
   }
 }
 
-__device__ inline void unpack8(const uint4 v, int (&s)[8]) {
-  s[0] = v.x & 0xffff; s[1] = v.x >> 16; s[2] = v.y & 0xffff; s[3] = v.y >> 16;
-  s[4] = v.z & 0xffff; s[5] = v.z >> 16; s[6] = v.w & 0xffff; s[7] = v.w >> 16;
-}
-__device__ inline uint4 pack8(const int (&s)[8]) {
-  return make_uint4((uint32_t)s[0] | ((uint32_t)s[1] << 16), (uint32_t)s[2] | ((uint32_t)s[3] << 16),
-                    (uint32_t)s[4] | ((uint32_t)s[5] << 16), (uint32_t)s[6] | ((uint32_t)s[7] << 16));
-}
-struct __attribute__((aligned(8))) U4a8 { uint32_t x, y, z, w; };    // 16 bytes at 8-byte alignment
-
-// luma decisions for one 4-line unit (xEdgeFilterLuma :587-650); l[i] = line i, 8 samples across the edge
-__device__ inline void filter_luma_unit(int (&l)[4][8], int bs, int qp, int tc_offset_div2, int beta_offset_div2, int bd,
+// luma decisions and filtering of one 4-line unit (xEdgeFilterLuma :587-650); a[k] = sample k across the edge of lines 0
+// (low half) and 1 (high half), b[k] = the same of lines 2 and 3
+__device__ inline void filter_luma_unit(uint32_t (&a)[8], uint32_t (&b)[8], int bs, int qp, int tc_offset_div2, int beta_offset_div2, int bd,
                                         bool p_nofilt = false, bool q_nofilt = false) {
   const int scale = 1 << (bd - 8);
   const int tc = c_tc_table[clip3(0, 53, qp + 2 * (bs - 1) + (tc_offset_div2 << 1))] * scale;
   const int beta = c_beta_table[clip3(0, 51, qp + (beta_offset_div2 << 1))] * scale;
   const int side = (beta + (beta >> 1)) >> 3;
-  const int dp0 = abs(l[0][1] - 2 * l[0][2] + l[0][3]), dq0 = abs(l[0][4] - 2 * l[0][5] + l[0][6]);
-  const int dp3 = abs(l[3][1] - 2 * l[3][2] + l[3][3]), dq3 = abs(l[3][4] - 2 * l[3][5] + l[3][6]);
+  int l0[8], l3[8];                                   // the decisions look at lines 0 and 3
+#pragma unroll
+  for (int k = 0; k < 8; k++) { l0[k] = (int)(a[k] & 0xffffu); l3[k] = (int)(b[k] >> 16); }
+  const int dp0 = abs(l0[1] - 2 * l0[2] + l0[3]), dq0 = abs(l0[4] - 2 * l0[5] + l0[6]);
+  const int dp3 = abs(l3[1] - 2 * l3[2] + l3[3]), dq3 = abs(l3[4] - 2 * l3[5] + l3[6]);
   const int d0 = dp0 + dq0, d3 = dp3 + dq3, d = d0 + d3;
   if (d >= beta) return;
   const bool fp = (dp0 + dp3) < side, fq = (dq0 + dq3) < side;
-  const bool s0 = (abs(l[0][0] - l[0][3]) + abs(l[0][7] - l[0][4]) < (beta >> 3)) && (2 * d0 < (beta >> 2)) &&
-                  (abs(l[0][3] - l[0][4]) < ((tc * 5 + 1) >> 1));
-  const bool s3 = (abs(l[3][0] - l[3][3]) + abs(l[3][7] - l[3][4]) < (beta >> 3)) && (2 * d3 < (beta >> 2)) &&
-                  (abs(l[3][3] - l[3][4]) < ((tc * 5 + 1) >> 1));
+  const bool s0 = (abs(l0[0] - l0[3]) + abs(l0[7] - l0[4]) < (beta >> 3)) && (2 * d0 < (beta >> 2)) &&
+                  (abs(l0[3] - l0[4]) < ((tc * 5 + 1) >> 1));
+  const bool s3 = (abs(l3[0] - l3[3]) + abs(l3[7] - l3[4]) < (beta >> 3)) && (2 * d3 < (beta >> 2)) &&
+                  (abs(l3[3] - l3[4]) < ((tc * 5 + 1) >> 1));
   const int maxv = (1 << bd) - 1;
+  // bPartPNoFilter / bPartQNoFilter (xPelFilterLuma :847-858): a lossless / PCM side keeps its samples
+  uint32_t ka[8], kb[8];
 #pragma unroll
-  for (int i = 0; i < 4; i++) {
-    // bPartPNoFilter / bPartQNoFilter (xPelFilterLuma :847-858): a lossless / PCM side keeps its samples
-    const int k0 = l[i][0], k1 = l[i][1], k2 = l[i][2], k3 = l[i][3], k4 = l[i][4], k5 = l[i][5], k6 = l[i][6], k7 = l[i][7];
-    filter_luma_line(l[i], tc, s0 && s3, tc * 10, fp, fq, maxv);
-    if (p_nofilt) { l[i][0] = k0; l[i][1] = k1; l[i][2] = k2; l[i][3] = k3; }
-    if (q_nofilt) { l[i][4] = k4; l[i][5] = k5; l[i][6] = k6; l[i][7] = k7; }
+  for (int k = 0; k < 8; k++) { ka[k] = a[k]; kb[k] = b[k]; }
+  if (s0 && s3) {
+    filter_luma_pair_strong(a, tc);
+    filter_luma_pair_strong(b, tc);
+  } else {
+    filter_luma_pair_weak(a, tc, tc * 10, fp, fq, maxv);
+    filter_luma_pair_weak(b, tc, tc * 10, fp, fq, maxv);
+  }
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    if (p_nofilt) { a[k] = ka[k]; b[k] = kb[k]; }
+    if (q_nofilt) { a[4 + k] = ka[4 + k]; b[4 + k] = kb[4 + k]; }
+  }
+}
+
+// lines 0..3 of a vertical-edge unit arrive as rows of eight contiguous samples (four dwords each); transpose them into the
+// line-pair form above and back.  v_perm_b32 selectors: 0x05040100 = low halves of (second, first), 0x07060302 = high halves
+__device__ inline void rows_to_pairs(const uint32_t (&r0)[4], const uint32_t (&r1)[4], uint32_t (&a)[8]) {
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    a[2 * j] = __builtin_amdgcn_perm(r1[j], r0[j], 0x05040100u);
+    a[2 * j + 1] = __builtin_amdgcn_perm(r1[j], r0[j], 0x07060302u);
+  }
+}
+__device__ inline void pairs_to_rows(const uint32_t (&a)[8], uint32_t (&r0)[4], uint32_t (&r1)[4]) {
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    r0[j] = __builtin_amdgcn_perm(a[2 * j + 1], a[2 * j], 0x05040100u);
+    r1[j] = __builtin_amdgcn_perm(a[2 * j + 1], a[2 * j], 0x07060302u);
   }
 }
 
@@ -102,10 +147,6 @@ __device__ inline int chroma_tc(int qp_avg, int pps_off, int tc_offset_div2, int
 }
 
 
-typedef short s16x2 __attribute__((ext_vector_type(2)));
-__device__ inline s16x2 as_s16x2(uint32_t v) { return __builtin_bit_cast(s16x2, v); }
-__device__ inline uint32_t as_u32(s16x2 v) { return __builtin_bit_cast(uint32_t, v); }
-__device__ inline s16x2 splat(int v) { return (s16x2){(short)v, (short)v}; }
 
 // availability bit (SaoDev::avail order L,R,A,B,AL,AR,BL,BR; 8 = inside the CTB) of the CTU that holds a position with
 // vertical class v (0 above, 1 inside, 2 below) and horizontal class hcls (0 left, 1 inside, 2 right)

@@ -34,35 +34,40 @@ __global__ void __launch_bounds__(256) k_deblock(const PicDev* __restrict__ pics
   const int qp = ((int)p.qp + (int)q.qp + 1) >> 1;
   const int pitch = P.pitch[0];
   int16_t* base = P.rec[0] + (size_t)y * pitch + x;
-  int l[4][8];
+  // the unit as line pairs (filter_core.h): la = lines 0|1, lb = lines 2|3, index = position across the edge
+  uint32_t la[8], lb[8];
   if (DIR == 0) {
+    uint32_t r[4][4];
 #pragma unroll
     for (int i = 0; i < 4; i++) {
       const u32x4 v = ldg4_a8(base + (size_t)i * pitch - 4);
-      unpack8(make_uint4(v.x, v.y, v.z, v.w), l[i]);
+      r[i][0] = v.x; r[i][1] = v.y; r[i][2] = v.z; r[i][3] = v.w;
     }
+    rows_to_pairs(r[0], r[1], la);
+    rows_to_pairs(r[2], r[3], lb);
   } else {
 #pragma unroll
-    for (int r = 0; r < 8; r++) {
-      const u32x2 v = ldg2(base + (ptrdiff_t)(r - 4) * pitch);
-      l[0][r] = v.x & 0xffff; l[1][r] = v.x >> 16; l[2][r] = v.y & 0xffff; l[3][r] = v.y >> 16;
+    for (int k = 0; k < 8; k++) {
+      const u32x2 v = ldg2(base + (ptrdiff_t)(k - 4) * pitch);      // four contiguous samples = the four lines at position k
+      la[k] = v.x; lb[k] = v.y;
     }
   }
   const bool p_nf = (p.flags & BF_NOFILT) != 0, q_nf = (q.flags & BF_NOFILT) != 0;
-  filter_luma_unit(l, bs, qp, tc_off, beta_off, P.bd[0], p_nf, q_nf);
+  filter_luma_unit(la, lb, bs, qp, tc_off, beta_off, P.bd[0], p_nf, q_nf);
   if (DIR == 0) {
+    uint32_t r[4][4];
+    pairs_to_rows(la, r[0], r[1]);
+    pairs_to_rows(lb, r[2], r[3]);
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-      const uint4 v = pack8(l[i]);
-      u32x4 o = {v.x, v.y, v.z, v.w};
+      u32x4 o = {r[i][0], r[i][1], r[i][2], r[i][3]};
       stg4_a8(base + (size_t)i * pitch - 4, o);
     }
   } else {
 #pragma unroll
-    for (int r = 1; r < 7; r++)
-    {
-      u32x2 o = {(uint32_t)l[0][r] | ((uint32_t)l[1][r] << 16), (uint32_t)l[2][r] | ((uint32_t)l[3][r] << 16)};
-      stg2(base + (ptrdiff_t)(r - 4) * pitch, o);
+    for (int k = 1; k < 7; k++) {
+      u32x2 o = {la[k], lb[k]};
+      stg2(base + (ptrdiff_t)(k - 4) * pitch, o);
     }
   }
   // chroma: Bs 2 only, edges on the 8-sample chroma grid = 16-sample luma grid (:225-229, :684-692, :727)

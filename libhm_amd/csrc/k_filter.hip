@@ -144,39 +144,40 @@ __device__ inline void edge_unit(const PicDev& P, FilterLds& L, int x0, int y0, 
   const int tc_off = sl.tc_off, beta_off = sl.beta_off;
   const int qp = ((int)p.qp + (int)q.qp + 1) >> 1;
   int16_t* base = &L.y[y - (y0 - 4)][x - (x0 - 8)];
-  int l[4][8];
+  // the unit as line pairs (filter_core.h): a = lines 0|1, b = lines 2|3, index = position across the edge
+  uint32_t a[8], b[8];
   if (DIR == 0) {
     // a line = 8 contiguous samples starting 4 before the edge: 8-byte aligned in the copy
+    uint32_t r[4][4];
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-      const u32x2 a = *reinterpret_cast<const u32x2*>(base + i * kYW - 4), c = *reinterpret_cast<const u32x2*>(base + i * kYW);
-      l[i][0] = a.x & 0xffff; l[i][1] = a.x >> 16; l[i][2] = a.y & 0xffff; l[i][3] = a.y >> 16;
-      l[i][4] = c.x & 0xffff; l[i][5] = c.x >> 16; l[i][6] = c.y & 0xffff; l[i][7] = c.y >> 16;
+      const u32x2 lo = *reinterpret_cast<const u32x2*>(base + i * kYW - 4), hi = *reinterpret_cast<const u32x2*>(base + i * kYW);
+      r[i][0] = lo.x; r[i][1] = lo.y; r[i][2] = hi.x; r[i][3] = hi.y;
     }
+    rows_to_pairs(r[0], r[1], a);
+    rows_to_pairs(r[2], r[3], b);
   } else {
-    // a row of the unit = 4 contiguous samples: one 8-byte access
+    // position k across the edge = 4 contiguous samples (the four lines): one 8-byte access
 #pragma unroll
-    for (int r = 0; r < 8; r++) {
-      const u32x2 a = *reinterpret_cast<const u32x2*>(base + (r - 4) * kYW);
-      l[0][r] = a.x & 0xffff; l[1][r] = a.x >> 16; l[2][r] = a.y & 0xffff; l[3][r] = a.y >> 16;
+    for (int k = 0; k < 8; k++) {
+      const u32x2 v = *reinterpret_cast<const u32x2*>(base + (k - 4) * kYW);
+      a[k] = v.x; b[k] = v.y;
     }
   }
   const bool p_nf = NF && (p.flags & BF_NOFILT) != 0, q_nf = NF && (q.flags & BF_NOFILT) != 0;
-  filter_luma_unit(l, bs, qp, tc_off, beta_off, P.bd[0], p_nf, q_nf);
+  filter_luma_unit(a, b, bs, qp, tc_off, beta_off, P.bd[0], p_nf, q_nf);
   if (DIR == 0) {
+    uint32_t r[4][4];
+    pairs_to_rows(a, r[0], r[1]);
+    pairs_to_rows(b, r[2], r[3]);
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-      u32x2 a = {(uint32_t)l[i][0] | ((uint32_t)l[i][1] << 16), (uint32_t)l[i][2] | ((uint32_t)l[i][3] << 16)};
-      u32x2 c = {(uint32_t)l[i][4] | ((uint32_t)l[i][5] << 16), (uint32_t)l[i][6] | ((uint32_t)l[i][7] << 16)};
-      *reinterpret_cast<u32x2*>(base + i * kYW - 4) = a;
-      *reinterpret_cast<u32x2*>(base + i * kYW) = c;
+      *reinterpret_cast<u32x2*>(base + i * kYW - 4) = (u32x2){r[i][0], r[i][1]};
+      *reinterpret_cast<u32x2*>(base + i * kYW) = (u32x2){r[i][2], r[i][3]};
     }
   } else {
 #pragma unroll
-    for (int r = 1; r < 7; r++) {
-      u32x2 a = {(uint32_t)l[0][r] | ((uint32_t)l[1][r] << 16), (uint32_t)l[2][r] | ((uint32_t)l[3][r] << 16)};
-      *reinterpret_cast<u32x2*>(base + (r - 4) * kYW) = a;
-    }
+    for (int k = 1; k < 7; k++) *reinterpret_cast<u32x2*>(base + (k - 4) * kYW) = (u32x2){a[k], b[k]};
   }
   // chroma: Bs 2 only, edges on the 8-sample chroma grid (TComLoopFilter.cpp:225-229, 684-692, 727)
   if (bs == 2 && ((DIR == 0 ? x : y) & 15) == 0) {
