@@ -26,9 +26,13 @@ constexpr int kYC = kTW + 16, kYH = kTH + 8;      // luma copy: columns [x0-8, x
 constexpr int kCC = kTW / 2 + 16, kCH = kTH / 2 + 4;   // chroma copy: columns [cx0-8, cx0+40), rows [cy0-2, cy0+34)
 constexpr int kYW = kYC + 8, kCW = kCC + 8;       // row pitch in LDS: an odd number of 16-byte units (conflict-free 16-byte row accesses)
 
+constexpr int kUnits = 9 * 18;                     // edge units of one direction per tile (see k_filter_fused)
 struct FilterLds {
   __attribute__((aligned(16))) int16_t y[kYH][kYW];
   __attribute__((aligned(16))) int16_t c[2][kCH][kCW];
+  // the edge units that really filter (Bs > 0), compacted per classifying wave: [direction][wave][slot] and their counts
+  uint32_t unit[2][3][64];
+  int32_t units[2][4];
 };
 
 // SAO of one group of 8 samples at (x, row) of component comp, reading the deblocked copy; (ox, oy) = picture coordinates
@@ -126,23 +130,55 @@ __device__ inline EdgeBlk edge_fetch(const PicDev& P, int x, int y, bool mine) {
   return e;
 }
 
-// one deblocking edge unit of direction DIR at luma (x, y) (its Q block), on the copies
+// Deblocking runs in two steps so that lanes are spent on real work only: every edge unit of the tile is CLASSIFIED by its
+// own thread (edge flags, Bs; most units of large blocks stop here), the units that filter are compacted into a list in LDS
+// and APPLIED by the first threads of the block -- a tile of 32x32 CUs keeps one wave busy with the filter arithmetic instead
+// of three.  A list entry: unit index | Bs << 8 | P side unfiltered << 10 | Q side unfiltered << 11 | (QP + 64) << 12 |
+// Q side's slice << 20.
 struct SliceLf { int tc_off, beta_off, cb_off, cr_off; };     // the deblocking constants of one slice
 __device__ inline SliceLf slice_lf(const SliceDev* s) {
   return {ldg(&s->tc_offset_div2), ldg(&s->beta_offset_div2), ldg(&s->pps_cb_qp_offset), ldg(&s->pps_cr_qp_offset)};
 }
+static_assert(HMGPU_MAX_SLICES <= 4096, "slice index must fit the 12 bits of a list entry");
 
 template <int DIR, bool NF>
-__device__ inline void edge_unit(const PicDev& P, FilterLds& L, int x0, int y0, int x, int y, const EdgeBlk& e, const SliceLf& s0) {
-  if (!e.on) return;
+__device__ inline uint32_t edge_classify(const EdgeBlk& e, int u) {
+  if (!e.on) return 0u;
   const BlkInfo q = __builtin_bit_cast(BlkInfo, e.q), p = __builtin_bit_cast(BlkInfo, e.p);
-  if (!(q.edge & (DIR == 0 ? BE_VER_FILTER : BE_HOR_FILTER))) return;
+  if (!(q.edge & (DIR == 0 ? BE_VER_FILTER : BE_HOR_FILTER))) return 0u;
   const int bs = boundary_strength(p, q, (q.edge & (DIR == 0 ? BE_VER_TRANSFORM : BE_HOR_TRANSFORM)) != 0);
-  if (bs == 0) return;
-  // offsets come from the Q side's slice (TComLoopFilter.cpp:565-566); slice 0's were fetched at kernel entry
-  const SliceLf sl = q.slice == 0 ? s0 : slice_lf(P.slices + q.slice);
-  const int tc_off = sl.tc_off, beta_off = sl.beta_off;
+  if (bs == 0) return 0u;
   const int qp = ((int)p.qp + (int)q.qp + 1) >> 1;
+  const uint32_t p_nf = NF && (p.flags & BF_NOFILT) != 0, q_nf = NF && (q.flags & BF_NOFILT) != 0;
+  return (uint32_t)u | ((uint32_t)bs << 8) | (p_nf << 10) | (q_nf << 11) | ((uint32_t)(qp + 64) << 12) | ((uint32_t)q.slice << 20);
+}
+
+// append the wave's active units to its list; called by the three waves that classify
+__device__ inline void push_units(uint32_t (&list)[3][64], int32_t (&count)[4], uint32_t rec, int t) {
+  const unsigned long long m = __ballot(rec != 0u);
+  const int wave = t >> 6, lane = t & 63;
+  if (rec != 0u) list[wave][__popcll(m & ((1ull << lane) - 1ull))] = rec;
+  if (lane == 0) count[wave] = __popcll(m);
+}
+__device__ inline uint32_t pop_unit(const uint32_t (&list)[3][64], const int32_t (&count)[4], int t) {
+  const int c0 = count[0], c1 = count[1], c2 = count[2];
+  if (t < c0) return list[0][t];
+  if (t < c0 + c1) return list[1][t - c0];
+  if (t < c0 + c1 + c2) return list[2][t - c0 - c1];
+  return 0u;
+}
+
+// one classified edge unit of direction DIR, filtered on the copies
+template <int DIR, bool NF>
+__device__ inline void edge_apply(const PicDev& P, FilterLds& L, int x0, int y0, uint32_t rec, const SliceLf& s0) {
+  if (rec == 0u) return;
+  const int u = rec & 0xff, bs = (rec >> 8) & 3, qp = (int)((rec >> 12) & 0xff) - 64, slice = rec >> 20;
+  const bool p_nf = NF && ((rec >> 10) & 1), q_nf = NF && ((rec >> 11) & 1);
+  const int x = DIR == 0 ? x0 + 8 * (u % 9) : x0 - 4 + 4 * (u % 18);
+  const int y = DIR == 0 ? y0 - 4 + 4 * (u / 9) : y0 + 8 * (u / 18);
+  // offsets come from the Q side's slice (TComLoopFilter.cpp:565-566); slice 0's were fetched at kernel entry
+  const SliceLf sl = slice == 0 ? s0 : slice_lf(P.slices + slice);
+  const int tc_off = sl.tc_off, beta_off = sl.beta_off;
   int16_t* base = &L.y[y - (y0 - 4)][x - (x0 - 8)];
   // the unit as line pairs (filter_core.h): a = lines 0|1, b = lines 2|3, index = position across the edge
   uint32_t a[8], b[8];
@@ -164,7 +200,6 @@ __device__ inline void edge_unit(const PicDev& P, FilterLds& L, int x0, int y0, 
       a[k] = v.x; b[k] = v.y;
     }
   }
-  const bool p_nf = NF && (p.flags & BF_NOFILT) != 0, q_nf = NF && (q.flags & BF_NOFILT) != 0;
   filter_luma_unit(a, b, bs, qp, tc_off, beta_off, P.bd[0], p_nf, q_nf);
   if (DIR == 0) {
     uint32_t r[4][4];
@@ -216,7 +251,7 @@ __global__ void __launch_bounds__(256) k_filter_fused(const PicDev* __restrict__
   // edge units of this thread: vertical edges x0, x0+8 .. x0+64 over the rows [y0-4, y0+68) (9 edges x 18 units), horizontal
   // edges y0 .. y0+64 over the columns [x0-4, x0+68)
   const int vx = x0 + 8 * (t % 9), vy = y0 - 4 + 4 * (t / 9), hx = x0 - 4 + 4 * (t % 18), hy = y0 + 8 * (t / 18);
-  const EdgeBlk ev = edge_fetch<0>(P, vx, vy, t < 9 * 18), eh = edge_fetch<1>(P, hx, hy, t < 9 * 18);
+  const EdgeBlk ev = edge_fetch<0>(P, vx, vy, t < kUnits), eh = edge_fetch<1>(P, hx, hy, t < kUnits);
   const SliceLf s0 = slice_lf(P.slices);
   // SAO groups of this thread (8 samples each): two of luma (64 rows x 8 groups), one of Cb or Cr (32 rows x 4 groups each);
   // their parameters are requested now as well
@@ -230,27 +265,43 @@ __global__ void __launch_bounds__(256) k_filter_fused(const PicDev* __restrict__
   }
   const int ccomp = 1 + (t >> 7), ccx = (x0 >> 1) + (t & 3) * 8, ccy = (y0 >> 1) + ((t & 127) >> 2);
   const SaoPrm sc = sao_fetch(P, ccomp, ccx, ccy);
-  // ---- 1. the tile and its halo, before any filtering (pictures carry margins: every address is inside the allocation)
+  // ---- 1. the tile and its halo, before any filtering (pictures carry margins: every address is inside the allocation):
+  // all loads of the thread are issued, the edge units are classified while they fly, then the copy is written
+  constexpr int VPR = kYC / 8, VPC = kCC / 8, NY = (kYH * VPR + 255) / 256, NC = (2 * kCH * VPC + 255) / 256;
+  u32x4 ty[NY], tc[NC];
   {
     const int16_t* src = P.rec[0] + (ptrdiff_t)(y0 - 4) * P.pitch[0] + (x0 - 8);
-    constexpr int VPR = kYC / 8;
-    for (int i = t; i < kYH * VPR; i += 256) {
-      const int r = i / VPR, v = i % VPR;
-      *reinterpret_cast<u32x4*>(&L.y[r][8 * v]) = ldg4(src + (ptrdiff_t)r * P.pitch[0] + 8 * v);
+#pragma unroll
+    for (int k = 0; k < NY; k++) {
+      const int i = t + 256 * k, r = i / VPR, v = i % VPR;
+      if (i < kYH * VPR) ty[k] = ldg4(src + (ptrdiff_t)r * P.pitch[0] + 8 * v);
     }
-    constexpr int VPC = kCC / 8;
-    for (int i = t; i < 2 * kCH * VPC; i += 256) {
-      const int comp = i / (kCH * VPC), j = i % (kCH * VPC), r = j / VPC, v = j % VPC;
-      const int16_t* cs = P.rec[1 + comp] + (ptrdiff_t)((y0 >> 1) - 2 + r) * P.pitch[1] + ((x0 >> 1) - 8) + 8 * v;
-      *reinterpret_cast<u32x4*>(&L.c[comp][r][8 * v]) = ldg4(cs);
+#pragma unroll
+    for (int k = 0; k < NC; k++) {
+      const int i = t + 256 * k, comp = i / (kCH * VPC), j = i % (kCH * VPC), r = j / VPC, v = j % VPC;
+      if (i < 2 * kCH * VPC) tc[k] = ldg4(P.rec[1 + comp] + (ptrdiff_t)((y0 >> 1) - 2 + r) * P.pitch[1] + ((x0 >> 1) - 8) + 8 * v);
     }
+  }
+  if (t < 192) {
+    push_units(L.unit[0], L.units[0], edge_classify<0, NF>(ev, t), t);
+    push_units(L.unit[1], L.units[1], edge_classify<1, NF>(eh, t), t);
+  }
+#pragma unroll
+  for (int k = 0; k < NY; k++) {
+    const int i = t + 256 * k, r = i / VPR, v = i % VPR;
+    if (i < kYH * VPR) *reinterpret_cast<u32x4*>(&L.y[r][8 * v]) = ty[k];
+  }
+#pragma unroll
+  for (int k = 0; k < NC; k++) {
+    const int i = t + 256 * k, comp = i / (kCH * VPC), j = i % (kCH * VPC), r = j / VPC, v = j % VPC;
+    if (i < 2 * kCH * VPC) *reinterpret_cast<u32x4*>(&L.c[comp][r][8 * v]) = tc[k];
   }
   __syncthreads();
   // ---- 2. vertical edges
-  edge_unit<0, NF>(P, L, x0, y0, vx, vy, ev, s0);
+  edge_apply<0, NF>(P, L, x0, y0, pop_unit(L.unit[0], L.units[0], t), s0);
   __syncthreads();
   // ---- 3. horizontal edges
-  edge_unit<1, NF>(P, L, x0, y0, hx, hy, eh, s0);
+  edge_apply<1, NF>(P, L, x0, y0, pop_unit(L.unit[1], L.units[1], t), s0);
   __syncthreads();
   // ---- 4. SAO of the tile from the deblocked copy
 #pragma unroll
