@@ -148,12 +148,6 @@ __device__ inline int chroma_tc(int qp_avg, int pps_off, int tc_offset_div2, int
 
 
 
-// availability bit (SaoDev::avail order L,R,A,B,AL,AR,BL,BR; 8 = inside the CTB) of the CTU that holds a position with
-// vertical class v (0 above, 1 inside, 2 below) and horizontal class hcls (0 left, 1 inside, 2 right)
-__device__ inline int region_bit(int v, int hcls) {
-  return v == 1 ? (hcls == 0 ? 0 : (hcls == 2 ? 1 : 8)) : (v == 0 ? (hcls == 0 ? 4 : (hcls == 2 ? 5 : 2)) : (hcls == 0 ? 6 : (hcls == 2 ? 7 : 3)));
-}
-
 // neighbour samples x+DX .. x+7+DX of a row as four packed pairs; `e` = the row's 8 samples, l / r = samples x-1 / x+8
 template <int DX>
 __device__ inline void shifted(const u32x4 e, uint32_t l, uint32_t r, uint32_t (&n)[4]) {
@@ -199,27 +193,41 @@ __device__ inline void sao_eo_core(int x, int row, const u32x4 cur, const uint32
   // availability: interior samples face positions in the CTB's own columns; sample 0 / the last sample may face the
   // left / right CTU column
   const int va = ya < y0 ? 0 : (ya > y1 ? 2 : 1), vb = yb < y0 ? 0 : (yb > y1 ? 2 : 1);
-  const bool mid_ok = ((av >> region_bit(va, 1)) & 1) && ((av >> region_bit(vb, 1)) & 1);
+  // rows of the availability grid (SaoDev::avail) that hold the two compared positions: bit h = column class
+  const unsigned ra = av >> (3 * va), rb = av >> (3 * vb);
+  const bool mid_ok = ((ra & rb) >> 1) & 1;
   const int last = min(7, x1 - x);                          // last sample of the group that lies inside the CTB / picture
   const int ha0 = (x + DX) < x0 ? 0 : 1, hb0 = (x - DX) < x0 ? 0 : 1;
   const int hal = (x + last + DX) > x1 ? 2 : 1, hbl = (x + last - DX) > x1 ? 2 : 1;
-  const bool ok0 = ((av >> region_bit(va, ha0)) & 1) && ((av >> region_bit(vb, hb0)) & 1);
-  const bool okl = ((av >> region_bit(va, hal)) & 1) && ((av >> region_bit(vb, hbl)) & 1);
+  const bool ok0 = ((ra >> ha0) & (rb >> hb0)) & 1;
+  const bool okl = ((ra >> hal) & (rb >> hbl)) & 1;
   const uint32_t c[4] = {cur.x, cur.y, cur.z, cur.w};
+  // per-half enable masks.  Groups start at multiples of 8 and component widths are multiples of 4 (luma: 8), so `last` is 7,
+  // or 3 for the last chroma group of a picture whose chroma width is 4 mod 8: sample 0 takes ok0, sample `last` okl, the rest
+  // (and whatever lies beyond the picture, inside the margin) mid_ok
+  const uint32_t midm = mid_ok ? 0xffffffffu : 0u;
+  const uint32_t lastm = (midm & 0x0000ffffu) | (okl ? 0xffff0000u : 0u);
+  uint32_t m[4] = {midm, midm, midm, midm};
+  if constexpr (DX != 0) {                                  // vertical class: no sample faces another CTU column
+    m[0] = (midm & 0xffff0000u) | (ok0 ? 0x0000ffffu : 0u);
+    m[1] = last == 3 ? lastm : midm;
+    m[3] = last == 3 ? midm : lastm;
+  }
+  // the two clamp bounds are hidden from the optimiser: with visible constants it turns clamp(c - n, -1, 1) into two 16-bit
+  // compares and selects per HALF (90 instructions per group instead of 16 packed min / max)
+  uint32_t one_u = 0x00010001u, mone_u = 0xffffffffu;
+  asm("" : "+v"(one_u));
+  asm("" : "+v"(mone_u));
+  const s16x2 one = as_s16x2(one_u), mone = as_s16x2(mone_u);
 #pragma unroll
   for (int j = 0; j < 4; j++) {
     const s16x2 cc = as_s16x2(c[j]);
-    const s16x2 one = splat(1), mone = splat(-1);
     const s16x2 sa = __builtin_elementwise_max(__builtin_elementwise_min(cc - as_s16x2(na[j]), one), mone);
     const s16x2 sb = __builtin_elementwise_max(__builtin_elementwise_min(cc - as_s16x2(nb[j]), one), mone);
     const uint32_t et = as_u32(sa + sb + splat(2));         // edge class 0..4 in each half
     const s16x2 off = lut_offsets(et, off_lo, off_hi);
     const s16x2 res = __builtin_elementwise_min(__builtin_elementwise_max(cc + off, splat(0)), splat(maxv));
-    // per-half enable mask
-    const bool ok_lo = (2 * j == 0) ? ok0 : ((2 * j == last) ? okl : mid_ok);
-    const bool ok_hi = (2 * j + 1 == last) ? okl : mid_ok;
-    const uint32_t m = (ok_lo ? 0xffffu : 0u) | (ok_hi ? 0xffff0000u : 0u);
-    out[j] = (as_u32(res) & m) | (c[j] & ~m);
+    out[j] = (as_u32(res) & m[j]) | (c[j] & ~m[j]);
   }
 }
 

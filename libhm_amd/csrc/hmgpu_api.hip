@@ -294,11 +294,11 @@ hmgpu_status stage_sao(hmgpu_ctx* c, Picture& p, const hmgpu_pic_params* pp, con
     auto same = [&](int o) { return slice_idx[o] == slice_idx[a] && tile_idx[o] == tile_idx[a]; };
     if (cx > 0 && same(a - 1)) merge[HMGPU_SAO_MERGE_LEFT] = &rec[(size_t)(a - 1) * 3];
     if (cy > 0 && same(a - c->ctus_w)) merge[HMGPU_SAO_MERGE_ABOVE] = &rec[(size_t)(a - c->ctus_w) * 3];
-    // neighbour availability, order L,R,A,B,AL,AR,BL,BR
-    static const int dx[8] = {-1, 1, 0, 0, -1, 1, -1, 1}, dy[8] = {0, 0, -1, 1, -1, -1, 1, 1};
-    unsigned avail = 0;
-    for (int k = 0; k < 8; k++) {
-      const int nx = cx + dx[k], ny = cy + dy[k];
+    // neighbour availability as a 3x3 grid (SaoDev::avail): bit 3 * (dy + 1) + (dx + 1)
+    unsigned avail = 1u << 4;
+    for (int k = 0; k < 9; k++) {
+      if (k == 4) continue;
+      const int nx = cx + k % 3 - 1, ny = cy + k / 3 - 1;
       if (nx < 0 || nx >= c->ctus_w || ny < 0 || ny >= c->ctus_h) continue;
       const int o = ny * c->ctus_w + nx;
       bool ok = true;
@@ -329,7 +329,7 @@ hmgpu_status stage_sao(hmgpu_ctx* c, Picture& p, const hmgpu_pic_params* pp, con
       SaoDev& d = dev[(size_t)a * 3 + comp];
       memset(&d, 0, sizeof(d));
       d.type = r.mode_idc == HMGPU_SAO_OFF ? -1 : (int8_t)r.type_idc;
-      d.avail = (uint8_t)avail;
+      d.avail = (uint16_t)avail;
       if (d.type == HMGPU_SAO_BO) {
         d.band = (uint8_t)(r.type_aux_info & 31);
         for (int i = 0; i < 4; i++) d.off[i] = (int8_t)r.offset[(r.type_aux_info + i) & 31];

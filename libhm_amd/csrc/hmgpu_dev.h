@@ -71,9 +71,9 @@ struct SliceDev {
 
 struct SaoDev {                 // reconstructed SAO parameters of one CTU component, 12 bytes
   int8_t  type;                 // -1 off, else HMGPU_SAO_EO_0..BO
-  uint8_t avail;                // bit k = neighbour CTU k available (L,R,A,B,AL,AR,BL,BR)
   uint8_t band;                 // BO: first band
-  uint8_t pad;
+  uint16_t avail;               // 3x3 grid around the CTU, bit 3 * v + h (v: 0 above, 1 same row, 2 below; h: 0 left, 1 same
+                                // column, 2 right): that CTU may be read by SAO (bit 4, the CTU itself, is always set)
   int8_t  off[8];               // EO: [0..4] by edge class (class 2 == 0); BO: [0..3] = offsets of bands band+0..3 (mod 32)
 };
 static_assert(sizeof(SaoDev) == 12, "SaoDev layout");

@@ -66,7 +66,7 @@ __device__ inline void sao_group(const PicDev& P, int comp, const int16_t (*t)[W
   const int bd = P.bd[comp], maxv = (1 << bd) - 1;
   uint32_t out[4];
   if (type == HMGPU_SAO_BO) {
-    const int shift = bd - 5, band0 = (w0 >> 16) & 0xff;
+    const int shift = bd - 5, band0 = (w0 >> 8) & 0xff;
     const uint32_t c[4] = {cur.x, cur.y, cur.z, cur.w};
 #pragma unroll
     for (int j = 0; j < 4; j++) {
@@ -79,7 +79,7 @@ __device__ inline void sao_group(const PicDev& P, int comp, const int16_t (*t)[W
     const int ctb = 1 << log2ctb;
     const int x0 = cx << log2ctb, y0 = cy << log2ctb;
     const int x1 = min(x0 + ctb, w) - 1, y1 = min(y0 + ctb, h) - 1;
-    const unsigned av = ((w0 >> 8) & 0xff) | 0x100u;
+    const unsigned av = w0 >> 16;
     // neighbour rows straight from the copy (its halo holds the deblocked samples around the tile; positions outside the
     // picture hold margin samples, which the availability mask never lets through)
     auto run = [&](auto dxc, auto dyc) {

@@ -66,7 +66,7 @@ __global__ void __launch_bounds__(256) k_sao(const PicDev* __restrict__ pics, Ba
   uint32_t out[4];
   if (type == HMGPU_SAO_BO) {
     // band k = (sample >> (bd-5)) - first band (mod 32); bands 0..3 carry offsets, every other band maps to table entry 4 (= 0)
-    const int shift = bd - 5, band0 = (w0 >> 16) & 0xff;
+    const int shift = bd - 5, band0 = (w0 >> 8) & 0xff;
     const uint32_t c[4] = {cur.x, cur.y, cur.z, cur.w};
 #pragma unroll
     for (int j = 0; j < 4; j++) {
@@ -79,7 +79,7 @@ __global__ void __launch_bounds__(256) k_sao(const PicDev* __restrict__ pics, Ba
     const int ctb = 1 << log2ctb;
     const int x0 = cx << log2ctb, y0 = cy << log2ctb;
     const int x1 = min(x0 + ctb, w) - 1, y1 = min(y0 + ctb, h) - 1;     // CTB clipped to the picture (offsetCTU :679-682)
-    const unsigned av = ((w0 >> 8) & 0xff) | 0x100u;
+    const unsigned av = w0 >> 16;
     switch (type) {                                                      // a = (x+DX, y+DY), b = (x-DX, y-DY)
       case HMGPU_SAO_EO_0:   sao_eo_row<-1, 0>(src, pitch, w, h, x, row, cur, off_lo, off_hi, av, x0, y0, x1, y1, maxv, out); break;
       case HMGPU_SAO_EO_90:  sao_eo_row<0, -1>(src, pitch, w, h, x, row, cur, off_lo, off_hi, av, x0, y0, x1, y1, maxv, out); break;
