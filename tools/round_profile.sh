@@ -21,5 +21,8 @@ python3 bench.py --workload decode --steps 3 --warmup 1 > $out/bench_decode_2160
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline > $out/stats.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -- python3 bench.py --steps 2 --warmup 1 --profile-steps 1 --no-cpu-baseline > $out/pmc_fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/pmc_write -- python3 bench.py --steps 2 --warmup 1 --profile-steps 1 --no-cpu-baseline > $out/pmc_write.log 2>&1
+python3 tools/trace_summary.py $(find $out/stats -name "*kernel_trace.csv" | head -1) > $out/kernel_stats_batched.csv
+cp $(find $out/stats -name "*kernel_stats.csv" | head -1) $out/kernel_stats.csv
+python3 tools/pmc_summary.py --json $out/hbm_traffic.json $out/pmc_fetch $out/pmc_write > $out/pmc_hbm.txt
 find $out -name "*.csv" -size +3M -delete      # per-dispatch traces are large; the stats summaries stay
 ls -R $out | head -40
