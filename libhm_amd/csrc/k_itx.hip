@@ -32,7 +32,8 @@ __device__ inline void itx_class(const PicDev& P, int shard, int bx, int nbx, ch
   // Waves run independently.  One loop iteration of a wave covers a group of U*TPW consecutive TUs (lane slot jw takes
   // TUs base + u*TPW + jw, u < U, one after the other through the same LDS tile), and the loop is a software pipeline:
   // while group g is transformed the levels and prediction rows of group g+1 are in flight and the records of group g+2
-  // are being fetched.  Measured at 2160p: U > 1 does not pay (the kernel is bound by VALU issue, not by bytes in flight).
+  // are being fetched.  Measured at 2160p: U > 1 does not pay, not even for the 4x4 / 8x8 classes alone (U = 4 / 2: +3 %
+  // time) -- those classes move 1.1 / 1.9 TB/s of algorithmic bytes but 32-byte sectors for 8- and 16-byte rows.
   constexpr int TPW = 64 / N;
   constexpr int U = 1;
   const int jw = (threadIdx.x & 63) / N;                          // TU slot inside the wave
