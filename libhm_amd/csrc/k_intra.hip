@@ -179,8 +179,9 @@ __device__ inline void intra_tu(const PicDev& P, const TuCtx& t, IntraLds& L) {
       int v = L.line[i];
       if (filt && i > 0 && i < total - 1) {
         if (strong) {
-          if (i < corner) v = ((2 * N - i) * bl + i * tl + N) >> (LOG2N + 1);
-          else if (i > corner) v = ((2 * N - (i - corner)) * tl + (i - corner) * tr + N) >> (LOG2N + 1);
+          // (24-bit multiplies throughout the prediction: samples and weights are small, v_mul_lo_u32 runs at quarter rate)
+          if (i < corner) v = (__mul24(2 * N - i, bl) + __mul24(i, tl) + N) >> (LOG2N + 1);
+          else if (i > corner) v = (__mul24(2 * N - (i - corner), tl) + __mul24(i - corner, tr) + N) >> (LOG2N + 1);
         } else {
           v = (L.line[i - 1] + 2 * v + L.line[i + 1] + 2) >> 2;
         }
@@ -199,7 +200,7 @@ __device__ inline void intra_tu(const PicDev& P, const TuCtx& t, IntraLds& L) {
 #pragma unroll
     for (int x = 0; x < N; x++) {
       const int ab = f[corner + 1 + x];
-      p[x] = ((left << LOG2N) + N + (x + 1) * (tr - left) + (ab << LOG2N) + (n + 1) * (bl - ab)) >> (LOG2N + 1);
+      p[x] = ((left << LOG2N) + N + __mul24(x + 1, tr - left) + (ab << LOG2N) + __mul24(n + 1, bl - ab)) >> (LOG2N + 1);
     }
   } else if (t.mode == 1) {
     const int dc = (wave_sum(active ? f[corner + 1 + n] + f[corner - 1 - n] : 0) + N) >> (LOG2N + 1);
@@ -226,7 +227,7 @@ __device__ inline void intra_tu(const PicDev& P, const TuCtx& t, IntraLds& L) {
     for (int k = lane - N; k <= 2 * N; k += 64) {
       int v = 0;
       if (k >= 0) { if (ang >= 0 || k <= N) v = f[corner + sgn * min(k, 2 * N)]; }
-      else if (ang < 0 && k > ((N * ang) >> 5)) v = f[corner - sgn * ((128 + (-k) * inv) >> 8)];
+      else if (ang < 0 && k > ((N * ang) >> 5)) v = f[corner - sgn * ((128 + __mul24(-k, inv)) >> 8)];
       L.proj[k + 32] = v;
     }
     wave_lds_sync();
@@ -234,8 +235,8 @@ __device__ inline void intra_tu(const PicDev& P, const TuCtx& t, IntraLds& L) {
 #pragma unroll
     for (int x = 0; x < N; x++) {
       const int a_ = ver ? n : x, b_ = ver ? x : n;        // a_: index along the prediction direction, b_: across it
-      const int pos = (a_ + 1) * ang, di = pos >> 5, df = pos & 31;
-      int v = df ? ((32 - df) * r[b_ + di + 1] + df * r[b_ + di + 2] + 16) >> 5 : r[b_ + di + 1];
+      const int pos = __mul24(a_ + 1, ang), di = pos >> 5, df = pos & 31;
+      int v = df ? (__mul24(32 - df, r[b_ + di + 1]) + __mul24(df, r[b_ + di + 2]) + 16) >> 5 : r[b_ + di + 1];
       if (ang == 0 && edge && b_ == 0) v = clip3(0, maxv, v + ((f[corner - sgn * (a_ + 1)] - f[corner]) >> 1));
       p[x] = v;
     }

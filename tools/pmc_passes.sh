@@ -1,5 +1,6 @@
 #!/bin/bash
-# usage (on the GPU box, from the repo root): bash tools/pmc_passes.sh <outdir> -- separate rocprofv3 --pmc passes over a short bench run
+# usage (on the GPU box, from the repo root): [BENCH_ARGS="--workload intra --batch 1"] bash tools/pmc_passes.sh <outdir>
+# separate rocprofv3 --pmc passes over a short bench run; tools/pmc_kernel_sums.py <outdir> adds the counters up per kernel
 set -e
 out=$1
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
@@ -10,5 +11,5 @@ for set in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_VMEM_R
            "TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum GRBM_GUI_ACTIVE" \
            "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TOTAL_ACCESSES_sum TA_TA_BUSY_sum"; do
   i=$((i+1))
-  rocprofv3 --kernel-trace --pmc $set --output-format csv -d $out/pass$i -- python3 bench.py --steps 2 --warmup 1 --profile-steps 1 --no-cpu-baseline > $out/pass$i.log 2>&1 || echo "pass $i failed"
+  rocprofv3 --kernel-trace --pmc $set --output-format csv -d $out/pass$i -- python3 bench.py --steps 2 --warmup 1 --profile-steps 1 --no-cpu-baseline $BENCH_ARGS > $out/pass$i.log 2>&1 || echo "pass $i failed"
 done
