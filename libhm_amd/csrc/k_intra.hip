@@ -163,21 +163,21 @@ __device__ inline void intra_tu(const PicDev& P, const TuCtx& t, IntraLds& L) {
   }
   wave_lds_sync();
 
-  // ---- B. smoothing (filteringIntraReferenceSamples + initAdiPatternChType)
-  {
-    const int thr = LOG2N == 2 ? 10 : LOG2N == 3 ? 7 : LOG2N == 4 ? 1 : 0;
-    const int d0 = abs(t.mode - 10), d1 = abs(t.mode - 26);
-    const bool filt = comp == 0 && t.mode != 1 && min(d0, d1) > thr;
+  // ---- B. smoothing (filteringIntraReferenceSamples + initAdiPatternChType); most TUs are not smoothed (chroma, 4x4, DC,
+  // the modes near horizontal / vertical) and predict straight from line[]: one LDS round trip less on the serial chain
+  const int thr = LOG2N == 2 ? 10 : LOG2N == 3 ? 7 : LOG2N == 4 ? 1 : 0;
+  const bool filt = comp == 0 && t.mode != 1 && min(abs(t.mode - 10), abs(t.mode - 26)) > thr;
+  if (filt) {
     bool strong = false;
     int bl = 0, tl = 0, tr = 0;
-    if (filt && N == 32 && P.strong_intra_smoothing) {
+    if (N == 32 && P.strong_intra_smoothing) {
       bl = L.line[0]; tl = L.line[corner]; tr = L.line[total - 1];
       const int th = 1 << (bd - 5);
       strong = abs(bl + tl - 2 * L.line[N]) < th && abs(tl + tr - 2 * L.line[corner + N]) < th;
     }
     for (int i = lane; i < total; i += 64) {
       int v = L.line[i];
-      if (filt && i > 0 && i < total - 1) {
+      if (i > 0 && i < total - 1) {
         if (strong) {
           // (24-bit multiplies throughout the prediction: samples and weights are small, v_mul_lo_u32 runs at quarter rate)
           if (i < corner) v = (__mul24(2 * N - i, bl) + __mul24(i, tl) + N) >> (LOG2N + 1);
@@ -188,11 +188,11 @@ __device__ inline void intra_tu(const PicDev& P, const TuCtx& t, IntraLds& L) {
       }
       L.filt[i] = v;
     }
+    wave_lds_sync();
   }
-  wave_lds_sync();
 
   // ---- C. prediction of row n by lane n
-  const int* f = L.filt;
+  const int* f = filt ? L.filt : L.line;
   const bool edge = comp == 0 && N <= 16;                   // MAXIMUM_INTRA_FILTERED_WIDTH (TypeDef.h:117)
   int p[N];
   if (t.mode == 0) {
@@ -222,23 +222,34 @@ __device__ inline void intra_tu(const PicDev& P, const TuCtx& t, IntraLds& L) {
     const int ang_abs = aa == 0 ? 0 : aa == 1 ? 2 : aa == 2 ? 5 : aa == 3 ? 9 : aa == 4 ? 13 : aa == 5 ? 17 : aa == 6 ? 21 : aa == 7 ? 26 : 32;
     const int inv = aa == 0 ? 0 : aa == 1 ? 4096 : aa == 2 ? 1638 : aa == 3 ? 910 : aa == 4 ? 630 : aa == 5 ? 482 : aa == 6 ? 390 : aa == 7 ? 315 : 256;
     const int ang = am_ < 0 ? -ang_abs : ang_abs;
-    // main reference with its extension: proj[k + 32], k in [-N, 2N]; main = row above for vertical modes, left column otherwise
     const int sgn = ver ? 1 : -1;                           // MAIN(i) = f[corner + sgn*i], SIDE(i) = f[corner - sgn*i]
-    for (int k = lane - N; k <= 2 * N; k += 64) {
-      int v = 0;
-      if (k >= 0) { if (ang >= 0 || k <= N) v = f[corner + sgn * min(k, 2 * N)]; }
-      else if (ang < 0 && k > ((N * ang) >> 5)) v = f[corner - sgn * ((128 + __mul24(-k, inv)) >> 8)];
-      L.proj[k + 32] = v;
-    }
-    wave_lds_sync();
-    const int* r = L.proj + 32;
+    if (ang >= 0) {
+      // no projected side samples: the main reference is f[] itself (another LDS round trip less)
 #pragma unroll
-    for (int x = 0; x < N; x++) {
-      const int a_ = ver ? n : x, b_ = ver ? x : n;        // a_: index along the prediction direction, b_: across it
-      const int pos = __mul24(a_ + 1, ang), di = pos >> 5, df = pos & 31;
-      int v = df ? (__mul24(32 - df, r[b_ + di + 1]) + __mul24(df, r[b_ + di + 2]) + 16) >> 5 : r[b_ + di + 1];
-      if (ang == 0 && edge && b_ == 0) v = clip3(0, maxv, v + ((f[corner - sgn * (a_ + 1)] - f[corner]) >> 1));
-      p[x] = v;
+      for (int x = 0; x < N; x++) {
+        const int a_ = ver ? n : x, b_ = ver ? x : n;      // a_: index along the prediction direction, b_: across it
+        const int pos = __mul24(a_ + 1, ang), di = pos >> 5, df = pos & 31;
+        const int i0 = corner + sgn * (b_ + di + 1);
+        int v = df ? (__mul24(32 - df, f[i0]) + __mul24(df, f[i0 + sgn]) + 16) >> 5 : f[i0];
+        if (ang == 0 && edge && b_ == 0) v = clip3(0, maxv, v + ((f[corner - sgn * (a_ + 1)] - f[corner]) >> 1));
+        p[x] = v;
+      }
+    } else {
+      // main reference with its extension: proj[k + 32], k in [-N, N]; main = row above for vertical modes, left column otherwise
+      for (int k = lane - N; k <= N; k += 64) {
+        int v = 0;
+        if (k >= 0) v = f[corner + sgn * k];
+        else if (k > ((N * ang) >> 5)) v = f[corner - sgn * ((128 + __mul24(-k, inv)) >> 8)];
+        L.proj[k + 32] = v;
+      }
+      wave_lds_sync();
+      const int* r = L.proj + 32;
+#pragma unroll
+      for (int x = 0; x < N; x++) {
+        const int a_ = ver ? n : x, b_ = ver ? x : n;
+        const int pos = __mul24(a_ + 1, ang), di = pos >> 5, df = pos & 31;
+        p[x] = df ? (__mul24(32 - df, r[b_ + di + 1]) + __mul24(df, r[b_ + di + 2]) + 16) >> 5 : r[b_ + di + 1];
+      }
     }
   }
 
