@@ -289,8 +289,9 @@ __device__ inline void intra_tu_any(const PicDev& P, const TuCtx& t, IntraLds& L
   }
 }
 
-// all intra CUs of one CTU, one component, in decoding order (xReconIntraQT per CU, xIntraRecQT over its TU tree)
-__device__ inline void intra_ctu(const PicDev& P, int comp, int ctu, IntraLds& L) {
+// what a CTU can fetch before its neighbours are finished: its TComDataCU arrays and its own samples (inter CUs are final --
+// written by earlier launches --, intra ones get overwritten below)
+__device__ inline void intra_stage(const PicDev& P, int comp, int ctu, IntraLds& L) {
   const int parts = P.parts;
   const size_t base = (size_t)ctu * parts;
   const int ctu_x = (ctu % P.ctus_w) << P.log2ctu, ctu_y = (ctu / P.ctus_w) << P.log2ctu;
@@ -306,11 +307,9 @@ __device__ inline void intra_ctu(const PicDev& P, int comp, int ctu, IntraLds& L
     put(L.m_dir, a7); put(L.m_dirl, a8); put(L.m_byp, a9); put(L.m_pcm, a10);
   }
   {
-    // samples: the CTU itself (inter CUs are final, intra ones get overwritten below), its left column and the row above
     const int S = (1 << P.log2ctu) >> cs;                   // CTU size in samples of this component
     const int16_t* org = P.rec[comp] + (ptrdiff_t)(ctu_y >> cs) * P.pitch[comp] + (ctu_x >> cs);
-    // the interior was written by the MC / residual kernels (earlier launches): plain 16-byte loads; the left neighbour's
-    // columns and the row above may come from other waves of THIS launch: coherent loads
+    // the interior was written by the MC / residual kernels (earlier launches): plain 16-byte loads
     const int vpr = S / 8;                                  // 16-byte vectors per row
     for (int i = lane; i < S * vpr; i += 64) {
       const int r = i / vpr, v = i % vpr;
@@ -318,6 +317,19 @@ __device__ inline void intra_ctu(const PicDev& P, int comp, int ctu, IntraLds& L
       uint32_t* d = reinterpret_cast<uint32_t*>(&L.pix[r][2 + 8 * v]);
       d[0] = q.x; d[1] = q.y; d[2] = q.z; d[3] = q.w;
     }
+  }
+}
+
+// all intra CUs of one CTU, one component, in decoding order (xReconIntraQT per CU, xIntraRecQT over its TU tree)
+__device__ inline void intra_ctu(const PicDev& P, int comp, int ctu, IntraLds& L) {
+  const int parts = P.parts;
+  const int ctu_x = (ctu % P.ctus_w) << P.log2ctu, ctu_y = (ctu / P.ctus_w) << P.log2ctu;
+  const int cs = comp ? 1 : 0;
+  const int lane = threadIdx.x & 63;
+  {
+    // the left neighbour's columns and the row above may come from other waves of THIS launch: coherent loads, after the wait
+    const int S = (1 << P.log2ctu) >> cs;
+    const int16_t* org = P.rec[comp] + (ptrdiff_t)(ctu_y >> cs) * P.pitch[comp] + (ctu_x >> cs);
     for (int r = lane; r < S; r += 64)
       reinterpret_cast<uint32_t*>(&L.pix[r][0])[0] = ld_coh(reinterpret_cast<const uint32_t*>(org + (ptrdiff_t)r * P.pitch[comp] - 2));
     for (int d = lane; d < S + 1; d += 64)                  // row -1, columns -2..2S-1
@@ -435,6 +447,7 @@ __global__ void __launch_bounds__(64) k_intra(const PicDev* __restrict__ pics, B
     const int16_t* src = P.coef[comp] + (size_t)ctu * n_lev;
     for (int i = lane * 8; i < n_lev; i += 64 * 8) *reinterpret_cast<u32x4*>(&L.lev[i]) = ldg4(src + i);
   }
+  intra_stage(P, comp, ctu, L);
   unsigned my_l, my_r, my_t, my_b;
   border_mask(ctu, my_l, my_r, my_t, my_b);
 #pragma unroll
