@@ -52,6 +52,31 @@ def test_synthetic_picture_matches_oracle(oracle, width, height, bd, bi, intra):
         assert st["inter_partitions"] == int((p.inside & ~p.intra).sum())
 
 
+@pytest.mark.parametrize("mode_probs,intra", [((0, 0, 0, 1, 0), 0.0), ((1, 0, 0, 0, 0), 0.0), ((0, 1, 0, 0, 0), 0.3),
+                                              ((0, 0, 0.5, 0, 0.5), 0.1), ((0.25, 0.25, 0.25, 0.25, 0), 0.0)])
+def test_fused_loop_filter_matches_oracle_on_partition_extremes(oracle, mode_probs, intra):
+    """all three loop-filter stages in ONE call (the fused kernel: edge units classified, compacted and applied per 64x64 tile)
+    on pictures whose tiles hold every edge unit (all 8x8 CUs: three full waves of units), almost none (64x64 CUs) and mixes"""
+    import libhm_amd
+    width, height, bd = 1920, 1080, 10
+    p = synth.make_picture(width, height, bd, seed=77 + int(100 * intra) + int(10 * mode_probs[3]), intra_frac=intra,
+                           mode_probs=mode_probs, ref_handles=([0], [1]))
+    ref0 = synth.noise_planes(width, height, bd, 21)
+    ref1 = synth.blocky_planes(width, height, bd, 22)
+    cur = synth.blocky_planes(width, height, bd, 23)
+    _, _, want_fin = _oracle_chain(oracle, p, cur, [ref0, ref1])
+    with libhm_amd.Context(p.seq) as ctx:
+        h0, h1, hc = ctx.acquire(), ctx.acquire(), ctx.acquire()
+        ctx.upload(h0, ref0)
+        ctx.upload(h1, ref1)
+        ctx.upload(hc, cur)
+        ctx.decompress_slice(hc, 0, p.slice, p.meta, p.coeffs)
+        ctx.filter_picture(hc, p.pp, p.sao_raw)
+        got = ctx.download(hc)
+        for c in range(3):
+            assert np.array_equal(got[c], want_fin[c]), "final picture comp %d" % c
+
+
 @pytest.mark.parametrize("across", [0, 1])
 def test_multi_slice_picture_matches_oracle(oracle, across):
     """five slices starting at arbitrary CTUs (own QP / deblocking offsets), one hmgpu_decompress_slice call per slice: slice
