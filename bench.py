@@ -87,6 +87,7 @@ def main():
     ap.add_argument("--mode-probs", default=None, help="experiment: CTU partition probabilities 64x64,32x32,16x16,8x8,AMP (comma separated)")
     ap.add_argument("--intra-frac", type=float, default=None, help="experiment: fraction of CUs that are intra (with intra modes: reconstructed on the GPU)")
     ap.add_argument("--cbf-prob", type=float, default=None, help="experiment: probability that a TU is coded")
+    ap.add_argument("--mv-range", type=int, default=None, help="experiment: integer MV range in luma samples (default 64)")
     ap.add_argument("--streams", type=int, default=1, choices=(1, 2), help="2: the batch runs as two half-batches on two HIP streams (kernels of different kinds overlap)")
     ap.add_argument("--threads", type=int, default=8, help="decode workload: parser threads of libhmdec (1 = all on the calling thread)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -130,6 +131,8 @@ def main():
         kw["cbf_prob"] = args.cbf_prob
     if args.intra_frac is not None:
         kw["intra_frac"] = args.intra_frac
+    if args.mv_range is not None:
+        kw["mv_range"] = args.mv_range
     if args.mode_probs:
         kw["mode_probs"] = tuple(float(v) for v in args.mode_probs.split(","))
     # two distinct parsed pictures, staged alternately into nb device pictures with their own buffers

@@ -6,7 +6,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libhmgpu.so")
-SOURCES = ["k_prep.hip", "k_mc.hip", "k_itx.hip", "k_intra.hip", "k_dbk.hip", "k_sao.hip", "k_filter.hip", "k_out.hip", "hmgpu_api.hip"]
+SOURCES = ["k_prep.hip", "k_mc.hip", "k_mc_cells.hip", "k_itx.hip", "k_intra.hip", "k_dbk.hip", "k_sao.hip", "k_filter.hip", "k_out.hip", "hmgpu_api.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function", "-Wno-unused-value"]
 
 
@@ -19,7 +19,7 @@ def _stale(target, deps):
 
 def build(force=False, verbose=False):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    headers = [os.path.join(CSRC, "hmgpu_dev.h"), os.path.join(CSRC, "itx_core.h"), os.path.join(CSRC, "filter_core.h"), os.path.join(os.path.dirname(HERE), "include", "hmgpu.h")]
+    headers = [os.path.join(CSRC, "hmgpu_dev.h"), os.path.join(CSRC, "itx_core.h"), os.path.join(CSRC, "mc_core.h"), os.path.join(CSRC, "filter_core.h"), os.path.join(os.path.dirname(HERE), "include", "hmgpu.h")]
     objdir = os.path.join(HERE, "build")
     os.makedirs(objdir, exist_ok=True)
     objs, procs = [], []

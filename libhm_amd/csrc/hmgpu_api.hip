@@ -21,7 +21,8 @@ enum { K_PREP = 0, K_MC_LUMA, K_MC_CHROMA, K_ITX, K_DBK_VER, K_DBK_HOR, K_SAO, K
 const char* const kKernelNames[HMGPU_NUM_KERNELS] = {"prep", "mc_luma", "mc_chroma", "itx", "deblock_ver", "deblock_hor", "sao",
                                                      "extend_border", "h2d_stage", "intra", "filter_fused", ""};
 
-struct SliceCall { int first_ctu, num_ctus, slice_idx; bool intra, wp; };   // intra: the range holds intra CUs the device reconstructs
+struct SliceCall { int first_ctu, num_ctus, slice_idx; bool intra, wp, cells, bi; };   // intra: the range holds intra CUs the device reconstructs;
+                                                                                    // cells: it holds PUs that cut an 8x8 luma tile (k_mc_cells.hip); bi: B slices
 
 struct Picture {
   bool in_use = false;
@@ -67,8 +68,13 @@ struct hmgpu_ctx {
   std::vector<Picture> pics;
   PicDev* d_pics = nullptr;
   PlaneSet* d_finals = nullptr;
+  // sample planes of all device pictures in ONE allocation: picture i at plane_slab + i * 2 * plane_bytes (reconstruction planes, then
+  // SAO planes), so that a kernel finds the final planes of a reference picture by arithmetic on its handle (McArgs, k_mc.hip)
+  char* plane_slab = nullptr;
+  size_t plane_bytes = 0;
   int32_t* d_ctu_order = nullptr;     // CTU addresses by anti-diagonal (dispatch order of the intra wavefront)
   std::vector<PlaneSet> h_finals;
+  unsigned long long* dbg_stamps = nullptr; size_t dbg_nstamps = 0;   // MC_STAMP diagnostic builds
   // profiling
   bool profiling = false;
   std::vector<EventPair> pending;
@@ -127,10 +133,8 @@ struct ProfScope {
 
 hmgpu_status alloc_picture(hmgpu_ctx* c, Picture& p) {
   const hmgpu_seq_params& s = c->seq;
-  size_t plane_bytes = 0;
-  for (int k = 0; k < 3; k++) plane_bytes += align_up((size_t)c->pitch[k] * c->rows[k] * sizeof(int16_t), 256);
-  HIP_TRY(c, hipMalloc(&p.planes, plane_bytes * 2));
-  HIP_TRY(c, hipMemset(p.planes, 0, plane_bytes * 2));
+  const size_t plane_bytes = c->plane_bytes;
+  p.planes = c->plane_slab + (size_t)(&p - c->pics.data()) * 2 * plane_bytes;     // (zeroed with the slab)
   const size_t np = (size_t)c->num_ctus * c->parts;
   // raw metadata: 11 byte arrays + 2 mv arrays (4 B) + 2 ref_idx + slice/tile idx
   Carver cm(nullptr);
@@ -160,6 +164,7 @@ hmgpu_status alloc_picture(hmgpu_ctx* c, Picture& p) {
     Carver m(pass ? p.derived : nullptr);
     PicDev& d = p.dev;
     d.blk = m.take<BlkInfo>((size_t)c->grid_w * c->grid_h);
+    d.tmv = m.take<TileMv>((size_t)(c->grid_w / 2) * (c->grid_h / 2));
     for (int k = 0; k < 4; k++) d.tu[k] = m.take<TuRec>((size_t)c->tu_cap[k] * kTuShards);
     d.tu_count = m.take<uint32_t>(4 * kTuShards);
     d.stats = m.take<unsigned long long>(2 * kTuShards);
@@ -194,8 +199,7 @@ hmgpu_status alloc_picture(hmgpu_ctx* c, Picture& p) {
 }
 
 void free_picture(Picture& p) {
-  if (p.planes) hipFree(p.planes);
-  if (p.pcm) hipFree(p.pcm);
+  if (p.pcm) hipFree(p.pcm);                       // (the planes belong to the context's slab)
   if (p.meta) hipFree(p.meta);
   if (p.coef) hipFree(p.coef);
   if (p.derived) hipFree(p.derived);
@@ -239,12 +243,50 @@ hmgpu_status ensure_refs_extended(hmgpu_ctx* c, const Batch& b, size_t call_idx)
 }
 
 // device work of one batch of slice calls (one call per picture): counters, prep, MC, inverse transforms
-hmgpu_status run_recon(hmgpu_ctx* c, const Batch& b, bool any_intra, bool any_wp) {
+hmgpu_status run_recon(hmgpu_ctx* c, const Batch& b, bool any_intra, bool any_wp, bool any_cells, bool any_bi) {
   int max_ctus = 0;
   for (int i = 0; i < b.n; i++) max_ctus = std::max(max_ctus, b.num_ctus[i]);
   { ProfScope ps(c, K_PREP); launch_prep(c->d_pics, b, max_ctus, c->parts, any_intra, c->stream); }
-  { ProfScope ps(c, K_MC_LUMA); launch_mc_luma(c->d_pics, c->d_finals, b, max_ctus, c->seq.log2_ctu_size, any_wp, c->stream); }
-  { ProfScope ps(c, K_MC_CHROMA); launch_mc_chroma(c->d_pics, c->d_finals, b, max_ctus, c->seq.log2_ctu_size, any_wp, c->stream); }
+  McArgs ma;
+  memset(&ma, 0, sizeof(ma));
+  ma.n = b.n; ma.width = c->seq.width; ma.height = c->seq.height; ma.log2ctu = c->seq.log2_ctu_size; ma.ctus_w = c->ctus_w;
+  ma.tw = c->grid_w / 2; ma.npics = c->seq.max_pictures;
+  ma.slab = c->plane_slab; ma.pic_stride = 2 * c->plane_bytes; ma.sao_off = (uint32_t)c->plane_bytes;
+  for (size_t i = 0; i < c->pics.size(); i++)
+    if (c->pics[i].sao_applied) (i < 32 ? ma.sao_mask_lo : ma.sao_mask_hi) |= 1u << (i & 31);
+  for (int i = 0; i < b.n; i++) {
+    const PicDev& d = c->pics[b.pic[i]].dev;
+    ma.first_ctu[i] = b.first_ctu[i]; ma.num_ctus[i] = b.num_ctus[i];
+    ma.tmv[i] = d.tmv; ma.slices[i] = d.slices;
+  }
+  const PicDev& d0 = c->pics[b.pic[0]].dev;           // plane offsets inside a picture's part of the slab: the same for every picture
+  const char* const base0 = (const char*)c->pics[b.pic[0]].planes;
+  {
+    ProfScope ps(c, K_MC_LUMA);
+    ma.pitch = c->pitch[0]; ma.bd = c->seq.bit_depth_luma;
+    ma.origin_off = (uint32_t)((const char*)d0.rec[0] - base0);
+    for (int i = 0; i < b.n; i++) ma.dst[i] = c->pics[b.pic[i]].dev.rec[0];
+#ifdef MC_STAMP
+    // diagnostic build: time stamps of the last luma launch of a full batch, dumped to /tmp/mc_stamps.bin at context destruction
+    static unsigned long long* d_stamps = nullptr;
+    const size_t nst = (size_t)kMaxBatch * c->num_ctus * 4 * 8;
+    if (!d_stamps) hipMalloc((void**)&d_stamps, nst * 8);
+    ma.stamps = b.n == kMaxBatch ? d_stamps : nullptr;
+    c->dbg_stamps = d_stamps; c->dbg_nstamps = nst;
+#endif
+    launch_mc_luma(ma, max_ctus, any_wp, any_bi, c->stream);
+    ma.stamps = nullptr;
+    if (any_cells) launch_mc_luma_cells(c->d_pics, c->d_finals, b, max_ctus, c->seq.log2_ctu_size, any_wp, c->stream);
+  }
+  {
+    ProfScope ps(c, K_MC_CHROMA);
+    ma.pitch = c->pitch[1]; ma.bd = c->seq.bit_depth_chroma;
+    ma.origin_off = (uint32_t)((const char*)d0.rec[1] - base0);
+    ma.cr_off = (uint32_t)((const char*)d0.rec[2] - (const char*)d0.rec[1]);
+    for (int i = 0; i < b.n; i++) { ma.dst[i] = c->pics[b.pic[i]].dev.rec[1]; ma.dst2[i] = c->pics[b.pic[i]].dev.rec[2]; }
+    launch_mc_chroma(ma, max_ctus, any_wp, any_bi, c->stream);
+    if (any_cells) launch_mc_chroma_cells(c->d_pics, c->d_finals, b, max_ctus, c->seq.log2_ctu_size, any_wp, c->stream);
+  }
   // blocks per shard: enough to keep the chip busy on a full picture, few enough that a short list costs nothing
   uint32_t bps = (uint32_t)std::max(4, std::min(24, max_ctus / 8 + 1));   // blocks per shard; 24 measured best at 2160p (768 blocks, 3 per CU)
   if (const char* e = getenv("HMGPU_ITX_BPS")) bps = (uint32_t)std::max(1, atoi(e));   // tuning knob
@@ -410,6 +452,9 @@ hmgpu_status hmgpu_create(const hmgpu_seq_params* seq, int device_ordinal, hmgpu
   c->pics.resize(seq->max_pictures);
   c->h_finals.resize(seq->max_pictures);
   hmgpu_status st = HMGPU_OK;
+  for (int k = 0; k < 3; k++) c->plane_bytes += align_up((size_t)c->pitch[k] * c->rows[k] * sizeof(int16_t), 256);
+  if (hipMalloc((void**)&c->plane_slab, c->plane_bytes * 2 * seq->max_pictures) != hipSuccess ||
+      hipMemset(c->plane_slab, 0, c->plane_bytes * 2 * seq->max_pictures) != hipSuccess) st = HMGPU_EDEVICE;
   for (int i = 0; i < seq->max_pictures && st == HMGPU_OK; i++) st = alloc_picture(c, c->pics[i]);
   if (st == HMGPU_OK) {
     {
@@ -435,11 +480,19 @@ void hmgpu_destroy(hmgpu_ctx* c) {
   if (!c) return;
   hipSetDevice(c->device);
   if (c->stream) hipStreamSynchronize(c->stream);
+#ifdef MC_STAMP
+  if (c->dbg_stamps) {                 // diagnostic build only: the time stamps of the last batched luma launch, raw
+    std::vector<unsigned long long> h(c->dbg_nstamps);
+    hipMemcpy(h.data(), c->dbg_stamps, h.size() * 8, hipMemcpyDeviceToHost);
+    if (FILE* f = fopen("/tmp/mc_stamps.bin", "wb")) { fwrite(h.data(), 8, h.size(), f); fclose(f); }
+  }
+#endif
   prof_drain(c);
   for (EventPair& ep : c->free_events) { hipEventDestroy(ep.a); hipEventDestroy(ep.b); }
   for (Picture& p : c->pics) free_picture(p);
   if (c->d_pics) hipFree(c->d_pics);
   if (c->d_finals) hipFree(c->d_finals);
+  if (c->plane_slab) hipFree(c->plane_slab);
   if (c->d_ctu_order) hipFree(c->d_ctu_order);
   if (c->stream) hipStreamDestroy(c->stream);
   if (c->stream2) hipStreamDestroy(c->stream2);
@@ -734,7 +787,20 @@ static hmgpu_status stage_and_run(hmgpu_ctx* c, hmgpu_pic cur, int32_t slice_idx
                   return o.first_ctu < first_ctu + num_ctus && first_ctu < o.first_ctu + o.num_ctus; }), p.calls.end());
   // the caller's arrays are at hand: whether the range holds intra CUs at all decides if the intra kernel is launched
   const bool has_intra = p.dev.has_intra_dir && memchr(m->pred_mode + po, HMGPU_MODE_INTRA, pn) != nullptr;
-  SliceCall call = {first_ctu, num_ctus, slice_idx, has_intra, any_wp};
+  // PUs that cut an 8x8 luma tile: 2NxN / Nx2N (/ NxN) parts of 8x8 CUs, the 4- and 12-sample parts of AMP in 16x16 CUs
+  bool cells = false;
+  {
+    const int d8 = c->seq.log2_ctu_size - 3;
+    const int8_t* ps = m->part_size + po;
+    const uint8_t* dp = m->depth + po;
+    const int8_t* pm = m->pred_mode + po;
+    for (size_t i = 0; i < pn && !cells; i++)
+      cells = ps[i] != HMGPU_SIZE_2Nx2N && ps[i] != HMGPU_SIZE_NONE && pm[i] != HMGPU_MODE_INTRA &&
+              (dp[i] >= d8 || (dp[i] == d8 - 1 && ps[i] >= HMGPU_SIZE_2NxnU));
+  }
+  bool any_b = false;
+  for (int si : slices) any_b |= p.slices[si].slice_type == HMGPU_B_SLICE;
+  SliceCall call = {first_ctu, num_ctus, slice_idx, has_intra, any_wp, cells, any_b};
   p.calls.push_back(call);
 
   Batch b; memset(&b, 0, sizeof(b));
@@ -746,7 +812,7 @@ static hmgpu_status stage_and_run(hmgpu_ctx* c, hmgpu_pic cur, int32_t slice_idx
       for (int r = 0; r < HMGPU_MAX_REF; r++)
         if (sd.ref_pic[l][r] >= 0) { hmgpu_status st = ensure_extended(c, sd.ref_pic[l][r]); if (st != HMGPU_OK) return st; }
   }
-  return run_recon(c, b, has_intra, any_wp);
+  return run_recon(c, b, has_intra, any_wp, cells, any_b);
 }
 
 static bool meta_complete(const hmgpu_ctu_meta* m, const hmgpu_coeffs* co) {
@@ -854,14 +920,14 @@ hmgpu_status hmgpu_replay_batch(hmgpu_ctx* c, const hmgpu_pic* pics, int32_t n, 
         for (size_t k = 0; k < ncalls && result == HMGPU_OK; k++) {
           Batch b; memset(&b, 0, sizeof(b));
           b.n = hi - lo;
-          bool any_intra = false, any_wp = false;
+          bool any_intra = false, any_wp = false, any_cells = false, any_bi = false;
           for (int i = lo; i < hi; i++) {
             const SliceCall& sc = c->pics[pics[i]].calls[k];
             b.pic[i - lo] = pics[i]; b.first_ctu[i - lo] = sc.first_ctu; b.num_ctus[i - lo] = sc.num_ctus;
-            any_intra |= sc.intra; any_wp |= sc.wp;
+            any_intra |= sc.intra; any_wp |= sc.wp; any_cells |= sc.cells; any_bi |= sc.bi;
           }
           result = ensure_refs_extended(c, b, k);
-          if (result == HMGPU_OK) result = run_recon(c, b, any_intra, any_wp);
+          if (result == HMGPU_OK) result = run_recon(c, b, any_intra, any_wp, any_cells, any_bi);
         }
       }
       if ((stages & 7) && result == HMGPU_OK) {

@@ -44,6 +44,22 @@ enum : uint8_t {
   BE_HOR_TRANSFORM = 8,
 };
 
+// ---- motion of one 8x8 luma tile (raster grid, grid_w/2 x grid_h/2), written by k_prep for the motion-compensation kernels --
+// A tile is ACTIVE when its four 4x4 cells are inter-predicted with identical motion (k_mc.hip predicts those); slot 0 is
+// the first list the tile predicts from, slot 1 is list 1 of a bi-predicted tile.  The vectors are CLIPPED (TComDataCU::clipMv)
+// and split into integer luma samples and the quarter-sample fraction; unused fields are 0, so that two tiles continue each
+// other vertically iff their first 12 bytes are equal.
+struct __attribute__((aligned(16))) TileMv {
+  int16_t ix0, iy0, ix1, iy1;   // integer parts of the clipped motion vectors of slot 0 / slot 1 (luma samples)
+  uint8_t frac;                 // xf0 | yf0 << 2 | xf1 << 4 | yf1 << 6 (quarter samples)
+  uint8_t ref0, ref1;           // device picture handles of slot 0 / slot 1
+  uint8_t flags;                // TM_*
+  uint8_t ridx0, ridx1;         // reference indices of slot 0 / slot 1 (explicit weighted prediction)
+  uint16_t slice;               // index into the picture's slice table
+};
+static_assert(sizeof(TileMv) == 16, "TileMv must be 16 bytes");
+enum : uint8_t { TM_ACTIVE = 1, TM_BI = 2, TM_FIRST_L1 = 4 };
+
 // ---- coded transform unit ---------------------------------------------------------------------------------------
 struct TuRec {
   uint16_t x4, y4;        // origin in 4-luma-sample units (picture coordinates)
@@ -107,6 +123,7 @@ struct PicDev {
   const SliceDev* slices;
   // derived
   BlkInfo* blk;
+  TileMv* tmv;                     // [grid_h / 2][grid_w / 2]
   TuRec* tu[4];                    // by log2 size - 2: kTuShards shards of tu_cap[] records each
   uint32_t* tu_count;              // [4][kTuShards]
   uint32_t tu_cap[4];              // capacity of ONE shard
@@ -127,6 +144,26 @@ struct Batch {
   int32_t pic[kMaxBatch];          // index into the PicDev table
   int32_t first_ctu[kMaxBatch];
   int32_t num_ctus[kMaxBatch];
+};
+
+// everything the motion-compensation kernels need about a batch, in kernel-argument memory: nothing stands between a workgroup's
+// start and the load of its tile records (k_mc.hip).  Filled by the host from its mirrors of the PicDev descriptors.
+struct McArgs {
+  int32_t n, mode, log2n, per;                 // pictures of the batch; grid mapping (launch_mc)
+  int32_t width, height, log2ctu, ctus_w;      // geometry (the same for every picture of a context)
+  int32_t tw, pitch, bd, npics;                // TileMv grid width; pitch / bit depth of the component; entries of finals[]
+  int32_t first_ctu[kMaxBatch], num_ctus[kMaxBatch];
+  const TileMv* tmv[kMaxBatch];
+  int16_t* dst[kMaxBatch];                     // luma: the picture's reconstruction plane; chroma: Cb
+  int16_t* dst2[kMaxBatch];                    // chroma: Cr
+  const SliceDev* slices[kMaxBatch];           // slice tables (explicit weighted prediction)
+  // final planes: every picture of a context lives in one slab, picture i at slab + i * pic_stride; its final luma plane (sample
+  // (0,0)) is at + origin_off, or + sao_off + origin_off when bit i of the SAO mask is set (the picture went through SAO)
+  const char* slab;
+  uint64_t pic_stride;
+  uint32_t sao_off, origin_off, cr_off;        // origin_off: luma launch: Y plane; chroma launch: Cb plane; cr_off: Cb -> Cr
+  uint32_t sao_mask_lo, sao_mask_hi;
+  unsigned long long* stamps;                  // diagnostic builds (MC_STAMP): 8 time stamps per wave, else null
 };
 
 // Pointers stored inside PicDev / PlaneSet reach the kernels through memory, so the compiler only knows them as generic
@@ -178,8 +215,13 @@ __host__ inline int xcd_grid(int n, int nb) {
 
 // ---- launchers (one per kernel family; defined in the .hip files) ---------------------------------------------------
 void launch_prep(const PicDev* pics, const Batch& b, int max_ctus, int parts, bool intra, hipStream_t s);
-void launch_mc_luma(const PicDev* pics, const PlaneSet* finals, const Batch& b, int max_ctus, int log2ctu, bool wp, hipStream_t s);
-void launch_mc_chroma(const PicDev* pics, const PlaneSet* finals, const Batch& b, int max_ctus, int log2ctu, bool wp, hipStream_t s);
+// npics = entries of the finals table (device pictures of the context, <= kMaxPics)
+// bi: the batch holds B slices (the variants that run the H and V passes once per list)
+void launch_mc_luma(McArgs& a, int max_ctus, bool wp, bool bi, hipStream_t s);
+void launch_mc_chroma(McArgs& a, int max_ctus, bool wp, bool bi, hipStream_t s);
+// the 4x4 cells of tiles with mixed motion (8x4 / 4x8 PUs, AMP in 16x16 CUs): only for calls that contain such PUs
+void launch_mc_luma_cells(const PicDev* pics, const PlaneSet* finals, const Batch& b, int max_ctus, int log2ctu, bool wp, hipStream_t s);
+void launch_mc_chroma_cells(const PicDev* pics, const PlaneSet* finals, const Batch& b, int max_ctus, int log2ctu, bool wp, hipStream_t s);
 void launch_itx(const PicDev* pics, const Batch& b, int log2size, uint32_t blocks_per_shard, hipStream_t s);
 void launch_filter_fused(const PicDev* pics, const Batch& b, int width, int height, bool nofilt, hipStream_t s);
 void launch_pack(const int16_t* src, int pitch, int x0, int y0, int w, int h, int bytes, uint8_t* dst, int dst_stride, hipStream_t s);

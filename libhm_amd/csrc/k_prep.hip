@@ -112,6 +112,8 @@ __global__ void __launch_bounds__(256) k_prep(const PicDev* __restrict__ pics, B
     const int slice_type = ldg(&sl->slice_type);
     const bool wp = ldg(&sl->weighted_pred) != 0;
     const uint32_t mvw0[4] = {mv0.x, mv0.y, mv0.z, mv0.w}, mvw1[4] = {mv1.x, mv1.y, mv1.z, mv1.w};
+    // the tile's motion for k_mc.hip: what the four cells must agree on (TileMv)
+    uint32_t tm_mv[4][2], tm_key[4];
 #pragma unroll
     for (int j = 0; j < 4; j++) {
       const int xj = x4 + (j & 1), yj = y4 + (j >> 1);
@@ -130,14 +132,19 @@ __global__ void __launch_bounds__(256) k_prep(const PicDev* __restrict__ pics, B
         bi.slice = (uint16_t)q.sidx;
         if (!q.intra) {
           const int r0 = (int)(int8_t)((r04 >> (8 * j)) & 0xff), r1 = (int)(int8_t)((r14 >> (8 * j)) & 0xff);
-          int use0 = r0 >= 0, use1 = r1 >= 0;
+          int use0 = r0 >= 0, use1 = r1 >= 0 && slice_type == HMGPU_B_SLICE;   // (a P slice has no list 1: HM leaves its indices at -1)
           if (use0) { bi.mv[0][0] = (int16_t)(mvw0[j] & 0xffff); bi.mv[0][1] = (int16_t)(mvw0[j] >> 16); bi.ref[0] = ldg(&sl->ref_pic[0][r0]); }
           if (use1) { bi.mv[1][0] = (int16_t)(mvw1[j] & 0xffff); bi.mv[1][1] = (int16_t)(mvw1[j] >> 16); bi.ref[1] = ldg(&sl->ref_pic[1][r1]); }
           // xCheckIdenticalMotion (TComPrediction.cpp:497-512): B slice, both lists, same POC and same MV -> list 0 only
           // (not with weighted bi-prediction: the two lists may carry different weights, :499)
           if (slice_type == HMGPU_B_SLICE && !wp && use0 && use1 && ldg(&sl->ref_poc[0][r0]) == ldg(&sl->ref_poc[1][r1]) && mvw0[j] == mvw1[j]) use1 = 0;
           bi.flags |= (use0 ? BF_MC_L0 : 0) | (use1 ? BF_MC_L1 : 0);
-        }
+          tm_mv[j][0] = use0 ? mvw0[j] : 0u; tm_mv[j][1] = use1 ? mvw1[j] : 0u;
+          // reference pictures and lists; with explicit weighted prediction the reference INDICES too (two indices may name one
+          // picture with different weights)
+          tm_key[j] = (uint32_t)(uint8_t)bi.ref[0] | ((uint32_t)(uint8_t)bi.ref[1] << 8) | (use0 ? 1u << 16 : 0u) | (use1 ? 1u << 17 : 0u) |
+                      (wp ? ((uint32_t)(use0 ? r0 & 15 : 0) << 20) | ((uint32_t)(use1 ? r1 & 15 : 0) << 24) : 0u);
+        } else { tm_mv[j][0] = tm_mv[j][1] = 0; tm_key[j] = 0; }
         // ---- deblocking edge flags (TComLoopFilter.cpp:269-409); only partitions on the 8x8 grid carry an edge
         if (deblock) {
           const int cux = xj & ~(cu_parts - 1), cuy = yj & ~(cu_parts - 1);
@@ -191,6 +198,39 @@ __global__ void __launch_bounds__(256) k_prep(const PicDev* __restrict__ pics, B
         }
       }
       stg4(&P.blk[(size_t)gy * P.grid_w + gx], __builtin_bit_cast(u32x4, bi));
+      if (!q.valid) { tm_mv[j][0] = tm_mv[j][1] = 0; tm_key[j] = 0; }
+    }
+    {
+      TileMv tm;
+      tm.ix0 = tm.iy0 = tm.ix1 = tm.iy1 = 0; tm.frac = 0; tm.ref0 = tm.ref1 = 0; tm.flags = 0; tm.ridx0 = tm.ridx1 = 0; tm.slice = 0;
+      bool uni = q.valid && !q.intra && (tm_key[0] & (3u << 16)) != 0;
+#pragma unroll
+      for (int j = 1; j < 4; j++) uni = uni && tm_mv[j][0] == tm_mv[0][0] && tm_mv[j][1] == tm_mv[0][1] && tm_key[j] == tm_key[0];
+      if (uni) {
+        // TComDataCU::clipMv (TComDataCU.cpp:3102-3114) against the CU origin
+        const int cs = 1 << q.log2cu, ctu_sz = 1 << P.log2ctu;
+        const int cu_x = (q.gx0 * 4) & ~(cs - 1), cu_y = (q.gy0 * 4) & ~(cs - 1);
+        const bool use0 = (tm_key[0] >> 16) & 1, both = use0 && ((tm_key[0] >> 17) & 1);
+        const int r0 = (int)(int8_t)((r04) & 0xff), r1 = (int)(int8_t)((r14) & 0xff);
+        int ix[2] = {0, 0}, iy[2] = {0, 0}, rf[2] = {0, 0}, ri[2] = {0, 0}, fr = 0;
+#pragma unroll
+        for (int s2 = 0; s2 < 2; s2++) {
+          if (s2 == 1 && !both) break;
+          const bool l1 = s2 == 1 || !use0;
+          const uint32_t w = l1 ? tm_mv[0][1] : tm_mv[0][0];
+          int mvx = (int)(int16_t)(w & 0xffff), mvy = (int)(int16_t)(w >> 16);
+          mvx = min((P.width + 8 - cu_x - 1) << 2, max((-ctu_sz - 8 - cu_x + 1) * 4, mvx));
+          mvy = min((P.height + 8 - cu_y - 1) << 2, max((-ctu_sz - 8 - cu_y + 1) * 4, mvy));
+          ix[s2] = mvx >> 2; iy[s2] = mvy >> 2;
+          fr |= ((mvx & 3) | ((mvy & 3) << 2)) << (4 * s2);
+          rf[s2] = (int)((tm_key[0] >> (l1 ? 8 : 0)) & 0xff); ri[s2] = (l1 ? r1 : r0) & 0xff;
+        }
+        tm.ix0 = (int16_t)ix[0]; tm.iy0 = (int16_t)iy[0]; tm.ix1 = (int16_t)ix[1]; tm.iy1 = (int16_t)iy[1];
+        tm.frac = (uint8_t)fr; tm.ref0 = (uint8_t)rf[0]; tm.ref1 = (uint8_t)rf[1]; tm.ridx0 = (uint8_t)ri[0]; tm.ridx1 = (uint8_t)ri[1];
+        tm.flags = TM_ACTIVE | (both ? TM_BI : 0) | (use0 ? 0 : TM_FIRST_L1);
+        tm.slice = (uint16_t)q.sidx;
+      }
+      stg4(&P.tmv[(size_t)(q.gy0 >> 1) * (P.grid_w >> 1) + (q.gx0 >> 1)], __builtin_bit_cast(u32x4, tm));
     }
     if (q.valid) atomicAdd(&lds_stat[q.intra ? 0 : 1], 4u);
     if (q.valid && q.intra) stg(P.ctu_intra + q.ctu, (uint8_t)1);        // same value from every writer
