@@ -67,7 +67,6 @@ __device__ inline uint32_t pk_sub(uint32_t a, uint32_t b) {                     
 #define STAMP_DRAIN() do {} while (0)
 #endif
 
-constexpr uint32_t TM_TOP = 0x80;          // local: set in the flags byte of a run's first tile
 
 // ---- tap tables: entry (fraction f, parity p) of an N-tap filter c[]: with A = (c0,c1)(c2,c3).. and B = (0,c0)(c1,c2)..(c[N-1],0)
 //   p = 0: even columns A,0   odd columns B        p = 1: even columns B   odd columns 0,A
@@ -110,11 +109,6 @@ __device__ inline int dot2_first(uint32_t samples, uint32_t taps) {
   return d;
 }
 
-// LDS: H-pass results as 8-byte pieces (two columns x one row pair), laid out [tile row][piece][row pair][tile column] so that
-// every DS instruction of both passes touches each bank once: the 16 / 32 lanes an LDS cycle serves are the eight tiles of a
-// tile row times two / four row pairs (ds_write_b64 / ds_read_b64), whichever region (own tile, tile above, halo) a lane reads.
-//   luma:   piece c = columns 2c, 2c+1 (c < 4), row pair g < 4:            byte (ty, c, g, tx) = ty * 1024 + c * 256 + g * 64 + tx * 8
-//   chroma: plane p, piece c = columns 2c, 2c+1 (c < 2), row pair g < 2:   byte (ty, p, c, g, tx) = ty * 512 + p * 256 + c * 128 + g * 64 + tx * 8
 __device__ inline int dot2_seed(uint32_t samples, uint32_t taps, int seed) {       // seed: wave-uniform (a scalar register)
   int d;
   asm("v_dot2_i32_i16 %0, %1, %2, %3" : "=v"(d) : "v"(samples), "v"(taps), "s"(seed));
@@ -129,10 +123,14 @@ __device__ inline uint32_t pack_shr(int lo, int hi, int sh) {
   return d;
 }
 
+// LDS: H-pass results as 8-byte pieces (two columns x one row pair).  Every wave owns a STRIP of the square (two tile rows) and a
+// slice of LDS of its own, laid out [tile row][piece][row pair][tile column] so that every DS instruction of both passes touches
+// each bank once (the 16 / 32 lanes an LDS cycle serves are the eight tiles of a tile row times two / four row pairs).
+//   luma:   piece c = columns 2c, 2c+1 (c < 4), row pair g < 4:            dword (r, c, g, tx) = r * 256 + c * 64 + g * 16 + tx * 2
+//   chroma: plane p, piece c = columns 2c, 2c+1 (c < 2), row pair g < 2:   dword (r, p, c, g, tx) = r * 128 + p * 64 + c * 32 + g * 16 + tx * 2
 template <bool CHROMA> struct McLds {
   static constexpr int ROW_DW = CHROMA ? 128 : 256;           // dwords per tile row
-  uint32_t body[8 * ROW_DW];
-  uint32_t halo[8 * ROW_DW];                                  // the first 8 (4) window rows of run tops, at the top tile's position
+  struct { uint32_t body[2 * ROW_DW], halo[2 * ROW_DW]; } w[4];   // halo: the first 8 (4) window rows of run tops, at the top tile's position
   uint32_t taps[CHROMA ? 128 : 96];                           // the tap table (every wave writes the same values, reads its own)
 #ifdef MC_LDS_PAD
   uint32_t pad[MC_LDS_PAD / 4];                               // experiment: fewer workgroups per CU
@@ -233,36 +231,20 @@ __device__ inline void finish_rows(int (&v6)[2][W], uint32_t (&park)[W], int pas
   }
 }
 
-// ---- what every wave knows after the prologue (lane = tile of the square)
-struct WaveTiles {
-  uint32_t w0, w1, w2, w3;     // this lane's TileMv (w2: frac | ref0 << 8 | ref1 << 16 | (flags | TM_TOP) << 24)
-  int tl;                      // lane r: the r-th run top (raster order)
-  int ntop;
-  bool any_bi;
-};
-__device__ inline u32x4 load_tile_rec(const McArgs& a, int slot, const Square& g) {
-  const int lane = threadIdx.x & 63, ltx = lane & 7, lty = lane >> 3;
-  const bool tin = ltx * 8 < g.ext && lty * 8 < g.ext && g.sx + ltx * 8 < a.width && g.sy + lty * 8 < a.height;
+// the TileMv record of the tile (tx, strip row r) a lane works on, and whether that tile starts a vertical run inside the strip.
+// Lanes l and l ^ 32 (luma) / l ^ 16 (chroma) hold the two tiles of a column: one bpermute per dword tells a second-row tile
+// whether it continues the first-row tile (same lists, pictures, vectors: the windows are then exactly one tile apart).
+__device__ inline u32x4 load_tile_rec(const McArgs& a, int slot, const Square& g, int x, int y) {
+  const bool tin = x < g.sx + g.ext && y < g.sy + g.ext && x < a.width && y < a.height;
   u32x4 tm = {0, 0, 0, 0};
-  if (tin) tm = ldg4(a.tmv[slot] + (size_t)((g.sy >> 3) + lty) * a.tw + (g.sx >> 3) + ltx);
+  if (tin) tm = ldg4(a.tmv[slot] + (size_t)(y >> 3) * a.tw + (x >> 3));
   return tm;
 }
-__device__ inline bool wave_prologue(const u32x4 tm, WaveTiles& T) {
-  const int lane = threadIdx.x & 63;
-  const bool active = ((tm.z >> 24) & TM_ACTIVE) != 0;
-  const unsigned long long mact = __ballot(active);
-  if (!mact) return false;
-  // the tile continues the run of the tile above: same lists, pictures, vectors (the windows are then exactly one tile apart)
-  const uint32_t u0 = __shfl_up(tm.x, 8), u1 = __shfl_up(tm.y, 8), u2 = __shfl_up(tm.z, 8);
-  const bool top = active && !(lane >= 8 && u0 == tm.x && u1 == tm.y && u2 == tm.z);
-  const unsigned long long mtop = __ballot(top);
-  const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mtop >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mtop, 0u));
-  T.ntop = __popcll(mtop);
-  T.tl = __builtin_amdgcn_ds_permute((top ? rank : T.ntop + lane - rank) * 4, lane);
-  T.w0 = tm.x; T.w1 = tm.y; T.w2 = tm.z | (top ? TM_TOP << 24 : 0u); T.w3 = tm.w;
-  T.any_bi = __ballot(((tm.z >> 24) & TM_BI) != 0) != 0;
-  return true;
+__device__ inline bool tile_is_top(const u32x4 tm, int r, int partner_lane) {
+  const uint32_t u0 = __shfl((int)tm.x, partner_lane), u1 = __shfl((int)tm.y, partner_lane), u2 = __shfl((int)tm.z, partner_lane);
+  return r == 0 || !(u0 == tm.x && u1 == tm.y && u2 == tm.z);
 }
+
 // address of sample (0,0) of the final luma / Cb plane of device picture `ref` (all pictures of a context live in one slab, a
 // finished picture is its SAO output or, without SAO, its reconstruction)
 __device__ inline const char* final_plane(const McArgs& a, int ref) {
@@ -295,86 +277,79 @@ __device__ inline void h_item_luma(const u32x4 (&r)[4], const uint32_t* __restri
     *reinterpret_cast<u32x2*>(out + c * 64) = u32x2{pack_shr(sum[0][2 * c], sum[1][2 * c], sh1), pack_shr(sum[0][2 * c + 1], sum[1][2 * c + 1], sh1)};
 }
 
+// One wave = one strip of the square: tile rows 2w, 2w+1.  Lane -> tile (tx = lane & 7, strip row r = lane >> 5), row pair
+// q = (lane >> 3) & 3: the lane's H items are window rows 8+2q, 9+2q ("body") and, if its tile starts a run, rows 2q, 2q+1
+// ("halo") of THAT tile; its V item is output rows 2q, 2q+1 of the same tile.  The first tile row of a strip always starts a run
+// (the strip above belongs to another wave), so the waves of a workgroup never wait for each other: no barrier, no shared state
+// but the tap table, whose copies are identical.
 template <bool WP, bool BI>
 __global__ void __launch_bounds__(256, MC_LB_LUMA) k_mc_luma(const McArgs a) {
   __shared__ __attribute__((aligned(16))) McLds<false> S;
-#ifdef MC_STAMP
-  unsigned long long stamp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  const bool stamp_on = a.stamps != nullptr;
-  STAMP(0);
-#endif
   int slot; Square g;
   if (!square_of_block(a, slot, g)) return;
-  const int tid = threadIdx.x, lane = tid & 63;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (wave * 16 >= g.ext) return;
   const int pitch = a.pitch, bd = a.bd;
-  // ---- prologue: tile records, the tap table
-  WaveTiles T;
-  const u32x4 tmrec = load_tile_rec(a, slot, g);
+  const int tx = lane & 7, q = (lane >> 3) & 3, r = lane >> 5;
+  const int x0 = g.sx + tx * 8, y0 = g.sy + wave * 16 + r * 8;
+  // ---- prologue: the lane's tile record, the tap table
+  const u32x4 tm = load_tile_rec(a, slot, g, x0, y0);
   if (lane < 48) *reinterpret_cast<u32x2*>(&S.taps[2 * lane]) = ldg2(&g_taps_luma.e[0][0] + 2 * lane);
-  STAMP_DRAIN(); STAMP(1);
-  if (!wave_prologue(tmrec, T)) return;
+  const uint32_t flags = tm.z >> 24;
+  const bool active = (flags & TM_ACTIVE) != 0;
+  if (!__ballot(active)) return;
+  const bool top = tile_is_top(tm, r, lane ^ 32);
+  const bool any_bi = BI && __ballot((flags & TM_BI) != 0) != 0;
   wave_lds_sync();
 #ifdef MC_LDS_PAD
   if (a.n < 0) S.pad[tid] = 1;                               // (keeps the padding allocated)
 #endif
-  const int npass = (BI && T.any_bi) ? 2 : 1;
+  const int npass = any_bi ? 2 : 1;
   const int head = bd >= 12 ? 2 : 14 - bd;
   const int sh1 = 6 - head;
-  // body item / V item of this thread: tile t = (tx, ty), row pair q;  halo item: the t-th run top, row pair q
-  const int tx = tid & 7, q = (tid >> 3) & 3, ty = tid >> 5, t = ty * 8 + tx;
-  const uint32_t b0 = __shfl((int)T.w0, t), b1 = BI ? __shfl((int)T.w1, t) : 0u, b2 = __shfl((int)T.w2, t);
-  const bool has_halo = t < T.ntop;
-  const int t2 = __shfl(T.tl, t);
-  const uint32_t h0 = __shfl((int)T.w0, t2), h1 = BI ? __shfl((int)T.w1, t2) : 0u, h2 = __shfl((int)T.w2, t2);
-  const uint32_t bflags = b2 >> 24, hflags = h2 >> 24;
-  WpTile wp = {false, 1, 0, 1, 0, 0};
-  if constexpr (WP) wp = wp_tile<WP>(a.slices[slot], bflags, (uint32_t)__shfl((int)T.w3, t), 0);
-  const int x0 = g.sx + tx * 8, y0 = g.sy + ty * 8;
-  uint32_t* const body_t = &S.body[ty * 256 + tx * 2];                   // (ty, piece 0, row pair 0, tx)
-  uint32_t* const halo_t2 = &S.halo[(t2 >> 3) * 256 + (t2 & 7) * 2];
+  uint32_t* const body_t = &S.w[wave].body[r * 256 + tx * 2];              // (r, piece 0, row pair 0, tx)
+  uint32_t* const halo_t = &S.w[wave].halo[r * 256 + tx * 2];
   const char* const dummy = reinterpret_cast<const char*>(a.tmv[slot]);   // where lanes without a work item load from (valid memory)
+  WpTile wp = {false, 1, 0, 1, 0, 0};
+  if constexpr (WP) wp = wp_tile<WP>(a.slices[slot], flags, tm.w, 0);
   uint32_t park[8];
 #pragma unroll
   for (int x = 0; x < 8; x++) park[x] = 0;
 #pragma unroll 1
   for (int pass = 0; pass < npass; pass++) {
-    const bool bact = (bflags & TM_ACTIVE) && (pass == 0 || (bflags & TM_BI));
-    const bool hact = has_halo && (pass == 0 || (hflags & TM_BI));
-    const uint32_t bmv = pass ? b1 : b0, hmv = pass ? h1 : h0;
-    const uint32_t bfr = (b2 >> (4 * pass)) & 15, hfr = (h2 >> (4 * pass)) & 15;
-    // the H pass of this thread's body item and, in waves that hold run tops, of its halo item.  Loads are unconditional (lanes
-    // without an item read a dummy address): values that are only defined in some lanes would have to be initialised in the others
+    const bool bact = active && (pass == 0 || (flags & TM_BI));
+    const bool hact = bact && top;
+    const uint32_t mv = pass ? tm.y : tm.x;
+    const uint32_t fr = (tm.z >> (4 * pass)) & 15;
+    const int xs = x0 + (int)(int16_t)(mv & 0xffff) - 3;
+    const uint32_t* const tap = &S.taps[((fr & 3) * 2 + (xs & 1)) * 12];
+    // window row 2q of the tile (the halo item's first row; the body item's is 8 rows down)
+    const char* const pw = final_plane(a, (int)((tm.z >> (8 + 8 * pass)) & (kMaxPics - 1))) +
+                           ((ptrdiff_t)(y0 + ((int)mv >> 16) - 3 + 2 * q) * pitch + (xs & ~1)) * 2;
+    // the H pass of the lane's body item and, in waves that hold run tops, of its halo item.  Loads are unconditional (lanes without
+    // an item read a dummy address): values that are only defined in some lanes would have to be initialised in the others
     auto h_phase = [&](auto with_halo) {
       constexpr bool HALO = decltype(with_halo)::value;
       u32x4 rb[4], rh[4];
-      const int bxs = x0 + (int)(int16_t)(bmv & 0xffff) - 3;
       {
-        const int ys = y0 + ((int)bmv >> 16) - 3 + 8 + 2 * q;
-        const char* p0 = final_plane(a, (int)((b2 >> (8 + 8 * pass)) & (kMaxPics - 1))) + ((ptrdiff_t)ys * pitch + (bxs & ~1)) * 2;
-        if (!bact) p0 = dummy;
+        const char* p0 = bact ? pw + (ptrdiff_t)pitch * 16 : dummy;
         rb[0] = ldg4_a4(p0); rb[1] = ldg4_a4(p0 + 16); rb[2] = ldg4_a4(p0 + pitch * 2); rb[3] = ldg4_a4(p0 + pitch * 2 + 16);
       }
-      const int hxs = g.sx + (t2 & 7) * 8 + (int)(int16_t)(hmv & 0xffff) - 3;
       if constexpr (HALO) {
-        const int ys = g.sy + (t2 >> 3) * 8 + ((int)hmv >> 16) - 3 + 2 * q;
-        const char* p0 = final_plane(a, (int)((h2 >> (8 + 8 * pass)) & (kMaxPics - 1))) + ((ptrdiff_t)ys * pitch + (hxs & ~1)) * 2;
-        if (!hact) p0 = dummy;
+        const char* p0 = hact ? pw : dummy;
         rh[0] = ldg4_a4(p0); rh[1] = ldg4_a4(p0 + 16); rh[2] = ldg4_a4(p0 + pitch * 2); rh[3] = ldg4_a4(p0 + pitch * 2 + 16);
       }
-      STAMP(2); STAMP_DRAIN(); STAMP(3);
-      if (bact) h_item_luma(rb, &S.taps[((bfr & 3) * 2 + (bxs & 1)) * 12], sh1, body_t + q * 16);
-      if constexpr (HALO) { if (hact) h_item_luma(rh, &S.taps[((hfr & 3) * 2 + (hxs & 1)) * 12], sh1, halo_t2 + q * 16); }
+      if (bact) h_item_luma(rb, tap, sh1, body_t + q * 16);
+      if constexpr (HALO) { if (hact) h_item_luma(rh, tap, sh1, halo_t + q * 16); }
     };
     if (__ballot(hact)) h_phase(std::true_type()); else h_phase(std::false_type());
-    STAMP(4);
-    __syncthreads();
-    STAMP(5);
+    wave_lds_sync();
     if (bact) {
       // output rows 2q, 2q+1 of the tile: window row pairs q .. q+4, the first four of a tile's eight pairs belong to the tile above
-      const uint32_t* above = (bflags & TM_TOP) ? &S.halo[ty * 256 + tx * 2] : body_t - 256;
-      const uint32_t* tap = &S.taps[((bfr >> 2) & 3) * 2 * 12];
-      const u32x4 t0 = *reinterpret_cast<const u32x4*>(tap), t1 = *reinterpret_cast<const u32x4*>(tap + 4);
-      const u32x2 t2v = *reinterpret_cast<const u32x2*>(tap + 8);
+      const uint32_t* above = top ? halo_t : body_t - 256;
+      const uint32_t* vtap = &S.taps[((fr >> 2) & 3) * 2 * 12];
+      const u32x4 t0 = *reinterpret_cast<const u32x4*>(vtap), t1 = *reinterpret_cast<const u32x4*>(vtap + 4);
+      const u32x2 t2v = *reinterpret_cast<const u32x2*>(vtap + 8);
       const uint32_t A[4] = {t0.x, t0.y, t0.z, t0.w}, B[5] = {t1.y, t1.z, t1.w, t2v.x, t2v.y};
       const int seed = (!WP && !BI) ? 32 << head : 0;       // uni-prediction without weights: the final rounding constant
       int v6[2][8];
@@ -394,17 +369,10 @@ __global__ void __launch_bounds__(256, MC_LB_LUMA) k_mc_luma(const McArgs a) {
           }
         }
       }
-      finish_rows<8, WP, BI>(v6, park, pass, (bflags & TM_BI) != 0, bd, wp, a.dst[slot] + (ptrdiff_t)(y0 + 2 * q) * pitch + x0, pitch);
+      finish_rows<8, WP, BI>(v6, park, pass, (flags & TM_BI) != 0, bd, wp, a.dst[slot] + (ptrdiff_t)(y0 + 2 * q) * pitch + x0, pitch);
     }
-    if (BI && pass + 1 < npass) __syncthreads();           // the next list's H pass overwrites what this V pass reads
+    if (BI && pass + 1 < npass) wave_lds_sync();           // the next list's H pass overwrites what this V pass reads
   }
-#ifdef MC_STAMP
-  STAMP(6); STAMP_DRAIN(); STAMP(7);
-  if (stamp_on && lane == 0) {
-    const size_t w = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 4 + (tid >> 6);
-    for (int i = 0; i < 8; i++) a.stamps[w * 8 + i] = stamp[i];
-  }
-#endif
 }
 
 // ====================================================================================================== chroma
@@ -434,68 +402,65 @@ __device__ inline void h_item_chroma(const u32x4 (&r)[4], const uint32_t* __rest
   }
 }
 
+// One wave = one strip (tile rows 2w, 2w+1) as in k_mc_luma.  Lane -> tile (tx = lane & 7, strip row r = (lane >> 4) & 1) for both
+// passes.  H item: lanes 0..31 window rows 4+2hq, 5+2hq ("body"), lanes 32..63 rows 2hq, 2hq+1 ("halo", tiles that start a run) of
+// both planes, hq = (lane >> 3) & 1.  V item: plane vp = lane >> 5, output rows 2k, 2k+1 with k = (lane >> 3) & 1.
 template <bool WP, bool BI>
 __global__ void __launch_bounds__(256, MC_LB_CHROMA) k_mc_chroma(const McArgs a) {
   __shared__ __attribute__((aligned(16))) McLds<true> S;
   int slot; Square g;
   if (!square_of_block(a, slot, g)) return;
-  const int tid = threadIdx.x, lane = tid & 63;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (wave * 16 >= g.ext) return;
   const int pitch = a.pitch, bd = a.bd;
-  WaveTiles T;
-  const u32x4 tmrec = load_tile_rec(a, slot, g);
+  const int tx = lane & 7, hq = (lane >> 3) & 1, r = (lane >> 4) & 1, hi = lane >> 5;     // hi: H pass halo item / V pass plane
+  const int x0 = g.sx + tx * 8, y0 = g.sy + wave * 16 + r * 8;                            // luma position of the tile
+  const u32x4 tm = load_tile_rec(a, slot, g, x0, y0);
   *reinterpret_cast<u32x2*>(&S.taps[2 * lane]) = ldg2(&g_taps_chroma.e[0][0] + 2 * lane);
-  if (!wave_prologue(tmrec, T)) return;
+  const uint32_t flags = tm.z >> 24;
+  const bool active = (flags & TM_ACTIVE) != 0;
+  if (!__ballot(active)) return;
+  const bool top = tile_is_top(tm, r, lane ^ 16);
+  const bool any_bi = BI && __ballot((flags & TM_BI) != 0) != 0;
   wave_lds_sync();
-  const int npass = (BI && T.any_bi) ? 2 : 1;
+  const int npass = any_bi ? 2 : 1;
   const int head = bd >= 12 ? 2 : 14 - bd;
   const int sh1 = 6 - head;
-  // H item: threads 0..127 the body items (tile, row pair hq) of both planes; threads 128..255 the halo items of the run tops
-  const int tx = tid & 7, hq = (tid >> 3) & 1;
-  const bool is_halo = tid >= 128;
-  const int hi = ((tid & 127) >> 4) * 8 + tx;              // body: tile;  halo: index into the run tops
-  const bool has_item = !is_halo || hi < T.ntop;
-  const int th = is_halo ? __shfl(T.tl, hi) : hi;
-  const uint32_t h0 = __shfl((int)T.w0, th), h1 = BI ? __shfl((int)T.w1, th) : 0u, h2 = __shfl((int)T.w2, th);
-  const uint32_t hflags = has_item ? h2 >> 24 : 0u;
-  // V item: tile t = (tx, ty), plane vp, output rows 2k, 2k+1
-  const int k = (tid >> 3) & 1, vp = (tid >> 4) & 1, ty = tid >> 5, t = ty * 8 + tx;
-  const uint32_t v0 = __shfl((int)T.w0, t), v1 = BI ? (uint32_t)__shfl((int)T.w1, t) : 0u, v2 = __shfl((int)T.w2, t);
-  const uint32_t vflags = v2 >> 24;
+  uint32_t* const hout = (hi ? S.w[wave].halo : S.w[wave].body) + r * 128 + tx * 2 + hq * 16;     // (r, plane 0, piece 0, hq, tx)
+  uint32_t* const body_v = &S.w[wave].body[r * 128 + hi * 64 + tx * 2];                           // (r, vp, piece 0, row pair 0, tx)
+  uint32_t* const halo_v = &S.w[wave].halo[r * 128 + hi * 64 + tx * 2];
   WpTile wp = {false, 1, 0, 1, 0, 0};
-  if constexpr (WP) wp = wp_tile<WP>(a.slices[slot], vflags, (uint32_t)__shfl((int)T.w3, t), 1 + vp);
-  uint32_t* const hout = (is_halo ? S.halo : S.body) + (th >> 3) * 128 + (th & 7) * 2 + hq * 16;      // (ty, plane 0, piece 0, hq, tx)
-  uint32_t* const body_v = &S.body[ty * 128 + vp * 64 + tx * 2];                                   // (ty, vp, piece 0, row pair 0, tx)
+  if constexpr (WP) wp = wp_tile<WP>(a.slices[slot], flags, tm.w, 1 + hi);
   uint32_t park[4] = {0, 0, 0, 0};
 #pragma unroll 1
   for (int pass = 0; pass < npass; pass++) {
-    const bool hact = (hflags & TM_ACTIVE) && (pass == 0 || (hflags & TM_BI));
-    const bool vact = (vflags & TM_ACTIVE) && (pass == 0 || (vflags & TM_BI));
+    const bool vact = active && (pass == 0 || (flags & TM_BI));
+    const bool hact = vact && (hi == 0 || top);
+    const uint32_t mv = pass ? tm.y : tm.x, fr = (tm.z >> (4 * pass)) & 15;
+    const int ix = (int)(int16_t)(mv & 0xffff), iy = (int)mv >> 16;
     if (hact) {
-      const uint32_t mv = pass ? h1 : h0, fr = (h2 >> (4 * pass)) & 15;
-      const int ix = (int)(int16_t)(mv & 0xffff), iy = (int)mv >> 16;
       // chroma vector = luma vector in eighth samples: integer part ix >> 1, fraction (ix & 1) * 4 + quarter fraction
-      const int xs = ((g.sx >> 1) + (th & 7) * 4) + (ix >> 1) - 1, ys = ((g.sy >> 1) + (th >> 3) * 4) + (iy >> 1) - 1 + (is_halo ? 0 : 4) + 2 * hq;
+      const int xs = (x0 >> 1) + (ix >> 1) - 1, ys = (y0 >> 1) + (iy >> 1) - 1 + (hi ? 0 : 4) + 2 * hq;
       const int xf = ((ix & 1) << 2) | (fr & 3);
-      const char* p0 = final_plane(a, (int)((h2 >> (8 + 8 * pass)) & (kMaxPics - 1))) + ((ptrdiff_t)ys * pitch + (xs & ~1)) * 2;
+      const char* p0 = final_plane(a, (int)((tm.z >> (8 + 8 * pass)) & (kMaxPics - 1))) + ((ptrdiff_t)ys * pitch + (xs & ~1)) * 2;
       const char* p1 = p0 + a.cr_off;
-      u32x4 r[4];
-      r[0] = ldg4_a4(p0); r[1] = ldg4_a4(p0 + pitch * 2); r[2] = ldg4_a4(p1); r[3] = ldg4_a4(p1 + pitch * 2);
-      h_item_chroma(r, &S.taps[(xf * 2 + (xs & 1)) * 8], sh1, hout);
+      u32x4 rr[4];
+      rr[0] = ldg4_a4(p0); rr[1] = ldg4_a4(p0 + pitch * 2); rr[2] = ldg4_a4(p1); rr[3] = ldg4_a4(p1 + pitch * 2);
+      h_item_chroma(rr, &S.taps[(xf * 2 + (xs & 1)) * 8], sh1, hout);
     }
-    __syncthreads();
+    wave_lds_sync();
     if (vact) {
-      const int iy = (int)(pass ? v1 : v0) >> 16;
-      const int yf = ((iy & 1) << 2) | ((v2 >> (4 * pass + 2)) & 3);
-      const uint32_t* above = (vflags & TM_TOP) ? &S.halo[ty * 128 + vp * 64 + tx * 2] : body_v - 128;
-      const uint32_t* tap = &S.taps[yf * 2 * 8];
-      const u32x4 t0 = *reinterpret_cast<const u32x4*>(tap);
-      const u32x2 t1 = *reinterpret_cast<const u32x2*>(tap + 4);
+      const int yf = ((iy & 1) << 2) | ((fr >> 2) & 3);
+      const uint32_t* above = top ? halo_v : body_v - 128;
+      const uint32_t* vtap = &S.taps[yf * 2 * 8];
+      const u32x4 t0 = *reinterpret_cast<const u32x4*>(vtap);
+      const u32x2 t1 = *reinterpret_cast<const u32x2*>(vtap + 4);
       const uint32_t A[2] = {t0.x, t0.y}, B[3] = {t0.w, t1.x, t1.y};
       const int seed = (!WP && !BI) ? 32 << head : 0;
       int v6[2][4];
 #pragma unroll
       for (int j = 0; j < 3; j++) {
-        const int gp = k + j;
+        const int gp = hq + j;
         const uint32_t* src = gp < 2 ? above + gp * 16 : body_v + (gp - 2) * 16;
         const u32x2 c0 = *reinterpret_cast<const u32x2*>(src), c1 = *reinterpret_cast<const u32x2*>(src + 32);
         const uint32_t pr[4] = {c0.x, c0.y, c1.x, c1.y};
@@ -508,10 +473,10 @@ __global__ void __launch_bounds__(256, MC_LB_CHROMA) k_mc_chroma(const McArgs a)
           }
         }
       }
-      const int xc = (g.sx >> 1) + tx * 4, yc = (g.sy >> 1) + ty * 4 + 2 * k;
-      finish_rows<4, WP, BI>(v6, park, pass, (vflags & TM_BI) != 0, bd, wp, (vp ? a.dst2[slot] : a.dst[slot]) + (ptrdiff_t)yc * pitch + xc, pitch);
+      const int xc = x0 >> 1, yc = (y0 >> 1) + 2 * hq;
+      finish_rows<4, WP, BI>(v6, park, pass, (flags & TM_BI) != 0, bd, wp, (hi ? a.dst2[slot] : a.dst[slot]) + (ptrdiff_t)yc * pitch + xc, pitch);
     }
-    if (BI && pass + 1 < npass) __syncthreads();
+    if (BI && pass + 1 < npass) wave_lds_sync();
   }
 }
 
