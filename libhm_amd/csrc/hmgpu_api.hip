@@ -289,9 +289,7 @@ hmgpu_status run_recon(hmgpu_ctx* c, const Batch& b, bool any_intra, bool any_wp
   }
   // blocks per shard: enough to keep the chip busy on a full picture, few enough that a short list costs nothing
   uint32_t bps = (uint32_t)std::max(4, std::min(24, max_ctus / 8 + 1));   // blocks per shard; 24 measured best at 2160p (768 blocks, 3 per CU)
-  if (const char* e = getenv("HMGPU_ITX_BPS")) bps = (uint32_t)std::max(1, atoi(e));   // tuning knob
-  int cmask = 0;
-  if (const char* e = getenv("HMGPU_ITX_CLASSES")) cmask = atoi(e);              // tuning aid (wrong output unless 15)
+  const int cmask = 0;                                      // all four size classes
   { ProfScope ps(c, K_ITX); launch_itx(c->d_pics, b, cmask, bps, c->stream); }
   // intra CUs predict from finished neighbours (inter ones included): after motion compensation and the inter residuals
   if (any_intra) { ProfScope ps(c, K_INTRA); launch_intra(c->d_pics, b, c->d_ctu_order, c->num_ctus, c->stream); }
@@ -301,7 +299,7 @@ hmgpu_status run_recon(hmgpu_ctx* c, const Batch& b, bool any_intra, bool any_wp
 
 hmgpu_status run_filter(hmgpu_ctx* c, const Batch& b, int stages) {
   // all three stages on pictures that all carry SAO: one pass through LDS instead of three through HBM (k_filter.hip)
-  bool all_sao = stages == 7 && !getenv("HMGPU_NO_FUSED_FILTER");
+  bool all_sao = stages == 7;
   for (int i = 0; i < b.n && all_sao; i++) all_sao = c->pics[b.pic[i]].sao_any;
   if (all_sao) {
     bool nofilt = false;

@@ -286,6 +286,9 @@ template <bool WP, bool BI>
 __global__ void __launch_bounds__(256, MC_LB_LUMA) k_mc_luma(const McArgs a) {
   __shared__ __attribute__((aligned(16))) McLds<false> S;
   int slot; Square g;
+#ifdef MC_PRIO
+  __builtin_amdgcn_s_setprio(3);
+#endif
   if (!square_of_block(a, slot, g)) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   if (wave * 16 >= g.ext) return;
@@ -339,6 +342,9 @@ __global__ void __launch_bounds__(256, MC_LB_LUMA) k_mc_luma(const McArgs a) {
         const char* p0 = hact ? pw : dummy;
         rh[0] = ldg4_a4(p0); rh[1] = ldg4_a4(p0 + 16); rh[2] = ldg4_a4(p0 + pitch * 2); rh[3] = ldg4_a4(p0 + pitch * 2 + 16);
       }
+#ifdef MC_PRIO
+      __builtin_amdgcn_s_setprio(0);
+#endif
       if (bact) h_item_luma(rb, tap, sh1, body_t + q * 16);
       if constexpr (HALO) { if (hact) h_item_luma(rh, tap, sh1, halo_t + q * 16); }
     };
@@ -409,6 +415,9 @@ template <bool WP, bool BI>
 __global__ void __launch_bounds__(256, MC_LB_CHROMA) k_mc_chroma(const McArgs a) {
   __shared__ __attribute__((aligned(16))) McLds<true> S;
   int slot; Square g;
+#ifdef MC_PRIO
+  __builtin_amdgcn_s_setprio(3);
+#endif
   if (!square_of_block(a, slot, g)) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   if (wave * 16 >= g.ext) return;
@@ -446,6 +455,9 @@ __global__ void __launch_bounds__(256, MC_LB_CHROMA) k_mc_chroma(const McArgs a)
       const char* p1 = p0 + a.cr_off;
       u32x4 rr[4];
       rr[0] = ldg4_a4(p0); rr[1] = ldg4_a4(p0 + pitch * 2); rr[2] = ldg4_a4(p1); rr[3] = ldg4_a4(p1 + pitch * 2);
+#ifdef MC_PRIO
+      __builtin_amdgcn_s_setprio(0);
+#endif
       h_item_chroma(rr, &S.taps[(xf * 2 + (xs & 1)) * 8], sh1, hout);
     }
     wave_lds_sync();

@@ -81,6 +81,18 @@ bool Decoder::push(const uint8_t* d, size_t len, int max_tl, int* nal_type_out) 
     if (len < 3) throw ParseError("slice NAL unit without payload");
     if ((d[2] & 0x80) && cur_) {           // first_slice_segment_in_pic_flag while a picture is open: close it, unit comes again
       if (!threaded()) { finish_picture(); return true; }
+      // A unit that activates another sequence parameter set replaces the picture store (activate()): it must not be taken in before
+      // the application has fetched what is still to be output.  Answer "new picture" with the pipeline drained, exactly as the
+      // single-threaded decoder does; the unit is decoded when it comes again.
+      bool reseq = true;
+      try {
+        std::vector<uint8_t> probe = nal_to_rbsp(d + 2, len - 2, nullptr);
+        BitReader pbr(probe.data(), probe.size());
+        SliceHeader psh;
+        parse_slice_header(pbr, type, tid, ps_, have_independent_ ? &last_independent_ : nullptr, psh);
+        reseq = opens_new_sequence(psh);
+      } catch (...) {}                     // (an unparsable header is reported when the unit comes again)
+      if (reseq) { finish_picture(); return true; }
       // Parser threads: the finished picture is closed (its thread may still be busy: nobody waits here) and the new unit is taken
       // in at once, so that its parsing overlaps whatever the caller does before repeating it -- typically fetching output
       // pictures, which waits for the device.  The answer is still "new picture"; the repetition is skipped above.
@@ -146,14 +158,23 @@ void Decoder::parse_sei(const std::vector<uint8_t>& rbsp, bool suffix) {
 }
 
 // ------------------------------------------------------------------------------------------------ picture level
+// the slice's parameter sets need another picture store / device context than the active ones
+bool Decoder::opens_new_sequence(const SliceHeader& sh) const {
+  if (sh.pps_id < 0 || sh.pps_id >= 64 || !ps_.pps[sh.pps_id]) return true;
+  const std::shared_ptr<Pps>& pps = ps_.pps[sh.pps_id];
+  if (pps->sps_id < 0 || pps->sps_id >= 16 || !ps_.sps[pps->sps_id]) return true;
+  const std::shared_ptr<Sps>& sps = ps_.sps[pps->sps_id];
+  return !sps_ || sps_->width != sps->width || sps_->height != sps->height || sps_->log2_ctb != sps->log2_ctb ||
+         sps_->bit_depth_luma != sps->bit_depth_luma || sps_->bit_depth_chroma != sps->bit_depth_chroma || sps_->pcm != sps->pcm ||
+         sps_->pcm_bit_depth_luma != sps->pcm_bit_depth_luma || sps_->pcm_bit_depth_chroma != sps->pcm_bit_depth_chroma ||
+         sps_->pcm_loop_filter_disabled != sps->pcm_loop_filter_disabled || sps_->strong_intra_smoothing != sps->strong_intra_smoothing ||
+         sps_->max_dec_pic_buffering[sps_->max_sub_layers - 1] != sps->max_dec_pic_buffering[sps->max_sub_layers - 1];
+}
+
 void Decoder::activate(const SliceHeader& sh) {
   std::shared_ptr<Pps> pps = ps_.pps[sh.pps_id];
   std::shared_ptr<Sps> sps = ps_.sps[pps->sps_id];
-  const bool new_seq = !sps_ || sps_->width != sps->width || sps_->height != sps->height || sps_->log2_ctb != sps->log2_ctb ||
-                       sps_->bit_depth_luma != sps->bit_depth_luma || sps_->bit_depth_chroma != sps->bit_depth_chroma || sps_->pcm != sps->pcm ||
-                       sps_->pcm_bit_depth_luma != sps->pcm_bit_depth_luma || sps_->pcm_bit_depth_chroma != sps->pcm_bit_depth_chroma ||
-                       sps_->pcm_loop_filter_disabled != sps->pcm_loop_filter_disabled || sps_->strong_intra_smoothing != sps->strong_intra_smoothing ||
-                       sps_->max_dec_pic_buffering[sps_->max_sub_layers - 1] != sps->max_dec_pic_buffering[sps->max_sub_layers - 1];
+  const bool new_seq = opens_new_sequence(sh);
   if (new_seq && threaded()) { close_current(); retire_ready(true); }      // nothing of the old sequence may still be in flight
   sps_ = sps;
   pps_ = pps;
@@ -166,8 +187,19 @@ void Decoder::activate(const SliceHeader& sh) {
   }
   if (!new_seq) return;
   if (!is_irap(sh.nal_type)) throw ParseError("a new sequence parameter set is activated by a picture that is not an IRAP picture");
-  // a new coded video sequence with another geometry: the picture store starts over (pictures not yet output are dropped)
+  // a new coded video sequence with another geometry: the picture store starts over.  Pictures the application holds or has still
+  // to fetch from the output queue stay alive (retired_, samples on the host) until the next change of sequence; pictures that were
+  // never put out are dropped, as in HM.
+  retired_.clear();
+  for (auto& p : pool_) {
+    const bool queued = std::find(out_queue_.begin(), out_queue_.end(), p.get()) != out_queue_.end();
+    if (queued) fetch_planes(p.get());     // (the device context that holds the samples goes away below)
+    if (queued || p->lent) retired_.push_back(std::move(p));
+  }
   pool_.clear();
+  scan_.clear();
+  scan_idx_ = 0;
+  last_decoded_ = nullptr;
   if (gpu_) { hmgpu_destroy(gpu_); gpu_ = nullptr; }
   zscan_.init(sps_->log2_ctb);
   memset(&seq_, 0, sizeof(seq_));
@@ -564,7 +596,6 @@ void Decoder::worker_main() {
         }
         continue;
       }
-      if (getenv("HMDEC_TRACE")) { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); fprintf(stderr, "%ld.%06ld begin POC %d slice %d\n", ts.tv_sec % 1000, ts.tv_nsec / 1000, t->pic->poc, job.slice_idx); }
       try {
         SliceDecoder sd(*job.sps, *job.pps, *t->pic, t->state, &hooks_);
         sd.decode(job.sh, job.slice_idx, job.rbsp.data(), job.rbsp.size());
@@ -572,7 +603,6 @@ void Decoder::worker_main() {
         std::lock_guard<std::mutex> lk(mu_);
         t->error = e.what();
       }
-      if (getenv("HMDEC_TRACE")) { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); fprintf(stderr, "%ld.%06ld end   POC %d\n", ts.tv_sec % 1000, ts.tv_nsec / 1000, t->pic->poc); }
     }
     {
       std::lock_guard<std::mutex> lk(mu_);
@@ -593,7 +623,6 @@ void Decoder::run_wpp_rows(const SliceJob& job, PicTask* t) {
       for (auto it = wpp_sessions_.begin(); it != wpp_sessions_.end(); ++it)
         if (it->job->wpp.get() == &w) { wpp_sessions_.erase(it); break; }
     }
-    if (getenv("HMDEC_TRACE")) { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); fprintf(stderr, "%ld.%06ld POC %d unit %d begins (thread %lx)\n", ts.tv_sec % 1000, ts.tv_nsec / 1000, t->pic->poc, row, (unsigned long)pthread_self() & 0xffffff); }
     PicParseState st;
     SliceDecoder sd(*job.sps, *job.pps, *t->pic, st, &hooks_);
     if (w.tiles) sd.decode_tile(job.sh, job.slice_idx, job.rbsp.data(), job.rbsp.size(), row, w);

@@ -53,6 +53,7 @@ class Decoder {
 
  private:
   void activate(const SliceHeader& sh);
+  bool opens_new_sequence(const SliceHeader& sh) const;
   void start_picture(const SliceHeader& sh);
   void decode_slice(const std::vector<uint8_t>& rbsp, BitReader& br, SliceHeader& sh, const std::vector<size_t>& epb);
   int compute_poc(const SliceHeader& sh);
@@ -76,6 +77,7 @@ class Decoder {
   hmgpu_ctx* gpu_ = nullptr;
   hmgpu_seq_params seq_{};
   std::vector<std::unique_ptr<PicData>> pool_;            // DPB + free buffers
+  std::vector<std::unique_ptr<PicData>> retired_;         // pictures of the previous sequence the application may still hold
   PicData* cur_ = nullptr;
   PicData* last_decoded_ = nullptr;
   PicParseState parse_state_;

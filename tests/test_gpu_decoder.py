@@ -30,6 +30,25 @@ def test_bitstream_to_pictures_matches_hm(name, threads):
     assert hmdec.lib().libHMDEC_get_internal_bit_depth(0) == want[out[0]].bd_y
 
 
+@pytest.mark.parametrize("threads", [1, 3])
+def test_change_of_sequence_mid_stream_on_the_device(threads):
+    """two HM clips of different geometry back to back (the second IDR activates another SPS: new picture store, new device
+    context): every picture of both clips comes out with HM's samples, with parser threads too"""
+    names = ("ldp_main8_416x240", "ldp_main10_208x120")
+    data = b"".join(bytes(gu.load("stream_" + n)["bitstream"]) for n in names)
+    want = [{p.poc: p for p in gu.stream_pictures(n)} for n in names]
+    out = []
+    with hmdec.Decoder(threads=threads) as d:
+        def on_output(p):
+            clip = 0 if p.size(0) == (416, 240) else 1
+            out.append((clip, p.poc))
+            for c in range(3):
+                assert np.array_equal(p.plane(c), want[clip][p.poc].fin[c]), "clip %d POC %d component %d" % (clip, p.poc, c)
+        d.decode_stream(data, on_output=on_output)
+        assert d.hash_mismatches == 0
+    assert out == [(0, poc) for poc in sorted(want[0])] + [(1, poc) for poc in sorted(want[1])]
+
+
 def test_hash_check_notices_a_wrong_picture():
     """the SEI check is live: the same stream with one SEI digest byte flipped reports a mismatch (and still decodes)"""
     z = gu.load("stream_ldp_main8_416x240")

@@ -19,10 +19,11 @@ def _oracle_picture(oracle, p, sl, refs):
     return oracle.sao_process(p.seq, [sl], p.pp, p.meta, prm, cur)
 
 
-def test_gop_of_8_matches_oracle(oracle):
+@pytest.mark.parametrize("w,h", [(416, 240), (3840, 2160)])     # BASELINE config #5 at its full size too (one GOP, one GPU)
+def test_gop_of_8_matches_oracle(oracle, w, h):
     import libhm_amd
     from libhm_amd import abi
-    w, h, bd = 416, 240, 10
+    bd = 10
     pics = {poc: synth.make_picture(w, h, bd, seed=40 + poc, bi=True, ref_handles=([0], [0])) for poc in fp.RA_GOP8}
     anchor = synth.noise_planes(w, h, bd, 7)
     # oracle: decode order, every picture from the finished planes of its two references

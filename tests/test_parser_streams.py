@@ -219,3 +219,26 @@ def test_parser_threads_change_nothing_at_full_size(stream, threads):
     assert sorted(a) == sorted(b) and len(a) >= 5
     for poc in a:
         assert a[poc] == b[poc], "POC %d: %s" % (poc, [n for n in a[poc] if a[poc][n] != b[poc][n]])
+
+
+@pytest.mark.parametrize("threads", [1, 3])
+def test_change_of_sequence_mid_stream(threads):
+    """two clips of different geometry back to back: the second IDR activates another SPS, the picture store starts over -- after
+    every picture of the first clip has come out, with parser threads too (the unit that opens the new sequence is not taken in
+    before the application has flushed: it used to free pictures that were still queued for output)"""
+    a, b = gu.load("stream_ldp_main8_416x240"), gu.load("stream_ldp_main10_208x120")
+    data = bytes(a["bitstream"]) + bytes(b["bitstream"])
+    na, nb = int(a["num_pics"][0]), int(b["num_pics"][0])
+    out = []
+    with hmdec.Decoder(parse_only=True, threads=threads) as d:
+        d.decode_stream(data, on_output=lambda p: out.append((p.poc, p.geometry()["width"], p.geometry()["height"], p.hash_sei())))
+        assert d.pictures_decoded == na + nb
+    assert [(w, h) for _, w, h, _ in out] == [(416, 240)] * na + [(208, 120)] * nb
+    assert [poc for poc, _, _, _ in out[:na]] == sorted(poc for poc, _, _, _ in out[:na])
+    assert [poc for poc, _, _, _ in out[na:]] == sorted(poc for poc, _, _, _ in out[na:])
+    ref = {}
+    for z, n in ((a, na), (b, nb)):
+        with hmdec.Decoder(parse_only=True) as d:
+            d.decode_stream(z["bitstream"], on_output=lambda p: ref.setdefault((p.geometry()["width"], p.poc), p.hash_sei()))
+    for poc, w, h, hs in out:
+        assert hs == ref[(w, poc)]
