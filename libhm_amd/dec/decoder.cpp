@@ -61,6 +61,14 @@ Decoder::~Decoder() {
 
 // ------------------------------------------------------------------------------------------------ NAL level
 bool Decoder::push(const uint8_t* d, size_t len, int max_tl, int* nal_type_out) {
+  const bool again = push_unit(d, len, max_tl, nal_type_out);
+  // a picture further back in the parser pipeline failed: said now that this unit has been processed (when the unit has to come
+  // again -- "new picture" -- the report waits for the repetition)
+  if (!again && !deferred_error_.empty()) throw ParseError(take_deferred_error());
+  return again;
+}
+
+bool Decoder::push_unit(const uint8_t* d, size_t len, int max_tl, int* nal_type_out) {
   if (len >= 3 && d[0] == 0 && d[1] == 0 && d[2] == 1) { d += 3; len -= 3; }
   else if (len >= 4 && d[0] == 0 && d[1] == 0 && d[2] == 0 && d[3] == 1) { d += 4; len -= 4; }
   if (len < 2) throw ParseError("NAL unit shorter than its header");
@@ -663,7 +671,10 @@ void Decoder::retire_ready(bool wait_all) {
       p->is_reference = p->is_long_term = false;
       p->needed_for_output = false;
       p->decoded = false;
-      throw ParseError(error);
+      // reported once the unit that is being pushed has been dealt with (push()): the error belongs to an EARLIER picture, and
+      // the pictures behind it in the pipeline still have to be retired
+      if (deferred_error_.empty()) deferred_error_ = error;
+      continue;
     }
     submit_picture(p, parsed);
     begin_output_scan(max_tl_);

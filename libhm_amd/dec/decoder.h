@@ -36,6 +36,7 @@ class Decoder {
   // One NAL unit (with or without a start code).  Returns true when the unit starts a new picture while the previous one was still
   // open: that picture has then been finished and the SAME unit must be pushed again (libHM's bNewPicture protocol).
   bool push(const uint8_t* data, size_t len, int max_temporal_layer, int* nal_type_out);
+  std::string take_deferred_error() { std::string e; e.swap(deferred_error_); return e; }   // error of a picture retired earlier, if any
   void finish_picture();                                  // TDecTop::executeLoopFilters
   void flush();                                           // end of stream / EOS: everything still waiting becomes output
   // output: libHM's rules (libHMDecoder.cpp:248-339)
@@ -101,6 +102,8 @@ class Decoder {
   int device_ = 0, hash_mismatches_ = 0, pictures_decoded_ = 0;
   uint64_t submitted_seq_ = 0, synced_seq_ = 0;            // device submissions / the last one known to have completed
   std::string last_error_;
+  std::string deferred_error_;                            // parse error of a picture that left the pipeline while another unit was pushed
+  bool push_unit(const uint8_t* data, size_t len, int max_temporal_layer, int* nal_type_out);
   // ---- frame-parallel parsing
   struct SliceJob {
     SliceHeader sh; int slice_idx = 0; std::vector<uint8_t> rbsp; std::shared_ptr<Sps> sps; std::shared_ptr<Pps> pps;

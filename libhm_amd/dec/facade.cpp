@@ -87,6 +87,10 @@ libHMDec_error libHMDec_push_nal_unit(libHMDec_context* ctx, const void* data8, 
       return LIBHMDEC_ERROR_READ_ERROR;
     }
     checkOutputPictures = true;
+    if (eof) {                             // a picture dropped while the pipeline drained: nothing follows that could report it
+      const std::string late = w->dec.take_deferred_error();
+      if (!late.empty()) { w->dec.set_error(std::string("bitstream: ") + late); return LIBHMDEC_ERROR_READ_ERROR; }
+    }
     return LIBHMDEC_OK;
   }
   w->flush_output = false;
