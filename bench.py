@@ -91,6 +91,7 @@ def main():
     ap.add_argument("--streams", type=int, default=1, choices=(1, 2), help="2: the batch runs as two half-batches on two HIP streams (kernels of different kinds overlap)")
     ap.add_argument("--threads", type=int, default=8, help="decode workload: parser threads of libhmdec (1 = all on the calling thread)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-host-inclusive", action="store_true", help="skip the host-inclusive (staging included) measurement of the default workload")
     ap.add_argument("--profile-steps", type=int, default=5)
     args = ap.parse_args()
 
@@ -111,7 +112,9 @@ def main():
     nb = args.batch
     wl = args.workload
     RECON, FILTER = 8, 7
-    stages, roof_kernel, kw = RECON | FILTER, None, {}
+    # the roofline object is pinned to the motion-compensation kernel, the one kernel BASELINE.json's north star puts a number on
+    # (>= 40 % of the HBM roofline); `kernels` lists all of them
+    stages, roof_kernel, kw = RECON | FILTER, "mc_luma", {}
     if wl == "idct":
         w, h = 1920, 1080
         stages, roof_kernel = RECON, "itx"
@@ -138,13 +141,15 @@ def main():
     # two distinct parsed pictures, staged alternately into nb device pictures with their own buffers
     # every picture of the batch predicts from its OWN reference pictures (no flattering reuse of one reference in cache)
     metas = [synth.make_picture(w, h, bd, seed=0x484D3136 + 7 * rank + i, bi=bool(args.bi), ref_handles=([0], [1]), **kw) for i in range(2)]
-    seq = abi.make_seq(w, h, bd, bd, log2_ctu=6, max_pictures=3 * nb)
+    host_incl = wl == "full" and world == 1 and not args.no_host_inclusive and 4 * nb <= 64
+    seq = abi.make_seq(w, h, bd, bd, log2_ctu=6, max_pictures=(4 if host_incl else 3) * nb)
     ctx = libhm_amd.Context(seq, device=local_rank)
     ref_planes = [synth.noise_planes(w, h, bd, 100 + rank), synth.blocky_planes(w, h, bd, 200 + rank)]
-    pics = []
+    pics, refs_of = [], []
     t_stage = time.time()
     for i in range(nb):
         r0, r1 = ctx.acquire(), ctx.acquire()
+        refs_of.append((r0, r1))
         ctx.upload(r0, ref_planes[0])
         ctx.upload(r1, ref_planes[1])
         hc = ctx.acquire()
@@ -173,6 +178,13 @@ def main():
     st = ctx.stats(reset=True)
     ctx.set_profiling(False)
 
+    # ---- host-inclusive steady state (SURVEY 8d "slice" figure): the same pictures through the product entry points
+    # hmgpu_decompress_pictures + hmgpu_filter_pictures, every input travelling from page-locked staging blocks over PCIe each
+    # step; two sets of device pictures, so that the inputs of one step are copied while the kernels of the previous one run
+    hi = None
+    if host_incl:
+        hi = host_inclusive(ctx, metas, pics, refs_of, nb, w, h, args)
+
     if rank == 0:
         luma_px = w * h
         total_px = world * nb * args.steps * luma_px
@@ -194,14 +206,22 @@ def main():
             roof_kernel = "filter_fused"                   # all three loop-filter stages run as one kernel when every picture has SAO
         if roof_kernel is not None:
             dom = roof_kernel
-        # HBM traffic per launch from the committed PMC passes of this same command (tools/round_profile.sh + pmc_summary.py):
-        # counters cannot be read from inside the process, so the figure is only reported for the workload it was taken on
-        traffic = None
+        # HBM traffic per launch: counters cannot be read from inside the process, so the figure comes from the PMC passes of this
+        # same command (tools/round_profile.sh + tools/pmc_summary.py -> profiles/hbm_traffic.json) -- and only when that file was
+        # taken from the kernel sources this run is built from (sha256 over libhm_amd/csrc), else null
+        traffic, traffic_source = None, None
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if wl == "full" and nb == 16 and args.streams == 1 and not args.bi and (w, h) == (3840, 2160) and os.path.exists(tpath):
-            traffic = json.load(open(tpath))["kernels"].get(dom, {}).get("traffic_bytes")
+            tj = json.load(open(tpath))
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import pmc_summary_digest
+            if tj.get("csrc_sha16") == pmc_summary_digest.csrc_digest():
+                traffic = tj["kernels"].get(dom, {}).get("traffic_bytes")
+                traffic_source = "profiles/hbm_traffic.json@csrc:" + tj["csrc_sha16"]
+            else:
+                traffic_source = "none: profiles/hbm_traffic.json was taken from other kernel sources (%s)" % tj.get("csrc_sha16")
         roof = {"kernel": dom, "bound": "hbm", "achieved": kernels[dom]["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": kernels[dom]["frac"], "traffic": traffic,
+                "frac": kernels[dom]["frac"], "traffic": traffic, "traffic_source": traffic_source,
                 "algorithmic_bytes_per_launch": int(kernels[dom]["alg_MB"] * 1e6)}
         dev_ms = sum(k["avg_ms"] for k in kernels.values())
         out = {
@@ -225,12 +245,58 @@ def main():
         }
         if copy_gbps is not None:
             out["hbm_copy_GBps_measured"] = copy_gbps
+        if hi is not None:
+            out.update(hi)
         if not args.no_cpu_baseline and world == 1 and wl == "full":
-            out["cpu_baseline"] = cpu_baseline(metas[0], w, h, bd)
+            out["cpu_baseline"] = cpu_baseline(metas[0], w, h, bd, 1, 10.0)
+            out["cpu_baseline_all_cores"] = cpu_baseline(metas[0], w, h, bd, 0, 10.0)
         print(json.dumps(out), flush=True)
     ctx.close()
     if dist is not None:
         dist.destroy_process_group()
+
+
+def host_inclusive(ctx, metas, pics, refs_of, nb, w, h, args):
+    """steady-state throughput of the product path with host -> device staging inside the timed region"""
+    from libhm_amd import abi
+    stg = []
+    for i in range(nb):                                        # one staging block per picture of a step (page-locked, filled once)
+        s = ctx.staging_alloc()
+        s.fill(metas[i % 2].meta, metas[i % 2].coeffs)
+        stg.append(s)
+    sets = [pics, [ctx.acquire() for _ in range(nb)]]
+    slices = []
+    for i in range(nb):
+        sl = abi.clone_slice(metas[i % 2].slice)
+        for l, r in ((0, refs_of[i][0]), (1, refs_of[i][1])):
+            if sl.num_ref_idx[l] > 0:
+                sl.ref_pic[l][0] = r
+        slices.append(sl)
+    sao = [abi.sao_array_from_raw(m.sao_raw) for m in metas]
+    djobs = [ctx.picture_jobs([(hset[i], [slices[i]], stg[i], stg[i]) for i in range(nb)]) for hset in sets]
+    fjobs = [ctx.filter_jobs([(hset[i], metas[i % 2].pp, sao[i % 2]) for i in range(nb)]) for hset in sets]
+
+    def step(k):
+        ctx.decompress_pictures(djobs[k & 1])
+        ctx.filter_pictures(fjobs[k & 1])
+    for k in range(4):
+        step(k)
+    ctx.sync()
+    n = max(4, args.steps)
+    t0 = time.perf_counter()
+    for k in range(n):
+        step(k)
+    ctx.sync()
+    dt = time.perf_counter() - t0
+    staged = stg[0].arrays["depth"].nbytes and sum(a.nbytes for a in stg[0].arrays.values()) + sum(a.nbytes for a in stg[0].levels)
+    for s in stg:
+        ctx.staging_free(s)
+    return {"host_inclusive_Mpixels_s": round(n * nb * w * h / dt / 1e6, 1),
+            "host_inclusive": {"ms_per_step": round(dt / n * 1e3, 3), "steps": n, "staged_bytes_per_picture": int(staged),
+                               "PCIe_GBps": round(n * nb * staged / dt / 1e9, 1),
+                               "what": "hmgpu_decompress_pictures + hmgpu_filter_pictures per step, inputs copied from page-locked staging "
+                                       "blocks every step (two DMAs per picture on a copy stream, two sets of device pictures: "
+                                       "the copies of a step overlap the kernels of the previous one)"}}
 
 
 def gop_main(args, hdist, dist, rank, world, local_rank, copy_gbps):
@@ -395,29 +461,57 @@ def measured_copy_bandwidth(device):
     return gbps
 
 
-def cpu_baseline(p, w, h, bd):
-    """the oracle (C restatement of HM, pinned against HM goldens) on this box's host: single thread, whole pictures"""
+def cpu_baseline(p, w, h, bd, threads, seconds):
+    """the oracle (C restatement of HM, pinned against HM goldens) on this box's host: whole pictures of the same workload.
+    threads = 1: one picture after the other on one core; threads = 0: one worker per core this process may use, every worker
+    its own independent pictures (frame-parallel, as the device batch is) -- the C calls release the interpreter lock"""
+    import threading
     from oracle import hmoracle
     from tests import synth
     from libhm_amd import abi
     hmoracle.lib()
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    nthr = cores if threads == 0 else threads
     refs = [synth.noise_planes(w, h, bd, 100), synth.blocky_planes(w, h, bd, 200)]
     sl = abi.clone_slice(p.slice)             # the device run re-pointed the reference handles at its own pictures
     for l in range(2):
         if sl.num_ref_idx[l] > 0:
             sl.ref_pic[l][0] = l
-    n, t_total = 0, 0.0
-    while t_total < 10.0 and n < 40:
+    done = [0] * nthr
+    t_end = [0.0]
+
+    def one_picture():
         cur = [np.zeros_like(r) for r in refs[0]]
-        t0 = time.perf_counter()
         hmoracle.decompress_ctus(p.seq, [sl], p.meta, p.coeffs, cur, refs)
         hmoracle.loop_filter_pic(p.seq, [sl], p.meta, p.pp, cur, 3)
         prm = hmoracle.sao_reconstruct_params(p.seq, p.pp, p.meta, p.sao_raw)
         hmoracle.sao_process(p.seq, [sl], p.pp, p.meta, prm, cur)
-        t_total += time.perf_counter() - t0
-        n += 1
-    return {"value": round(n * w * h / t_total / 1e6, 2), "unit": "Mpixels/s", "cores": 1, "kind": "port",
-            "sample": "%d whole %dx%d pictures of the same synthetic workload through oracle/hm_oracle.c (recon+deblock+SAO), %.1f s" % (n, w, h, t_total)}
+
+    def worker(i, deadline):
+        while time.perf_counter() < deadline and done[i] < 40:
+            one_picture()
+            done[i] += 1
+        t_end[0] = max(t_end[0], time.perf_counter())
+
+    t0 = time.perf_counter()
+    ts = [threading.Thread(target=worker, args=(i, t0 + seconds)) for i in range(nthr)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    t_total = t_end[0] - t0
+    n = sum(done)
+    model = ""
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return {"value": round(n * w * h / t_total / 1e6, 2), "unit": "Mpixels/s", "cores": nthr, "kind": "port", "cpu": model,
+            "sample": "%d whole %dx%d pictures of the same synthetic workload through oracle/hm_oracle.c (recon+deblock+SAO) on %d thread%s, %.1f s" %
+                      (n, w, h, nthr, "" if nthr == 1 else "s (one picture each at a time)", t_total)}
 
 
 if __name__ == "__main__":

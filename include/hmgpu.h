@@ -222,6 +222,37 @@ hmgpu_status hmgpu_decompress_slice(hmgpu_ctx* ctx, hmgpu_pic cur, int32_t slice
 hmgpu_status hmgpu_decompress_picture(hmgpu_ctx* ctx, hmgpu_pic cur, int32_t num_slices, const hmgpu_slice_params* const* slices,
                                       const hmgpu_ctu_meta* meta, const hmgpu_coeffs* coeffs);
 
+/* ------------------------------------------------------------------------------------------------ several pictures per call
+ * TDecGop::decompressSlice / filterPicture (TDecGop.cpp:105,157) are called once per picture; a caller that holds several parsed
+ * pictures which do not reference each other -- the B pictures of one temporal level, the pictures of independent streams -- hands
+ * them over together: the inputs of all of them are staged on a copy stream of their own (so they travel while the kernels of the
+ * previous call still run) and every kernel is launched ONCE for the whole set (n <= 16).  Equivalent to hmgpu_decompress_picture /
+ * hmgpu_filter_picture per picture.  The input arrays must stay untouched until hmgpu_sync() or until a later call that names the
+ * same picture returns (that call waits for the earlier copy). */
+typedef struct hmgpu_picture_job {
+  hmgpu_pic pic;
+  int32_t num_slices;
+  const hmgpu_slice_params* const* slices;
+  const hmgpu_ctu_meta* meta;
+  const hmgpu_coeffs* coeffs;
+} hmgpu_picture_job;
+typedef struct hmgpu_filter_job {
+  hmgpu_pic pic;
+  const hmgpu_pic_params* pp;
+  const hmgpu_sao_param* sao;      /* [num_ctus][3], or NULL when pp->sao_enabled == 0 */
+} hmgpu_filter_job;
+hmgpu_status hmgpu_decompress_pictures(hmgpu_ctx* ctx, int32_t n, const hmgpu_picture_job* jobs);
+hmgpu_status hmgpu_filter_pictures(hmgpu_ctx* ctx, int32_t n, const hmgpu_filter_job* jobs);
+
+/* Staging blocks: ONE page-locked allocation that holds all input arrays of a picture (TComDataCU's arrays, TComDataCU.h:86-157, and
+ * the levels m_pcTrCoeff*) in the order the device keeps them.  hmgpu_staging_alloc fills *meta and *coeffs with pointers into the
+ * block -- a parser writes HM's arrays there directly, part_size pre-set to HMGPU_SIZE_NONE, ref_idx to -1, everything else to 0 --
+ * and a whole-picture call that is handed exactly these structs moves the metadata in one DMA and the levels in another instead of
+ * one copy per array.  PCM samples are not part of the block (coeffs->pcm_sample stays the caller's). */
+typedef struct hmgpu_staging hmgpu_staging;
+hmgpu_status hmgpu_staging_alloc(hmgpu_ctx* ctx, hmgpu_staging** out, hmgpu_ctu_meta* meta, hmgpu_coeffs* coeffs);
+void         hmgpu_staging_free(hmgpu_ctx* ctx, hmgpu_staging* staging);
+
 /* ------------------------------------------------------------------------------------------------ call 2
  * Replaces TDecGop::filterPicture (TDecGop.cpp:157-217): TComLoopFilter::loopFilterPic (all vertical edges, then
  * all horizontal edges), then reconstructBlkSAOParams + SAOProcess.  Uses the metadata of every CTU handed to

@@ -81,6 +81,11 @@ def lib():
                                              C.POINTER(abi.Coeffs), C.c_int32, C.c_int32]
         L.hmgpu_filter_picture.argtypes = [C.c_void_p, C.c_int32, C.POINTER(abi.PicParams), C.c_void_p]
         L.hmgpu_filter_picture_stages.argtypes = [C.c_void_p, C.c_int32, C.POINTER(abi.PicParams), C.c_void_p, C.c_int32]
+        L.hmgpu_decompress_pictures.argtypes = [C.c_void_p, C.c_int32, C.POINTER(abi.PictureJob)]
+        L.hmgpu_filter_pictures.argtypes = [C.c_void_p, C.c_int32, C.POINTER(abi.FilterJob)]
+        L.hmgpu_staging_alloc.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(abi.CtuMeta), C.POINTER(abi.Coeffs)]
+        L.hmgpu_staging_free.argtypes = [C.c_void_p, C.c_void_p]
+        L.hmgpu_staging_free.restype = None
         L.hmgpu_replay.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32]
         L.hmgpu_replay_batch.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.c_int32, C.c_int32, C.c_int32]
         L.hmgpu_set_profiling.argtypes = [C.c_void_p, C.c_int32]
@@ -197,6 +202,48 @@ class Context:
         arr = abi.sao_array_from_raw(sao_raw) if sao_raw is not None else None
         st = lib().hmgpu_filter_picture_stages(self._h, pic, C.byref(pic_params), arr, stages)
         self._chk(st, "hmgpu_filter_picture_stages")
+
+    # ---- the same for several independent pictures per call
+    @staticmethod
+    def picture_jobs(jobs):
+        """jobs: [(pic, [slice_params, ...], meta, coeffs), ...] with meta / coeffs anything that has .struct (MetaHolder, CoeffHolder)
+        or a StagingHolder passed for both -> the C array (reusable; keeps what it points to alive)"""
+        arr = (abi.PictureJob * len(jobs))()
+        arr._keep = [jobs]
+        for i, (pic, slices, meta, coeffs) in enumerate(jobs):
+            sl = (C.POINTER(abi.SliceParams) * len(slices))(*[C.pointer(s) for s in slices])
+            arr._keep.append(sl)
+            arr[i].pic, arr[i].num_slices, arr[i].slices = pic, len(slices), sl
+            arr[i].meta = C.pointer(meta.struct)
+            arr[i].coeffs = C.pointer(coeffs.coeffs if isinstance(coeffs, abi.StagingHolder) else coeffs.struct)
+        return arr
+
+    @staticmethod
+    def filter_jobs(jobs):
+        """jobs: [(pic, pic_params, sao_array or None), ...]; sao_array = abi.sao_array_from_raw(...)"""
+        arr = (abi.FilterJob * len(jobs))()
+        arr._keep = [jobs]
+        for i, (pic, pp, sao) in enumerate(jobs):
+            arr[i].pic, arr[i].pp = pic, C.pointer(pp)
+            arr[i].sao = C.cast(sao, C.c_void_p) if sao is not None else None
+        return arr
+
+    def decompress_pictures(self, jobs):
+        arr = jobs if isinstance(jobs, C.Array) else self.picture_jobs(jobs)
+        self._chk(lib().hmgpu_decompress_pictures(self._h, len(arr), arr), "hmgpu_decompress_pictures")
+
+    def filter_pictures(self, jobs):
+        arr = jobs if isinstance(jobs, C.Array) else self.filter_jobs(jobs)
+        self._chk(lib().hmgpu_filter_pictures(self._h, len(arr), arr), "hmgpu_filter_pictures")
+
+    def staging_alloc(self):
+        h = C.c_void_p()
+        m, co = abi.CtuMeta(), abi.Coeffs()
+        self._chk(lib().hmgpu_staging_alloc(self._h, C.byref(h), C.byref(m), C.byref(co)), "hmgpu_staging_alloc")
+        return abi.StagingHolder(h, m, co, self.num_ctus, abi.parts_per_ctu(self.seq), 1 << self.seq.log2_ctu_size)
+
+    def staging_free(self, st):
+        lib().hmgpu_staging_free(self._h, st.handle)
 
     def replay(self, pics, stages, iters):
         pics = list(pics) if isinstance(pics, (list, tuple)) else [pics]

@@ -61,6 +61,15 @@ class PicParams(C.Structure):
                 ("sao_offset_shift_chroma", C.c_int32), ("reserved", C.c_int32 * 8)]
 
 
+class PictureJob(C.Structure):
+    _fields_ = [("pic", C.c_int32), ("num_slices", C.c_int32), ("slices", C.POINTER(C.POINTER(SliceParams))),
+                ("meta", C.POINTER(CtuMeta)), ("coeffs", C.POINTER(Coeffs))]
+
+
+class FilterJob(C.Structure):
+    _fields_ = [("pic", C.c_int32), ("pp", C.POINTER(PicParams)), ("sao", C.c_void_p)]
+
+
 class Stats(C.Structure):
     _fields_ = [("kernel_ms", C.c_double * NUM_KERNELS), ("kernel_launches", C.c_uint64 * NUM_KERNELS),
                 ("intra_partitions", C.c_uint64), ("inter_partitions", C.c_uint64), ("coded_tus", (C.c_uint64 * 3) * 4)]
@@ -122,6 +131,41 @@ class MetaHolder:
         m.transquant_bypass, m.ipcm = _ptr(g["bypass"]), _ptr(g["ipcm"])
         m.slice_idx, m.tile_idx = _ptr(g["slice_idx"]), _ptr(g["tile_idx"])
         self.struct = m
+
+
+class StagingHolder:
+    """numpy views of a staging block (hmgpu_staging_alloc): .arrays[name] / .levels[k] alias the page-locked memory, .struct /
+    .coeffs are the structs to hand to the whole-picture calls; fill(meta_holder, coeff_holder) copies ordinary arrays in."""
+
+    def __init__(self, handle, meta_struct, coeff_struct, num_ctus, parts, ctu):
+        self.handle, self.struct, self.coeffs = handle, meta_struct, coeff_struct
+        np_ = num_ctus * parts
+
+        def view(addr, dt, n):
+            return np.ctypeslib.as_array(C.cast(addr, C.POINTER(C.c_uint8)), shape=(n * np.dtype(dt).itemsize,)).view(dt)
+        m = meta_struct
+        addr = {"depth": m.depth, "part_size": m.part_size, "pred_mode": m.pred_mode, "qp": m.qp, "tr_idx": m.tr_idx,
+                "cbf_y": m.cbf[0], "cbf_u": m.cbf[1], "cbf_v": m.cbf[2], "ts_y": m.transform_skip[0], "ts_u": m.transform_skip[1],
+                "ts_v": m.transform_skip[2], "mv0": m.mv[0], "mv1": m.mv[1], "ref_idx0": m.ref_idx[0], "ref_idx1": m.ref_idx[1],
+                "intra_dir_l": m.intra_dir[0], "intra_dir_c": m.intra_dir[1], "bypass": m.transquant_bypass, "ipcm": m.ipcm,
+                "slice_idx": m.slice_idx, "tile_idx": m.tile_idx}
+        self.arrays = {}
+        for name, dt in META_ARRAYS:
+            n = num_ctus if name in ("slice_idx", "tile_idx") else (2 * np_ if name in ("mv0", "mv1") else np_)
+            self.arrays[name] = view(addr[name], dt, n)
+        self.levels = [view(coeff_struct.level[k], np.int16, num_ctus * ctu * ctu >> (2 if k else 0)) for k in range(3)]
+
+    def fill(self, meta, coeffs):
+        for name, _ in META_ARRAYS:
+            src = meta.arrays.get(name)
+            if src is not None:
+                self.arrays[name][:] = src.reshape(-1)
+            elif name in ("ref_idx0", "ref_idx1"):
+                self.arrays[name][:] = -1
+            else:
+                self.arrays[name][:] = 0
+        for k in range(3):
+            self.levels[k][:] = coeffs.arrays[k].reshape(-1)
 
 
 class CoeffHolder:

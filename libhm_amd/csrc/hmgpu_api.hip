@@ -44,17 +44,33 @@ struct Picture {
   std::vector<SaoDev> h_saoprm;         // host copy of the resolved SAO parameters the asynchronous upload reads from
   std::vector<uint16_t> h_slice_idx, h_tile_idx;   // host mirrors of the per-CTU slice / tile index (SAO merge resolution needs them)
   int max_slice = -1;
+  uint64_t last_use = 0;                // use_seq of the last batch of kernels that read this picture's input arrays (0: none)
 };
 
 struct EventPair { hipEvent_t a, b; int kind; };
 
 }  // namespace
 
+// one page-locked block that holds a picture's input arrays in the order the device keeps them (hmgpu_staging_alloc)
+struct hmgpu_staging {
+  char* host = nullptr;
+  size_t meta_bytes = 0, coef_bytes = 0;
+  hmgpu_ctu_meta m;
+  hmgpu_coeffs co;
+};
+
 struct hmgpu_ctx {
   hmgpu_seq_params seq;
   int device = 0;
   hipStream_t stream = nullptr;
   hipStream_t stream2 = nullptr;      // second lane of the replay pipeline (hmgpu_set_streams)
+  // host -> device staging of hmgpu_decompress_pictures runs on its own stream, so that the inputs of the next batch travel while the
+  // kernels of this one run.  Two rings of events order it against the compute stream: copy_ev (inputs of a batch have arrived) and
+  // use_ev (the kernels that read a picture's inputs have finished: its device arrays may be overwritten)
+  hipStream_t copy_stream = nullptr;
+  hipEvent_t copy_ev[8] = {}, use_ev[8] = {};
+  uint64_t copy_seq = 0, use_seq = 0;
+  std::vector<hmgpu_staging*> stagings;
   hipEvent_t lane_ev[2] = {nullptr, nullptr};
   int replay_streams = 1;
   int32_t last_err = 0;
@@ -131,25 +147,28 @@ struct ProfScope {
   ~ProfScope() { prof_end(c, &ep); if (c->pending.size() > 8192) prof_drain(c); }
 };
 
+// the raw HM arrays of one picture inside one block (device allocation; staging blocks mirror it, so that one copy moves them all)
+void carve_meta(Carver& m, PicDev& d, size_t np, int num_ctus) {
+  d.depth = m.take<uint8_t>(np); d.part_size = m.take<int8_t>(np); d.pred_mode = m.take<int8_t>(np);
+  d.qp = m.take<int8_t>(np); d.tr_idx = m.take<uint8_t>(np);
+  for (int k = 0; k < 3; k++) d.cbf[k] = m.take<uint8_t>(np);
+  for (int k = 0; k < 3; k++) d.tskip[k] = m.take<uint8_t>(np);
+  for (int k = 0; k < 2; k++) d.mv[k] = m.take<int16_t>(np * 2);
+  for (int k = 0; k < 2; k++) d.ref_idx[k] = m.take<int8_t>(np);
+  for (int k = 0; k < 2; k++) d.intra_dir[k] = m.take<uint8_t>(np);
+  d.bypass = m.take<uint8_t>(np); d.ipcm = m.take<uint8_t>(np);
+  d.slice_idx = m.take<uint16_t>(num_ctus); d.tile_idx = m.take<uint16_t>(num_ctus);
+}
+
 hmgpu_status alloc_picture(hmgpu_ctx* c, Picture& p) {
   const hmgpu_seq_params& s = c->seq;
   const size_t plane_bytes = c->plane_bytes;
   p.planes = c->plane_slab + (size_t)(&p - c->pics.data()) * 2 * plane_bytes;     // (zeroed with the slab)
   const size_t np = (size_t)c->num_ctus * c->parts;
   // raw metadata: 11 byte arrays + 2 mv arrays (4 B) + 2 ref_idx + slice/tile idx
-  Carver cm(nullptr);
   for (int pass = 0; pass < 2; pass++) {
     Carver m(pass ? p.meta : nullptr);
-    PicDev& d = p.dev;
-    d.depth = m.take<uint8_t>(np); d.part_size = m.take<int8_t>(np); d.pred_mode = m.take<int8_t>(np);
-    d.qp = m.take<int8_t>(np); d.tr_idx = m.take<uint8_t>(np);
-    for (int k = 0; k < 3; k++) d.cbf[k] = m.take<uint8_t>(np);
-    for (int k = 0; k < 3; k++) d.tskip[k] = m.take<uint8_t>(np);
-    for (int k = 0; k < 2; k++) d.mv[k] = m.take<int16_t>(np * 2);
-    for (int k = 0; k < 2; k++) d.ref_idx[k] = m.take<int8_t>(np);
-    for (int k = 0; k < 2; k++) d.intra_dir[k] = m.take<uint8_t>(np);
-    d.bypass = m.take<uint8_t>(np); d.ipcm = m.take<uint8_t>(np);
-    d.slice_idx = m.take<uint16_t>(c->num_ctus); d.tile_idx = m.take<uint16_t>(c->num_ctus);
+    carve_meta(m, p.dev, np, c->num_ctus);
     if (!pass) { HIP_TRY(c, hipMalloc(&p.meta, m.off)); HIP_TRY(c, hipMemset(p.meta, 0, m.off)); }
   }
   {
@@ -324,16 +343,18 @@ hmgpu_status run_filter(hmgpu_ctx* c, const Batch& b, int stages) {
 hmgpu_status stage_sao(hmgpu_ctx* c, Picture& p, const hmgpu_pic_params* pp, const hmgpu_sao_param* sao,
                        const std::vector<uint16_t>& slice_idx, const std::vector<uint16_t>& tile_idx) {
   const int n = c->num_ctus;
-  std::vector<hmgpu_sao_param> rec(sao, sao + (size_t)n * 3);
+  // merge resolution by reference: res[a][comp] = the NEW / OFF entry that CTU a's parameters come from (a merged CTU takes all
+  // three components of its left / upper neighbour's RESOLVED parameters); nothing of the caller's array is copied
+  std::vector<const hmgpu_sao_param*> res((size_t)n * 3);
   std::vector<SaoDev>& dev = p.h_saoprm;  // lives with the picture: the upload below is asynchronous
-  dev.assign((size_t)n * 3, SaoDev());
+  dev.resize((size_t)n * 3);
   bool any = false;
   for (int a = 0; a < n; a++) {
     const int cx = a % c->ctus_w, cy = a / c->ctus_w;
-    const hmgpu_sao_param* merge[2] = {nullptr, nullptr};
+    const hmgpu_sao_param* const* merge[2] = {nullptr, nullptr};
     auto same = [&](int o) { return slice_idx[o] == slice_idx[a] && tile_idx[o] == tile_idx[a]; };
-    if (cx > 0 && same(a - 1)) merge[HMGPU_SAO_MERGE_LEFT] = &rec[(size_t)(a - 1) * 3];
-    if (cy > 0 && same(a - c->ctus_w)) merge[HMGPU_SAO_MERGE_ABOVE] = &rec[(size_t)(a - c->ctus_w) * 3];
+    if (cx > 0 && same(a - 1)) merge[HMGPU_SAO_MERGE_LEFT] = &res[(size_t)(a - 1) * 3];
+    if (cy > 0 && same(a - c->ctus_w)) merge[HMGPU_SAO_MERGE_ABOVE] = &res[(size_t)(a - c->ctus_w) * 3];
     // neighbour availability as a 3x3 grid (SaoDev::avail): bit 3 * (dy + 1) + (dx + 1)
     unsigned avail = 1u << 4;
     for (int k = 0; k < 9; k++) {
@@ -351,30 +372,23 @@ hmgpu_status stage_sao(hmgpu_ctx* c, Picture& p, const hmgpu_pic_params* pp, con
       if (ok) avail |= 1u << k;
     }
     for (int comp = 0; comp < 3; comp++) {
-      hmgpu_sao_param& r = rec[(size_t)a * 3 + comp];
-      const int shift = comp == 0 ? pp->sao_offset_shift_luma : pp->sao_offset_shift_chroma;
-      if (r.mode_idc == HMGPU_SAO_NEW) {
-        int32_t coded[32];
-        memcpy(coded, r.offset, sizeof(coded));
-        memset(r.offset, 0, sizeof(r.offset));
-        if (r.type_idc == HMGPU_SAO_BO) {
-          for (int i = 0; i < 4; i++) { const int band = (r.type_aux_info + i) & 31; r.offset[band] = coded[band] * (1 << shift); }
-        } else {
-          for (int i = 0; i < 5; i++) r.offset[i] = coded[i] * (1 << shift);
-        }
-      } else if (r.mode_idc == HMGPU_SAO_MERGE) {
-        if (r.type_idc < 0 || r.type_idc > 1 || !merge[r.type_idc]) return HMGPU_EINVAL;     // HM: assert(mergeTarget != NULL)
-        r = merge[r.type_idc][comp];
+      const hmgpu_sao_param* r = &sao[(size_t)a * 3 + comp];
+      if (r->mode_idc == HMGPU_SAO_MERGE) {
+        if (r->type_idc < 0 || r->type_idc > 1 || !merge[r->type_idc]) return HMGPU_EINVAL;     // HM: assert(mergeTarget != NULL)
+        r = merge[r->type_idc][comp];
       }
+      res[(size_t)a * 3 + comp] = r;
+      const int shift = comp == 0 ? pp->sao_offset_shift_luma : pp->sao_offset_shift_chroma;
       SaoDev& d = dev[(size_t)a * 3 + comp];
       memset(&d, 0, sizeof(d));
-      d.type = r.mode_idc == HMGPU_SAO_OFF ? -1 : (int8_t)r.type_idc;
+      d.type = r->mode_idc == HMGPU_SAO_OFF ? -1 : (int8_t)r->type_idc;
       d.avail = (uint16_t)avail;
+      // offsets of a NEW entry: the coded ones scaled by log2_sao_offset_scale (reconstructBlkSAOParam, TComSampleAdaptiveOffset.cpp:229-372)
       if (d.type == HMGPU_SAO_BO) {
-        d.band = (uint8_t)(r.type_aux_info & 31);
-        for (int i = 0; i < 4; i++) d.off[i] = (int8_t)r.offset[(r.type_aux_info + i) & 31];
+        d.band = (uint8_t)(r->type_aux_info & 31);
+        for (int i = 0; i < 4; i++) d.off[i] = (int8_t)(r->offset[(r->type_aux_info + i) & 31] * (1 << shift));
       } else if (d.type >= 0) {
-        for (int i = 0; i < 5; i++) d.off[i] = (int8_t)r.offset[i];
+        for (int i = 0; i < 5; i++) d.off[i] = (int8_t)(r->offset[i] * (1 << shift));
       }
       any |= d.type >= 0;
     }
@@ -422,6 +436,9 @@ hmgpu_status hmgpu_create(const hmgpu_seq_params* seq, int device_ordinal, hmgpu
   hipError_t e = hipSetDevice(device_ordinal);
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking);
+  for (int k = 0; k < 8 && e == hipSuccess; k++) e = hipEventCreateWithFlags(&c->copy_ev[k], hipEventDisableTiming);
+  for (int k = 0; k < 8 && e == hipSuccess; k++) e = hipEventCreateWithFlags(&c->use_ev[k], hipEventDisableTiming);
   for (int k = 0; k < 2 && e == hipSuccess; k++) e = hipEventCreateWithFlags(&c->lane_ev[k], hipEventDisableTiming);
   if (e != hipSuccess) { delete c; return HMGPU_EDEVICE; }
   c->ctu = 1 << seq->log2_ctu_size; c->pw = c->ctu / 4; c->parts = c->pw * c->pw;
@@ -494,6 +511,9 @@ void hmgpu_destroy(hmgpu_ctx* c) {
   if (c->d_ctu_order) hipFree(c->d_ctu_order);
   if (c->stream) hipStreamDestroy(c->stream);
   if (c->stream2) hipStreamDestroy(c->stream2);
+  if (c->copy_stream) { hipStreamSynchronize(c->copy_stream); hipStreamDestroy(c->copy_stream); }
+  for (int k = 0; k < 8; k++) { if (c->copy_ev[k]) hipEventDestroy(c->copy_ev[k]); if (c->use_ev[k]) hipEventDestroy(c->use_ev[k]); }
+  for (hmgpu_staging* st : c->stagings) { if (st->host) hipHostFree(st->host); delete st; }
   for (int k = 0; k < 2; k++) if (c->lane_ev[k]) hipEventDestroy(c->lane_ev[k]);
   delete c;
 }
@@ -508,6 +528,7 @@ void* hmgpu_host_alloc(size_t bytes) {
 void hmgpu_host_free(void* p) { if (p) (void)hipHostFree(p); }
 
 hmgpu_status hmgpu_sync(hmgpu_ctx* c) {
+  if (c && c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
   if (!c) return HMGPU_EINVAL;
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   prof_drain(c);
@@ -665,7 +686,7 @@ hmgpu_status hmgpu_picture_commit_received(hmgpu_ctx* c, hmgpu_pic pic) {
 void* hmgpu_stream(hmgpu_ctx* c) { return c ? (void*)c->stream : nullptr; }
 
 // slice table entry of one slice (validation, SliceDev, scaling lists): the part of a slice call that does not depend on CTUs
-static hmgpu_status register_slice(hmgpu_ctx* c, hmgpu_pic cur, int32_t slice_idx, const hmgpu_slice_params* sl) {
+static hmgpu_status register_slice(hmgpu_ctx* c, hmgpu_pic cur, int32_t slice_idx, const hmgpu_slice_params* sl, hipStream_t hs) {
   if (slice_idx < 0 || slice_idx >= HMGPU_MAX_SLICES || !sl) return HMGPU_EINVAL;
   if (sl->weighted_pred && (sl->wp_log2_denom[0] < 0 || sl->wp_log2_denom[0] > 7 || sl->wp_log2_denom[1] < 0 || sl->wp_log2_denom[1] > 7)) return HMGPU_EINVAL;
   Picture& p = c->pics[cur];
@@ -710,18 +731,26 @@ static hmgpu_status register_slice(hmgpu_ctx* c, hmgpu_pic cur, int32_t slice_id
             t[y * n + x] = (uint8_t)v;
           }
       }
-    HIP_TRY(c, hipMemcpyAsync(p.sl_table, p.sl_host.data(), p.sl_host.size(), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(p.sl_table, p.sl_host.data(), p.sl_host.size(), hipMemcpyHostToDevice, hs));
     p.dev.sl_m = p.sl_table;
   }
-  HIP_TRY(c, hipMemcpyAsync((void*)(p.dev.slices + slice_idx), &p.slices[slice_idx], sizeof(SliceDev), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipMemcpyAsync((void*)(p.dev.slices + slice_idx), &p.slices[slice_idx], sizeof(SliceDev), hipMemcpyHostToDevice, hs));
   return HMGPU_OK;
 }
 
-// HM arrays of a CTU range to the device, then the reconstruction kernels over the range.  `slices` lists the slice table entries
-// whose reference pictures the range may read (their borders must be extended first); slice_idx is the one a missing
-// meta->slice_idx array stands for.
-static hmgpu_status stage_and_run(hmgpu_ctx* c, hmgpu_pic cur, int32_t slice_idx, const std::vector<int>& slices, bool any_wp,
-                                  const hmgpu_ctu_meta* m, const hmgpu_coeffs* co, int32_t first_ctu, int32_t num_ctus) {
+// a staging block whose arrays the caller handed over for a whole picture: its metadata is ONE copy, its levels another
+static const hmgpu_staging* staging_of(const hmgpu_ctx* c, const hmgpu_ctu_meta* m, const hmgpu_coeffs* co) {
+  for (const hmgpu_staging* st : c->stagings)
+    if (m->depth == st->m.depth && memcmp(m, &st->m, sizeof(*m)) == 0 && co->level[0] == st->co.level[0] && co->level[1] == st->co.level[1] &&
+        co->level[2] == st->co.level[2]) return st;
+  return nullptr;
+}
+
+// HM arrays of a CTU range to the device (on stream hs) and the record of the call.  `slices` lists the slice table entries whose
+// reference pictures the range may read; slice_idx is the one a missing meta->slice_idx array stands for.
+static hmgpu_status stage_inputs(hmgpu_ctx* c, hmgpu_pic cur, int32_t slice_idx, const std::vector<int>& slices, bool any_wp,
+                                 const hmgpu_ctu_meta* m, const hmgpu_coeffs* co, int32_t first_ctu, int32_t num_ctus, hipStream_t hs,
+                                 SliceCall* call_out) {
   Picture& p = c->pics[cur];
   const size_t po = (size_t)first_ctu * c->parts, pn = (size_t)num_ctus * c->parts;
   // lossless / PCM CUs need their own inputs
@@ -731,13 +760,20 @@ static hmgpu_status stage_and_run(hmgpu_ctx* c, hmgpu_pic cur, int32_t slice_idx
   if (any_pcm && (c->seq.pcm_bit_depth_luma < 1 || c->seq.pcm_bit_depth_luma > c->seq.bit_depth_luma ||
                   c->seq.pcm_bit_depth_chroma < 1 || c->seq.pcm_bit_depth_chroma > c->seq.bit_depth_chroma)) return HMGPU_EINVAL;
   p.dev.has_intra_dir = (m->intra_dir[0] && m->intra_dir[1]) ? 1 : 0;      // without the modes intra CUs are left untouched
-  {
+  const hmgpu_staging* stg = (first_ctu == 0 && num_ctus == c->num_ctus) ? staging_of(c, m, co) : nullptr;
+  if (stg) {
+    // the caller filled a staging block: the whole metadata block in one DMA, the levels in another
+    HIP_TRY(c, hipMemcpyAsync(p.meta, stg->host, stg->meta_bytes, hipMemcpyHostToDevice, hs));
+    HIP_TRY(c, hipMemcpyAsync(p.coef, stg->host + stg->meta_bytes, stg->coef_bytes, hipMemcpyHostToDevice, hs));
+    p.h_slice_idx.assign(m->slice_idx, m->slice_idx + c->num_ctus);
+    p.h_tile_idx.assign(m->tile_idx, m->tile_idx + c->num_ctus);
+  } else {
     ProfScope ps(c, K_H2D);
     // ---- HM arrays of the CTU range (field-by-field, exactly the arrays TComDataCU owns)
 #define STAGE(dst, src, elem_bytes)                                                                                       \
     if (src) HIP_TRY(c, hipMemcpyAsync((char*)(dst) + po * (elem_bytes), (const char*)(src) + po * (elem_bytes), pn * (elem_bytes), \
-                                       hipMemcpyHostToDevice, c->stream));                                                \
-    else HIP_TRY(c, hipMemsetAsync((char*)(dst) + po * (elem_bytes), 0, pn * (elem_bytes), c->stream))
+                                       hipMemcpyHostToDevice, hs));                                                \
+    else HIP_TRY(c, hipMemsetAsync((char*)(dst) + po * (elem_bytes), 0, pn * (elem_bytes), hs))
     STAGE(p.dev.depth, m->depth, 1); STAGE(p.dev.part_size, m->part_size, 1); STAGE(p.dev.pred_mode, m->pred_mode, 1);
     STAGE(p.dev.qp, m->qp, 1); STAGE(p.dev.tr_idx, m->tr_idx, 1);
     for (int k = 0; k < 3; k++) { STAGE(p.dev.cbf[k], m->cbf[k], 1); STAGE(p.dev.tskip[k], m->transform_skip[k], 1); }
@@ -752,14 +788,16 @@ static hmgpu_status stage_and_run(hmgpu_ctx* c, hmgpu_pic cur, int32_t slice_idx
       p.h_tile_idx.resize(c->num_ctus);
       for (int i = 0; i < num_ctus; i++) p.h_slice_idx[first_ctu + i] = m->slice_idx ? m->slice_idx[first_ctu + i] : (uint16_t)slice_idx;
       for (int i = 0; i < num_ctus; i++) p.h_tile_idx[first_ctu + i] = m->tile_idx ? m->tile_idx[first_ctu + i] : (uint16_t)0;
-      HIP_TRY(c, hipMemcpyAsync((void*)(p.dev.slice_idx + first_ctu), p.h_slice_idx.data() + first_ctu, (size_t)num_ctus * 2, hipMemcpyHostToDevice, c->stream));
-      HIP_TRY(c, hipMemcpyAsync((void*)(p.dev.tile_idx + first_ctu), p.h_tile_idx.data() + first_ctu, (size_t)num_ctus * 2, hipMemcpyHostToDevice, c->stream));
+      HIP_TRY(c, hipMemcpyAsync((void*)(p.dev.slice_idx + first_ctu), p.h_slice_idx.data() + first_ctu, (size_t)num_ctus * 2, hipMemcpyHostToDevice, hs));
+      HIP_TRY(c, hipMemcpyAsync((void*)(p.dev.tile_idx + first_ctu), p.h_tile_idx.data() + first_ctu, (size_t)num_ctus * 2, hipMemcpyHostToDevice, hs));
     }
     for (int k = 0; k < 3; k++) {
       const size_t per = (size_t)(c->ctu * c->ctu) >> (k ? 2 : 0);
       HIP_TRY(c, hipMemcpyAsync((void*)(p.dev.coef[k] + first_ctu * per), co->level[k] + first_ctu * per, (size_t)num_ctus * per * 2,
-                                hipMemcpyHostToDevice, c->stream));
+                                hipMemcpyHostToDevice, hs));
     }
+  }
+  {
     if (any_pcm) {
       size_t bytes = 0;
       for (int k = 0; k < 3; k++) bytes += align_up(c->coef_elems[k] * sizeof(int16_t), 256);
@@ -771,14 +809,13 @@ static hmgpu_status stage_and_run(hmgpu_ctx* c, hmgpu_pic cur, int32_t slice_idx
       for (int k = 0; k < 3; k++) {
         const size_t per = (size_t)(c->ctu * c->ctu) >> (k ? 2 : 0);
         HIP_TRY(c, hipMemcpyAsync((void*)(p.dev.pcm[k] + first_ctu * per), co->pcm_sample[k] + first_ctu * per, (size_t)num_ctus * per * 2,
-                                  hipMemcpyHostToDevice, c->stream));
+                                  hipMemcpyHostToDevice, hs));
       }
       p.dev.pcm_shift[0] = c->seq.bit_depth_luma - c->seq.pcm_bit_depth_luma;
       p.dev.pcm_shift[1] = p.dev.pcm_shift[2] = c->seq.bit_depth_chroma - c->seq.pcm_bit_depth_chroma;
     }
     if (any_bypass || (any_pcm && c->seq.pcm_loop_filter_disable)) p.dev.any_nofilt = 1;
-    hmgpu_status st = push_picdev(c, cur);
-    if (st != HMGPU_OK) return st;
+    HIP_TRY(c, hipMemcpyAsync(c->d_pics + cur, &p.dev, sizeof(PicDev), hipMemcpyHostToDevice, hs));
   }
   // a range decoded again (picture buffer reused without release/acquire) replaces the earlier record
   p.calls.erase(std::remove_if(p.calls.begin(), p.calls.end(), [&](const SliceCall& o) {
@@ -792,7 +829,9 @@ static hmgpu_status stage_and_run(hmgpu_ctx* c, hmgpu_pic cur, int32_t slice_idx
     const int8_t* ps = m->part_size + po;
     const uint8_t* dp = m->depth + po;
     const int8_t* pm = m->pred_mode + po;
-    for (size_t i = 0; i < pn && !cells; i++)
+    unsigned other = 0;                                       // (a loop the compiler vectorises: most pictures stop here)
+    for (size_t i = 0; i < pn; i++) other |= (unsigned)(ps[i] != HMGPU_SIZE_2Nx2N && ps[i] != HMGPU_SIZE_NONE);
+    for (size_t i = 0; other && i < pn && !cells; i += 4)     // 8x8 is the minimum CU size: four consecutive partitions share these fields
       cells = ps[i] != HMGPU_SIZE_2Nx2N && ps[i] != HMGPU_SIZE_NONE && pm[i] != HMGPU_MODE_INTRA &&
               (dp[i] >= d8 || (dp[i] == d8 - 1 && ps[i] >= HMGPU_SIZE_2NxnU));
   }
@@ -800,17 +839,33 @@ static hmgpu_status stage_and_run(hmgpu_ctx* c, hmgpu_pic cur, int32_t slice_idx
   for (int si : slices) any_b |= p.slices[si].slice_type == HMGPU_B_SLICE;
   SliceCall call = {first_ctu, num_ctus, slice_idx, has_intra, any_wp, cells, any_b};
   p.calls.push_back(call);
-
-  Batch b; memset(&b, 0, sizeof(b));
-  b.n = 1; b.pic[0] = cur; b.first_ctu[0] = first_ctu; b.num_ctus[0] = num_ctus;
   p.extended = false;
+  *call_out = call;
+  return HMGPU_OK;
+}
+
+// reference pictures named by the slice table entries `slices` of picture `cur`: their borders must be extended before the kernels read them
+static hmgpu_status extend_refs_of(hmgpu_ctx* c, hmgpu_pic cur, const std::vector<int>& slices) {
+  const Picture& p = c->pics[cur];
   for (int si : slices) {
     const SliceDev& sd = p.slices[si];
     for (int l = 0; l < 2; l++)
       for (int r = 0; r < HMGPU_MAX_REF; r++)
         if (sd.ref_pic[l][r] >= 0) { hmgpu_status st = ensure_extended(c, sd.ref_pic[l][r]); if (st != HMGPU_OK) return st; }
   }
-  return run_recon(c, b, has_intra, any_wp, cells, any_b);
+  return HMGPU_OK;
+}
+
+// staging + the reconstruction kernels of ONE call, everything on the context's stream
+static hmgpu_status stage_and_run(hmgpu_ctx* c, hmgpu_pic cur, int32_t slice_idx, const std::vector<int>& slices, bool any_wp,
+                                  const hmgpu_ctu_meta* m, const hmgpu_coeffs* co, int32_t first_ctu, int32_t num_ctus) {
+  SliceCall call;
+  hmgpu_status st = stage_inputs(c, cur, slice_idx, slices, any_wp, m, co, first_ctu, num_ctus, c->stream, &call);
+  if (st == HMGPU_OK) st = extend_refs_of(c, cur, slices);
+  if (st != HMGPU_OK) return st;
+  Batch b; memset(&b, 0, sizeof(b));
+  b.n = 1; b.pic[0] = cur; b.first_ctu[0] = first_ctu; b.num_ctus[0] = num_ctus;
+  return run_recon(c, b, call.intra, call.wp, call.cells, call.bi);
 }
 
 static bool meta_complete(const hmgpu_ctu_meta* m, const hmgpu_coeffs* co) {
@@ -832,7 +887,7 @@ hmgpu_status hmgpu_decompress_slice(hmgpu_ctx* c, hmgpu_pic cur, int32_t slice_i
   if (!c || !valid_pic(c, cur) || !sl || !meta_complete(m, co)) return HMGPU_EINVAL;
   if (first_ctu < 0 || num_ctus <= 0 || first_ctu + num_ctus > c->num_ctus) return HMGPU_EINVAL;
   hmgpu_status st = reopen_picture(c, cur);
-  if (st == HMGPU_OK) st = register_slice(c, cur, slice_idx, sl);
+  if (st == HMGPU_OK) st = register_slice(c, cur, slice_idx, sl, c->stream);
   if (st != HMGPU_OK) return st;
   return stage_and_run(c, cur, slice_idx, std::vector<int>{slice_idx}, sl->weighted_pred != 0, m, co, first_ctu, num_ctus);
 }
@@ -846,12 +901,156 @@ hmgpu_status hmgpu_decompress_picture(hmgpu_ctx* c, hmgpu_pic cur, int32_t num_s
   std::vector<int> all;
   bool any_wp = false;
   for (int i = 0; i < num_slices && st == HMGPU_OK; i++) {
-    st = register_slice(c, cur, i, slices[i]);
+    st = register_slice(c, cur, i, slices[i], c->stream);
     all.push_back(i);
     any_wp |= slices[i] && slices[i]->weighted_pred != 0;
   }
   if (st != HMGPU_OK) return st;
   return stage_and_run(c, cur, 0, all, any_wp, m, co, 0, c->num_ctus);
+}
+
+// ---- staging blocks
+hmgpu_status hmgpu_staging_alloc(hmgpu_ctx* c, hmgpu_staging** out, hmgpu_ctu_meta* meta, hmgpu_coeffs* coeffs) {
+  if (!c || !out || !meta || !coeffs) return HMGPU_EINVAL;
+  hipSetDevice(c->device);
+  hmgpu_staging* st = new (std::nothrow) hmgpu_staging();
+  if (!st) return HMGPU_ENOMEM;
+  const size_t np = (size_t)c->num_ctus * c->parts;
+  PicDev lay;
+  memset(&lay, 0, sizeof(lay));
+  { Carver m(nullptr); carve_meta(m, lay, np, c->num_ctus); st->meta_bytes = m.off; }
+  for (int k = 0; k < 3; k++) st->coef_bytes += align_up(c->coef_elems[k] * sizeof(int16_t), 256);
+  if (hipHostMalloc((void**)&st->host, st->meta_bytes + st->coef_bytes, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); delete st; return HMGPU_ENOMEM; }
+  memset(st->host, 0, st->meta_bytes + st->coef_bytes);
+  { Carver m(st->host); carve_meta(m, lay, np, c->num_ctus); }
+  hmgpu_ctu_meta& h = st->m;
+  memset(&h, 0, sizeof(h));
+  h.depth = lay.depth; h.part_size = lay.part_size; h.pred_mode = lay.pred_mode; h.qp = lay.qp; h.tr_idx = lay.tr_idx;
+  for (int k = 0; k < 3; k++) { h.cbf[k] = lay.cbf[k]; h.transform_skip[k] = lay.tskip[k]; }
+  for (int k = 0; k < 2; k++) { h.mv[k] = lay.mv[k]; h.ref_idx[k] = lay.ref_idx[k]; h.intra_dir[k] = lay.intra_dir[k]; }
+  h.transquant_bypass = lay.bypass; h.ipcm = lay.ipcm; h.slice_idx = lay.slice_idx; h.tile_idx = lay.tile_idx;
+  // (decoded nowhere yet: HM marks that with part_size = NUMBER_OF_PART_SIZES and ref_idx = -1)
+  memset(const_cast<int8_t*>(h.part_size), HMGPU_SIZE_NONE, np);
+  memset(const_cast<int8_t*>(h.ref_idx[0]), 0xff, np); memset(const_cast<int8_t*>(h.ref_idx[1]), 0xff, np);
+  memset(&st->co, 0, sizeof(st->co));
+  { Carver m(st->host + st->meta_bytes); for (int k = 0; k < 3; k++) st->co.level[k] = m.take<int16_t>(c->coef_elems[k]); }
+  c->stagings.push_back(st);
+  *meta = st->m; *coeffs = st->co; *out = st;
+  return HMGPU_OK;
+}
+
+void hmgpu_staging_free(hmgpu_ctx* c, hmgpu_staging* st) {
+  if (!c || !st) return;
+  hipSetDevice(c->device);
+  if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
+  c->stagings.erase(std::remove(c->stagings.begin(), c->stagings.end(), st), c->stagings.end());
+  if (st->host) (void)hipHostFree(st->host);
+  delete st;
+}
+
+// the copy stream may overwrite a picture's input arrays once the kernels that last read them have finished
+static void wait_for_last_use(hmgpu_ctx* c, const Picture& p) {
+  if (!p.last_use) return;
+  // (events older than the ring are gone: the newest one was recorded later and is a safe stand-in)
+  const uint64_t seq = c->use_seq - p.last_use < 8 ? p.last_use : c->use_seq;
+  (void)hipStreamWaitEvent(c->copy_stream, c->use_ev[seq % 8], 0);
+}
+static void mark_use(hmgpu_ctx* c, const Batch& b) {
+  c->use_seq++;
+  (void)hipEventRecord(c->use_ev[c->use_seq % 8], c->stream);
+  for (int i = 0; i < b.n; i++) c->pics[b.pic[i]].last_use = c->use_seq;
+}
+
+hmgpu_status hmgpu_decompress_pictures(hmgpu_ctx* c, int32_t n, const hmgpu_picture_job* jobs) {
+  if (!c || !jobs || n < 1 || n > kMaxBatch) return HMGPU_EINVAL;
+  for (int i = 0; i < n; i++) {
+    const hmgpu_picture_job& j = jobs[i];
+    if (!valid_pic(c, j.pic) || !j.slices || j.num_slices < 1 || j.num_slices > HMGPU_MAX_SLICES || !meta_complete(j.meta, j.coeffs)) return HMGPU_EINVAL;
+    if (j.num_slices > 1 && !j.meta->slice_idx) return HMGPU_EINVAL;
+    if (j.meta->slice_idx) for (int k = 0; k < c->num_ctus; k++) if (j.meta->slice_idx[k] >= j.num_slices) return HMGPU_EINVAL;
+    for (int k = 0; k < i; k++) if (jobs[k].pic == j.pic) return HMGPU_EINVAL;
+    // independent pictures only: none of them may be a reference of another one of the call
+    for (int s2 = 0; s2 < j.num_slices; s2++)
+      for (int l = 0; l < 2 && j.slices[s2]; l++)
+        for (int r = 0; r < j.slices[s2]->num_ref_idx[l] && r < HMGPU_MAX_REF; r++)
+          for (int k = 0; k < n; k++) if (j.slices[s2]->ref_pic[l][r] == jobs[k].pic) return HMGPU_EINVAL;
+  }
+  hipSetDevice(c->device);
+  Batch b; memset(&b, 0, sizeof(b));
+  b.n = n;
+  bool any_intra = false, any_wp = false, any_cells = false, any_bi = false;
+  hmgpu_status st = HMGPU_OK;
+  std::vector<std::vector<int>> all(n);
+  {
+    ProfScope ps(c, K_H2D);              // (events on the compute stream: the staging itself runs beside it on the copy stream)
+    for (int i = 0; i < n && st == HMGPU_OK; i++) {
+      const hmgpu_picture_job& j = jobs[i];
+      Picture& p = c->pics[j.pic];
+      wait_for_last_use(c, p);
+      if (p.sao_applied) { p.sao_applied = false; p.dev.sao_applied = 0; for (int k = 0; k < 3; k++) c->h_finals[j.pic].p[k] = p.dev.rec[k];
+                           HIP_TRY(c, hipMemcpyAsync(c->d_finals + j.pic, &c->h_finals[j.pic], sizeof(PlaneSet), hipMemcpyHostToDevice, c->copy_stream)); }
+      bool wp = false;
+      for (int k = 0; k < j.num_slices && st == HMGPU_OK; k++) {
+        st = register_slice(c, j.pic, k, j.slices[k], c->copy_stream);
+        all[i].push_back(k);
+        wp |= j.slices[k] && j.slices[k]->weighted_pred != 0;
+      }
+      SliceCall call;
+      if (st == HMGPU_OK) st = stage_inputs(c, j.pic, 0, all[i], wp, j.meta, j.coeffs, 0, c->num_ctus, c->copy_stream, &call);
+      if (st != HMGPU_OK) break;
+      b.pic[i] = j.pic; b.first_ctu[i] = 0; b.num_ctus[i] = c->num_ctus;
+      any_intra |= call.intra; any_wp |= call.wp; any_cells |= call.cells; any_bi |= call.bi;
+    }
+    if (st != HMGPU_OK) return st;
+    c->copy_seq++;
+    HIP_TRY(c, hipEventRecord(c->copy_ev[c->copy_seq % 8], c->copy_stream));
+    HIP_TRY(c, hipStreamWaitEvent(c->stream, c->copy_ev[c->copy_seq % 8], 0));
+  }
+  for (int i = 0; i < n && st == HMGPU_OK; i++) st = extend_refs_of(c, jobs[i].pic, all[i]);
+  if (st == HMGPU_OK) st = run_recon(c, b, any_intra, any_wp, any_cells, any_bi);
+  mark_use(c, b);
+  return st;
+}
+
+hmgpu_status hmgpu_filter_pictures(hmgpu_ctx* c, int32_t n, const hmgpu_filter_job* jobs) {
+  if (!c || !jobs || n < 1 || n > kMaxBatch) return HMGPU_EINVAL;
+  for (int i = 0; i < n; i++) {
+    if (!valid_pic(c, jobs[i].pic) || !jobs[i].pp) return HMGPU_EINVAL;
+    if (jobs[i].pp->sao_enabled && !jobs[i].sao) return HMGPU_EINVAL;
+    for (int k = 0; k < i; k++) if (jobs[k].pic == jobs[i].pic) return HMGPU_EINVAL;
+  }
+  hipSetDevice(c->device);
+  Batch b; memset(&b, 0, sizeof(b));
+  b.n = n;
+  for (int i = 0; i < n; i++) {
+    Picture& p = c->pics[jobs[i].pic];
+    p.sao_any = false;
+    if (jobs[i].pp->sao_enabled) {
+      std::vector<uint16_t> sidx = p.h_slice_idx, tidx = p.h_tile_idx;
+      sidx.resize(c->num_ctus, 0);
+      tidx.resize(c->num_ctus, 0);
+      hmgpu_status st = stage_sao(c, p, jobs[i].pp, jobs[i].sao, sidx, tidx);
+      if (st != HMGPU_OK) return st;
+    }
+    p.filter_ready = true;
+    b.pic[i] = jobs[i].pic; b.first_ctu[i] = 0; b.num_ctus[i] = c->num_ctus;
+  }
+  hmgpu_status st = run_filter(c, b, 7);
+  if (st != HMGPU_OK) return st;
+  for (int i = 0; i < n && st == HMGPU_OK; i++) {
+    Picture& p = c->pics[jobs[i].pic];
+    if (p.sao_any) {
+      p.sao_applied = true; p.dev.sao_applied = 1;
+      st = push_final(c, jobs[i].pic);
+      if (st == HMGPU_OK) st = push_picdev(c, jobs[i].pic);
+    }
+    p.extended = true;                   // (the batched border extension below)
+  }
+  if (st != HMGPU_OK) return st;
+  { ProfScope ps(c, K_EXTEND); launch_extend(c->d_pics, b, c->seq.width, c->seq.height, c->mx[0], c->my[0], c->stream); }
+  HIP_TRY(c, hipGetLastError());
+  mark_use(c, b);
+  return HMGPU_OK;
 }
 
 hmgpu_status hmgpu_filter_picture_stages(hmgpu_ctx* c, hmgpu_pic cur, const hmgpu_pic_params* pp, const hmgpu_sao_param* sao,

@@ -85,6 +85,53 @@ def test_fused_loop_filter_matches_oracle_on_partition_extremes(oracle, mode_pro
             assert np.array_equal(got[c], want_fin[c]), "final picture comp %d" % c
 
 
+@pytest.mark.parametrize("width,height,bd", [(832, 480, 10), (3840, 2160, 10)])
+def test_pictures_batch_entry_matches_oracle(oracle, width, height, bd):
+    """hmgpu_decompress_pictures + hmgpu_filter_pictures: several independent pictures per call (one batch of launches, inputs staged
+    on the copy stream), from ordinary arrays and from a staging block (one DMA for the metadata, one for the levels); called twice
+    on the same pictures, as a decoder that reuses its buffers does"""
+    import libhm_amd
+    n = 3
+    pics = [synth.make_picture(width, height, bd, seed=300 + i, bi=(i == 1), intra_frac=0.1 * i, ref_handles=([0], [1])) for i in range(n)]
+    ref0 = synth.noise_planes(width, height, bd, 41)
+    ref1 = synth.blocky_planes(width, height, bd, 42)
+    cur = synth.blocky_planes(width, height, bd, 43)
+    want = [_oracle_chain(oracle, p, cur, [ref0, ref1])[2] for p in pics]
+    with libhm_amd.Context(abi.make_seq(width, height, bd, bd, log2_ctu=6, max_pictures=2 + n)) as ctx:
+        h0, h1 = ctx.acquire(), ctx.acquire()
+        ctx.upload(h0, ref0)
+        ctx.upload(h1, ref1)
+        hs = [ctx.acquire() for _ in range(n)]
+        stg = ctx.staging_alloc()
+        stg.fill(pics[2].meta, pics[2].coeffs)                       # picture 2 travels through a staging block
+        sao = [abi.sao_array_from_raw(p.sao_raw) for p in pics]
+        for rnd in range(2):
+            for h in hs:
+                ctx.upload(h, cur)
+            ctx.decompress_pictures([(hs[0], [pics[0].slice], pics[0].meta, pics[0].coeffs), (hs[1], [pics[1].slice], pics[1].meta, pics[1].coeffs),
+                                     (hs[2], [pics[2].slice], stg, stg)])
+            ctx.filter_pictures([(hs[i], pics[i].pp, sao[i]) for i in range(n)])
+            for i in range(n):
+                got = ctx.download(hs[i])
+                for c in range(3):
+                    assert np.array_equal(got[c], want[i][c]), "round %d picture %d comp %d" % (rnd, i, c)
+        # a finished picture of the batch is a reference like any other
+        q = synth.make_picture(width, height, bd, seed=310, ref_handles=([0], [0]))
+        _, _, want_q = _oracle_chain(oracle, q, cur, [want[0]])
+        qsl = abi.clone_slice(q.slice)
+        qsl.ref_pic[0][0] = hs[0]
+        hq = h1                                                      # (reuse a buffer nobody references any more)
+        ctx.upload(hq, cur)
+        ctx.decompress_pictures([(hq, [qsl], q.meta, q.coeffs)])
+        ctx.filter_pictures([(hq, q.pp, abi.sao_array_from_raw(q.sao_raw))])
+        got = ctx.download(hq)
+        for c in range(3):
+            assert np.array_equal(got[c], want_q[c]), "picture predicted from a picture of the batch, comp %d" % c
+        ctx.staging_free(stg)
+        with pytest.raises(libhm_amd.HmgpuError):                    # a picture and its reference in one call: not independent
+            ctx.decompress_pictures([(hs[0], [pics[0].slice], pics[0].meta, pics[0].coeffs), (hs[1], [qsl], q.meta, q.coeffs)])
+
+
 @pytest.mark.parametrize("across", [0, 1])
 def test_multi_slice_picture_matches_oracle(oracle, across):
     """five slices starting at arbitrary CTUs (own QP / deblocking offsets), one hmgpu_decompress_slice call per slice: slice

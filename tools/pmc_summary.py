@@ -5,10 +5,15 @@ prescribes for gfx950: bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 (FETCH_SIZE 
 import collections
 import csv
 import glob
+import hashlib
 import json
+import os
 import sys
 
-BENCH_NAME = {"k_itx": "itx", "k_mc_luma<false>": "mc_luma", "k_mc_chroma<false>": "mc_chroma", "k_deblock<0>": "deblock_ver",
+
+from pmc_summary_digest import csrc_digest
+
+BENCH_NAME = {"k_itx": "itx", "k_mc_luma<false, false>": "mc_luma", "k_mc_chroma<false, false>": "mc_chroma", "k_deblock<0>": "deblock_ver",
               "k_deblock<1>": "deblock_hor", "k_sao": "sao", "k_prep": "prep", "k_extend": "extend_border",
               "k_filter_fused<false>": "filter_fused", "k_intra": "intra"}
 args = sys.argv[1:]
@@ -41,4 +46,4 @@ if json_out:
     json.dump({"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of `python3 bench.py --steps 2 --warmup 1 "
                          "--profile-steps 1 --no-cpu-baseline`; per launch = largest dispatch (batch of 16 pictures); "
                          "traffic = (2*FETCH_SIZE + WRITE_SIZE) KiB, the gfx950 correction of MI355X_MICROARCH.md",
-               "kernels": out}, open(json_out, "w"), indent=1)
+               "csrc_sha16": csrc_digest(), "kernels": out}, open(json_out, "w"), indent=1)
