@@ -259,10 +259,15 @@ def main():
 def host_inclusive(ctx, metas, pics, refs_of, nb, w, h, args):
     """steady-state throughput of the product path with host -> device staging inside the timed region"""
     from libhm_amd import abi
-    stg = []
+    import libhm_amd
+    stg, level_bytes = [], 0
     for i in range(nb):                                        # one staging block per picture of a step (page-locked, filled once)
         s = ctx.staging_alloc()
-        s.fill(metas[i % 2].meta, metas[i % 2].coeffs)
+        # levels in the compact form (coded TUs only, hmgpu_pack_levels): what a parser that appends TU after TU produces
+        level_bytes = s.fill_compact(libhm_amd.lib(), ctx.seq, metas[i % 2].meta, metas[i % 2].coeffs)
+        mnp = metas[i % 2].meta_np
+        has_intra = bool((mnp["pred_mode"] == 1).any())
+        s.set_groups(intra=has_intra, flags=False)           # (the synthetic pictures use no transform skip / lossless / PCM CUs)
         stg.append(s)
     sets = [pics, [ctx.acquire() for _ in range(nb)]]
     slices = []
@@ -288,14 +293,22 @@ def host_inclusive(ctx, metas, pics, refs_of, nb, w, h, args):
         step(k)
     ctx.sync()
     dt = time.perf_counter() - t0
-    staged = stg[0].arrays["depth"].nbytes and sum(a.nbytes for a in stg[0].arrays.values()) + sum(a.nbytes for a in stg[0].levels)
+    a0 = stg[0].arrays
+    group = {"base": ["slice_idx", "tile_idx", "depth", "part_size", "pred_mode", "qp", "tr_idx", "cbf_y", "cbf_u", "cbf_v", "mv0", "ref_idx0"],
+             "list1": ["mv1", "ref_idx1"], "intra": ["intra_dir_l", "intra_dir_c"]}
+    meta_bytes = sum(a0[k].nbytes for k in group["base"]) + (sum(a0[k].nbytes for k in group["list1"]) if args.bi else 0) + \
+        (sum(a0[k].nbytes for k in group["intra"]) if has_intra else 0)
+    staged = meta_bytes + level_bytes + 3 * 4 * (ctx.num_ctus + 1)
+    dense = sum(a.nbytes for a in stg[0].arrays.values()) + sum(a.nbytes for a in stg[0].levels)
     for s in stg:
         ctx.staging_free(s)
     return {"host_inclusive_Mpixels_s": round(n * nb * w * h / dt / 1e6, 1),
             "host_inclusive": {"ms_per_step": round(dt / n * 1e3, 3), "steps": n, "staged_bytes_per_picture": int(staged),
+                               "staged_bytes_per_picture_dense_levels": int(dense),
                                "PCIe_GBps": round(n * nb * staged / dt / 1e9, 1),
                                "what": "hmgpu_decompress_pictures + hmgpu_filter_pictures per step, inputs copied from page-locked staging "
-                                       "blocks every step (two DMAs per picture on a copy stream, two sets of device pictures: "
+                                       "blocks every step (the metadata a P picture without intra CUs needs in one DMA, compact levels -- coded TUs only -- in "
+                                       "three, on a copy stream; two sets of device pictures: "
                                        "the copies of a step overlap the kernels of the previous one)"}}
 
 

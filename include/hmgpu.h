@@ -133,6 +133,12 @@ typedef struct hmgpu_coeffs {
   const int16_t* level[3];
   const int16_t* pcm_sample[3];   /* TComDataCU::getPCMSample (m_pcIPCMSample*): the transmitted samples of PCM CUs, same layout as
                                      the levels; needed only if meta->ipcm marks PCM CUs (may be NULL otherwise) */
+  /* Compact levels (optional; all three NULL = HM's dense layout above).  level[c] then holds ONLY the coded transform units of
+   * component c -- the blocks HM's layout would hold, in the same order (CTU by CTU, z-order of the TU origins inside a CTU, raster
+   * inside a TU), with the uncoded ones left out; a TU is coded iff its cbf bits are set down to its transform depth
+   * (TComTrQuant.cpp:1558-1564).  ctu_level_start[c][a] = element offset of CTU a's first coded TU, [num_ctus] = total: only that
+   * many elements cross the bus.  Whole-picture calls only.  hmgpu_pack_levels() converts HM's arrays. */
+  const uint32_t* ctu_level_start[3];
 } hmgpu_coeffs;
 
 /* SAOBlkParam as parsed (TDecSbac::parseSAOBlkParam), before reconstructBlkSAOParams: [num_ctus][3] */
@@ -252,6 +258,13 @@ hmgpu_status hmgpu_filter_pictures(hmgpu_ctx* ctx, int32_t n, const hmgpu_filter
 typedef struct hmgpu_staging hmgpu_staging;
 hmgpu_status hmgpu_staging_alloc(hmgpu_ctx* ctx, hmgpu_staging** out, hmgpu_ctu_meta* meta, hmgpu_coeffs* coeffs);
 void         hmgpu_staging_free(hmgpu_ctx* ctx, hmgpu_staging* staging);
+/* (the block also holds the three ctu_level_start arrays: coeffs->ctu_level_start[] of hmgpu_staging_alloc points at them; a caller
+ * that fills the block with HM's dense layout sets the three pointers to NULL in the struct it passes to the calls) */
+
+/* HM's dense level arrays -> the compact form (host, no device involved): out_level[c] needs room for the dense size in the worst
+ * case, out_start[c] for num_ctus + 1 entries.  The walk over depth / tr_idx / cbf is the one the device's flattener does. */
+hmgpu_status hmgpu_pack_levels(const hmgpu_seq_params* seq, const hmgpu_ctu_meta* meta, const hmgpu_coeffs* dense,
+                               int16_t* const out_level[3], uint32_t* const out_start[3]);
 
 /* ------------------------------------------------------------------------------------------------ call 2
  * Replaces TDecGop::filterPicture (TDecGop.cpp:157-217): TComLoopFilter::loopFilterPic (all vertical edges, then

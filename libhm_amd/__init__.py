@@ -86,6 +86,7 @@ def lib():
         L.hmgpu_staging_alloc.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(abi.CtuMeta), C.POINTER(abi.Coeffs)]
         L.hmgpu_staging_free.argtypes = [C.c_void_p, C.c_void_p]
         L.hmgpu_staging_free.restype = None
+        L.hmgpu_pack_levels.argtypes = [C.POINTER(abi.SeqParams), C.POINTER(abi.CtuMeta), C.POINTER(abi.Coeffs), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
         L.hmgpu_replay.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32]
         L.hmgpu_replay_batch.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.c_int32, C.c_int32, C.c_int32]
         L.hmgpu_set_profiling.argtypes = [C.c_void_p, C.c_int32]
@@ -99,6 +100,22 @@ def lib():
 
 def _p(a):
     return a.ctypes.data_as(C.c_void_p)
+
+
+def pack_levels(seq, meta, coeffs):
+    """HM's dense level arrays -> a CoeffHolder with compact levels (coded TUs only) + CTU starts (hmgpu_pack_levels: host code)"""
+    n = abi.num_ctus(seq)
+    ctu = 1 << seq.log2_ctu_size
+    out = abi.CoeffHolder(*[np.zeros(n * ctu * ctu >> (2 if k else 0), dtype=np.int16) for k in range(3)])
+    out.starts = [np.zeros(n + 1, dtype=np.uint32) for _ in range(3)]
+    lv = (C.c_void_p * 3)(*[out.struct.level[k] for k in range(3)])
+    stt = (C.c_void_p * 3)(*[s.ctypes.data for s in out.starts])
+    st = lib().hmgpu_pack_levels(C.byref(seq), C.byref(meta.struct), C.byref(coeffs.struct), lv, stt)
+    if st != 0:
+        raise HmgpuError(st, "hmgpu_pack_levels")
+    for k in range(3):
+        out.struct.ctu_level_start[k] = out.starts[k].ctypes.data
+    return out
 
 
 class Context:
@@ -241,6 +258,9 @@ class Context:
         m, co = abi.CtuMeta(), abi.Coeffs()
         self._chk(lib().hmgpu_staging_alloc(self._h, C.byref(h), C.byref(m), C.byref(co)), "hmgpu_staging_alloc")
         return abi.StagingHolder(h, m, co, self.num_ctus, abi.parts_per_ctu(self.seq), 1 << self.seq.log2_ctu_size)
+
+    def pack_levels(self, meta, coeffs):
+        return pack_levels(self.seq, meta, coeffs)
 
     def staging_free(self, st):
         lib().hmgpu_staging_free(self._h, st.handle)

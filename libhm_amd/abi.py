@@ -49,7 +49,7 @@ class CtuMeta(C.Structure):
 
 
 class Coeffs(C.Structure):
-    _fields_ = [("level", C.c_void_p * 3), ("pcm_sample", C.c_void_p * 3)]
+    _fields_ = [("level", C.c_void_p * 3), ("pcm_sample", C.c_void_p * 3), ("ctu_level_start", C.c_void_p * 3)]
 
 
 class SaoParam(C.Structure):
@@ -134,11 +134,13 @@ class MetaHolder:
 
 
 class StagingHolder:
-    """numpy views of a staging block (hmgpu_staging_alloc): .arrays[name] / .levels[k] alias the page-locked memory, .struct /
-    .coeffs are the structs to hand to the whole-picture calls; fill(meta_holder, coeff_holder) copies ordinary arrays in."""
+    """numpy views of a staging block (hmgpu_staging_alloc): .arrays[name] / .levels[k] / .starts[k] alias the page-locked memory;
+    .struct / .coeffs are the structs to hand to the whole-picture calls.  fill() copies ordinary arrays in, levels in HM's dense
+    layout; fill_compact() packs the levels (hmgpu_pack_levels: coded TUs only)."""
 
     def __init__(self, handle, meta_struct, coeff_struct, num_ctus, parts, ctu):
-        self.handle, self.struct, self.coeffs = handle, meta_struct, coeff_struct
+        self.handle, self.struct = handle, meta_struct
+        self.num_ctus = num_ctus
         np_ = num_ctus * parts
 
         def view(addr, dt, n):
@@ -154,8 +156,16 @@ class StagingHolder:
             n = num_ctus if name in ("slice_idx", "tile_idx") else (2 * np_ if name in ("mv0", "mv1") else np_)
             self.arrays[name] = view(addr[name], dt, n)
         self.levels = [view(coeff_struct.level[k], np.int16, num_ctus * ctu * ctu >> (2 if k else 0)) for k in range(3)]
+        self.starts = [view(coeff_struct.ctu_level_start[k], np.uint32, num_ctus + 1) for k in range(3)]
+        self._all = {"intra": (m.intra_dir[0], m.intra_dir[1]), "ts": tuple(m.transform_skip[k] for k in range(3)),
+                     "bypass": m.transquant_bypass, "ipcm": m.ipcm}
+        self._compact = coeff_struct
+        self._dense = Coeffs()
+        for k in range(3):
+            self._dense.level[k] = coeff_struct.level[k]
+        self.coeffs = self._dense
 
-    def fill(self, meta, coeffs):
+    def _fill_meta(self, meta):
         for name, _ in META_ARRAYS:
             src = meta.arrays.get(name)
             if src is not None:
@@ -164,8 +174,33 @@ class StagingHolder:
                 self.arrays[name][:] = -1
             else:
                 self.arrays[name][:] = 0
+
+    def set_groups(self, intra=True, flags=True):
+        """leave optional groups of the block out of the copy: the intra modes (a picture without intra CUs), the transform-skip /
+        lossless / PCM flags (a picture that uses none of them)"""
+        m = self.struct
+        m.intra_dir[0], m.intra_dir[1] = self._all["intra"] if intra else (None, None)
+        for k in range(3):
+            m.transform_skip[k] = self._all["ts"][k] if flags else None
+        m.transquant_bypass = self._all["bypass"] if flags else None
+        m.ipcm = self._all["ipcm"] if flags else None
+
+    def fill(self, meta, coeffs):
+        self._fill_meta(meta)
         for k in range(3):
             self.levels[k][:] = coeffs.arrays[k].reshape(-1)
+        self.coeffs = self._dense
+
+    def fill_compact(self, lib, seq, meta, coeffs):
+        """lib: the loaded libhmgpu (hmgpu_pack_levels is host code); returns the number of level bytes that will cross the bus"""
+        self._fill_meta(meta)
+        lv = (C.c_void_p * 3)(*[self._compact.level[k] for k in range(3)])
+        stt = (C.c_void_p * 3)(*[self._compact.ctu_level_start[k] for k in range(3)])
+        st = lib.hmgpu_pack_levels(C.byref(seq), C.byref(meta.struct), C.byref(coeffs.struct), lv, stt)
+        if st != 0:
+            raise RuntimeError("hmgpu_pack_levels: status %d" % st)
+        self.coeffs = self._compact
+        return 2 * int(sum(int(self.starts[k][self.num_ctus]) for k in range(3)))
 
 
 class CoeffHolder:

@@ -38,12 +38,14 @@ struct Picture {
   void* pcm = nullptr;                  // PCM sample buffers, allocated when the first PCM CU shows up
   void* derived = nullptr;              // blk, tu lists, counters, sao params, slices
   uint8_t* sl_table = nullptr;          // device: expanded scaling-list matrices (inside `derived`)
+  uint32_t* coef_start = nullptr;       // device: [3][num_ctus + 1] CTU starts of compact levels (inside `derived`)
   std::vector<uint8_t> sl_host;         // host copy the asynchronous upload reads from
   PicDev dev;                           // host mirror of the device descriptor
   std::vector<SliceDev> slices;         // host mirror of the slice table
   std::vector<SaoDev> h_saoprm;         // host copy of the resolved SAO parameters the asynchronous upload reads from
   std::vector<uint16_t> h_slice_idx, h_tile_idx;   // host mirrors of the per-CTU slice / tile index (SAO merge resolution needs them)
   int max_slice = -1;
+  bool flags_staged = true;             // the device copies of transform_skip / bypass / ipcm may hold non-zero values
   uint64_t last_use = 0;                // use_seq of the last batch of kernels that read this picture's input arrays (0: none)
 };
 
@@ -54,7 +56,8 @@ struct EventPair { hipEvent_t a, b; int kind; };
 // one page-locked block that holds a picture's input arrays in the order the device keeps them (hmgpu_staging_alloc)
 struct hmgpu_staging {
   char* host = nullptr;
-  size_t meta_bytes = 0, coef_bytes = 0;
+  size_t meta_bytes = 0, coef_bytes = 0, start_bytes = 0;   // metadata block | dense-capacity levels | [3][num_ctus + 1] CTU starts
+  size_t grp[5] = {0, 0, 0, 0, 0};                         // carve_meta: where the optional groups of the metadata block start
   hmgpu_ctu_meta m;
   hmgpu_coeffs co;
 };
@@ -147,17 +150,27 @@ struct ProfScope {
   ~ProfScope() { prof_end(c, &ep); if (c->pending.size() > 8192) prof_drain(c); }
 };
 
-// the raw HM arrays of one picture inside one block (device allocation; staging blocks mirror it, so that one copy moves them all)
-void carve_meta(Carver& m, PicDev& d, size_t np, int num_ctus) {
+// the raw HM arrays of one picture inside one block (device allocation; staging blocks mirror it, so that one copy moves them all).
+// Order: what every picture needs first, then the groups a picture may do without -- list 1 (P slices), intra modes (no intra CUs),
+// transform skip / lossless / PCM flags -- so that a copy from a staging block moves a prefix, or a prefix and one more piece.
+// grp[0..4]: byte offsets where the groups start / the block ends.
+void carve_meta(Carver& m, PicDev& d, size_t np, int num_ctus, size_t* grp = nullptr) {
+  size_t g[5];
+  g[0] = m.off;
+  d.slice_idx = m.take<uint16_t>(num_ctus); d.tile_idx = m.take<uint16_t>(num_ctus);
   d.depth = m.take<uint8_t>(np); d.part_size = m.take<int8_t>(np); d.pred_mode = m.take<int8_t>(np);
   d.qp = m.take<int8_t>(np); d.tr_idx = m.take<uint8_t>(np);
   for (int k = 0; k < 3; k++) d.cbf[k] = m.take<uint8_t>(np);
-  for (int k = 0; k < 3; k++) d.tskip[k] = m.take<uint8_t>(np);
-  for (int k = 0; k < 2; k++) d.mv[k] = m.take<int16_t>(np * 2);
-  for (int k = 0; k < 2; k++) d.ref_idx[k] = m.take<int8_t>(np);
+  d.mv[0] = m.take<int16_t>(np * 2); d.ref_idx[0] = m.take<int8_t>(np);
+  g[1] = m.off;
+  d.mv[1] = m.take<int16_t>(np * 2); d.ref_idx[1] = m.take<int8_t>(np);
+  g[2] = m.off;
   for (int k = 0; k < 2; k++) d.intra_dir[k] = m.take<uint8_t>(np);
+  g[3] = m.off;
+  for (int k = 0; k < 3; k++) d.tskip[k] = m.take<uint8_t>(np);
   d.bypass = m.take<uint8_t>(np); d.ipcm = m.take<uint8_t>(np);
-  d.slice_idx = m.take<uint16_t>(num_ctus); d.tile_idx = m.take<uint16_t>(num_ctus);
+  g[4] = m.off;
+  if (grp) memcpy(grp, g, sizeof(g));
 }
 
 hmgpu_status alloc_picture(hmgpu_ctx* c, Picture& p) {
@@ -184,6 +197,8 @@ hmgpu_status alloc_picture(hmgpu_ctx* c, Picture& p) {
     PicDev& d = p.dev;
     d.blk = m.take<BlkInfo>((size_t)c->grid_w * c->grid_h);
     d.tmv = m.take<TileMv>((size_t)(c->grid_w / 2) * (c->grid_h / 2));
+    for (int k = 0; k < 3; k++) d.quad_off[k] = m.take<uint32_t>((size_t)c->num_ctus * (c->parts / 4));
+    p.coef_start = m.take<uint32_t>((size_t)3 * (c->num_ctus + 1));
     for (int k = 0; k < 4; k++) d.tu[k] = m.take<TuRec>((size_t)c->tu_cap[k] * kTuShards);
     d.tu_count = m.take<uint32_t>(4 * kTuShards);
     d.stats = m.take<unsigned long long>(2 * kTuShards);
@@ -203,7 +218,7 @@ hmgpu_status alloc_picture(hmgpu_ctx* c, Picture& p) {
   d.lf_across_tiles = 1; d.sao_applied = 0;
   d.has_intra_dir = 0; d.strong_intra_smoothing = s.strong_intra_smoothing ? 1 : 0;
   d.sl_m = nullptr;
-  for (int k = 0; k < 3; k++) { d.pcm[k] = nullptr; d.pcm_shift[k] = 0; }
+  for (int k = 0; k < 3; k++) { d.pcm[k] = nullptr; d.pcm_shift[k] = 0; d.coef_start[k] = nullptr; }
   d.pcm_lf_disable = s.pcm_loop_filter_disable ? 1 : 0; d.any_nofilt = 0;
   for (int k = 0; k < 4; k++) d.tu_cap[k] = c->tu_cap[k];
   {
@@ -738,11 +753,24 @@ static hmgpu_status register_slice(hmgpu_ctx* c, hmgpu_pic cur, int32_t slice_id
   return HMGPU_OK;
 }
 
+static bool stg_starts_contiguous(const hmgpu_coeffs* co, int num_ctus) {
+  return co->ctu_level_start[1] == co->ctu_level_start[0] + (num_ctus + 1) && co->ctu_level_start[2] == co->ctu_level_start[1] + (num_ctus + 1);
+}
+
 // a staging block whose arrays the caller handed over for a whole picture: its metadata is ONE copy, its levels another
 static const hmgpu_staging* staging_of(const hmgpu_ctx* c, const hmgpu_ctu_meta* m, const hmgpu_coeffs* co) {
-  for (const hmgpu_staging* st : c->stagings)
-    if (m->depth == st->m.depth && memcmp(m, &st->m, sizeof(*m)) == 0 && co->level[0] == st->co.level[0] && co->level[1] == st->co.level[1] &&
-        co->level[2] == st->co.level[2]) return st;
+  for (const hmgpu_staging* st : c->stagings) {
+    const hmgpu_ctu_meta& h = st->m;
+    if (m->depth != h.depth) continue;
+    // the required arrays are the block's; the optional ones are the block's or left out (NULL: that group does not travel)
+    bool ok = m->part_size == h.part_size && m->pred_mode == h.pred_mode && m->qp == h.qp && m->tr_idx == h.tr_idx && m->slice_idx == h.slice_idx &&
+              m->tile_idx == h.tile_idx;
+    for (int k = 0; k < 3 && ok; k++) ok = m->cbf[k] == h.cbf[k] && (!m->transform_skip[k] || m->transform_skip[k] == h.transform_skip[k]);
+    for (int k = 0; k < 2 && ok; k++) ok = m->mv[k] == h.mv[k] && m->ref_idx[k] == h.ref_idx[k] && (!m->intra_dir[k] || m->intra_dir[k] == h.intra_dir[k]);
+    ok = ok && (!m->transquant_bypass || m->transquant_bypass == h.transquant_bypass) && (!m->ipcm || m->ipcm == h.ipcm);
+    for (int k = 0; k < 3 && ok; k++) ok = co->level[k] == st->co.level[k];
+    if (ok) return st;
+  }
   return nullptr;
 }
 
@@ -761,14 +789,47 @@ static hmgpu_status stage_inputs(hmgpu_ctx* c, hmgpu_pic cur, int32_t slice_idx,
                   c->seq.pcm_bit_depth_chroma < 1 || c->seq.pcm_bit_depth_chroma > c->seq.bit_depth_chroma)) return HMGPU_EINVAL;
   p.dev.has_intra_dir = (m->intra_dir[0] && m->intra_dir[1]) ? 1 : 0;      // without the modes intra CUs are left untouched
   const hmgpu_staging* stg = (first_ctu == 0 && num_ctus == c->num_ctus) ? staging_of(c, m, co) : nullptr;
+  const bool compact = co->ctu_level_start[0] && co->ctu_level_start[1] && co->ctu_level_start[2];
+  if (!compact && (co->ctu_level_start[0] || co->ctu_level_start[1] || co->ctu_level_start[2])) return HMGPU_EINVAL;
+  if (compact) {
+    if (first_ctu != 0 || num_ctus != c->num_ctus) return HMGPU_EINVAL;      // whole pictures only
+    for (int k = 0; k < 3; k++) if (co->ctu_level_start[k][c->num_ctus] > c->coef_elems[k]) return HMGPU_EINVAL;
+    // the CTU starts (from a staging block: its three arrays in one copy)
+    const bool one = stg_starts_contiguous(co, c->num_ctus);
+    for (int k = 0; k < (one ? 1 : 3); k++)
+      HIP_TRY(c, hipMemcpyAsync(p.coef_start + (size_t)k * (c->num_ctus + 1), co->ctu_level_start[k],
+                                (size_t)(one ? 3 : 1) * (c->num_ctus + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, hs));
+    for (int k = 0; k < 3; k++) {
+      p.dev.coef_start[k] = p.coef_start + (size_t)k * (c->num_ctus + 1);
+      const size_t n = co->ctu_level_start[k][c->num_ctus];
+      if (n) HIP_TRY(c, hipMemcpyAsync((void*)p.dev.coef[k], co->level[k], n * sizeof(int16_t), hipMemcpyHostToDevice, hs));
+    }
+  } else {
+    for (int k = 0; k < 3; k++) p.dev.coef_start[k] = nullptr;
+  }
   if (stg) {
-    // the caller filled a staging block: the whole metadata block in one DMA, the levels in another
-    HIP_TRY(c, hipMemcpyAsync(p.meta, stg->host, stg->meta_bytes, hipMemcpyHostToDevice, hs));
-    HIP_TRY(c, hipMemcpyAsync(p.coef, stg->host + stg->meta_bytes, stg->coef_bytes, hipMemcpyHostToDevice, hs));
+    // the caller filled a staging block: the metadata block in one DMA (the dense levels in another) -- minus the groups this
+    // picture does without: list 1 when no slice is a B slice (k_prep ignores it then), the intra modes and the transform-skip /
+    // lossless / PCM flags when the caller left them out (the device copies of the flags are cleared if an earlier picture set them)
+    bool any_b_slice = false;
+    for (int si : slices) any_b_slice |= p.slices[si].slice_type == HMGPU_B_SLICE;
+    const bool flags_used = m->transform_skip[0] || m->transform_skip[1] || m->transform_skip[2] || m->transquant_bypass || m->ipcm;
+    const bool want[4] = {true, any_b_slice, p.dev.has_intra_dir != 0, flags_used};
+    for (int g0 = 0; g0 < 4;) {
+      if (!want[g0]) { g0++; continue; }
+      int g1 = g0 + 1;
+      while (g1 < 4 && want[g1]) g1++;
+      HIP_TRY(c, hipMemcpyAsync((char*)p.meta + stg->grp[g0], stg->host + stg->grp[g0], stg->grp[g1] - stg->grp[g0], hipMemcpyHostToDevice, hs));
+      g0 = g1;
+    }
+    if (!flags_used && p.flags_staged) HIP_TRY(c, hipMemsetAsync((char*)p.meta + stg->grp[3], 0, stg->grp[4] - stg->grp[3], hs));
+    p.flags_staged = flags_used;
+    if (!compact) HIP_TRY(c, hipMemcpyAsync(p.coef, stg->host + stg->meta_bytes, stg->coef_bytes, hipMemcpyHostToDevice, hs));
     p.h_slice_idx.assign(m->slice_idx, m->slice_idx + c->num_ctus);
     p.h_tile_idx.assign(m->tile_idx, m->tile_idx + c->num_ctus);
   } else {
     ProfScope ps(c, K_H2D);
+    p.flags_staged = true;
     // ---- HM arrays of the CTU range (field-by-field, exactly the arrays TComDataCU owns)
 #define STAGE(dst, src, elem_bytes)                                                                                       \
     if (src) HIP_TRY(c, hipMemcpyAsync((char*)(dst) + po * (elem_bytes), (const char*)(src) + po * (elem_bytes), pn * (elem_bytes), \
@@ -791,7 +852,7 @@ static hmgpu_status stage_inputs(hmgpu_ctx* c, hmgpu_pic cur, int32_t slice_idx,
       HIP_TRY(c, hipMemcpyAsync((void*)(p.dev.slice_idx + first_ctu), p.h_slice_idx.data() + first_ctu, (size_t)num_ctus * 2, hipMemcpyHostToDevice, hs));
       HIP_TRY(c, hipMemcpyAsync((void*)(p.dev.tile_idx + first_ctu), p.h_tile_idx.data() + first_ctu, (size_t)num_ctus * 2, hipMemcpyHostToDevice, hs));
     }
-    for (int k = 0; k < 3; k++) {
+    for (int k = 0; k < 3 && !compact; k++) {
       const size_t per = (size_t)(c->ctu * c->ctu) >> (k ? 2 : 0);
       HIP_TRY(c, hipMemcpyAsync((void*)(p.dev.coef[k] + first_ctu * per), co->level[k] + first_ctu * per, (size_t)num_ctus * per * 2,
                                 hipMemcpyHostToDevice, hs));
@@ -909,6 +970,47 @@ hmgpu_status hmgpu_decompress_picture(hmgpu_ctx* c, hmgpu_pic cur, int32_t num_s
   return stage_and_run(c, cur, 0, all, any_wp, m, co, 0, c->num_ctus);
 }
 
+// HM's dense level arrays -> compact streams.  The same walk as k_prep's count (k_prep.hip): per 8x8 luma area in z-order, the TUs
+// that originate there; a TU is coded iff its cbf bits are set down to its transform depth.
+hmgpu_status hmgpu_pack_levels(const hmgpu_seq_params* seq, const hmgpu_ctu_meta* m, const hmgpu_coeffs* dense,
+                               int16_t* const out_level[3], uint32_t* const out_start[3]) {
+  if (!seq || !m || !dense || !out_level || !out_start || !m->depth || !m->part_size || !m->tr_idx || !m->cbf[0] || !m->cbf[1] || !m->cbf[2]) return HMGPU_EINVAL;
+  for (int k = 0; k < 3; k++) if (!dense->level[k] || !out_level[k] || !out_start[k]) return HMGPU_EINVAL;
+  const int log2ctu = seq->log2_ctu_size, ctu_sz = 1 << log2ctu, pw = ctu_sz / 4, parts = pw * pw;
+  const int ctus_w = (seq->width + ctu_sz - 1) / ctu_sz, n_ctus = hmgpu_num_ctus(seq);
+  uint32_t pos[3] = {0, 0, 0};
+  for (int a = 0; a < n_ctus; a++) {
+    const int cx = (a % ctus_w) * ctu_sz, cy = (a / ctus_w) * ctu_sz;
+    for (int k = 0; k < 3; k++) out_start[k][a] = pos[k];
+    for (int z0 = 0; z0 < parts; z0 += 4) {
+      const size_t idx = (size_t)a * parts + z0;
+      const int x4 = zscan_x(z0), y4 = zscan_y(z0);
+      if (cx + 4 * x4 >= seq->width || cy + 4 * y4 >= seq->height || m->part_size[idx] == HMGPU_SIZE_NONE) continue;
+      const int tr = m->tr_idx[idx], log2tu = log2ctu - m->depth[idx] - tr;
+      if (log2tu > 5) continue;
+      const unsigned chain = (1u << (tr + 1)) - 1;
+      auto emit = [&](int comp, size_t src_off, uint32_t n) {
+        memcpy(out_level[comp] + pos[comp], dense->level[comp] + src_off, n * sizeof(int16_t));
+        pos[comp] += n;
+      };
+      const size_t base_l = (size_t)a * ctu_sz * ctu_sz, base_c = base_l / 4;
+      if (log2tu > 2) {
+        const int tu_parts = 1 << (log2tu - 2);
+        if ((x4 & (tu_parts - 1)) || (y4 & (tu_parts - 1))) continue;
+        if ((m->cbf[0][idx] & chain) == chain) emit(0, base_l + 16 * (size_t)z0, 1u << (2 * log2tu));
+        if ((m->cbf[1][idx] & chain) == chain) emit(1, base_c + 4 * (size_t)z0, 1u << (2 * log2tu - 2));
+        if ((m->cbf[2][idx] & chain) == chain) emit(2, base_c + 4 * (size_t)z0, 1u << (2 * log2tu - 2));
+      } else {
+        for (int j = 0; j < 4; j++) if ((m->cbf[0][idx + j] & chain) == chain) emit(0, base_l + 16 * (size_t)(z0 + j), 16);
+        if ((m->cbf[1][idx] & chain) == chain) emit(1, base_c + 4 * (size_t)z0, 16);
+        if ((m->cbf[2][idx] & chain) == chain) emit(2, base_c + 4 * (size_t)z0, 16);
+      }
+    }
+  }
+  for (int k = 0; k < 3; k++) out_start[k][n_ctus] = pos[k];
+  return HMGPU_OK;
+}
+
 // ---- staging blocks
 hmgpu_status hmgpu_staging_alloc(hmgpu_ctx* c, hmgpu_staging** out, hmgpu_ctu_meta* meta, hmgpu_coeffs* coeffs) {
   if (!c || !out || !meta || !coeffs) return HMGPU_EINVAL;
@@ -918,10 +1020,12 @@ hmgpu_status hmgpu_staging_alloc(hmgpu_ctx* c, hmgpu_staging** out, hmgpu_ctu_me
   const size_t np = (size_t)c->num_ctus * c->parts;
   PicDev lay;
   memset(&lay, 0, sizeof(lay));
-  { Carver m(nullptr); carve_meta(m, lay, np, c->num_ctus); st->meta_bytes = m.off; }
+  { Carver m(nullptr); carve_meta(m, lay, np, c->num_ctus, st->grp); st->meta_bytes = m.off; }
   for (int k = 0; k < 3; k++) st->coef_bytes += align_up(c->coef_elems[k] * sizeof(int16_t), 256);
-  if (hipHostMalloc((void**)&st->host, st->meta_bytes + st->coef_bytes, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); delete st; return HMGPU_ENOMEM; }
-  memset(st->host, 0, st->meta_bytes + st->coef_bytes);
+  st->start_bytes = align_up((size_t)3 * (c->num_ctus + 1) * sizeof(uint32_t), 256);
+  const size_t total = st->meta_bytes + st->coef_bytes + st->start_bytes;
+  if (hipHostMalloc((void**)&st->host, total, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); delete st; return HMGPU_ENOMEM; }
+  memset(st->host, 0, total);
   { Carver m(st->host); carve_meta(m, lay, np, c->num_ctus); }
   hmgpu_ctu_meta& h = st->m;
   memset(&h, 0, sizeof(h));
@@ -934,6 +1038,7 @@ hmgpu_status hmgpu_staging_alloc(hmgpu_ctx* c, hmgpu_staging** out, hmgpu_ctu_me
   memset(const_cast<int8_t*>(h.ref_idx[0]), 0xff, np); memset(const_cast<int8_t*>(h.ref_idx[1]), 0xff, np);
   memset(&st->co, 0, sizeof(st->co));
   { Carver m(st->host + st->meta_bytes); for (int k = 0; k < 3; k++) st->co.level[k] = m.take<int16_t>(c->coef_elems[k]); }
+  for (int k = 0; k < 3; k++) st->co.ctu_level_start[k] = reinterpret_cast<const uint32_t*>(st->host + st->meta_bytes + st->coef_bytes) + (size_t)k * (c->num_ctus + 1);
   c->stagings.push_back(st);
   *meta = st->m; *coeffs = st->co; *out = st;
   return HMGPU_OK;

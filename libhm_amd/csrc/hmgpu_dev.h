@@ -120,6 +120,8 @@ struct PicDev {
   int32_t any_nofilt;              // some partition of the picture carries BF_NOFILT (host-side scan): SAO looks at the flags
   const uint16_t* slice_idx; const uint16_t* tile_idx;
   const int16_t* coef[3];
+  const uint32_t* coef_start[3];   // compact levels: element offset of every CTU's first coded TU (+ total), else null (HM's dense layout)
+  uint32_t* quad_off[3];           // compact levels: offset of the first TU that starts in every 8x8 luma area (z-order), written by k_prep
   const SliceDev* slices;
   // derived
   BlkInfo* blk;

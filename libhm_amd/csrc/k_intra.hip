@@ -63,11 +63,13 @@ struct IntraLds {
   // the CTU's coefficient levels of this component (HM layout), staged while the block still waits for its neighbours: the
   // serial TU chain would otherwise pay one trip to HBM per coded TU (the levels are read exactly once: never a cache hit)
   __attribute__((aligned(16))) int16_t lev[64 * 64];
+  uint32_t qoff[64];                     // compact levels: offset in lev[] of the first TU of every 8x8 luma area of the CTU
   __attribute__((aligned(4))) uint8_t m_depth[256], m_part[256], m_pred[256], m_tr[256], m_qp[256], m_cbf[256], m_ts[256], m_dir[256], m_dirl[256], m_byp[256], m_pcm[256];
 };
 
 struct TuCtx {
   int comp, ctu, z_tu, log2n, mode, cbf, skip, bypass, x0, y0, qp_cu;     // x0, y0: component samples
+  int lev_off;                                                    // of the TU's levels in IntraLds::lev
   int cip, cqo, slice, tile, nb_same;                             // per-CTU constants: constrained intra pred, chroma QP offset, slice / tile index, neighbours in the same slice and tile
   int cx0, cy0;                                                   // CTU origin in component samples
 };
@@ -121,7 +123,7 @@ __device__ inline void intra_tu(const PicDev& P, const TuCtx& t, IntraLds& L) {
 #pragma unroll
   for (int i = 0; i < N / 2; i++) lv[i] = 0;
   if (t.cbf && active) {
-    const int16_t* lev = &L.lev[(comp ? 4 : 16) * t.z_tu + n * N];          // staged by k_intra before the wait for the neighbours
+    const int16_t* lev = &L.lev[t.lev_off + n * N];                        // staged by k_intra before the wait for the neighbours
     if constexpr (N == 4) { const u32x2 a = *reinterpret_cast<const u32x2*>(lev); lv[0] = a.x; lv[1] = a.y; }
     else {
 #pragma unroll
@@ -322,6 +324,7 @@ __device__ inline void intra_stage(const PicDev& P, int comp, int ctu, IntraLds&
 
 // all intra CUs of one CTU, one component, in decoding order (xReconIntraQT per CU, xIntraRecQT over its TU tree)
 __device__ inline void intra_ctu(const PicDev& P, int comp, int ctu, IntraLds& L) {
+  const bool compact = P.coef_start[0] != nullptr;
   const int parts = P.parts;
   const int ctu_x = (ctu % P.ctus_w) << P.log2ctu, ctu_y = (ctu / P.ctus_w) << P.log2ctu;
   const int cs = comp ? 1 : 0;
@@ -381,6 +384,7 @@ __device__ inline void intra_ctu(const PicDev& P, int comp, int ctu, IntraLds& L
       continue;
     }
     int zc = z;
+    int coded_before = 0;                                  // compact levels: coded 4x4 luma TUs of the current 8x8 area before this one
     while (zc < cu_end) {
       const int tr = L.m_tr[zc];
       const int log2tu = log2cu - tr;
@@ -399,6 +403,15 @@ __device__ inline void intra_ctu(const PicDev& P, int comp, int ctu, IntraLds& L
         t.cbf = (L.m_cbf[zc] >> tr) & 1;
         t.skip = L.m_ts[zc];
         t.bypass = L.m_byp[zc];
+        if (compact) {
+          // (HM descends to a TU only through coded ancestors: the cbf chain, as in k_prep's count)
+          const int chain = (1 << (tr + 1)) - 1;
+          if ((zc & 3) == 0) coded_before = 0;
+          t.lev_off = (int)L.qoff[zc >> 2] + ((comp == 0 && log2tu == 2) ? 16 * coded_before : 0);
+          if (comp == 0 && log2tu == 2 && (L.m_cbf[zc] & chain) == chain) coded_before++;
+        } else {
+          t.lev_off = (comp ? 4 : 16) * zc;
+        }
         intra_tu_any(P, t, L);
       }
       zc += 1 << (2 * (log2tu - 2));
@@ -442,7 +455,14 @@ __global__ void __launch_bounds__(64) k_intra(const PicDev* __restrict__ pics, B
     top = __builtin_amdgcn_ballot_w64(t) != 0; bottom = __builtin_amdgcn_ballot_w64(bm) != 0;
   };
   // the levels of this CTU do not depend on anybody: on their way into LDS while the neighbours finish
-  {
+  if (P.coef_start[0] != nullptr) {
+    // compact levels: the CTU's coded TUs are one contiguous piece of the stream; where each 8x8 area's TUs start in it (k_prep)
+    const uint32_t s0 = ldg(P.coef_start[comp] + ctu), s1 = ldg(P.coef_start[comp] + ctu + 1);
+    const int16_t* src = P.coef[comp] + s0;
+    for (uint32_t i = (uint32_t)lane * 8; i < s1 - s0; i += 64 * 8) *reinterpret_cast<u32x4*>(&L.lev[i]) = ldg4(src + i);
+    const int qpc = P.parts >> 2;
+    if (lane < qpc) L.qoff[lane] = ldg(P.quad_off[comp] + (size_t)ctu * qpc + lane) - s0;
+  } else {
     const int n_lev = (1 << (2 * P.log2ctu)) >> (comp ? 2 : 0);
     const int16_t* src = P.coef[comp] + (size_t)ctu * n_lev;
     for (int i = lane * 8; i < n_lev; i += 64 * 8) *reinterpret_cast<u32x4*>(&L.lev[i]) = ldg4(src + i);

@@ -69,6 +69,7 @@ __global__ void __launch_bounds__(256) k_prep(const PicDev* __restrict__ pics, B
   Quad q; q.valid = false; q.intra = false; q.log2tu = 3; q.tr = 0; q.ctu = 0; q.z0 = 0; q.gx0 = q.gy0 = 0;
   q.log2cu = 3; q.part_size = 0; q.qp_cu = 0; q.sidx = 0; q.bypass = 0;
   bool has[6] = {false, false, false, false, false, false};      // slots: luma TU of partition 0..3 (or one larger TU in slot 0), Cb, Cr
+  uint32_t cnt[3] = {0, 0, 0}, lmask = 0;                        // compact levels: coded coefficients that start in this area (intra CUs too), coded 4x4 luma TUs
   int cls[6] = {0, 0, 0, 0, 0, 0};
   uint32_t loc[6] = {0, 0, 0, 0, 0, 0};
   const SliceDev* sl = P.slices;
@@ -232,6 +233,24 @@ __global__ void __launch_bounds__(256) k_prep(const PicDev* __restrict__ pics, B
       }
       stg4(&P.tmv[(size_t)(q.gy0 >> 1) * (P.grid_w >> 1) + (q.gx0 >> 1)], __builtin_bit_cast(u32x4, tm));
     }
+    // compact levels: the coded TUs that originate here (same structural rule for inter and intra CUs)
+    if (q.valid && q.log2tu <= 5) {
+      const uint32_t chain = (1u << (q.tr + 1)) - 1;
+      if (q.log2tu > 2) {
+        const int tu_parts2 = 1 << (q.log2tu - 2);
+        if ((x4 & (tu_parts2 - 1)) == 0 && (y4 & (tu_parts2 - 1)) == 0) {
+          if (((q.cbf[0] & 0xff) & chain) == chain) cnt[0] = 1u << (2 * q.log2tu);
+          if (((q.cbf[1] & 0xff) & chain) == chain) cnt[1] = 1u << (2 * q.log2tu - 2);
+          if (((q.cbf[2] & 0xff) & chain) == chain) cnt[2] = 1u << (2 * q.log2tu - 2);
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; j++) if ((((q.cbf[0] >> (8 * j)) & 0xff) & chain) == chain) lmask |= 1u << j;
+        cnt[0] = 16u * __popc(lmask);
+        if (((q.cbf[1] & 0xff) & chain) == chain) cnt[1] = 16;
+        if (((q.cbf[2] & 0xff) & chain) == chain) cnt[2] = 16;
+      }
+    }
     if (q.valid) atomicAdd(&lds_stat[q.intra ? 0 : 1], 4u);
     if (q.valid && q.intra) stg(P.ctu_intra + q.ctu, (uint8_t)1);        // same value from every writer
     // ---- which transform units originate in this 8x8 area (the TUs of intra CUs are not listed: k_intra.hip walks them in decoding order)
@@ -258,6 +277,26 @@ __global__ void __launch_bounds__(256) k_prep(const PicDev* __restrict__ pics, B
       for (int k = 0; k < 6; k++) if (has[k]) loc[k] = atomicAdd(&lds_cnt[cls[k]], 1u);
     }
   }
+  // compact levels: where this area's TUs start = the CTU's start + the coefficients of the areas before it in the CTU (z-order).
+  // The areas of a CTU are consecutive lanes of one wave (64, 16 or 4 of them): an inclusive scan over the wave, minus what lies
+  // before the CTU's first lane.
+  uint32_t coff[3] = {0, 0, 0};
+  if (P.coef_start[0] != nullptr) {
+    const int lane = threadIdx.x & 63, qpc = parts >> 2;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+      uint32_t incl = cnt[c];
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(incl, d); if (lane >= d) incl += o; }
+      const uint32_t excl = incl - cnt[c];
+      const uint32_t seg = __shfl(excl, lane & ~(qpc - 1));
+      coff[c] = excl - seg;
+      if (active) {
+        coff[c] += ldg(P.coef_start[c] + q.ctu);
+        stg(P.quad_off[c] + (size_t)q.ctu * qpc + (q.z0 >> 2), coff[c]);
+      }
+    }
+  }
   __syncthreads();
   const int shard = blockIdx.x & (kTuShards - 1);
   if (threadIdx.x < 4) {
@@ -276,7 +315,8 @@ __global__ void __launch_bounds__(256) k_prep(const PicDev* __restrict__ pics, B
     const int j = k < 4 ? k : 0;                          // partition the TU starts at
     const int ts = (q.ts[comp] >> (8 * j)) & 0xff;
     const int flags = ((comp == 0 && q.log2tu == 2 && q.intra) ? 1 : 0) | (ts ? 2 : 0) | ((q.bypass & 0xff) ? 4 : 0);      // bit 2: cu_transquant_bypass
-    const uint32_t off = comp == 0 ? (uint32_t)q.ctu * ctu_luma + 16u * (q.z0 + j) : (uint32_t)q.ctu * (ctu_luma >> 2) + 4u * q.z0;
+    uint32_t off = comp == 0 ? (uint32_t)q.ctu * ctu_luma + 16u * (q.z0 + j) : (uint32_t)q.ctu * (ctu_luma >> 2) + 4u * q.z0;
+    if (P.coef_start[0] != nullptr) off = coff[comp] + (comp == 0 ? 16u * __popc(lmask & ((1u << j) - 1u)) : 0u);
     const TuRec r = make_tu(P, q, sl, q.gx0 + (j & 1), q.gy0 + (j >> 1), comp, flags, off);
     const int c = cls[k];
     const uint32_t i = lds_base[c] + loc[k];

@@ -85,3 +85,33 @@ def test_missing_gpu_fails_loudly(built_lib):
     with pytest.raises(libhm_amd.HmgpuError) as e:
         libhm_amd.Context(abi.make_seq(64, 64, 8))
     assert e.value.status == abi.HMGPU_EDEVICE
+
+
+def test_pack_levels_keeps_exactly_the_coded_transform_units():
+    """hmgpu_pack_levels (host code): the compact stream holds the coded TUs of HM's dense layout, in order, and nothing else"""
+    import numpy as np
+    import libhm_amd
+    from tests import synth
+    p = synth.make_picture(416, 240, 10, seed=4, intra_frac=0.2, ref_handles=([0], [0]))
+    packed = libhm_amd.pack_levels(p.seq, p.meta, p.coeffs)
+    m = p.meta_np
+    decoded = p.inside & (m["part_size"] != 8)
+    tr = m["tr_idx"]
+    log2tu = 6 - m["depth"] - tr
+    chain = (1 << (tr + 1)) - 1
+    for comp, key in enumerate(("cbf_y", "cbf_u", "cbf_v")):
+        coded = decoded & ((m[key] & chain) == chain)
+        # coded partitions -> coefficients: 16 per 4x4 luma partition of a coded luma TU; chroma: 4 per partition, except that the four
+        # 4x4 luma TUs of an 8x8 node share ONE 4x4 chroma TU (16 coefficients, signalled at the first of them)
+        if comp == 0:
+            want = int(coded.sum()) * 16
+        else:
+            big = coded & (log2tu > 2)
+            first = coded & (log2tu == 2) & ((np.arange(coded.shape[1])[None, :] & 3) == 0)
+            want = int(big.sum()) * 4 + int(first.sum()) * 16
+        total = int(packed.starts[comp][-1])
+        assert total == want, (comp, total, want)
+        dense = p.coeffs.arrays[comp].reshape(-1)
+        assert np.abs(packed.arrays[comp][:total].astype(np.int64)).sum() == np.abs(dense.astype(np.int64)).sum()
+        assert not packed.arrays[comp][total:].any()
+        assert np.all(np.diff(packed.starts[comp].astype(np.int64)) >= 0)

@@ -103,12 +103,20 @@ def test_pictures_batch_entry_matches_oracle(oracle, width, height, bd):
         ctx.upload(h1, ref1)
         hs = [ctx.acquire() for _ in range(n)]
         stg = ctx.staging_alloc()
-        stg.fill(pics[2].meta, pics[2].coeffs)                       # picture 2 travels through a staging block
+        packed1 = ctx.pack_levels(pics[1].meta, pics[1].coeffs)      # picture 1: compact levels (coded TUs only) from ordinary memory
         sao = [abi.sao_array_from_raw(p.sao_raw) for p in pics]
+        assert 0 < int(packed1.starts[0][-1]) < pics[1].coeffs.arrays[0].size
         for rnd in range(2):
             for h in hs:
                 ctx.upload(h, cur)
-            ctx.decompress_pictures([(hs[0], [pics[0].slice], pics[0].meta, pics[0].coeffs), (hs[1], [pics[1].slice], pics[1].meta, pics[1].coeffs),
+            # picture 2 travels through a staging block: dense levels in the first round, compact ones in the second
+            if rnd == 0:
+                stg.fill(pics[2].meta, pics[2].coeffs)
+            else:
+                ctx.sync()
+                assert stg.fill_compact(libhm_amd.lib(), ctx.seq, pics[2].meta, pics[2].coeffs) < 2 * sum(a.size for a in pics[2].coeffs.arrays)
+            stg.set_groups(intra=True, flags=(rnd == 0))     # second round: the flag arrays (all zero here) stay at home
+            ctx.decompress_pictures([(hs[0], [pics[0].slice], pics[0].meta, pics[0].coeffs), (hs[1], [pics[1].slice], pics[1].meta, packed1),
                                      (hs[2], [pics[2].slice], stg, stg)])
             ctx.filter_pictures([(hs[i], pics[i].pp, sao[i]) for i in range(n)])
             for i in range(n):
