@@ -404,20 +404,28 @@ def decode_main(args, hdist, dist, rank, world, local_rank):
         npic, pixels, bad = d.pictures_decoded, state["pixels"], d.hash_mismatches
     if bad or npic == 0 or state["pictures"] != npic:
         raise SystemExit("decode: %d of %d pictures disagree with their hash SEI (%d output)" % (bad, npic, state["pictures"]))
-    # timed: ONE decoder (device context, picture buffers) fed the stream args.steps times, as a player looping a clip would
-    d = hmdec.Decoder(device=local_rank, check_hash=False, threads=args.threads)
-    state = {"pixels": 0, "pictures": 0}
-    for _ in range(max(1, args.warmup)):
-        feed(d, state, False)
-    state = {"pixels": 0, "pictures": 0}
+    # timed: ONE decoder (device context, picture buffers) fed the stream args.steps times, as a player looping a clip would --
+    # with the decoded-picture-hash SEI check ON, libHM's default (the MD5s run on the decoder's hash threads), and once more with
+    # the check off (what HM's own timing below does)
+    def timed(check):
+        d = hmdec.Decoder(device=local_rank, check_hash=check, threads=args.threads)
+        state = {"pixels": 0, "pictures": 0}
+        for _ in range(max(1, args.warmup)):
+            feed(d, state, False)
+        state["pixels"] = state["pictures"] = 0
 
-    def steps():
-        for k in range(args.steps):
-            feed(d, state, k == args.steps - 1)
-    elapsed = hdist.timed_region(dist, steps, lambda: None, device=("cuda:%d" % local_rank) if dist is not None else None)
-    d.close()
-    # the warm-up passes leave pictures in the decoder that the first timed pass puts out: count what actually came out
-    pixels_timed, pictures_timed = state["pixels"], state["pictures"]
+        def steps():
+            for k in range(args.steps):
+                feed(d, state, k == args.steps - 1)
+        t = hdist.timed_region(dist, steps, lambda: None, device=("cuda:%d" % local_rank) if dist is not None else None)
+        bad_now = d.hash_mismatches
+        d.close()
+        if bad_now:
+            raise SystemExit("decode: %d pictures disagree with their hash SEI in the timed passes" % bad_now)
+        # the warm-up passes leave pictures in the decoder that the first timed pass puts out: count what actually came out
+        return t, state["pixels"], state["pictures"]
+    elapsed_off, pixels_off, pictures_off = timed(False)
+    elapsed, pixels_timed, pictures_timed = timed(True)
     # host parsing alone (no device work): what bounds the decoder today
     t0 = time.perf_counter()
     with hmdec.Decoder(parse_only=True, threads=args.threads) as d:
@@ -434,6 +442,8 @@ def decode_main(args, hdist, dist, rank, world, local_rank):
                                    "picture download, %d NAL units" % (w, h, args.threads, "" if args.threads == 1 else "s, frame-parallel", len(nals)),
                        "sub_benchmark": "decode", "parser_threads": args.threads, "pictures_per_step": npic, "parallelism": "replicas, 1 process per GPU"},
             "fps": round(world * pictures_timed / elapsed, 2),
+            "hash_sei_check": "on in the timed passes (MD5 of every picture on the decoder's hash threads)",
+            "fps_hash_check_off": round(world * pictures_off / elapsed_off, 2),
             "host_parse_only_Mpixels_s": round(pixels / t_parse / 1e6, 1),
             "host_parse_only_Mbit_s": round(len(data) * 8 / t_parse / 1e6, 1),
             "hash_sei_verified_pictures": npic,

@@ -182,6 +182,12 @@ hmgpu_status hmgpu_picture_release(hmgpu_ctx* ctx, hmgpu_pic pic);
 hmgpu_status hmgpu_picture_upload(hmgpu_ctx* ctx, hmgpu_pic pic, const int16_t* const planes[3], const int32_t strides[3]);
 hmgpu_status hmgpu_picture_download(hmgpu_ctx* ctx, hmgpu_pic pic, int16_t* const planes[3], const int32_t strides[3]);
 
+/* The same without waiting: the copies are enqueued and the call returns a ticket; hmgpu_download_wait(ticket) blocks until those
+ * copies have landed.  hmgpu_download_wait may be called from another thread than the one that drives the context (a thread that
+ * hashes or writes out pictures while the decoding thread keeps the device fed); planes should be page-locked (hmgpu_host_alloc). */
+hmgpu_status hmgpu_picture_download_begin(hmgpu_ctx* ctx, hmgpu_pic pic, int16_t* const planes[3], const int32_t strides[3], uint64_t* ticket);
+hmgpu_status hmgpu_download_wait(hmgpu_ctx* ctx, uint64_t ticket);
+
 /* Output side.  hmgpu_picture_download_packed: the finished picture as the application wants it -- one or two
  * bytes per sample (TVideoIOYuv::write, TVideoIOYuv.cpp:706-790: 8-bit files take the low byte), cropped to a window given in
  * luma samples (conformance / display window; 0,0,0,0 = the whole picture) -- converted on the device, so an 8-bit picture crosses

@@ -7,6 +7,7 @@
 #include "hmgpu_dev.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cstdio>
 #include <cstring>
 #include <cstdlib>
@@ -74,6 +75,10 @@ struct hmgpu_ctx {
   hipEvent_t copy_ev[8] = {}, use_ev[8] = {};
   uint64_t copy_seq = 0, use_seq = 0;
   std::vector<hmgpu_staging*> stagings;
+  hipEvent_t dl_ev[32] = {};           // hmgpu_picture_download_begin tickets: ticket t completes with dl_ev[t % 32]
+  std::atomic<uint64_t> dl_seq{0};
+  void* scratch = nullptr;            // device scratch of the output calls (packed download, picture hash): grown on demand, kept
+  size_t scratch_bytes = 0;
   hipEvent_t lane_ev[2] = {nullptr, nullptr};
   int replay_streams = 1;
   int32_t last_err = 0;
@@ -120,6 +125,18 @@ struct Carver {                       // sub-allocates one device block, 256-byt
   explicit Carver(void* b) : base((char*)b) {}
   template <typename T> T* take(size_t n) { T* p = base ? (T*)(base + off) : nullptr; off += align_up(n * sizeof(T), 256); return p; }
 };
+
+// device scratch of the output side: one allocation that lives with the context (hipMalloc / hipFree per call are device-wide
+// synchronisations on the per-picture output path)
+void* ctx_scratch(hmgpu_ctx* c, size_t bytes) {
+  if (bytes > c->scratch_bytes) {
+    if (c->scratch) { (void)hipStreamSynchronize(c->stream); (void)hipFree(c->scratch); c->scratch = nullptr; c->scratch_bytes = 0; }
+    const size_t want = align_up(bytes + bytes / 4, 1 << 20);
+    if (hipMalloc(&c->scratch, want) != hipSuccess) { c->scratch = nullptr; return nullptr; }
+    c->scratch_bytes = want;
+  }
+  return c->scratch;
+}
 
 // profiling: a pair of events around one launch, resolved lazily
 void prof_begin(hmgpu_ctx* c, int kind, EventPair* ep) {
@@ -454,6 +471,7 @@ hmgpu_status hmgpu_create(const hmgpu_seq_params* seq, int device_ordinal, hmgpu
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking);
   for (int k = 0; k < 8 && e == hipSuccess; k++) e = hipEventCreateWithFlags(&c->copy_ev[k], hipEventDisableTiming);
   for (int k = 0; k < 8 && e == hipSuccess; k++) e = hipEventCreateWithFlags(&c->use_ev[k], hipEventDisableTiming);
+  for (int k = 0; k < 32 && e == hipSuccess; k++) e = hipEventCreateWithFlags(&c->dl_ev[k], hipEventDisableTiming | hipEventBlockingSync);   // (waited for by helper threads: sleep, do not spin)
   for (int k = 0; k < 2 && e == hipSuccess; k++) e = hipEventCreateWithFlags(&c->lane_ev[k], hipEventDisableTiming);
   if (e != hipSuccess) { delete c; return HMGPU_EDEVICE; }
   c->ctu = 1 << seq->log2_ctu_size; c->pw = c->ctu / 4; c->parts = c->pw * c->pw;
@@ -523,12 +541,14 @@ void hmgpu_destroy(hmgpu_ctx* c) {
   if (c->d_pics) hipFree(c->d_pics);
   if (c->d_finals) hipFree(c->d_finals);
   if (c->plane_slab) hipFree(c->plane_slab);
+  if (c->scratch) hipFree(c->scratch);
   if (c->d_ctu_order) hipFree(c->d_ctu_order);
   if (c->stream) hipStreamDestroy(c->stream);
   if (c->stream2) hipStreamDestroy(c->stream2);
   if (c->copy_stream) { hipStreamSynchronize(c->copy_stream); hipStreamDestroy(c->copy_stream); }
   for (int k = 0; k < 8; k++) { if (c->copy_ev[k]) hipEventDestroy(c->copy_ev[k]); if (c->use_ev[k]) hipEventDestroy(c->use_ev[k]); }
   for (hmgpu_staging* st : c->stagings) { if (st->host) hipHostFree(st->host); delete st; }
+  for (int k = 0; k < 32; k++) if (c->dl_ev[k]) hipEventDestroy(c->dl_ev[k]);
   for (int k = 0; k < 2; k++) if (c->lane_ev[k]) hipEventDestroy(c->lane_ev[k]);
   delete c;
 }
@@ -606,6 +626,30 @@ hmgpu_status hmgpu_picture_download(hmgpu_ctx* c, hmgpu_pic pic, int16_t* const 
   return HMGPU_OK;
 }
 
+hmgpu_status hmgpu_picture_download_begin(hmgpu_ctx* c, hmgpu_pic pic, int16_t* const planes[3], const int32_t strides[3], uint64_t* ticket) {
+  if (!c || !valid_pic(c, pic) || !planes || !strides || !ticket) return HMGPU_EINVAL;
+  hipSetDevice(c->device);
+  Picture& p = c->pics[pic];
+  for (int k = 0; k < 3; k++) {
+    const int w = c->seq.width >> (k ? 1 : 0), h = c->seq.height >> (k ? 1 : 0);
+    const int16_t* src = p.sao_applied ? p.dev.sao[k] : p.dev.rec[k];
+    HIP_TRY(c, hipMemcpy2DAsync(planes[k], (size_t)strides[k] * 2, src, (size_t)c->pitch[k] * 2, (size_t)w * 2, h, hipMemcpyDeviceToHost, c->stream));
+  }
+  const uint64_t t = c->dl_seq.load() + 1;
+  HIP_TRY(c, hipEventRecord(c->dl_ev[t % 32], c->stream));
+  c->dl_seq.store(t);
+  *ticket = t;
+  return HMGPU_OK;
+}
+
+hmgpu_status hmgpu_download_wait(hmgpu_ctx* c, uint64_t ticket) {
+  if (!c || ticket == 0 || ticket > c->dl_seq.load()) return HMGPU_EINVAL;
+  hipSetDevice(c->device);
+  // a ticket whose event has been re-recorded is 32 downloads old: the event now stands for a LATER point of the same stream
+  if (hipEventSynchronize(c->dl_ev[ticket % 32]) != hipSuccess) return HMGPU_EDEVICE;
+  return HMGPU_OK;
+}
+
 hmgpu_status hmgpu_picture_download_packed(hmgpu_ctx* c, hmgpu_pic pic, void* const planes[3], const int32_t stride_bytes[3],
                                            int32_t bytes_per_sample, int32_t crop_left, int32_t crop_right, int32_t crop_top, int32_t crop_bottom) {
   if (!c || !valid_pic(c, pic) || !planes || !stride_bytes || (bytes_per_sample != 1 && bytes_per_sample != 2)) return HMGPU_EINVAL;
@@ -616,8 +660,8 @@ hmgpu_status hmgpu_picture_download_packed(hmgpu_ctx* c, hmgpu_pic pic, void* co
   Picture& p = c->pics[pic];
   size_t off[3], total = 0;
   for (int k = 0; k < 3; k++) { off[k] = total; total += align_up((size_t)(W >> (k ? 1 : 0)) * bytes_per_sample * (H >> (k ? 1 : 0)), 256); }
-  uint8_t* d = nullptr;
-  HIP_TRY(c, hipMalloc((void**)&d, total));
+  uint8_t* d = static_cast<uint8_t*>(ctx_scratch(c, total));
+  if (!d) return HMGPU_ENOMEM;
   hmgpu_status st = HMGPU_OK;
   for (int k = 0; k < 3 && st == HMGPU_OK; k++) {
     const int cs = k ? 1 : 0, w = W >> cs, h = H >> cs;
@@ -628,7 +672,6 @@ hmgpu_status hmgpu_picture_download_packed(hmgpu_ctx* c, hmgpu_pic pic, void* co
                          hipMemcpyDeviceToHost, c->stream) != hipSuccess) st = HMGPU_EDEVICE;
   }
   if (hipStreamSynchronize(c->stream) != hipSuccess) st = HMGPU_EDEVICE;
-  hipFree(d);
   prof_drain(c);
   return st;
 }
@@ -639,9 +682,9 @@ hmgpu_status hmgpu_picture_hash(hmgpu_ctx* c, hmgpu_pic pic, int32_t method, uin
   if (method != 2 && method != 3) return HMGPU_EINVAL;
   hipSetDevice(c->device);
   Picture& p = c->pics[pic];
-  uint32_t* d = nullptr;
   const size_t words = 4 + (size_t)c->seq.height;          // three results + the per-row CRCs of one plane
-  HIP_TRY(c, hipMalloc((void**)&d, words * 4));
+  uint32_t* d = static_cast<uint32_t*>(ctx_scratch(c, words * 4));
+  if (!d) return HMGPU_ENOMEM;
   hmgpu_status st = HMGPU_OK;
   if (hipMemsetAsync(d, 0, words * 4, c->stream) != hipSuccess) st = HMGPU_EDEVICE;
   for (int k = 0; k < 3 && st == HMGPU_OK; k++) {
@@ -655,7 +698,6 @@ hmgpu_status hmgpu_picture_hash(hmgpu_ctx* c, hmgpu_pic pic, int32_t method, uin
   uint32_t r[3] = {0, 0, 0};
   if (st == HMGPU_OK && hipMemcpyAsync(r, d, sizeof(r), hipMemcpyDeviceToHost, c->stream) != hipSuccess) st = HMGPU_EDEVICE;
   if (hipStreamSynchronize(c->stream) != hipSuccess) st = HMGPU_EDEVICE;
-  hipFree(d);
   if (st != HMGPU_OK) return st;
   memset(digest, 0, 48);
   for (int k = 0; k < 3; k++) {

@@ -44,6 +44,12 @@ static bool is_sub_layer_non_ref(int t) { return t < 16 && (t & 1) == 0; }
 Decoder::Decoder() { memset(pending_hash_val_, 0, sizeof(pending_hash_val_)); }
 
 Decoder::~Decoder() {
+  if (!hash_threads_.empty()) {
+    drain_hash_jobs();
+    { std::lock_guard<std::mutex> lk(hash_mu_); hash_stop_ = true; }
+    hash_cv_.notify_all();
+    for (std::thread& t : hash_threads_) t.join();
+  }
   if (!workers_.empty()) {
     { std::lock_guard<std::mutex> lk(mu_); stop_ = true; }
     cv_work_.notify_all();
@@ -198,6 +204,7 @@ void Decoder::activate(const SliceHeader& sh) {
   // a new coded video sequence with another geometry: the picture store starts over.  Pictures the application holds or has still
   // to fetch from the output queue stay alive (retired_, samples on the host) until the next change of sequence; pictures that were
   // never put out are dropped, as in HM.
+  drain_hash_jobs();                       // (the hash threads read the planes of the pictures that go away here)
   retired_.clear();
   for (auto& p : pool_) {
     const bool queued = std::find(out_queue_.begin(), out_queue_.end(), p.get()) != out_queue_.end();
@@ -549,6 +556,7 @@ void Decoder::set_threads(int n) {
   hooks_.wait_rows = &Decoder::hook_wait_rows;
   hooks_.rows_done = &Decoder::hook_rows_done;
   for (int i = 0; i < n; i++) workers_.emplace_back([this] { worker_main(); });
+  for (int i = 0; i < std::min(6, std::max(3, n)); i++) hash_threads_.emplace_back([this] { hash_main(); });
 }
 
 void Decoder::hook_wait_rows(void* self, const PicData* pic, int rows) {
@@ -761,6 +769,11 @@ void Decoder::submit_picture(PicData* p, int parsed_ctbs) {
 bool Decoder::fetch_planes(PicData* pic) {
   if (!gpu_ || !pic) return false;
   if (pic->planes_valid) return true;
+  if (const uint64_t t = pic->dl_ticket.load()) {        // begun for the hash check: wait for it instead of copying again
+    if (hmgpu_download_wait(gpu_, t) != HMGPU_OK) return false;
+    pic->planes_valid = true;
+    return true;
+  }
   pic->plane[0].resize((size_t)pic->width * pic->height);
   pic->plane[1].resize((size_t)pic->width * pic->height / 4);
   pic->plane[2].resize((size_t)pic->width * pic->height / 4);
@@ -773,6 +786,60 @@ bool Decoder::fetch_planes(PicData* pic) {
   return true;
 }
 
+// MD5 of one plane as the SEI defines it (TComPicYuvMD5.cpp:183-205): samples as 1 or 2 little-endian bytes, row by row
+bool Decoder::md5_plane_matches(const PicData* pic, int comp, int bd, const uint8_t want[16]) {
+  Md5 md5;
+  const HostVec<int16_t>& pl = pic->plane[comp];
+  if (bd > 8) {
+    md5.update(reinterpret_cast<const uint8_t*>(pl.data()), pl.size() * 2);        // int16 samples on a little-endian host: the bytes as they lie
+  } else {
+    uint8_t buf[4096];
+    for (size_t i = 0; i < pl.size(); i += sizeof(buf)) {
+      const size_t n = std::min(sizeof(buf), pl.size() - i);
+      for (size_t k = 0; k < n; k++) buf[k] = (uint8_t)pl[i + k];
+      md5.update(buf, n);
+    }
+  }
+  uint8_t got[16];
+  md5.final(got);
+  return memcmp(got, want, 16) == 0;
+}
+
+void Decoder::hash_main() {
+  for (;;) {
+    HashJob j;
+    {
+      std::unique_lock<std::mutex> lk(hash_mu_);
+      hash_cv_.wait(lk, [&] { return hash_stop_ || !hash_jobs_.empty(); });
+      if (hash_jobs_.empty()) return;
+      j = hash_jobs_.front();
+      hash_jobs_.pop_front();
+      hash_busy_++;
+    }
+    bool landed = true;
+    if (const uint64_t t = j.pic->dl_ticket.load()) landed = hmgpu_download_wait(gpu_, t) == HMGPU_OK;
+    if (landed && !md5_plane_matches(j.pic, j.comp, j.bd, j.want)) {
+      if (!j.pic->hash_mismatch.exchange(true)) {
+        hash_mismatches_++;
+        fprintf(stderr, "hmdec: ***ERROR*** decoded picture hash mismatch, POC %d\n", j.pic->poc);
+      }
+    }
+    j.pic->users.fetch_sub(1);
+    {
+      std::lock_guard<std::mutex> lk(hash_mu_);
+      hash_busy_--;
+    }
+    hash_idle_cv_.notify_all();
+    cv_progress_.notify_all();             // (a picture buffer may have become free)
+  }
+}
+
+void Decoder::drain_hash_jobs() {
+  if (hash_threads_.empty()) return;
+  std::unique_lock<std::mutex> lk(hash_mu_);
+  hash_idle_cv_.wait(lk, [&] { return hash_jobs_.empty() && hash_busy_ == 0; });
+}
+
 // TDecGop.cpp:199-262: the reconstruction against the decoded picture hash SEI
 void Decoder::check_hash(PicData* pic) {
   if (!gpu_) return;
@@ -780,18 +847,42 @@ void Decoder::check_hash(PicData* pic) {
   memset(got, 0, sizeof(got));
   int len = 0;
   if (pic->sei_hash_method == 1) {
-    if (!fetch_planes(pic)) return;
-    for (int c = 0; c < 3; c++) {
-      const int bd = c ? sps_->bit_depth_chroma : sps_->bit_depth_luma;
-      Md5 md5;
-      const HostVec<int16_t>& pl = pic->plane[c];
-      std::vector<uint8_t> bytes(pl.size() * (bd > 8 ? 2 : 1));
-      if (bd > 8) for (size_t i = 0; i < pl.size(); i++) { bytes[2 * i] = (uint8_t)pl[i]; bytes[2 * i + 1] = (uint8_t)(pl[i] >> 8); }
-      else for (size_t i = 0; i < pl.size(); i++) bytes[i] = (uint8_t)pl[i];
-      md5.update(bytes.data(), bytes.size());
-      md5.final(got[c]);
+    // MD5 is a serial chain over every byte of a plane (~20-30 ms for a 2160p luma plane): with parser threads the three planes
+    // go to the hash threads, picture after picture, and the decoding thread carries on; the picture stays pinned meanwhile
+    if (!hash_threads_.empty()) {
+      // the copy is only enqueued here: the hash threads wait for it, the decoding thread goes on submitting pictures
+      if (!pic->planes_valid && !pic->dl_ticket.load()) {
+        pic->plane[0].resize((size_t)pic->width * pic->height);
+        pic->plane[1].resize((size_t)pic->width * pic->height / 4);
+        pic->plane[2].resize((size_t)pic->width * pic->height / 4);
+        int16_t* planes[3] = {pic->plane[0].data(), pic->plane[1].data(), pic->plane[2].data()};
+        const int32_t strides[3] = {pic->width, pic->width / 2, pic->width / 2};
+        uint64_t t = 0;
+        if (hmgpu_picture_download_begin(gpu_, pic->handle, planes, strides, &t) != HMGPU_OK) return;
+        pic->dl_ticket.store(t);
+      }
+      pic->users.fetch_add(3);
+      {
+        std::lock_guard<std::mutex> lk(hash_mu_);
+        for (int c = 0; c < 3; c++) {
+          HashJob j;
+          j.pic = pic; j.comp = c; j.bd = c ? sps_->bit_depth_chroma : sps_->bit_depth_luma;
+          memcpy(j.want, pic->sei_hash[c], 16);
+          hash_jobs_.push_back(j);
+        }
+      }
+      hash_cv_.notify_all();
+      return;
     }
-    len = 16;
+    if (!fetch_planes(pic)) return;
+    bool ok = true;
+    for (int c = 0; c < 3; c++) ok &= md5_plane_matches(pic, c, c ? sps_->bit_depth_chroma : sps_->bit_depth_luma, pic->sei_hash[c]);
+    if (!ok) {
+      pic->hash_mismatch = true;
+      hash_mismatches_++;
+      fprintf(stderr, "hmdec: ***ERROR*** decoded picture hash mismatch, POC %d\n", pic->poc);
+    }
+    return;
   } else {
     int32_t n = 0;
     if (hmgpu_picture_hash(gpu_, pic->handle, pic->sei_hash_method, got, &n) != HMGPU_OK) return;

@@ -5,6 +5,8 @@
 // applyReferencePictureSet), TDecGop.cpp, SEIread.cpp (decoded picture hash).
 #pragma once
 #include <condition_variable>
+#include <atomic>
+#include <condition_variable>
 #include <deque>
 #include <memory>
 #include <mutex>
@@ -45,7 +47,7 @@ class Decoder {
   const Sps* active_sps() const { return sps_.get(); }
   PicData* last_decoded() const { return last_decoded_; }
   PicData* open_picture() const { return cur_; }
-  int hash_mismatches() const { return hash_mismatches_; }
+  int hash_mismatches() { drain_hash_jobs(); return hash_mismatches_.load(); }   // (waits for the MD5 checks still running on the hash threads)
   int pictures_decoded() const { return pictures_decoded_; }
   const std::string& last_error() const { return last_error_; }
   void set_error(const std::string& s) { last_error_ = s; }
@@ -99,7 +101,19 @@ class Decoder {
   size_t scan_idx_ = 0;
   std::vector<PicData*> scan_;
   bool parse_only_ = false, check_hash_ = true;
-  int device_ = 0, hash_mismatches_ = 0, pictures_decoded_ = 0;
+  int device_ = 0, pictures_decoded_ = 0;
+  std::atomic<int> hash_mismatches_{0};
+  // MD5 checks of the decoded-picture-hash SEI off the decoding thread: one job per plane, a few threads (with parser threads only)
+  struct HashJob { PicData* pic; int comp, bd; uint8_t want[16]; };
+  std::vector<std::thread> hash_threads_;
+  std::deque<HashJob> hash_jobs_;
+  std::mutex hash_mu_;
+  std::condition_variable hash_cv_, hash_idle_cv_;
+  int hash_busy_ = 0;
+  bool hash_stop_ = false;
+  void hash_main();
+  void drain_hash_jobs();
+  static bool md5_plane_matches(const PicData* pic, int comp, int bd, const uint8_t want[16]);
   uint64_t submitted_seq_ = 0, synced_seq_ = 0;            // device submissions / the last one known to have completed
   std::string last_error_;
   std::string deferred_error_;                            // parse error of a picture that left the pipeline while another unit was pushed

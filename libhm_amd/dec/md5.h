@@ -12,6 +12,7 @@ class Md5 {
   void update(const uint8_t* p, size_t n) {
     total_ += n;
     while (n) {
+      if (fill_ == 0 && n >= 64) { block(p); p += 64; n -= 64; continue; }     // whole blocks straight from the caller's buffer
       const size_t take = n < 64 - fill_ ? n : 64 - fill_;
       memcpy(buf_ + fill_, p, take);
       fill_ += take; p += take; n -= take;
@@ -43,21 +44,20 @@ class Md5 {
     static const uint8_t S[64] = {7, 12, 17, 22, 7, 12, 17, 22, 7, 12, 17, 22, 7, 12, 17, 22, 5, 9,  14, 20, 5, 9,  14, 20, 5, 9,  14, 20, 5, 9,  14, 20,
                                   4, 11, 16, 23, 4, 11, 16, 23, 4, 11, 16, 23, 4, 11, 16, 23, 6, 10, 15, 21, 6, 10, 15, 21, 6, 10, 15, 21, 6, 10, 15, 21};
     uint32_t m[16];
-    for (int i = 0; i < 16; i++) m[i] = p[4 * i] | (p[4 * i + 1] << 8) | (p[4 * i + 2] << 16) | ((uint32_t)p[4 * i + 3] << 24);
+    memcpy(m, p, 64);                    // (little-endian host, as everything else in this decoder)
     uint32_t a = a_, b = b_, c = c_, d = d_;
-    for (int i = 0; i < 64; i++) {
-      uint32_t f;
-      int g;
-      if (i < 16) { f = (b & c) | (~b & d); g = i; }
-      else if (i < 32) { f = (d & b) | (~d & c); g = (5 * i + 1) & 15; }
-      else if (i < 48) { f = b ^ c ^ d; g = (3 * i + 5) & 15; }
-      else { f = c ^ (b | ~d); g = (7 * i) & 15; }
-      const uint32_t t = d;
-      d = c;
-      c = b;
-      b = b + rol(a + f + K[i] + m[g], S[i]);
-      a = t;
-    }
+    // four rounds of sixteen steps; the message index and the rotation of a step are compile-time constants once unrolled
+#define HMDEC_MD5_STEP(F, i, g)                                    \
+    { const uint32_t f = (F), t = d; d = c; c = b; b = b + rol(a + f + K[i] + m[g], S[i]); a = t; }
+#pragma GCC unroll 16
+    for (int i = 0; i < 16; i++) HMDEC_MD5_STEP((b & c) | (~b & d), i, i)
+#pragma GCC unroll 16
+    for (int i = 16; i < 32; i++) HMDEC_MD5_STEP((d & b) | (~d & c), i, (5 * i + 1) & 15)
+#pragma GCC unroll 16
+    for (int i = 32; i < 48; i++) HMDEC_MD5_STEP(b ^ c ^ d, i, (3 * i + 5) & 15)
+#pragma GCC unroll 16
+    for (int i = 48; i < 64; i++) HMDEC_MD5_STEP(c ^ (b | ~d), i, (7 * i) & 15)
+#undef HMDEC_MD5_STEP
     a_ += a; b_ += b; c_ += c; d_ += d;
   }
   uint32_t a_, b_, c_, d_;

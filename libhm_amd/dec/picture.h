@@ -90,10 +90,11 @@ struct PicData {
   uint64_t submit_seq = 0;           // device submission that last read these arrays
   // output side
   bool planes_valid = false;
+  std::atomic<uint64_t> dl_ticket{0};   // a download of the planes is under way (hmgpu_picture_download_begin): planes_valid once it has been waited for
   HostVec<int16_t> plane[3];
   uint8_t sei_hash[3][16];
   int sei_hash_method = 0;           // 0 = none, 1 = MD5, 2 = CRC, 3 = checksum
-  bool hash_mismatch = false;
+  std::atomic<bool> hash_mismatch{false};
 
   void allocate(const Sps& sps, const ZScan* z) {
     width = sps.width; height = sps.height; log2_ctb = sps.log2_ctb;
@@ -123,7 +124,9 @@ struct PicData {
     std::fill(slice_addr.begin(), slice_addr.end(), -1);
     slices.clear();
     slices.reserve(HMGPU_MAX_SLICES);   // entries are added while a parser thread reads earlier ones: the storage must not move
-    has_pcm = has_bypass = decoded = filtered = planes_valid = hash_mismatch = false;
+    has_pcm = has_bypass = decoded = filtered = planes_valid = false;
+    hash_mismatch = false;
+    dl_ticket = 0;
     sei_hash_method = 0;
   }
   void reset_ctu(int rs) {
