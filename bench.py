@@ -494,6 +494,13 @@ def cpu_baseline(p, w, h, bd, threads, seconds):
     from libhm_amd import abi
     hmoracle.lib()
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:                                                   # a container's CPU share (cgroup v2), when it is smaller than the affinity mask
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            cores = max(1, min(cores, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    cores = min(cores, 32)                                 # (bounded: every worker holds a 2160p picture and its references)
     nthr = cores if threads == 0 else threads
     refs = [synth.noise_planes(w, h, bd, 100), synth.blocky_planes(w, h, bd, 200)]
     sl = abi.clone_slice(p.slice)             # the device run re-pointed the reference handles at its own pictures
