@@ -159,7 +159,8 @@ typedef struct hmgpu_pic_params {
 /* ------------------------------------------------------------------------------------------------ context */
 hmgpu_status hmgpu_create(const hmgpu_seq_params* seq, int device_ordinal, hmgpu_ctx** out);
 void         hmgpu_destroy(hmgpu_ctx* ctx);
-int32_t      hmgpu_last_device_error(const hmgpu_ctx* ctx);        /* hipError_t of the last HMGPU_EDEVICE */
+int32_t      hmgpu_last_device_error(const hmgpu_ctx* ctx);        /* hipError_t of the last HMGPU_EDEVICE; -2: an intra wavefront gave up
+                                                                       waiting for a neighbouring CTU (reported by hmgpu_sync / hmgpu_picture_download) */
 const char*  hmgpu_status_string(hmgpu_status s);
 hmgpu_status hmgpu_sync(hmgpu_ctx* ctx);                           /* wait for everything enqueued so far */
 

@@ -77,6 +77,7 @@ struct hmgpu_ctx {
   std::vector<hmgpu_staging*> stagings;
   hipEvent_t dl_ev[32] = {};           // hmgpu_picture_download_begin tickets: ticket t completes with dl_ev[t % 32]
   std::atomic<uint64_t> dl_seq{0};
+  std::vector<int> intra_launched;    // pictures whose intra kernel ran since the last fault check (k_intra's bounded spin)
   void* scratch = nullptr;            // device scratch of the output calls (packed download, picture hash): grown on demand, kept
   size_t scratch_bytes = 0;
   hipEvent_t lane_ev[2] = {nullptr, nullptr};
@@ -136,6 +137,18 @@ void* ctx_scratch(hmgpu_ctx* c, size_t bytes) {
     c->scratch_bytes = want;
   }
   return c->scratch;
+}
+
+// after a synchronisation: did an intra wavefront give up waiting (k_intra.hip)?  The flag is sticky on the device until read here.
+hmgpu_status check_faults(hmgpu_ctx* c) {
+  hmgpu_status st = HMGPU_OK;
+  for (int pic : c->intra_launched) {
+    uint32_t f = 0;
+    if (hipMemcpy(&f, c->pics[pic].dev.fault, 4, hipMemcpyDeviceToHost) != hipSuccess) { st = HMGPU_EDEVICE; continue; }
+    if (f) { (void)hipMemset(c->pics[pic].dev.fault, 0, 4); c->last_err = -2; st = HMGPU_EDEVICE; }
+  }
+  c->intra_launched.clear();
+  return st;
 }
 
 // profiling: a pair of events around one launch, resolved lazily
@@ -216,6 +229,7 @@ hmgpu_status alloc_picture(hmgpu_ctx* c, Picture& p) {
     d.tmv = m.take<TileMv>((size_t)(c->grid_w / 2) * (c->grid_h / 2));
     for (int k = 0; k < 3; k++) d.quad_off[k] = m.take<uint32_t>((size_t)c->num_ctus * (c->parts / 4));
     p.coef_start = m.take<uint32_t>((size_t)3 * (c->num_ctus + 1));
+    d.fault = m.take<uint32_t>(1);
     for (int k = 0; k < 4; k++) d.tu[k] = m.take<TuRec>((size_t)c->tu_cap[k] * kTuShards);
     d.tu_count = m.take<uint32_t>(4 * kTuShards);
     d.stats = m.take<unsigned long long>(2 * kTuShards);
@@ -343,7 +357,11 @@ hmgpu_status run_recon(hmgpu_ctx* c, const Batch& b, bool any_intra, bool any_wp
   const int cmask = 0;                                      // all four size classes
   { ProfScope ps(c, K_ITX); launch_itx(c->d_pics, b, cmask, bps, c->stream); }
   // intra CUs predict from finished neighbours (inter ones included): after motion compensation and the inter residuals
-  if (any_intra) { ProfScope ps(c, K_INTRA); launch_intra(c->d_pics, b, c->d_ctu_order, c->num_ctus, c->stream); }
+  if (any_intra) {
+    ProfScope ps(c, K_INTRA);
+    launch_intra(c->d_pics, b, c->d_ctu_order, c->num_ctus, c->stream);
+    for (int i = 0; i < b.n; i++) if (std::find(c->intra_launched.begin(), c->intra_launched.end(), b.pic[i]) == c->intra_launched.end()) c->intra_launched.push_back(b.pic[i]);
+  }
   HIP_TRY(c, hipGetLastError());
   return HMGPU_OK;
 }
@@ -567,7 +585,7 @@ hmgpu_status hmgpu_sync(hmgpu_ctx* c) {
   if (!c) return HMGPU_EINVAL;
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   prof_drain(c);
-  return HMGPU_OK;
+  return check_faults(c);
 }
 
 hmgpu_status hmgpu_picture_acquire(hmgpu_ctx* c, hmgpu_pic* out) {
@@ -623,7 +641,7 @@ hmgpu_status hmgpu_picture_download(hmgpu_ctx* c, hmgpu_pic pic, int16_t* const 
   }
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   prof_drain(c);
-  return HMGPU_OK;
+  return check_faults(c);
 }
 
 hmgpu_status hmgpu_picture_download_begin(hmgpu_ctx* c, hmgpu_pic pic, int16_t* const planes[3], const int32_t strides[3], uint64_t* ticket) {

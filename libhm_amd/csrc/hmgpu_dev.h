@@ -138,6 +138,7 @@ struct PicDev {
   int32_t strong_intra_smoothing;  // SPS flag
   uint8_t* ctu_intra;              // [num_ctus] 1 = the CTU holds intra CUs (written by k_prep)
   uint32_t* intra_done;            // [3][num_ctus]: the CTU's intra CUs of that component are reconstructed
+  uint32_t* fault;                 // set by a kernel that gave up waiting (k_intra's bounded spin): checked by the host at hmgpu_sync
 };
 
 // batched launch descriptor, passed by value

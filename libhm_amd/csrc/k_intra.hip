@@ -481,7 +481,15 @@ __global__ void __launch_bounds__(64) k_intra(const PicDev* __restrict__ pics, B
     const bool need = k == 0 ? (my_l && n_r) : k == 1 ? ((my_l || my_t) && n_r && n_b) : (my_t && n_b);
     if (!need) continue;
     // poll with plain coherent loads (an acquire per poll would invalidate the caches of the CU's working waves over and over)
-    while (__hip_atomic_load(done + n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) __builtin_amdgcn_s_sleep(64);
+    // The wait cannot deadlock as long as workgroups are dispatched in linear order (the neighbours lie on earlier anti-diagonals,
+    // i.e. at smaller block indices: they are resident or finished when this block runs).  HIP does not promise that order, so the
+    // spin is bounded (~8 s): a block that gives up flags the picture (the host reports HMGPU_EDEVICE at its next sync) instead of
+    // hanging the device.
+    uint32_t spins = 0;
+    while (__hip_atomic_load(done + n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+      __builtin_amdgcn_s_sleep(64);
+      if (++spins > (1u << 22)) { if (lane == 0) atomicOr(P.fault, 1u); break; }
+    }
   }
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   wave_lds_sync();

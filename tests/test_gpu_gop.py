@@ -73,3 +73,35 @@ def test_received_picture_is_a_reference_like_the_original():
         got = ctx.download(hc)
         for x, y in zip(got, want):
             assert np.array_equal(x, y)
+
+
+def _run_two_ranks(env_extra, nproc=2):
+    """tools/gop_two_ranks.py under torch.distributed.run (fresh processes): every rank checks the pictures it owns against the oracle"""
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, **env_extra)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "tools", "gop_two_ranks.py")]
+    r = subprocess.run(cmd, env=env, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:]
+    assert r.stdout.count("0 mismatches") == nproc, r.stdout[-3000:]
+
+
+def test_two_ranks_exchange_reference_pictures_on_one_gpu():
+    """the multi-rank device path (plan, device regions, send/recv on the context's stream, commit) with two processes sharing the
+    card and gloo carrying the regions: what a one-GPU box can run of BASELINE config #5"""
+    _run_two_ranks({"HMGPU_DIST_BACKEND": "gloo", "HMGPU_SINGLE_DEVICE": "1"})
+
+
+def test_two_ranks_exchange_reference_pictures_over_rccl():
+    """the same with one GPU per rank and RCCL (needs two GPUs: skipped on the one-GPU boxes)"""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    _run_two_ranks({})
