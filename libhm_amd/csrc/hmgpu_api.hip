@@ -99,7 +99,6 @@ struct hmgpu_ctx {
   size_t plane_bytes = 0;
   int32_t* d_ctu_order = nullptr;     // CTU addresses by anti-diagonal (dispatch order of the intra wavefront)
   std::vector<PlaneSet> h_finals;
-  unsigned long long* dbg_stamps = nullptr; size_t dbg_nstamps = 0;   // MC_STAMP diagnostic builds
   // profiling
   bool profiling = false;
   std::vector<EventPair> pending;
@@ -331,16 +330,7 @@ hmgpu_status run_recon(hmgpu_ctx* c, const Batch& b, bool any_intra, bool any_wp
     ma.pitch = c->pitch[0]; ma.bd = c->seq.bit_depth_luma;
     ma.origin_off = (uint32_t)((const char*)d0.rec[0] - base0);
     for (int i = 0; i < b.n; i++) ma.dst[i] = c->pics[b.pic[i]].dev.rec[0];
-#ifdef MC_STAMP
-    // diagnostic build: time stamps of the last luma launch of a full batch, dumped to /tmp/mc_stamps.bin at context destruction
-    static unsigned long long* d_stamps = nullptr;
-    const size_t nst = (size_t)kMaxBatch * c->num_ctus * 4 * 8;
-    if (!d_stamps) hipMalloc((void**)&d_stamps, nst * 8);
-    ma.stamps = b.n == kMaxBatch ? d_stamps : nullptr;
-    c->dbg_stamps = d_stamps; c->dbg_nstamps = nst;
-#endif
     launch_mc_luma(ma, max_ctus, any_wp, any_bi, c->stream);
-    ma.stamps = nullptr;
     if (any_cells) launch_mc_luma_cells(c->d_pics, c->d_finals, b, max_ctus, c->seq.log2_ctu_size, any_wp, c->stream);
   }
   {
@@ -546,13 +536,6 @@ void hmgpu_destroy(hmgpu_ctx* c) {
   if (!c) return;
   hipSetDevice(c->device);
   if (c->stream) hipStreamSynchronize(c->stream);
-#ifdef MC_STAMP
-  if (c->dbg_stamps) {                 // diagnostic build only: the time stamps of the last batched luma launch, raw
-    std::vector<unsigned long long> h(c->dbg_nstamps);
-    hipMemcpy(h.data(), c->dbg_stamps, h.size() * 8, hipMemcpyDeviceToHost);
-    if (FILE* f = fopen("/tmp/mc_stamps.bin", "wb")) { fwrite(h.data(), 8, h.size(), f); fclose(f); }
-  }
-#endif
   prof_drain(c);
   for (EventPair& ep : c->free_events) { hipEventDestroy(ep.a); hipEventDestroy(ep.b); }
   for (Picture& p : c->pics) free_picture(p);

@@ -166,7 +166,6 @@ struct McArgs {
   uint64_t pic_stride;
   uint32_t sao_off, origin_off, cr_off;        // origin_off: luma launch: Y plane; chroma launch: Cb plane; cr_off: Cb -> Cr
   uint32_t sao_mask_lo, sao_mask_hi;
-  unsigned long long* stamps;                  // diagnostic builds (MC_STAMP): 8 time stamps per wave, else null
 };
 
 // Pointers stored inside PicDev / PlaneSet reach the kernels through memory, so the compiler only knows them as generic

@@ -59,14 +59,6 @@ __device__ inline uint32_t pk_sub(uint32_t a, uint32_t b) {                     
   return __builtin_bit_cast(uint32_t, __builtin_bit_cast(short2v, a) - __builtin_bit_cast(short2v, b));
 }
 
-#ifdef MC_STAMP
-#define STAMP(i) do { if (stamp_on) { stamp[i] = __builtin_amdgcn_s_memtime(); } } while (0)
-#define STAMP_DRAIN() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory")
-#else
-#define STAMP(i) do {} while (0)
-#define STAMP_DRAIN() do {} while (0)
-#endif
-
 
 // ---- tap tables: entry (fraction f, parity p) of an N-tap filter c[]: with A = (c0,c1)(c2,c3).. and B = (0,c0)(c1,c2)..(c[N-1],0)
 //   p = 0: even columns A,0   odd columns B        p = 1: even columns B   odd columns 0,A
