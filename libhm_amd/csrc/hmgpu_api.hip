@@ -344,8 +344,22 @@ hmgpu_status run_recon(hmgpu_ctx* c, const Batch& b, bool any_intra, bool any_wp
   }
   // blocks per shard: enough to keep the chip busy on a full picture, few enough that a short list costs nothing
   uint32_t bps = (uint32_t)std::max(4, std::min(24, max_ctus / 8 + 1));   // blocks per shard; 24 measured best at 2160p (768 blocks, 3 per CU)
-  const int cmask = 0;                                      // all four size classes
-  { ProfScope ps(c, K_ITX); launch_itx(c->d_pics, b, cmask, bps, c->stream); }
+  {
+    ItxArgs ia;
+    memset(&ia, 0, sizeof(ia));
+    ia.n = b.n; ia.class_mask = 0xf;                        // all four size classes
+    for (int k = 0; k < 3; k++) { ia.pitch[k] = c->pitch[k]; ia.bd[k] = d0.bd[k]; }
+    for (int k = 0; k < 4; k++) ia.tu_cap[k] = c->tu_cap[k];
+    for (int i = 0; i < b.n; i++) {
+      const PicDev& d = c->pics[b.pic[i]].dev;
+      for (int k = 0; k < 4; k++) ia.tu[i][k] = d.tu[k];
+      ia.tu_count[i] = d.tu_count;
+      for (int k = 0; k < 3; k++) { ia.coef[i][k] = d.coef[k]; ia.rec[i][k] = d.rec[k]; }
+      ia.sl_m[i] = d.sl_m;
+    }
+    ProfScope ps(c, K_ITX);
+    launch_itx(ia, bps, c->stream);
+  }
   // intra CUs predict from finished neighbours (inter ones included): after motion compensation and the inter residuals
   if (any_intra) {
     ProfScope ps(c, K_INTRA);

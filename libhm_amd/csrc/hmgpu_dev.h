@@ -168,6 +168,19 @@ struct McArgs {
   uint32_t sao_mask_lo, sao_mask_hi;
 };
 
+// the same for the residual kernel (k_itx.hip)
+struct ItxArgs {
+  int32_t n; uint32_t class_mask;              // pictures of the batch; size classes to run (bit = log2 size - 2)
+  int32_t blocks[4];                           // workgroups per shard and size class (launch_itx)
+  int32_t pitch[3], bd[3];
+  uint32_t tu_cap[4];                          // capacity of one shard's list
+  const TuRec* tu[kMaxBatch][4];
+  const uint32_t* tu_count[kMaxBatch];         // [4][kTuShards]
+  const int16_t* coef[kMaxBatch][3];
+  int16_t* rec[kMaxBatch][3];
+  const uint8_t* sl_m[kMaxBatch];
+};
+
 // Pointers stored inside PicDev / PlaneSet reach the kernels through memory, so the compiler only knows them as generic
 // ("flat") pointers: flat loads cannot be counted separately from LDS traffic and force a full s_waitcnt after every
 // batch.  Every hot pointer is therefore re-typed as a global-address-space pointer before use.
@@ -224,7 +237,7 @@ void launch_mc_chroma(McArgs& a, int max_ctus, bool wp, bool bi, hipStream_t s);
 // the 4x4 cells of tiles with mixed motion (8x4 / 4x8 PUs, AMP in 16x16 CUs): only for calls that contain such PUs
 void launch_mc_luma_cells(const PicDev* pics, const PlaneSet* finals, const Batch& b, int max_ctus, int log2ctu, bool wp, hipStream_t s);
 void launch_mc_chroma_cells(const PicDev* pics, const PlaneSet* finals, const Batch& b, int max_ctus, int log2ctu, bool wp, hipStream_t s);
-void launch_itx(const PicDev* pics, const Batch& b, int log2size, uint32_t blocks_per_shard, hipStream_t s);
+void launch_itx(ItxArgs& a, uint32_t blocks_per_shard, hipStream_t s);
 void launch_filter_fused(const PicDev* pics, const Batch& b, int width, int height, bool nofilt, hipStream_t s);
 void launch_pack(const int16_t* src, int pitch, int x0, int y0, int w, int h, int bytes, uint8_t* dst, int dst_stride, hipStream_t s);
 void launch_checksum(const int16_t* src, int pitch, int w, int h, int bd, uint32_t* out, hipStream_t s);

@@ -20,119 +20,215 @@ template <int LOG2N> struct ItxLds {
 };
 constexpr int kItxLdsBytes = std::max(std::max(ItxLds<2>::BYTES, ItxLds<3>::BYTES), std::max(ItxLds<4>::BYTES, ItxLds<5>::BYTES));
 
+// what a workgroup needs of its picture, taken from kernel-argument memory (ItxArgs): no descriptor in global memory stands between
+// the start of a wave and the load of its first TU records
+struct ItxPic {
+  const TuRec* list; uint32_t count_cap; const uint32_t* count;
+  const int16_t* coef[3]; int16_t* rec[3]; int32_t pitch[3], bd[3]; const uint8_t* sl_m;
+};
+template <typename T> __device__ inline T by_comp(const T (&v)[3], int comp) { return comp == 0 ? v[0] : comp == 1 ? v[1] : v[2]; }   // registers, not an indexed array
+
+// Picture rows are read and written in another lane order than the one the transform works in.  The transform wants lane rho =
+// (TU slot, row n) to own row n of its TU -- 64 rows per wave, each 8 N bytes in a different 128-byte line.  Memory wants the lanes of
+// an instruction to cover as few lines, in pieces as long, as possible (every line a lane group touches is a request of its own
+// from the vector L1 to L2; with 16 bytes per request that path, not HBM, set the kernel's time).  So lane L moves, in its k-th
+// load / store, the 16-byte piece seg(L) of wave row row(L, k):
+//   32x32: four lanes per row (one 64-byte request), 16x16: two lanes per row (32 bytes); 8x8 and 4x4: one lane per row, the lanes
+//   ordered row-major over the TUs of the wave, so the same row of horizontally adjacent TUs (neighbours in the z-ordered list) lands
+//   in adjacent lanes and merges.
+// The residual reaches that order through the wave's LDS tile (16x16, 32x32; XOR-swizzled, conflict-free both ways) or by
+// ds_bpermute (8x8, 4x4); the prediction is loaded in it, so the add and the store need nothing more.
+template <int LOG2N> struct IoMap {
+  static constexpr int N = 1 << LOG2N;
+  static constexpr int K = N >= 16 ? N / 8 : 1;                  // loads / stores per lane and TU group
+  __device__ static inline int row(int L, int k) {
+    if constexpr (N == 32) return (L >> 2) + 16 * k;
+    else if constexpr (N == 16) return (L >> 1) + 32 * k;
+    else if constexpr (N == 8) return (L & 7) * 8 + (L >> 3);
+    else return (L & 15) * 4 + (L >> 4);
+  }
+  __device__ static inline int seg(int L) { return N == 32 ? (L & 3) : (N == 16 ? (L & 1) : 0); }
+  __device__ static inline int swz(int rho) { return N == 32 ? ((rho >> 2) & 3) : ((rho >> 3) & 1); }   // 16x16, 32x32: LDS piece swizzle
+};
+__device__ inline int bperm(int src_lane, int v) { return __builtin_amdgcn_ds_bpermute(src_lane << 2, v); }
+constexpr int kNoRow = INT32_MIN;
+
 // all coded TUs of one size class and shard; blocks stride over a list whose length only the device knows
 template <int LOG2N>
-__device__ inline void itx_class(const PicDev& P, int shard, int bx, int nbx, char* __restrict__ lds_raw) {
+__device__ inline void itx_class(const ItxPic& P, int bx, int nbx, char* __restrict__ lds_raw) {
   constexpr int N = 1 << LOG2N;
-  const int cls = LOG2N - 2;
-  const uint32_t count = min(ldg(P.tu_count + cls * kTuShards + shard), P.tu_cap[cls]);
-  const TuRec* __restrict__ list = P.tu[cls] + (size_t)shard * P.tu_cap[cls];
-  const int j = threadIdx.x / N, n = threadIdx.x % N;
+  using Io = IoMap<LOG2N>;
+  constexpr int K = Io::K;
+  const TuRec* __restrict__ list = P.list;
+  const uint32_t cap = P.count_cap;
+  const int j = threadIdx.x / N, n = threadIdx.x % N, L = threadIdx.x & 63;
   int16_t* buf = reinterpret_cast<int16_t*>(lds_raw) + j * PkCfg<LOG2N>::TU_ELEMS;
-  // Waves run independently.  One loop iteration of a wave covers a group of U*TPW consecutive TUs (lane slot jw takes
-  // TUs base + u*TPW + jw, u < U, one after the other through the same LDS tile), and the loop is a software pipeline:
-  // while group g is transformed the levels and prediction rows of group g+1 are in flight and the records of group g+2
-  // are being fetched.  Measured at 2160p: U > 1 does not pay, not even for the 4x4 / 8x8 classes alone (U = 4 / 2: +3 %
-  // time) -- those classes move 1.1 / 1.9 TB/s of algorithmic bytes but 32-byte sectors for 8- and 16-byte rows.
+  // Waves run independently.  One loop iteration of a wave covers TPW consecutive TUs (lane slot jw takes TU base + jw), and
+  // the loop is a software pipeline: while group g is transformed the levels and prediction rows of group g+1 are in flight and
+  // the records of group g+2 are being fetched.  The first records are fetched together with the list length (records past the
+  // length are stale but inside the list's capacity; nothing is done with them).
   constexpr int TPW = 64 / N;
-  constexpr int U = 1;
-  const int jw = (threadIdx.x & 63) / N;                          // TU slot inside the wave
-  const uint32_t stride = (uint32_t)nbx * 4 * TPW * U;
-  uint32_t t = ((uint32_t)bx * 4 + (threadIdx.x >> 6)) * TPW * U + jw;
+  const int jw = L / N;                                           // TU slot inside the wave
+  char* const wtile = lds_raw + (threadIdx.x >> 6) * (TPW * PkCfg<LOG2N>::TU_ELEMS * 2);   // the wave's TU tiles, as one region
+  static_assert(TPW * PkCfg<LOG2N>::TU_ELEMS * 2 >= 64 * N * 2 || N < 16, "the residual rows of a wave must fit its tiles");
+  const uint32_t stride = (uint32_t)nbx * 4 * TPW;
+  uint32_t t = ((uint32_t)bx * 4 + (threadIdx.x >> 6)) * TPW + jw;
   struct Rec { uint32_t w0, w1, w2; };
   auto load_rec = [&](uint32_t ti, Rec& r) {
     r.w0 = r.w1 = r.w2 = 0;
-    if (ti < count) { const uint32_t* rp = reinterpret_cast<const uint32_t*>(list + ti); r.w0 = ldg(rp); r.w1 = ldg(rp + 1); r.w2 = ldg(rp + 2); }
+    if (ti < cap) { const uint32_t* rp = reinterpret_cast<const uint32_t*>(list + ti); r.w0 = ldg(rp); r.w1 = ldg(rp + 1); r.w2 = ldg(rp + 2); }
   };
-  auto row_ptr = [&](const Rec& r) {
+  Rec rc, rn;
+  load_rec(t, rc);
+  load_rec(t + stride, rn);
+  const uint32_t count = min(ldg(P.count), cap);
+  char* const plane0 = reinterpret_cast<char*>(P.rec[0]);
+  const uint32_t max_y = (uint32_t)((1 << P.bd[0]) - 1) * 0x10001u, max_c = (uint32_t)((1 << P.bd[1]) - 1) * 0x10001u;
+  const int plane_off[3] = {0, (int)(reinterpret_cast<char*>(P.rec[1]) - plane0), (int)(reinterpret_cast<char*>(P.rec[2]) - plane0)};
+  // byte offset (from the luma plane's origin) of the row this lane owns in the transform: row n of the TU of its slot
+  auto own_row = [&](uint32_t ti, const Rec& r) {
     const int comp = r.w1 & 3, cs = comp ? 1 : 0;
-    return P.rec[comp] + (size_t)((((int)(r.w0 >> 16) * 4) >> cs) + n) * P.pitch[comp] + (((int)(r.w0 & 0xffff) * 4) >> cs);
+    const int off = by_comp(plane_off, comp) + (((((int)(r.w0 >> 16) * 4) >> cs) + n) * by_comp(P.pitch, comp) + (((int)(r.w0 & 0xffff) * 4) >> cs)) * 2;
+    return ti < count ? off : kNoRow;
   };
-  auto load_data = [&](uint32_t ti, const Rec& r, uint32_t (&lv)[N / 2], uint32_t (&pw)[N / 2]) {
+  // ... and of the K pieces this lane moves
+  auto io_rows = [&](int own, int (&off)[K]) {
 #pragma unroll
-    for (int i = 0; i < N / 2; i++) { lv[i] = 0; pw[i] = 0; }
+    for (int k = 0; k < K; k++) {
+      const int o = bperm(Io::row(L, k), own);
+      off[k] = o == kNoRow ? kNoRow : o + Io::seg(L) * 16;
+    }
+  };
+  auto load_levels = [&](uint32_t ti, const Rec& r, uint32_t (&lv)[N / 2]) {
+#pragma unroll
+    for (int i = 0; i < N / 2; i++) lv[i] = 0;
     if (ti < count) {
-      const int16_t* lev = P.coef[r.w1 & 3] + r.w2 + n * N;       // lane n: row n of the level block
-      const int16_t* row = row_ptr(r);                            // lane n: row n of the prediction
-      if constexpr (N == 4) {
-        const u32x2 a = ldg2(lev), c = ldg2(row);
-        lv[0] = a.x; lv[1] = a.y; pw[0] = c.x; pw[1] = c.y;
-      } else {
+      const int16_t* lev = by_comp(P.coef, r.w1 & 3) + r.w2 + n * N;       // lane n: row n of the level block
+      if constexpr (N == 4) { const u32x2 a = ldg2(lev); lv[0] = a.x; lv[1] = a.y; }
+      else {
 #pragma unroll
         for (int i = 0; i < N / 8; i++) { const u32x4 a = ldg4(lev + i * 8); lv[4 * i] = a.x; lv[4 * i + 1] = a.y; lv[4 * i + 2] = a.z; lv[4 * i + 3] = a.w; }
-#pragma unroll
-        for (int i = 0; i < N / 8; i++) { const u32x4 c = ldg4(row + i * 8); pw[4 * i] = c.x; pw[4 * i + 1] = c.y; pw[4 * i + 2] = c.z; pw[4 * i + 3] = c.w; }
       }
     }
   };
-  Rec rc[U], rn[U];
-  uint32_t lv_c[U][N / 2], pw_c[U][N / 2];
+  auto load_pred = [&](const int (&off)[K], u32x4 (&pw)[K]) {
 #pragma unroll
-  for (int u = 0; u < U; u++) load_rec(t + u * TPW, rc[u]);
-#pragma unroll
-  for (int u = 0; u < U; u++) load_rec(t + stride + u * TPW, rn[u]);
-#pragma unroll
-  for (int u = 0; u < U; u++) load_data(t + u * TPW, rc[u], lv_c[u], pw_c[u]);
+    for (int k = 0; k < K; k++) {
+      pw[k] = u32x4{0, 0, 0, 0};
+      if (off[k] != kNoRow) {
+        if constexpr (N == 4) { const u32x2 c = ldg2(plane0 + off[k]); pw[k].x = c.x; pw[k].y = c.y; }
+        else pw[k] = ldg4(plane0 + off[k]);
+      }
+    }
+  };
+  uint32_t lv_c[N / 2];
+  u32x4 pw_c[K];
+  int off_c[K];
+  constexpr bool AHEAD = N <= 16;                                  // prediction rows one group ahead (registers allowing)
+  load_levels(t, rc, lv_c);
+  if constexpr (AHEAD) {
+    io_rows(own_row(t, rc), off_c);
+    load_pred(off_c, pw_c);
+  }
   for (uint32_t tw = t - jw; tw < count; tw += stride, t += stride) {   // tw: wave-uniform loop variable
-    uint32_t lv_n[U][N / 2], pw_n[U][N / 2];
-    Rec rnn[U];
-#pragma unroll
-    for (int u = 0; u < U; u++) load_data(t + stride + u * TPW, rn[u], lv_n[u], pw_n[u]);
-#pragma unroll
-    for (int u = 0; u < U; u++) load_rec(t + 2 * stride + u * TPW, rnn[u]);
-#pragma unroll
-    for (int u = 0; u < U; u++) {
-      if (tw + u * TPW >= count) break;                           // wave-uniform: the rest of the group is past the end
-      const bool active = t + u * TPW < count;
-      const Rec r = rc[u];
+    uint32_t lv_n[N / 2];
+    u32x4 pw_n[AHEAD ? K : 1];
+    int off_n[AHEAD ? K : 1];
+    Rec rnn;
+    load_levels(t + stride, rn, lv_n);
+    if constexpr (AHEAD) {
+      io_rows(own_row(t + stride, rn), off_n);
+      load_pred(off_n, pw_n);
+    } else {
+      io_rows(own_row(t, rc), off_c);                              // 32x32: the prediction of THIS group, needed after the transform
+      load_pred(off_c, pw_c);
+    }
+    load_rec(t + 2 * stride, rnn);
+    {
+      const Rec r = rc;
       const int comp = r.w1 & 3, flags = (r.w1 & 0xff) >> 2;
       const int per = (int)(int8_t)((r.w1 >> 8) & 0xff), rem = (int)(int8_t)((r.w1 >> 16) & 0xff);
-      const int bd = P.bd[comp];
+      const int bd = by_comp(P.bd, comp);
       uint32_t res[N / 2];
       // scaling lists (inter TUs: list 3 + component; not for transform-skip blocks other than 4x4, TComTrQuant.h:180)
       const uint8_t* mrow = (P.sl_m != nullptr && (!(flags & 2) || N == 4)) ? P.sl_m + (((LOG2N - 2) * 6 + 3 + comp) << 10) + n * N : nullptr;
-      itx_tu_pk<LOG2N>(lv_c[u], n, per, rem, (flags & 2) != 0, bd, buf, res, false, mrow, (flags & 4) != 0);
-      if (active) {
-        // recon row n: ClipBD(pred + resid) in place, two samples per lane operation
-        const uint32_t maxv2 = (uint32_t)((1 << bd) - 1) * 0x10001u;
-        int16_t* row = row_ptr(r);
-        uint32_t o[N / 2];
+      itx_tu_pk<LOG2N>(lv_c, n, per, rem, (flags & 2) != 0, bd, buf, res, false, mrow, (flags & 4) != 0);
+      // the residual rows, and the clipping range of their component, in the order the picture is accessed in
+      u32x4 rs[K];
+      if constexpr (N >= 16) {
+        constexpr int SEGS = N / 8;
 #pragma unroll
-        for (int i = 0; i < N / 2; i++) o[i] = pk_clip_u(pk_add_sat(pw_c[u][i], res[i]), maxv2);
-        if constexpr (N == 4) { u32x2 v = {o[0], o[1]}; stg2(row, v); }
+        for (int i = 0; i < SEGS; i++)
+          *reinterpret_cast<u32x4*>(wtile + (L * SEGS + (i ^ Io::swz(L))) * 16) = u32x4{res[4 * i], res[4 * i + 1], res[4 * i + 2], res[4 * i + 3]};
+        wave_lds_sync();
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+          const int rho = Io::row(L, k);
+          rs[k] = *reinterpret_cast<const u32x4*>(wtile + (rho * SEGS + (Io::seg(L) ^ Io::swz(rho))) * 16);
+        }
+        wave_lds_sync();                                          // the tiles are reused by the next TUs
+      } else {
+        const int rho = Io::row(L, 0);
+        rs[0] = u32x4{(uint32_t)bperm(rho, (int)res[0]), (uint32_t)bperm(rho, (int)res[1]), 0, 0};
+        if constexpr (N == 8) { rs[0].z = (uint32_t)bperm(rho, (int)res[2]); rs[0].w = (uint32_t)bperm(rho, (int)res[3]); }
+      }
+      // recon: ClipBD(pred + resid) in place, two samples per lane operation
+#pragma unroll
+      for (int k = 0; k < K; k++) {
+        if (off_c[k] == kNoRow) continue;
+        const uint32_t maxv2 = off_c[k] < plane_off[1] ? max_y : max_c;   // Cb and Cr share a bit depth; the planes lie Y, Cb, Cr
+        u32x4 o;
+        o.x = pk_clip_u(pk_add_sat(pw_c[k].x, rs[k].x), maxv2); o.y = pk_clip_u(pk_add_sat(pw_c[k].y, rs[k].y), maxv2);
+        if constexpr (N == 4) stg2(plane0 + off_c[k], u32x2{o.x, o.y});
         else {
-#pragma unroll
-          for (int seg = 0; seg < N / 8; seg++) { u32x4 v = {o[seg * 4], o[seg * 4 + 1], o[seg * 4 + 2], o[seg * 4 + 3]}; stg4(row + seg * 8, v); }
+          o.z = pk_clip_u(pk_add_sat(pw_c[k].z, rs[k].z), maxv2); o.w = pk_clip_u(pk_add_sat(pw_c[k].w, rs[k].w), maxv2);
+          stg4(plane0 + off_c[k], o);
         }
       }
     }
+    rc = rn; rn = rnn;
 #pragma unroll
-    for (int u = 0; u < U; u++) {
-      rc[u] = rn[u]; rn[u] = rnn[u];
+    for (int i = 0; i < N / 2; i++) lv_c[i] = lv_n[i];
 #pragma unroll
-      for (int i = 0; i < N / 2; i++) { lv_c[u][i] = lv_n[u][i]; pw_c[u][i] = pw_n[u][i]; }
-    }
+    for (int k = 0; k < K; k++) if constexpr (AHEAD) { pw_c[k] = pw_n[k]; off_c[k] = off_n[k]; }
   }
 }
 
-// one launch for all four size classes: blockIdx.y = class * kTuShards + shard, so short lists of one class share the
-// chip with the long lists of another instead of each class paying its own latency-bound launch
-__global__ void __launch_bounds__(256) k_itx(const PicDev* __restrict__ pics, Batch b, uint32_t class_mask) {
+// One launch for all four size classes: short lists of one class share the chip with the long lists of another instead of each
+// class paying its own latency-bound launch.  Workgroups go round-robin to the 8 XCDs by linear id and gridDim.x is a multiple of 8:
+// shard s (the TUs of every eighth group of four CTUs, all size classes) is the work of XCD s alone, so a 128-byte line of a
+// picture is only ever fetched into one L2.
+__global__ void __launch_bounds__(256) k_itx(const ItxArgs a) {
   __shared__ __attribute__((aligned(16))) char lds[kItxLdsBytes];
-  const PicDev& P = pics[b.pic[blockIdx.z]];
-  const int cls = blockIdx.y / kTuShards, shard = blockIdx.y % kTuShards;
-  if (!((class_mask >> cls) & 1)) return;                         // tuning aid: time one size class alone
+  const int cls = blockIdx.y, shard = blockIdx.x & (kTuShards - 1), z = blockIdx.z;
+  const int bx = blockIdx.x / kTuShards, nbx = a.blocks[cls];
+  if (bx >= nbx) return;                                          // the lists of large TUs are short: fewer, longer-lived workgroups
+  ItxPic P;
+  P.list = a.tu[z][cls] + (size_t)shard * a.tu_cap[cls];
+  P.count_cap = a.tu_cap[cls];
+  P.count = a.tu_count[z] + cls * kTuShards + shard;
+#pragma unroll
+  for (int k = 0; k < 3; k++) { P.coef[k] = a.coef[z][k]; P.rec[k] = a.rec[z][k]; P.pitch[k] = a.pitch[k]; P.bd[k] = a.bd[k]; }
+  P.sl_m = a.sl_m[z];
   switch (cls) {
-    case 0: itx_class<2>(P, shard, blockIdx.x, gridDim.x, lds); break;
-    case 1: itx_class<3>(P, shard, blockIdx.x, gridDim.x, lds); break;
-    case 2: itx_class<4>(P, shard, blockIdx.x, gridDim.x, lds); break;
-    default: itx_class<5>(P, shard, blockIdx.x, gridDim.x, lds); break;
+    case 0: itx_class<2>(P, bx, nbx, lds); break;
+    case 1: itx_class<3>(P, bx, nbx, lds); break;
+    case 2: itx_class<4>(P, bx, nbx, lds); break;
+    default: itx_class<5>(P, bx, nbx, lds); break;
   }
 }
 
-void launch_itx(const PicDev* pics, const Batch& b, int log2size, uint32_t blocks_per_shard, hipStream_t s) {
-  dim3 grid(blocks_per_shard, 4 * kTuShards, (unsigned)b.n);
-  hipLaunchKernelGGL(k_itx, grid, dim3(256), 0, s, pics, b, log2size ? (uint32_t)log2size : 0xfu);
+#ifndef ITX_B0
+#define ITX_B0 1
+#define ITX_B1 1
+#define ITX_B2 1
+#define ITX_B3 1
+#endif
+void launch_itx(ItxArgs& a, uint32_t blocks_per_shard, hipStream_t s) {
+  const uint32_t div[4] = {ITX_B0, ITX_B1, ITX_B2, ITX_B3};
+  for (int k = 0; k < 4; k++) a.blocks[k] = (a.class_mask >> k) & 1 ? (int32_t)std::max(1u, blocks_per_shard / div[k]) : 0;
+  dim3 grid(blocks_per_shard * kTuShards, 4, (unsigned)a.n);
+  hipLaunchKernelGGL(k_itx, grid, dim3(256), 0, s, a);
 }
 
 // ---- kernel-level seam: residual of n TUs from flat arrays (tests; hmgpu_inverse_transform_batch) ----------------------
