@@ -44,11 +44,12 @@ def algorithmic_bytes(p):
     out = {}
     out["mc_luma"] = 2 * ref_reads + 2 * luma_inter
     out["mc_chroma"] = (2 * ref_reads + 2 * luma_inter) // 2
-    # coded TU samples per size class: 2 (level) + 2 (prediction read) + 2 (reconstruction write)
+    # coded TU samples per size class: 2 (level) + 2 (residual written by k_itx) and 2 (residual read where MC writes the prediction)
     tr = m["tr_idx"]
     log2tu = 6 - m["depth"] - tr
     chain = (1 << (tr + 1)) - 1
     per_cls = {2: 0, 3: 0, 4: 0, 5: 0}
+    coded = [0, 0, 0]
     for comp, key in enumerate(("cbf_y", "cbf_u", "cbf_v")):
         has = inter & ((m[key] & chain) == chain)
         for l2 in (2, 3, 4, 5):
@@ -58,13 +59,16 @@ def algorithmic_bytes(p):
             else:
                 cls = max(l2 - 1, 2)
                 per_cls[cls] += n_part * 4
-    out["itx"] = 6 * sum(per_cls.values())                # all four TU sizes run in one launch
+            coded[comp] += n_part * (16 if comp == 0 else 4)
+    out["itx"] = 4 * sum(per_cls.values())                # all four TU sizes run in one launch
+    out["mc_luma"] += 2 * coded[0]
+    out["mc_chroma"] += 2 * (coded[1] + coded[2])
     samples = p.width * p.height * 3 // 2
     out["deblock_ver"] = 2 * samples                       # each pass = half of the 4 B/sample two-pass budget
     out["deblock_hor"] = 2 * samples
     out["sao"] = 4 * samples
     out["filter_fused"] = 4 * samples                      # deblocking (both directions) + SAO in one pass: picture read once, written once
-    out["prep"] = int(decoded.sum()) * (21 + 16)           # HM arrays read + BlkInfo written per partition
+    out["prep"] = int(decoded.sum()) * (21 + 16 + 4)       # HM arrays read + BlkInfo written per partition + TileMv written per four
     # intra CUs: levels read (coded TUs), reconstruction written once, reference samples read (~ 4N+1 per N x N TU: counted as 2 B/sample)
     intra_p = decoded & (m["pred_mode"] == 1)
     out["intra"] = int(intra_p.sum()) * 24 * (2 + 2 + 2)

@@ -226,6 +226,7 @@ hmgpu_status alloc_picture(hmgpu_ctx* c, Picture& p) {
     PicDev& d = p.dev;
     d.blk = m.take<BlkInfo>((size_t)c->grid_w * c->grid_h);
     d.tmv = m.take<TileMv>((size_t)(c->grid_w / 2) * (c->grid_h / 2));
+    for (int k = 0; k < 3; k++) d.resid[k] = m.take<int16_t>(c->coef_elems[k]);
     for (int k = 0; k < 3; k++) d.quad_off[k] = m.take<uint32_t>((size_t)c->num_ctus * (c->parts / 4));
     p.coef_start = m.take<uint32_t>((size_t)3 * (c->num_ctus + 1));
     d.fault = m.take<uint32_t>(1);
@@ -306,7 +307,7 @@ hmgpu_status ensure_refs_extended(hmgpu_ctx* c, const Batch& b, size_t call_idx)
   return HMGPU_OK;
 }
 
-// device work of one batch of slice calls (one call per picture): counters, prep, MC, inverse transforms
+// device work of one batch of slice calls (one call per picture): counters, prep, inverse transforms, MC (+ residual), intra
 hmgpu_status run_recon(hmgpu_ctx* c, const Batch& b, bool any_intra, bool any_wp, bool any_cells, bool any_bi) {
   int max_ctus = 0;
   for (int i = 0; i < b.n; i++) max_ctus = std::max(max_ctus, b.num_ctus[i]);
@@ -325,11 +326,31 @@ hmgpu_status run_recon(hmgpu_ctx* c, const Batch& b, bool any_intra, bool any_wp
   }
   const PicDev& d0 = c->pics[b.pic[0]].dev;           // plane offsets inside a picture's part of the slab: the same for every picture
   const char* const base0 = (const char*)c->pics[b.pic[0]].planes;
+  // the residual of the inter TUs first: the motion-compensation kernels add it when they write the prediction
+  // blocks per shard: enough to keep the chip busy on a full picture, few enough that a short list costs nothing
+  uint32_t bps = (uint32_t)std::max(4, std::min(24, max_ctus / 8 + 1));   // blocks per shard; 24 measured best at 2160p (768 blocks, 3 per CU)
+  {
+    ItxArgs ia;
+    memset(&ia, 0, sizeof(ia));
+    ia.n = b.n; ia.class_mask = 0xf;                        // all four size classes
+    for (int k = 0; k < 3; k++) { ia.rtw[k] = (c->grid_w / 2) >> (k ? 1 : 0); ia.bd[k] = d0.bd[k]; }
+    for (int k = 0; k < 4; k++) ia.tu_cap[k] = c->tu_cap[k];
+    for (int i = 0; i < b.n; i++) {
+      const PicDev& d = c->pics[b.pic[i]].dev;
+      for (int k = 0; k < 4; k++) ia.tu[i][k] = d.tu[k];
+      ia.tu_count[i] = d.tu_count;
+      for (int k = 0; k < 3; k++) { ia.coef[i][k] = d.coef[k]; ia.resid[i][k] = d.resid[k]; }
+      ia.sl_m[i] = d.sl_m;
+    }
+    ProfScope ps(c, K_ITX);
+    launch_itx(ia, bps, c->stream);
+  }
   {
     ProfScope ps(c, K_MC_LUMA);
     ma.pitch = c->pitch[0]; ma.bd = c->seq.bit_depth_luma;
     ma.origin_off = (uint32_t)((const char*)d0.rec[0] - base0);
-    for (int i = 0; i < b.n; i++) ma.dst[i] = c->pics[b.pic[i]].dev.rec[0];
+    ma.rtw = c->grid_w / 2;
+    for (int i = 0; i < b.n; i++) { ma.dst[i] = c->pics[b.pic[i]].dev.rec[0]; ma.resid[i] = c->pics[b.pic[i]].dev.resid[0]; }
     launch_mc_luma(ma, max_ctus, any_wp, any_bi, c->stream);
     if (any_cells) launch_mc_luma_cells(c->d_pics, c->d_finals, b, max_ctus, c->seq.log2_ctu_size, any_wp, c->stream);
   }
@@ -338,27 +359,13 @@ hmgpu_status run_recon(hmgpu_ctx* c, const Batch& b, bool any_intra, bool any_wp
     ma.pitch = c->pitch[1]; ma.bd = c->seq.bit_depth_chroma;
     ma.origin_off = (uint32_t)((const char*)d0.rec[1] - base0);
     ma.cr_off = (uint32_t)((const char*)d0.rec[2] - (const char*)d0.rec[1]);
-    for (int i = 0; i < b.n; i++) { ma.dst[i] = c->pics[b.pic[i]].dev.rec[1]; ma.dst2[i] = c->pics[b.pic[i]].dev.rec[2]; }
-    launch_mc_chroma(ma, max_ctus, any_wp, any_bi, c->stream);
-    if (any_cells) launch_mc_chroma_cells(c->d_pics, c->d_finals, b, max_ctus, c->seq.log2_ctu_size, any_wp, c->stream);
-  }
-  // blocks per shard: enough to keep the chip busy on a full picture, few enough that a short list costs nothing
-  uint32_t bps = (uint32_t)std::max(4, std::min(24, max_ctus / 8 + 1));   // blocks per shard; 24 measured best at 2160p (768 blocks, 3 per CU)
-  {
-    ItxArgs ia;
-    memset(&ia, 0, sizeof(ia));
-    ia.n = b.n; ia.class_mask = 0xf;                        // all four size classes
-    for (int k = 0; k < 3; k++) { ia.pitch[k] = c->pitch[k]; ia.bd[k] = d0.bd[k]; }
-    for (int k = 0; k < 4; k++) ia.tu_cap[k] = c->tu_cap[k];
+    ma.rtw = c->grid_w / 4;
     for (int i = 0; i < b.n; i++) {
       const PicDev& d = c->pics[b.pic[i]].dev;
-      for (int k = 0; k < 4; k++) ia.tu[i][k] = d.tu[k];
-      ia.tu_count[i] = d.tu_count;
-      for (int k = 0; k < 3; k++) { ia.coef[i][k] = d.coef[k]; ia.rec[i][k] = d.rec[k]; }
-      ia.sl_m[i] = d.sl_m;
+      ma.dst[i] = d.rec[1]; ma.dst2[i] = d.rec[2]; ma.resid[i] = d.resid[1]; ma.resid2[i] = d.resid[2];
     }
-    ProfScope ps(c, K_ITX);
-    launch_itx(ia, bps, c->stream);
+    launch_mc_chroma(ma, max_ctus, any_wp, any_bi, c->stream);
+    if (any_cells) launch_mc_chroma_cells(c->d_pics, c->d_finals, b, max_ctus, c->seq.log2_ctu_size, any_wp, c->stream);
   }
   // intra CUs predict from finished neighbours (inter ones included): after motion compensation and the inter residuals
   if (any_intra) {

@@ -54,11 +54,15 @@ struct __attribute__((aligned(16))) TileMv {
   uint8_t frac;                 // xf0 | yf0 << 2 | xf1 << 4 | yf1 << 6 (quarter samples)
   uint8_t ref0, ref1;           // device picture handles of slot 0 / slot 1
   uint8_t flags;                // TM_*
-  uint8_t ridx0, ridx1;         // reference indices of slot 0 / slot 1 (explicit weighted prediction)
+  uint8_t ridx;                 // reference indices of slot 0 | slot 1 << 4 (explicit weighted prediction)
+  uint8_t rmask;                // TR_*: which parts of the tile carry a residual (written for every tile, active or not)
   uint16_t slice;               // index into the picture's slice table
 };
 static_assert(sizeof(TileMv) == 16, "TileMv must be 16 bytes");
 enum : uint8_t { TM_ACTIVE = 1, TM_BI = 2, TM_FIRST_L1 = 4 };
+__host__ __device__ constexpr int resid_slot(int row) { return ((row & 1) << 2) | ((row & 7) >> 1); }   // 16-byte slot of row `row` in its tile
+// residual mask of an 8x8 luma tile: bits 0-3 its four 4x4 luma quadrants (raster order), bit 4 / 5 the 4x4 Cb / Cr block under it
+enum : uint8_t { TR_LUMA = 15, TR_CB = 16, TR_CR = 32 };
 
 // ---- coded transform unit ---------------------------------------------------------------------------------------
 struct TuRec {
@@ -120,6 +124,10 @@ struct PicDev {
   int32_t any_nofilt;              // some partition of the picture carries BF_NOFILT (host-side scan): SAO looks at the flags
   const uint16_t* slice_idx; const uint16_t* tile_idx;
   const int16_t* coef[3];
+  // residual of the inter TUs, written by k_itx and added by the motion-compensation kernels: per component 8x8-sample tiles of 128
+  // bytes (8 rows x 16 bytes), tile (tx, ty) at index ty * (padded component width / 8) + tx; inside a tile the even rows come first
+  // (resid_slot): a motion-compensation lane owns rows 2q, 2q+1, so each of its two loads reads 64 consecutive bytes per tile
+  int16_t* resid[3];
   const uint32_t* coef_start[3];   // compact levels: element offset of every CTU's first coded TU (+ total), else null (HM's dense layout)
   uint32_t* quad_off[3];           // compact levels: offset of the first TU that starts in every 8x8 luma area (z-order), written by k_prep
   const SliceDev* slices;
@@ -159,6 +167,9 @@ struct McArgs {
   const TileMv* tmv[kMaxBatch];
   int16_t* dst[kMaxBatch];                     // luma: the picture's reconstruction plane; chroma: Cb
   int16_t* dst2[kMaxBatch];                    // chroma: Cr
+  const int16_t* resid[kMaxBatch];             // residual tiles of the component (luma / Cb), PicDev::resid
+  const int16_t* resid2[kMaxBatch];            // chroma: Cr
+  int32_t rtw, pad_;                           // residual tiles per tile row of the component
   const SliceDev* slices[kMaxBatch];           // slice tables (explicit weighted prediction)
   // final planes: every picture of a context lives in one slab, picture i at slab + i * pic_stride; its final luma plane (sample
   // (0,0)) is at + origin_off, or + sao_off + origin_off when bit i of the SAO mask is set (the picture went through SAO)
@@ -172,12 +183,12 @@ struct McArgs {
 struct ItxArgs {
   int32_t n; uint32_t class_mask;              // pictures of the batch; size classes to run (bit = log2 size - 2)
   int32_t blocks[4];                           // workgroups per shard and size class (launch_itx)
-  int32_t pitch[3], bd[3];
+  int32_t rtw[3], bd[3];                       // residual tiles per tile row; bit depths
   uint32_t tu_cap[4];                          // capacity of one shard's list
   const TuRec* tu[kMaxBatch][4];
   const uint32_t* tu_count[kMaxBatch];         // [4][kTuShards]
   const int16_t* coef[kMaxBatch][3];
-  int16_t* rec[kMaxBatch][3];
+  int16_t* resid[kMaxBatch][3];
   const uint8_t* sl_m[kMaxBatch];
 };
 

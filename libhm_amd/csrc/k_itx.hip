@@ -1,13 +1,15 @@
-// k_itx.hip -- de-quantisation + inverse transform + reconstruction add for coded TUs.
+// k_itx.hip -- de-quantisation + inverse transform of the coded TUs of inter CUs.
 //   TComTrQuant::invTransformNxN -> xDeQuant (flat) -> xIT -> xITrMxN / xITransformSkip   TComTrQuant.cpp:1423,1203,1836,894,1920
-//   TComYuv::addClip (recon = ClipBD(pred + resid))                                      TComYuv.cpp:264
 //
 // One N-lane group per N x N TU (N = 4, 8, 16, 32; a wave holds 64/N TUs).  Stage 1: lane n owns coefficient column
 // n (coalesced 2-byte reads along the row), de-quantises it and runs the N-point 1-D inverse transform in registers
 // with the even/odd decomposition (full-rate 24-bit integer multiply-adds, all matrix entries are immediates).  The
 // 16-bit-clipped intermediates cross to the row owners through a padded LDS tile (conflict-free b32 writes / b128
-// reads).  Stage 2: lane y owns row y, transforms it, adds it to the prediction already sitting in the picture
-// (written by the MC kernels) and writes the clipped reconstruction back: the residual never touches HBM.
+// reads).  Stage 2: lane y owns row y of the residual, transforms it and writes it to the picture's residual tiles
+// (PicDev::resid: 8x8 samples = one 128-byte line per tile), where the motion-compensation kernels pick it up when they write the
+// prediction: reconstruction = ClipBD(prediction + residual) happens there (TComYuv::addClip, TComYuv.cpp:264), the prediction never
+// makes the round trip through HBM and this kernel is a pure stream -- levels in, residual out, every request a full line (rows of
+// a TU scattered over the picture plane, 8 to 64 bytes each, were what held its first version at a third of the roofline).
 // TUs come from the per-class lists built by k_prep; blocks stride over a list whose length only the device knows.
 #include "hmgpu_dev.h"
 #include "itx_core.h"
@@ -24,53 +26,24 @@ constexpr int kItxLdsBytes = std::max(std::max(ItxLds<2>::BYTES, ItxLds<3>::BYTE
 // the start of a wave and the load of its first TU records
 struct ItxPic {
   const TuRec* list; uint32_t count_cap; const uint32_t* count;
-  const int16_t* coef[3]; int16_t* rec[3]; int32_t pitch[3], bd[3]; const uint8_t* sl_m;
+  const int16_t* coef[3]; int16_t* resid[3]; int32_t rtw[3], bd[3]; const uint8_t* sl_m;
 };
 template <typename T> __device__ inline T by_comp(const T (&v)[3], int comp) { return comp == 0 ? v[0] : comp == 1 ? v[1] : v[2]; }   // registers, not an indexed array
-
-// Picture rows are read and written in another lane order than the one the transform works in.  The transform wants lane rho =
-// (TU slot, row n) to own row n of its TU -- 64 rows per wave, each 8 N bytes in a different 128-byte line.  Memory wants the lanes of
-// an instruction to cover as few lines, in pieces as long, as possible (every line a lane group touches is a request of its own
-// from the vector L1 to L2; with 16 bytes per request that path, not HBM, set the kernel's time).  So lane L moves, in its k-th
-// load / store, the 16-byte piece seg(L) of wave row row(L, k):
-//   32x32: four lanes per row (one 64-byte request), 16x16: two lanes per row (32 bytes); 8x8 and 4x4: one lane per row, the lanes
-//   ordered row-major over the TUs of the wave, so the same row of horizontally adjacent TUs (neighbours in the z-ordered list) lands
-//   in adjacent lanes and merges.
-// The residual reaches that order through the wave's LDS tile (16x16, 32x32; XOR-swizzled, conflict-free both ways) or by
-// ds_bpermute (8x8, 4x4); the prediction is loaded in it, so the add and the store need nothing more.
-template <int LOG2N> struct IoMap {
-  static constexpr int N = 1 << LOG2N;
-  static constexpr int K = N >= 16 ? N / 8 : 1;                  // loads / stores per lane and TU group
-  __device__ static inline int row(int L, int k) {
-    if constexpr (N == 32) return (L >> 2) + 16 * k;
-    else if constexpr (N == 16) return (L >> 1) + 32 * k;
-    else if constexpr (N == 8) return (L & 7) * 8 + (L >> 3);
-    else return (L & 15) * 4 + (L >> 4);
-  }
-  __device__ static inline int seg(int L) { return N == 32 ? (L & 3) : (N == 16 ? (L & 1) : 0); }
-  __device__ static inline int swz(int rho) { return N == 32 ? ((rho >> 2) & 3) : ((rho >> 3) & 1); }   // 16x16, 32x32: LDS piece swizzle
-};
-__device__ inline int bperm(int src_lane, int v) { return __builtin_amdgcn_ds_bpermute(src_lane << 2, v); }
-constexpr int kNoRow = INT32_MIN;
 
 // all coded TUs of one size class and shard; blocks stride over a list whose length only the device knows
 template <int LOG2N>
 __device__ inline void itx_class(const ItxPic& P, int bx, int nbx, char* __restrict__ lds_raw) {
   constexpr int N = 1 << LOG2N;
-  using Io = IoMap<LOG2N>;
-  constexpr int K = Io::K;
   const TuRec* __restrict__ list = P.list;
   const uint32_t cap = P.count_cap;
-  const int j = threadIdx.x / N, n = threadIdx.x % N, L = threadIdx.x & 63;
+  const int j = threadIdx.x / N, n = threadIdx.x % N;
   int16_t* buf = reinterpret_cast<int16_t*>(lds_raw) + j * PkCfg<LOG2N>::TU_ELEMS;
   // Waves run independently.  One loop iteration of a wave covers TPW consecutive TUs (lane slot jw takes TU base + jw), and
-  // the loop is a software pipeline: while group g is transformed the levels and prediction rows of group g+1 are in flight and
-  // the records of group g+2 are being fetched.  The first records are fetched together with the list length (records past the
-  // length are stale but inside the list's capacity; nothing is done with them).
+  // the loop is a software pipeline: while group g is transformed the levels of group g+1 are in flight and the records of group
+  // g+2 are being fetched.  The first records are fetched together with the list length (records past the length are stale but
+  // inside the list's capacity; nothing is done with them).
   constexpr int TPW = 64 / N;
-  const int jw = L / N;                                           // TU slot inside the wave
-  char* const wtile = lds_raw + (threadIdx.x >> 6) * (TPW * PkCfg<LOG2N>::TU_ELEMS * 2);   // the wave's TU tiles, as one region
-  static_assert(TPW * PkCfg<LOG2N>::TU_ELEMS * 2 >= 64 * N * 2 || N < 16, "the residual rows of a wave must fit its tiles");
+  const int jw = (threadIdx.x & 63) / N;                          // TU slot inside the wave
   const uint32_t stride = (uint32_t)nbx * 4 * TPW;
   uint32_t t = ((uint32_t)bx * 4 + (threadIdx.x >> 6)) * TPW + jw;
   struct Rec { uint32_t w0, w1, w2; };
@@ -82,23 +55,6 @@ __device__ inline void itx_class(const ItxPic& P, int bx, int nbx, char* __restr
   load_rec(t, rc);
   load_rec(t + stride, rn);
   const uint32_t count = min(ldg(P.count), cap);
-  char* const plane0 = reinterpret_cast<char*>(P.rec[0]);
-  const uint32_t max_y = (uint32_t)((1 << P.bd[0]) - 1) * 0x10001u, max_c = (uint32_t)((1 << P.bd[1]) - 1) * 0x10001u;
-  const int plane_off[3] = {0, (int)(reinterpret_cast<char*>(P.rec[1]) - plane0), (int)(reinterpret_cast<char*>(P.rec[2]) - plane0)};
-  // byte offset (from the luma plane's origin) of the row this lane owns in the transform: row n of the TU of its slot
-  auto own_row = [&](uint32_t ti, const Rec& r) {
-    const int comp = r.w1 & 3, cs = comp ? 1 : 0;
-    const int off = by_comp(plane_off, comp) + (((((int)(r.w0 >> 16) * 4) >> cs) + n) * by_comp(P.pitch, comp) + (((int)(r.w0 & 0xffff) * 4) >> cs)) * 2;
-    return ti < count ? off : kNoRow;
-  };
-  // ... and of the K pieces this lane moves
-  auto io_rows = [&](int own, int (&off)[K]) {
-#pragma unroll
-    for (int k = 0; k < K; k++) {
-      const int o = bperm(Io::row(L, k), own);
-      off[k] = o == kNoRow ? kNoRow : o + Io::seg(L) * 16;
-    }
-  };
   auto load_levels = [&](uint32_t ti, const Rec& r, uint32_t (&lv)[N / 2]) {
 #pragma unroll
     for (int i = 0; i < N / 2; i++) lv[i] = 0;
@@ -111,38 +67,12 @@ __device__ inline void itx_class(const ItxPic& P, int bx, int nbx, char* __restr
       }
     }
   };
-  auto load_pred = [&](const int (&off)[K], u32x4 (&pw)[K]) {
-#pragma unroll
-    for (int k = 0; k < K; k++) {
-      pw[k] = u32x4{0, 0, 0, 0};
-      if (off[k] != kNoRow) {
-        if constexpr (N == 4) { const u32x2 c = ldg2(plane0 + off[k]); pw[k].x = c.x; pw[k].y = c.y; }
-        else pw[k] = ldg4(plane0 + off[k]);
-      }
-    }
-  };
   uint32_t lv_c[N / 2];
-  u32x4 pw_c[K];
-  int off_c[K];
-  constexpr bool AHEAD = N <= 16;                                  // prediction rows one group ahead (registers allowing)
   load_levels(t, rc, lv_c);
-  if constexpr (AHEAD) {
-    io_rows(own_row(t, rc), off_c);
-    load_pred(off_c, pw_c);
-  }
   for (uint32_t tw = t - jw; tw < count; tw += stride, t += stride) {   // tw: wave-uniform loop variable
     uint32_t lv_n[N / 2];
-    u32x4 pw_n[AHEAD ? K : 1];
-    int off_n[AHEAD ? K : 1];
     Rec rnn;
     load_levels(t + stride, rn, lv_n);
-    if constexpr (AHEAD) {
-      io_rows(own_row(t + stride, rn), off_n);
-      load_pred(off_n, pw_n);
-    } else {
-      io_rows(own_row(t, rc), off_c);                              // 32x32: the prediction of THIS group, needed after the transform
-      load_pred(off_c, pw_c);
-    }
     load_rec(t + 2 * stride, rnn);
     {
       const Rec r = rc;
@@ -153,44 +83,21 @@ __device__ inline void itx_class(const ItxPic& P, int bx, int nbx, char* __restr
       // scaling lists (inter TUs: list 3 + component; not for transform-skip blocks other than 4x4, TComTrQuant.h:180)
       const uint8_t* mrow = (P.sl_m != nullptr && (!(flags & 2) || N == 4)) ? P.sl_m + (((LOG2N - 2) * 6 + 3 + comp) << 10) + n * N : nullptr;
       itx_tu_pk<LOG2N>(lv_c, n, per, rem, (flags & 2) != 0, bd, buf, res, false, mrow, (flags & 4) != 0);
-      // the residual rows, and the clipping range of their component, in the order the picture is accessed in
-      u32x4 rs[K];
-      if constexpr (N >= 16) {
-        constexpr int SEGS = N / 8;
-#pragma unroll
-        for (int i = 0; i < SEGS; i++)
-          *reinterpret_cast<u32x4*>(wtile + (L * SEGS + (i ^ Io::swz(L))) * 16) = u32x4{res[4 * i], res[4 * i + 1], res[4 * i + 2], res[4 * i + 3]};
-        wave_lds_sync();
-#pragma unroll
-        for (int k = 0; k < K; k++) {
-          const int rho = Io::row(L, k);
-          rs[k] = *reinterpret_cast<const u32x4*>(wtile + (rho * SEGS + (Io::seg(L) ^ Io::swz(rho))) * 16);
-        }
-        wave_lds_sync();                                          // the tiles are reused by the next TUs
-      } else {
-        const int rho = Io::row(L, 0);
-        rs[0] = u32x4{(uint32_t)bperm(rho, (int)res[0]), (uint32_t)bperm(rho, (int)res[1]), 0, 0};
-        if constexpr (N == 8) { rs[0].z = (uint32_t)bperm(rho, (int)res[2]); rs[0].w = (uint32_t)bperm(rho, (int)res[3]); }
-      }
-      // recon: ClipBD(pred + resid) in place, two samples per lane operation
-#pragma unroll
-      for (int k = 0; k < K; k++) {
-        if (off_c[k] == kNoRow) continue;
-        const uint32_t maxv2 = off_c[k] < plane_off[1] ? max_y : max_c;   // Cb and Cr share a bit depth; the planes lie Y, Cb, Cr
-        u32x4 o;
-        o.x = pk_clip_u(pk_add_sat(pw_c[k].x, rs[k].x), maxv2); o.y = pk_clip_u(pk_add_sat(pw_c[k].y, rs[k].y), maxv2);
-        if constexpr (N == 4) stg2(plane0 + off_c[k], u32x2{o.x, o.y});
+      if (t < count) {
+        // row n of the residual into the tiles it crosses: the eight lanes that hold the rows of one tile write its 128 bytes
+        const int cs = comp ? 1 : 0;
+        const int x = ((int)(r.w0 & 0xffff) * 4) >> cs, y = ((((int)(r.w0 >> 16) * 4) >> cs)) + n;
+        int16_t* row = by_comp(P.resid, comp) + ((size_t)((y >> 3) * by_comp(P.rtw, comp) + (x >> 3)) * 8 + resid_slot(y)) * 8;
+        if constexpr (N == 4) stg2(row + (x & 4), u32x2{res[0], res[1]});
         else {
-          o.z = pk_clip_u(pk_add_sat(pw_c[k].z, rs[k].z), maxv2); o.w = pk_clip_u(pk_add_sat(pw_c[k].w, rs[k].w), maxv2);
-          stg4(plane0 + off_c[k], o);
+#pragma unroll
+          for (int i = 0; i < N / 8; i++) stg4(row + i * 64, u32x4{res[4 * i], res[4 * i + 1], res[4 * i + 2], res[4 * i + 3]});
         }
       }
     }
     rc = rn; rn = rnn;
 #pragma unroll
     for (int i = 0; i < N / 2; i++) lv_c[i] = lv_n[i];
-#pragma unroll
-    for (int k = 0; k < K; k++) if constexpr (AHEAD) { pw_c[k] = pw_n[k]; off_c[k] = off_n[k]; }
   }
 }
 
@@ -208,7 +115,7 @@ __global__ void __launch_bounds__(256) k_itx(const ItxArgs a) {
   P.count_cap = a.tu_cap[cls];
   P.count = a.tu_count[z] + cls * kTuShards + shard;
 #pragma unroll
-  for (int k = 0; k < 3; k++) { P.coef[k] = a.coef[z][k]; P.rec[k] = a.rec[z][k]; P.pitch[k] = a.pitch[k]; P.bd[k] = a.bd[k]; }
+  for (int k = 0; k < 3; k++) { P.coef[k] = a.coef[z][k]; P.resid[k] = a.resid[z][k]; P.rtw[k] = a.rtw[k]; P.bd[k] = a.bd[k]; }
   P.sl_m = a.sl_m[z];
   switch (cls) {
     case 0: itx_class<2>(P, bx, nbx, lds); break;

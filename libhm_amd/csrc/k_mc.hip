@@ -49,10 +49,10 @@ __device__ inline u32x4 ldg4_a4(const void* p) { return __builtin_nontemporal_lo
 __device__ inline u32x4 ldg4_a4(const void* p) { return *(const u32x4_a4 HMGPU_AS1*)p; }
 #endif
 #ifndef MC_LB_LUMA
-#define MC_LB_LUMA 1
+#define MC_LB_LUMA 8      // waves per SIMD the uni-prediction kernel is held to (64 registers: the residual rows would cost one wave)
 #endif
 #ifndef MC_LB_CHROMA
-#define MC_LB_CHROMA 1
+#define MC_LB_CHROMA 8
 #endif
 
 __device__ inline uint32_t pk_sub(uint32_t a, uint32_t b) {                           // per half: a - b (wrapping)
@@ -150,7 +150,7 @@ __device__ inline WpTile wp_tile(const SliceDev* __restrict__ slices, uint32_t f
     w.active = ldg(&sd.weighted_pred) != 0;
     if (w.active) {
       w.log2wd = ldg(&sd.wp_log2_denom[comp ? 1 : 0]);
-      const int l0 = (flags & TM_FIRST_L1) ? 1 : 0, r0 = wpw & 0xff, r1 = (wpw >> 8) & 0xff;
+      const int l0 = (flags & TM_FIRST_L1) ? 1 : 0, r0 = wpw & 15, r1 = (wpw >> 4) & 15;
       w.w0 = ldg(&sd.wp_weight[l0][r0][comp]); w.o0 = ldg(&sd.wp_offset[l0][r0][comp]);
       if (flags & TM_BI) { w.w1 = ldg(&sd.wp_weight[1][r1][comp]); w.o1 = ldg(&sd.wp_offset[1][r1][comp]); }
     }
@@ -161,9 +161,10 @@ __device__ inline WpTile wp_tile(const SliceDev* __restrict__ slices, uint32_t f
 // the end of a V-pass thread: v6[r][x] = vertical sums of two output rows WITHOUT HM's intermediate offset: v6 = HM's sum + 8192 * 64.
 //   pass 0, uni: final samples (filter isLast / weightUnidir) -> dst;  pass 0, bi: HM's 14-bit values (16-bit Pel) wait in park[];
 //   pass 1: addAvg / weightBidir with the parked first list -> dst
+// rsd: the residual of the two rows (zero where the tile carries none): reconstruction = ClipBD(prediction + residual), TComYuv::addClip
 template <int W, bool WP, bool BI>
 __device__ inline void finish_rows(int (&v6)[2][W], uint32_t (&park)[W], int pass, bool bi, int bd, const WpTile& wp,
-                                   int16_t* __restrict__ dst, int pitch) {
+                                   const uint32_t (&rsd)[2][W / 2], int16_t* __restrict__ dst, int pitch) {
   const int head = bd >= 12 ? 2 : 14 - bd;
   const uint32_t maxv2 = (uint32_t)((1 << bd) - 1) * 0x10001u;
   if (BI && pass == 0 && bi) {
@@ -215,6 +216,10 @@ __device__ inline void finish_rows(int (&v6)[2][W], uint32_t (&park)[W], int pas
 #if defined(MC_EXP) && (MC_EXP & 2)         // experiment: no stores (unless a value nobody produces shows up)
   if (res[0][0] != 0x7fff7fffu) return;
 #endif
+#pragma unroll
+  for (int r = 0; r < 2; r++)
+#pragma unroll
+    for (int x = 0; x < W / 2; x++) res[r][x] = pk_clip_u(pk_add_sat(res[r][x], rsd[r][x]), maxv2);
 #pragma unroll
   for (int r = 0; r < 2; r++) {
     int16_t* row = dst + (ptrdiff_t)r * pitch;
@@ -275,7 +280,7 @@ __device__ inline void h_item_luma(const u32x4 (&r)[4], const uint32_t* __restri
 // (the strip above belongs to another wave), so the waves of a workgroup never wait for each other: no barrier, no shared state
 // but the tap table, whose copies are identical.
 template <bool WP, bool BI>
-__global__ void __launch_bounds__(256, MC_LB_LUMA) k_mc_luma(const McArgs a) {
+__global__ void __launch_bounds__(256, (WP || BI) ? 1 : MC_LB_LUMA) k_mc_luma(const McArgs a) {
   __shared__ __attribute__((aligned(16))) McLds<false> S;
   int slot; Square g;
 #ifdef MC_PRIO
@@ -290,7 +295,7 @@ __global__ void __launch_bounds__(256, MC_LB_LUMA) k_mc_luma(const McArgs a) {
   // ---- prologue: the lane's tile record, the tap table
   const u32x4 tm = load_tile_rec(a, slot, g, x0, y0);
   if (lane < 48) *reinterpret_cast<u32x2*>(&S.taps[2 * lane]) = ldg2(&g_taps_luma.e[0][0] + 2 * lane);
-  const uint32_t flags = tm.z >> 24;
+  const uint32_t flags = tm.z >> 24, rmask = (tm.w >> 8) & 0xff;
   const bool active = (flags & TM_ACTIVE) != 0;
   if (!__ballot(active)) return;
   const bool top = tile_is_top(tm, r, lane ^ 32);
@@ -343,6 +348,18 @@ __global__ void __launch_bounds__(256, MC_LB_LUMA) k_mc_luma(const McArgs a) {
     if (__ballot(hact)) h_phase(std::true_type()); else h_phase(std::false_type());
     wave_lds_sync();
     if (bact) {
+      // the residual of output rows 2q, 2q+1 (32 consecutive bytes of the tile's line in PicDev::resid), in flight during the V pass;
+      // a row crosses two 4x4 quadrants, each with a residual or without
+      // (lanes without one load the buffer's first bytes and select zeros: no register holds a zero across the H pass)
+      uint32_t rsd[2][4];
+      {
+        uint32_t qm = (rmask >> (q & 2)) & 3;                       // quadrants left | right << 1 of the tile half the rows lie in
+        if (BI && pass == 0 && (flags & TM_BI)) qm = 0;
+        const int16_t* rp = a.resid[slot] + (qm ? ((size_t)(y0 >> 3) * a.rtw + (x0 >> 3)) * 64 + q * 8 : (size_t)0);   // rows 2q, 2q+1: slots q, q+4
+        const u32x4 r0 = ldg4(rp), r1 = ldg4(rp + 32);
+        rsd[0][0] = qm & 1 ? r0.x : 0u; rsd[0][1] = qm & 1 ? r0.y : 0u; rsd[1][0] = qm & 1 ? r1.x : 0u; rsd[1][1] = qm & 1 ? r1.y : 0u;
+        rsd[0][2] = qm & 2 ? r0.z : 0u; rsd[0][3] = qm & 2 ? r0.w : 0u; rsd[1][2] = qm & 2 ? r1.z : 0u; rsd[1][3] = qm & 2 ? r1.w : 0u;
+      }
       // output rows 2q, 2q+1 of the tile: window row pairs q .. q+4, the first four of a tile's eight pairs belong to the tile above
       const uint32_t* above = top ? halo_t : body_t - 256;
       const uint32_t* vtap = &S.taps[((fr >> 2) & 3) * 2 * 12];
@@ -367,7 +384,7 @@ __global__ void __launch_bounds__(256, MC_LB_LUMA) k_mc_luma(const McArgs a) {
           }
         }
       }
-      finish_rows<8, WP, BI>(v6, park, pass, (flags & TM_BI) != 0, bd, wp, a.dst[slot] + (ptrdiff_t)(y0 + 2 * q) * pitch + x0, pitch);
+      finish_rows<8, WP, BI>(v6, park, pass, (flags & TM_BI) != 0, bd, wp, rsd, a.dst[slot] + (ptrdiff_t)(y0 + 2 * q) * pitch + x0, pitch);
     }
     if (BI && pass + 1 < npass) wave_lds_sync();           // the next list's H pass overwrites what this V pass reads
   }
@@ -418,7 +435,7 @@ __global__ void __launch_bounds__(256, MC_LB_CHROMA) k_mc_chroma(const McArgs a)
   const int x0 = g.sx + tx * 8, y0 = g.sy + wave * 16 + r * 8;                            // luma position of the tile
   const u32x4 tm = load_tile_rec(a, slot, g, x0, y0);
   *reinterpret_cast<u32x2*>(&S.taps[2 * lane]) = ldg2(&g_taps_chroma.e[0][0] + 2 * lane);
-  const uint32_t flags = tm.z >> 24;
+  const uint32_t flags = tm.z >> 24, rmask = (tm.w >> 8) & 0xff;
   const bool active = (flags & TM_ACTIVE) != 0;
   if (!__ballot(active)) return;
   const bool top = tile_is_top(tm, r, lane ^ 16);
@@ -454,6 +471,15 @@ __global__ void __launch_bounds__(256, MC_LB_CHROMA) k_mc_chroma(const McArgs a)
     }
     wave_lds_sync();
     if (vact) {
+      // the residual of the plane's rows 2hq, 2hq+1 of the 4x4 block under the tile: 8 bytes each, 16 apart, in the 8x8 chroma tile
+      uint32_t rsd[2][2];
+      {
+        const bool coded = (rmask & (hi ? TR_CR : TR_CB)) && !(BI && pass == 0 && (flags & TM_BI));
+        const int xc = x0 >> 1, yc = (y0 >> 1) + 2 * hq;
+        const int16_t* rp = (hi ? a.resid2[slot] : a.resid[slot]) + (coded ? (((size_t)(yc >> 3) * a.rtw + (xc >> 3)) * 8 + resid_slot(yc)) * 8 + (xc & 4) : (size_t)0);
+        const u32x2 r0 = ldg2(rp), r1 = ldg2(rp + 32);
+        rsd[0][0] = coded ? r0.x : 0u; rsd[0][1] = coded ? r0.y : 0u; rsd[1][0] = coded ? r1.x : 0u; rsd[1][1] = coded ? r1.y : 0u;
+      }
       const int yf = ((iy & 1) << 2) | ((fr >> 2) & 3);
       const uint32_t* above = top ? halo_v : body_v - 128;
       const uint32_t* vtap = &S.taps[yf * 2 * 8];
@@ -478,7 +504,7 @@ __global__ void __launch_bounds__(256, MC_LB_CHROMA) k_mc_chroma(const McArgs a)
         }
       }
       const int xc = x0 >> 1, yc = (y0 >> 1) + 2 * hq;
-      finish_rows<4, WP, BI>(v6, park, pass, (flags & TM_BI) != 0, bd, wp, (hi ? a.dst2[slot] : a.dst[slot]) + (ptrdiff_t)yc * pitch + xc, pitch);
+      finish_rows<4, WP, BI>(v6, park, pass, (flags & TM_BI) != 0, bd, wp, rsd, (hi ? a.dst2[slot] : a.dst[slot]) + (ptrdiff_t)yc * pitch + xc, pitch);
     }
     if (BI && pass + 1 < npass) wave_lds_sync();
   }

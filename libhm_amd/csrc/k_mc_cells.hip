@@ -21,11 +21,13 @@ __global__ void __launch_bounds__(256) k_mc_luma_cells(const PicDev* __restrict_
   if (!tile_origin(P, b, slot, lb, x0, y0)) return;
   const BlkInfo* g = P.blk + (size_t)(y0 >> 2) * P.grid_w + (x0 >> 2);
   const BlkInfo c00 = ld_blk(g), c01 = ld_blk(g + 1), c10 = ld_blk(g + P.grid_w), c11 = ld_blk(g + P.grid_w + 1);
-  if (ldg(reinterpret_cast<const uint32_t*>(P.tmv + (size_t)(y0 >> 3) * (P.grid_w >> 1) + (x0 >> 3)) + 2) >> 24 & TM_ACTIVE) return;   // done by k_mc_luma
-  if (is_inter(c00)) luma_cell<WP>(P, finals, c00, x0, y0);
-  if (is_inter(c01)) luma_cell<WP>(P, finals, c01, x0 + 4, y0);
-  if (is_inter(c10)) luma_cell<WP>(P, finals, c10, x0, y0 + 4);
-  if (is_inter(c11)) luma_cell<WP>(P, finals, c11, x0 + 4, y0 + 4);
+  const uint32_t* tmw = reinterpret_cast<const uint32_t*>(P.tmv + (size_t)(y0 >> 3) * (P.grid_w >> 1) + (x0 >> 3));
+  if (ldg(tmw + 2) >> 24 & TM_ACTIVE) return;               // done by k_mc_luma
+  const uint32_t rmask = (ldg(tmw + 3) >> 8) & 0xff;
+  if (is_inter(c00)) luma_cell<WP>(P, finals, c00, x0, y0, rmask);
+  if (is_inter(c01)) luma_cell<WP>(P, finals, c01, x0 + 4, y0, rmask);
+  if (is_inter(c10)) luma_cell<WP>(P, finals, c10, x0, y0 + 4, rmask);
+  if (is_inter(c11)) luma_cell<WP>(P, finals, c11, x0 + 4, y0 + 4, rmask);
 }
 
 // chroma: the 2x2 samples of BOTH chroma planes under each 4x4 luma cell
@@ -37,11 +39,13 @@ __global__ void __launch_bounds__(256) k_mc_chroma_cells(const PicDev* __restric
   if (!tile_origin(P, b, slot, lb, x0, y0)) return;
   const BlkInfo* g = P.blk + (size_t)(y0 >> 2) * P.grid_w + (x0 >> 2);
   const BlkInfo c00 = ld_blk(g), c01 = ld_blk(g + 1), c10 = ld_blk(g + P.grid_w), c11 = ld_blk(g + P.grid_w + 1);
-  if (ldg(reinterpret_cast<const uint32_t*>(P.tmv + (size_t)(y0 >> 3) * (P.grid_w >> 1) + (x0 >> 3)) + 2) >> 24 & TM_ACTIVE) return;   // done by k_mc_chroma
-  if (is_inter(c00)) chroma_cell<WP>(P, finals, c00, x0, y0);
-  if (is_inter(c01)) chroma_cell<WP>(P, finals, c01, x0 + 4, y0);
-  if (is_inter(c10)) chroma_cell<WP>(P, finals, c10, x0, y0 + 4);
-  if (is_inter(c11)) chroma_cell<WP>(P, finals, c11, x0 + 4, y0 + 4);
+  const uint32_t* tmw = reinterpret_cast<const uint32_t*>(P.tmv + (size_t)(y0 >> 3) * (P.grid_w >> 1) + (x0 >> 3));
+  if (ldg(tmw + 2) >> 24 & TM_ACTIVE) return;               // done by k_mc_chroma
+  const uint32_t rmask = (ldg(tmw + 3) >> 8) & 0xff;
+  if (is_inter(c00)) chroma_cell<WP>(P, finals, c00, x0, y0, rmask);
+  if (is_inter(c01)) chroma_cell<WP>(P, finals, c01, x0 + 4, y0, rmask);
+  if (is_inter(c10)) chroma_cell<WP>(P, finals, c10, x0, y0 + 4, rmask);
+  if (is_inter(c11)) chroma_cell<WP>(P, finals, c11, x0 + 4, y0 + 4, rmask);
 }
 
 static int mc_blocks(int max_ctus, int log2ctu) {

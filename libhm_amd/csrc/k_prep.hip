@@ -203,7 +203,7 @@ __global__ void __launch_bounds__(256) k_prep(const PicDev* __restrict__ pics, B
     }
     {
       TileMv tm;
-      tm.ix0 = tm.iy0 = tm.ix1 = tm.iy1 = 0; tm.frac = 0; tm.ref0 = tm.ref1 = 0; tm.flags = 0; tm.ridx0 = tm.ridx1 = 0; tm.slice = 0;
+      tm.ix0 = tm.iy0 = tm.ix1 = tm.iy1 = 0; tm.frac = 0; tm.ref0 = tm.ref1 = 0; tm.flags = 0; tm.ridx = 0; tm.rmask = 0; tm.slice = 0;
       bool uni = q.valid && !q.intra && (tm_key[0] & (3u << 16)) != 0;
 #pragma unroll
       for (int j = 1; j < 4; j++) uni = uni && tm_mv[j][0] == tm_mv[0][0] && tm_mv[j][1] == tm_mv[0][1] && tm_key[j] == tm_key[0];
@@ -227,9 +227,23 @@ __global__ void __launch_bounds__(256) k_prep(const PicDev* __restrict__ pics, B
           rf[s2] = (int)((tm_key[0] >> (l1 ? 8 : 0)) & 0xff); ri[s2] = (l1 ? r1 : r0) & 0xff;
         }
         tm.ix0 = (int16_t)ix[0]; tm.iy0 = (int16_t)iy[0]; tm.ix1 = (int16_t)ix[1]; tm.iy1 = (int16_t)iy[1];
-        tm.frac = (uint8_t)fr; tm.ref0 = (uint8_t)rf[0]; tm.ref1 = (uint8_t)rf[1]; tm.ridx0 = (uint8_t)ri[0]; tm.ridx1 = (uint8_t)ri[1];
+        tm.frac = (uint8_t)fr; tm.ref0 = (uint8_t)rf[0]; tm.ref1 = (uint8_t)rf[1]; tm.ridx = (uint8_t)((ri[0] & 15) | (ri[1] << 4));
         tm.flags = TM_ACTIVE | (both ? TM_BI : 0) | (use0 ? 0 : TM_FIRST_L1);
         tm.slice = (uint16_t)q.sidx;
+      }
+      // which parts of the tile the residual kernel will have written (the TUs that COVER the tile, wherever they start): the
+      // same cbf chains that list the TUs further down
+      if (q.valid && !q.intra && q.log2tu <= 5) {
+        const uint32_t chain = (1u << (q.tr + 1)) - 1;
+        uint32_t rm = 0;
+        if (q.log2tu > 2) rm = ((q.cbf[0] & 0xff) & chain) == chain ? TR_LUMA : 0;
+        else {
+#pragma unroll
+          for (int j = 0; j < 4; j++) if ((((q.cbf[0] >> (8 * j)) & 0xff) & chain) == chain) rm |= 1u << j;
+        }
+        if (((q.cbf[1] & 0xff) & chain) == chain) rm |= TR_CB;
+        if (((q.cbf[2] & 0xff) & chain) == chain) rm |= TR_CR;
+        tm.rmask = (uint8_t)rm;
       }
       stg4(&P.tmv[(size_t)(q.gy0 >> 1) * (P.grid_w >> 1) + (q.gx0 >> 1)], __builtin_bit_cast(u32x4, tm));
     }

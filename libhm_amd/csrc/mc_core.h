@@ -2,6 +2,7 @@
 // the per-cell register path for 8x4 / 4x8 / 16x4-style PUs and the kernel-level test seam).
 #pragma once
 #include "hmgpu_dev.h"
+#include "itx_core.h"
 #include <algorithm>
 #include <cstdlib>
 
@@ -146,10 +147,11 @@ __device__ inline WpLane wp_lane(const PicDev& P, const BlkInfo& bi, int comp, i
   return w;
 }
 
-// prediction of one W x H tile of component `comp` with the motion of `bi`, written to dst (the picture being decoded)
+// prediction of one W x H tile of component `comp` with the motion of `bi`, written to dst (the picture being decoded) with the
+// residual added when the tile carries one (coded; PicDev::resid, written by k_itx; W x H lies inside one 4x4 block)
 template <int TAPS, int W, int H, bool WP = false>
 __device__ inline void predict_tile(const PicDev& P, const PlaneSet* __restrict__ finals, int comp, int x0, int y0,
-                                    const BlkInfo& bi, int cu_x, int cu_y, int16_t* __restrict__ dst, int lx = 0, int ly = 0) {
+                                    const BlkInfo& bi, int cu_x, int cu_y, int16_t* __restrict__ dst, int lx = 0, int ly = 0, bool coded = false) {
   WpLane wp = {false, {1, 1}, {0, 0}, 0};
   if constexpr (WP) wp = wp_lane(P, bi, comp, lx, ly);
   const int bd = P.bd[comp];
@@ -203,6 +205,17 @@ __device__ inline void predict_tile(const PicDev& P, const PlaneSet* __restrict_
         res[y][x / 2] = __builtin_amdgcn_perm((uint32_t)v1, (uint32_t)v0, 0x05040100u);
       }
   }
+  if (coded) {
+    const int rtw = (P.grid_w * 4 >> (comp ? 1 : 0)) >> 3;
+    const uint32_t maxv2 = (uint32_t)maxv * 0x10001u;
+#pragma unroll
+    for (int y = 0; y < H; y++) {
+      const int yy = y0 + y;
+      const uint32_t* rp = reinterpret_cast<const uint32_t*>(P.resid[comp] + (((size_t)(yy >> 3) * rtw + (x0 >> 3)) * 8 + resid_slot(yy)) * 8 + (x0 & 7));
+#pragma unroll
+      for (int x = 0; x < W / 2; x++) res[y][x] = pk_clip_u(pk_add_sat(res[y][x], ldg(rp + x)), maxv2);
+    }
+  }
 #pragma unroll
   for (int y = 0; y < H; y++) {
     int16_t* row = dst + (ptrdiff_t)(y0 + y) * pitch + x0;
@@ -223,16 +236,17 @@ __device__ inline bool is_inter(const BlkInfo& b) { return (b.flags & BF_VALID) 
 // one 4x4 luma cell / its 2x2 chroma samples on their own: only where the four cells of an 8x8 area do not share
 // their motion (8x4 / 4x8 PUs, AMP parts of 16x16 CUs, picture borders).  Out of line: rare, and it keeps the common
 // path's register budget small.
+// rmask: the TR_* residual mask of the 8x8 tile the cell lies in
 template <bool WP>
-__device__ __attribute__((noinline)) void luma_cell(const PicDev& P, const PlaneSet* __restrict__ finals, const BlkInfo c, int x, int y) {
+__device__ __attribute__((noinline)) void luma_cell(const PicDev& P, const PlaneSet* __restrict__ finals, const BlkInfo c, int x, int y, uint32_t rmask) {
   const int cs = 1 << c.log2cu;
-  predict_tile<8, 4, 4, WP>(P, finals, 0, x, y, c, x & ~(cs - 1), y & ~(cs - 1), P.rec[0], x, y);
+  predict_tile<8, 4, 4, WP>(P, finals, 0, x, y, c, x & ~(cs - 1), y & ~(cs - 1), P.rec[0], x, y, ((rmask >> (((y >> 2) & 1) * 2 + ((x >> 2) & 1))) & 1) != 0);
 }
 template <bool WP>
-__device__ __attribute__((noinline)) void chroma_cell(const PicDev& P, const PlaneSet* __restrict__ finals, const BlkInfo c, int lx, int ly) {
+__device__ __attribute__((noinline)) void chroma_cell(const PicDev& P, const PlaneSet* __restrict__ finals, const BlkInfo c, int lx, int ly, uint32_t rmask) {
   const int cs = 1 << c.log2cu;
-  predict_tile<4, 2, 2, WP>(P, finals, 1, lx >> 1, ly >> 1, c, lx & ~(cs - 1), ly & ~(cs - 1), P.rec[1], lx, ly);
-  predict_tile<4, 2, 2, WP>(P, finals, 2, lx >> 1, ly >> 1, c, lx & ~(cs - 1), ly & ~(cs - 1), P.rec[2], lx, ly);
+  predict_tile<4, 2, 2, WP>(P, finals, 1, lx >> 1, ly >> 1, c, lx & ~(cs - 1), ly & ~(cs - 1), P.rec[1], lx, ly, (rmask & TR_CB) != 0);
+  predict_tile<4, 2, 2, WP>(P, finals, 2, lx >> 1, ly >> 1, c, lx & ~(cs - 1), ly & ~(cs - 1), P.rec[2], lx, ly, (rmask & TR_CR) != 0);
 }
 
 // lane -> 8x8 luma area: a wave covers 8x8 areas = 64x64 luma samples, a block four such squares in CTU order
