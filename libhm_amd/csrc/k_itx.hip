@@ -132,6 +132,9 @@ __global__ void __launch_bounds__(256) k_itx(const ItxArgs a) {
 #define ITX_B3 1
 #endif
 void launch_itx(ItxArgs& a, uint32_t blocks_per_shard, hipStream_t s) {
+#ifdef ITX_BPS
+  blocks_per_shard = ITX_BPS;
+#endif
   const uint32_t div[4] = {ITX_B0, ITX_B1, ITX_B2, ITX_B3};
   for (int k = 0; k < 4; k++) a.blocks[k] = (a.class_mask >> k) & 1 ? (int32_t)std::max(1u, blocks_per_shard / div[k]) : 0;
   dim3 grid(blocks_per_shard * kTuShards, 4, (unsigned)a.n);

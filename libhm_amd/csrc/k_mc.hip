@@ -355,8 +355,16 @@ __global__ void __launch_bounds__(256, (WP || BI) ? 1 : MC_LB_LUMA) k_mc_luma(co
       {
         uint32_t qm = (rmask >> (q & 2)) & 3;                       // quadrants left | right << 1 of the tile half the rows lie in
         if (BI && pass == 0 && (flags & TM_BI)) qm = 0;
+#ifdef MC_RSD_COND
+        u32x4 r0 = {0, 0, 0, 0}, r1 = {0, 0, 0, 0};
+        if (qm) {
+          const int16_t* rp = a.resid[slot] + ((size_t)(y0 >> 3) * a.rtw + (x0 >> 3)) * 64 + q * 8;
+          r0 = ldg4(rp); r1 = ldg4(rp + 32);
+        }
+#else
         const int16_t* rp = a.resid[slot] + (qm ? ((size_t)(y0 >> 3) * a.rtw + (x0 >> 3)) * 64 + q * 8 : (size_t)0);   // rows 2q, 2q+1: slots q, q+4
         const u32x4 r0 = ldg4(rp), r1 = ldg4(rp + 32);
+#endif
         rsd[0][0] = qm & 1 ? r0.x : 0u; rsd[0][1] = qm & 1 ? r0.y : 0u; rsd[1][0] = qm & 1 ? r1.x : 0u; rsd[1][1] = qm & 1 ? r1.y : 0u;
         rsd[0][2] = qm & 2 ? r0.z : 0u; rsd[0][3] = qm & 2 ? r0.w : 0u; rsd[1][2] = qm & 2 ? r1.z : 0u; rsd[1][3] = qm & 2 ? r1.w : 0u;
       }
