@@ -322,22 +322,117 @@ __device__ inline void intra_stage(const PicDev& P, int comp, int ctu, IntraLds&
   }
 }
 
+// ---- progress between CTUs ----------------------------------------------------------------------------------------------------------
+// PicDev::intra_done[comp][ctu] = number of leading z-order partitions of the CTU whose samples of that component are final (parts =
+// all of it), published whenever the count crosses a multiple of 16 (a 16x16 luma area).  A CTU does not wait for its neighbours
+// as a whole: before a TU on its left / top border it waits until the neighbour has got past the partitions that TU's reference
+// samples lie in, and fetches as much of the neighbour's border as is final by then.  Row lag between CTU rows ~1 CTU time instead of
+// 2, column lag ~0.5 instead of 1: an I picture's critical path halves.
+struct Neighbours {
+  uint32_t* prog;            // intra_done of this component
+  int ctu[4];                // left, above-left, above, above-right (-1: none)
+  bool wait[4];              // the neighbour is reconstructed by this launch and its border towards this CTU holds intra samples
+  int left_rows, top_cols;   // rows of the left columns / columns of the row above (from column 0) already in LDS
+  bool corner;               // columns -2, -1 of the row above fetched
+  bool broken;               // a wait gave up (fault flagged): no further waiting in this block
+};
+
+// number of 4x4 units u in [0, pw) of a CTU's last column (vertical = true: units (pw-1, u)) or last row (units (u, pw-1)) that lie
+// before partition count `prog` in z order; both sequences are increasing in u
+__device__ inline int border_units_done(uint32_t prog, int pw, bool vertical) {
+  int u = 0;
+  while (u < pw) {
+    int z = 0;
+    const int x = vertical ? pw - 1 : u, y = vertical ? u : pw - 1;
+#pragma unroll
+    for (int k = 0; k < 4; k++) z |= (((x >> k) & 1) << (2 * k)) | (((y >> k) & 1) << (2 * k + 1));
+    if ((uint32_t)z >= prog) break;
+    u++;
+  }
+  return u;
+}
+
+// waits until pred(progress of CTU n) holds; bounded (a block that gives up flags the picture, see k_intra)
+template <typename F>
+__device__ inline uint32_t wait_progress(const PicDev& P, Neighbours& nb, int n, F enough) {
+  uint32_t spins = 0, v;
+  while (!enough(v = __hip_atomic_load(nb.prog + n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+    if (nb.broken) return (uint32_t)P.parts;
+    __builtin_amdgcn_s_sleep(16);
+    if (++spins > (1u << 22)) { if ((threadIdx.x & 63) == 0) atomicOr(P.fault, 1u); nb.broken = true; }   // ~2 s
+  }
+  return v;
+}
+
+// reference samples outside the CTU that the TU at (x0, y0), N samples wide, may read: into LDS, after they have become final
+__device__ inline void fetch_neighbours(const PicDev& P, int comp, int ctu, int x0, int y0, int n_tu, Neighbours& nb, IntraLds& L) {
+  const int cs = comp ? 1 : 0, lane = threadIdx.x & 63;
+  const int S = (1 << P.log2ctu) >> cs, us = 4 >> cs, pw = P.pw;
+  const int ctu_x = (ctu % P.ctus_w) << P.log2ctu, ctu_y = (ctu / P.ctus_w) << P.log2ctu;
+  const int16_t* org = P.rec[comp] + (ptrdiff_t)(ctu_y >> cs) * P.pitch[comp] + (ctu_x >> cs);
+  const int rx = x0 - (ctu_x >> cs), ry = y0 - (ctu_y >> cs);
+  bool fetched = false;
+  if (rx == 0) {
+    const int need = min(S, ry + 2 * n_tu);
+    if (need > nb.left_rows) {
+      int avail = S;
+      if (nb.wait[0]) {
+        const uint32_t v = wait_progress(P, nb, nb.ctu[0], [&](uint32_t pr) { return border_units_done(pr, pw, true) * us >= need; });
+        avail = border_units_done(v, pw, true) * us;
+        asm volatile("" ::: "memory");
+      }
+      for (int r = nb.left_rows + lane; r < avail; r += 64)
+        reinterpret_cast<uint32_t*>(&L.pix[r][0])[0] = ld_coh(reinterpret_cast<const uint32_t*>(org + (ptrdiff_t)r * P.pitch[comp] - 2));
+      nb.left_rows = avail; fetched = true;
+    }
+  }
+  if (ry == 0) {
+    const int need = min(2 * S, rx + 2 * n_tu);
+    if (need > nb.top_cols || !nb.corner) {
+      if (!nb.corner) {
+        if (nb.wait[1]) { wait_progress(P, nb, nb.ctu[1], [&](uint32_t pr) { return pr >= (uint32_t)P.parts; }); }
+      }
+      int avail = S;
+      if (nb.wait[2]) {
+        const uint32_t v = wait_progress(P, nb, nb.ctu[2], [&](uint32_t pr) { return border_units_done(pr, pw, false) * us >= min(need, S); });
+        avail = border_units_done(v, pw, false) * us;
+      }
+      if (avail == S) {
+        int more = S;
+        if (nb.wait[3]) {
+          const uint32_t v = wait_progress(P, nb, nb.ctu[3], [&](uint32_t pr) { return border_units_done(pr, pw, false) * us >= need - S; });
+          more = border_units_done(v, pw, false) * us;
+        }
+        avail += more;
+      }
+      asm volatile("" ::: "memory");
+      // dword d of top[] = columns 2d-2, 2d-1
+      const int d0 = nb.corner ? 1 + nb.top_cols / 2 : 0, d1 = 1 + avail / 2;
+      for (int d = d0 + lane; d < d1; d += 64)
+        reinterpret_cast<uint32_t*>(L.top)[d] = ld_coh(reinterpret_cast<const uint32_t*>(org - P.pitch[comp] - 2) + d);
+      nb.top_cols = max(nb.top_cols, avail); nb.corner = true; fetched = true;
+    }
+  }
+  if (fetched) wave_lds_sync();
+}
+
+// Every sample this kernel stores is an agent-scope atomic store (written through to the level all XCDs read from) and every
+// neighbour sample it loads an agent-scope atomic load, so no cache has to be written back or invalidated around the counter: the
+// producer waits until its stores are acknowledged, the consumer issues its loads after it has seen the count.  (Agent-scope
+// release / acquire FENCES also write back / invalidate L2 for ordinary accesses: once per 16x16 area and CTU that cost more than
+// the finer progress gained.)
+__device__ inline void publish_progress(uint32_t* prog, int ctu, uint32_t z) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if ((threadIdx.x & 63) == 0) __hip_atomic_store(prog + ctu, z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // all intra CUs of one CTU, one component, in decoding order (xReconIntraQT per CU, xIntraRecQT over its TU tree)
-__device__ inline void intra_ctu(const PicDev& P, int comp, int ctu, IntraLds& L) {
+__device__ inline void intra_ctu(const PicDev& P, int comp, int ctu, IntraLds& L, Neighbours& nb) {
   const bool compact = P.coef_start[0] != nullptr;
   const int parts = P.parts;
   const int ctu_x = (ctu % P.ctus_w) << P.log2ctu, ctu_y = (ctu / P.ctus_w) << P.log2ctu;
   const int cs = comp ? 1 : 0;
   const int lane = threadIdx.x & 63;
-  {
-    // the left neighbour's columns and the row above may come from other waves of THIS launch: coherent loads, after the wait
-    const int S = (1 << P.log2ctu) >> cs;
-    const int16_t* org = P.rec[comp] + (ptrdiff_t)(ctu_y >> cs) * P.pitch[comp] + (ctu_x >> cs);
-    for (int r = lane; r < S; r += 64)
-      reinterpret_cast<uint32_t*>(&L.pix[r][0])[0] = ld_coh(reinterpret_cast<const uint32_t*>(org + (ptrdiff_t)r * P.pitch[comp] - 2));
-    for (int d = lane; d < S + 1; d += 64)                  // row -1, columns -2..2S-1
-      reinterpret_cast<uint32_t*>(L.top)[d] = ld_coh(reinterpret_cast<const uint32_t*>(org - P.pitch[comp] - 2) + d);
-  }
   const int slice = ldg(P.slice_idx + ctu), tile = ldg(P.tile_idx + ctu);
   const SliceDev& sd = P.slices[slice];
   const int cip = ldg(&sd.constrained_intra_pred);
@@ -354,7 +449,12 @@ __device__ inline void intra_ctu(const PicDev& P, int comp, int ctu, IntraLds& L
   const int cqo = comp == 1 ? ldg(&sd.cb_qp_offset) : comp == 2 ? ldg(&sd.cr_qp_offset) : 0;
   wave_lds_sync();
   int z = 0;
+  uint32_t published = 0;
+  auto progress = [&](int zdone) {                          // all partitions before zdone are final
+    if (((uint32_t)zdone >> 4) != (published >> 4)) { published = (uint32_t)zdone; publish_progress(nb.prog, ctu, published); }
+  };
   while (z < parts) {
+    progress(z);
     const int px = ctu_x + 4 * zscan_x(z), py = ctu_y + 4 * zscan_y(z);
     const int ps = (int8_t)L.m_part[z];
     if (px >= P.width || py >= P.height || ps == HMGPU_SIZE_NONE) { z++; continue; }
@@ -412,9 +512,11 @@ __device__ inline void intra_ctu(const PicDev& P, int comp, int ctu, IntraLds& L
         } else {
           t.lev_off = (comp ? 4 : 16) * zc;
         }
+        fetch_neighbours(P, comp, ctu, t.x0, t.y0, 1 << t.log2n, nb, L);
         intra_tu_any(P, t, L);
       }
       zc += 1 << (2 * (log2tu - 2));
+      progress(zc);
     }
     z = cu_end;
   }
@@ -470,32 +572,27 @@ __global__ void __launch_bounds__(64) k_intra(const PicDev* __restrict__ pics, B
   intra_stage(P, comp, ctu, L);
   unsigned my_l, my_r, my_t, my_b;
   border_mask(ctu, my_l, my_r, my_t, my_b);
+  Neighbours nbs;
+  nbs.prog = done; nbs.left_rows = 0; nbs.top_cols = 0; nbs.corner = false; nbs.broken = false;
 #pragma unroll
   for (int k = 0; k < 4; k++) {
     const int n = nb[k];
+    nbs.ctu[k] = n; nbs.wait[k] = false;
     if (n < first || !ldg(P.ctu_intra + n)) continue;      // outside the picture / finished by an earlier call / no intra CUs: complete already
     unsigned n_l, n_r, n_t, n_b;
     border_mask(n, n_l, n_r, n_t, n_b);
     // left: my first column against its last column; above-left: the corner (covered by column and row tests, conservatively);
     // above and above-right: my first row against its last row
-    const bool need = k == 0 ? (my_l && n_r) : k == 1 ? ((my_l || my_t) && n_r && n_b) : (my_t && n_b);
-    if (!need) continue;
-    // poll with plain coherent loads (an acquire per poll would invalidate the caches of the CU's working waves over and over)
-    // The wait cannot deadlock as long as workgroups are dispatched in linear order (the neighbours lie on earlier anti-diagonals,
-    // i.e. at smaller block indices: they are resident or finished when this block runs).  HIP does not promise that order, so the
-    // spin is bounded (~8 s): a block that gives up flags the picture (the host reports HMGPU_EDEVICE at its next sync) instead of
-    // hanging the device.
-    uint32_t spins = 0;
-    while (__hip_atomic_load(done + n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
-      __builtin_amdgcn_s_sleep(64);
-      if (++spins > (1u << 22)) { if (lane == 0) atomicOr(P.fault, 1u); break; }
-    }
+    nbs.wait[k] = k == 0 ? (my_l && n_r) : k == 1 ? ((my_l || my_t) && n_r && n_b) : (my_t && n_b);
   }
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  // The waits (fetch_neighbours) cannot deadlock as long as workgroups are dispatched in linear order (the neighbours lie on earlier
+  // anti-diagonals, i.e. at smaller block indices: they are resident or finished when this block runs, and never wait for this one).
+  // HIP does not promise that order, so every spin is bounded: a block that gives up flags the picture (the host reports HMGPU_EDEVICE
+  // at its next sync) instead of hanging the device.
   wave_lds_sync();
-  intra_ctu(P, comp, ctu, L);
+  intra_ctu(P, comp, ctu, L, nbs);
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-  if (lane == 0) __hip_atomic_store(done + ctu, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  publish_progress(done, ctu, (uint32_t)P.parts);
 }
 
 void launch_intra(const PicDev* pics, const Batch& b, const int32_t* order, int num_ctus, hipStream_t s) {
