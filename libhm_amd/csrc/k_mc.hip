@@ -49,7 +49,7 @@ __device__ inline u32x4 ldg4_a4(const void* p) { return __builtin_nontemporal_lo
 __device__ inline u32x4 ldg4_a4(const void* p) { return *(const u32x4_a4 HMGPU_AS1*)p; }
 #endif
 #ifndef MC_LB_LUMA
-#define MC_LB_LUMA 8      // waves per SIMD the uni-prediction kernel is held to (64 registers: the residual rows would cost one wave)
+#define MC_LB_LUMA 7      // waves per SIMD the uni-prediction kernel is held to (72 registers; 8 would spill the residual rows)
 #endif
 #ifndef MC_LB_CHROMA
 #define MC_LB_CHROMA 8
@@ -312,6 +312,16 @@ __global__ void __launch_bounds__(256, (WP || BI) ? 1 : MC_LB_LUMA) k_mc_luma(co
   const char* const dummy = reinterpret_cast<const char*>(a.tmv[slot]);   // where lanes without a work item load from (valid memory)
   WpTile wp = {false, 1, 0, 1, 0, 0};
   if constexpr (WP) wp = wp_tile<WP>(a.slices[slot], flags, tm.w, 0);
+  // the residual of output rows 2q, 2q+1 (two 16-byte slots of the tile's line in PicDev::resid; a row crosses two 4x4 quadrants, each
+  // with a residual or without), requested with the tile record in hand.  Lanes without one load the buffer's first bytes.
+  uint32_t rsd[2][4];
+  {
+    const uint32_t qm = active ? (rmask >> (q & 2)) & 3 : 0u;
+    const int16_t* rp = a.resid[slot] + (qm ? ((size_t)(y0 >> 3) * a.rtw + (x0 >> 3)) * 64 + q * 8 : (size_t)0);
+    const u32x4 r0 = ldg4(rp), r1 = ldg4(rp + 32);
+    rsd[0][0] = qm & 1 ? r0.x : 0u; rsd[0][1] = qm & 1 ? r0.y : 0u; rsd[1][0] = qm & 1 ? r1.x : 0u; rsd[1][1] = qm & 1 ? r1.y : 0u;
+    rsd[0][2] = qm & 2 ? r0.z : 0u; rsd[0][3] = qm & 2 ? r0.w : 0u; rsd[1][2] = qm & 2 ? r1.z : 0u; rsd[1][3] = qm & 2 ? r1.w : 0u;
+  }
   uint32_t park[8];
 #pragma unroll
   for (int x = 0; x < 8; x++) park[x] = 0;
@@ -348,26 +358,10 @@ __global__ void __launch_bounds__(256, (WP || BI) ? 1 : MC_LB_LUMA) k_mc_luma(co
     if (__ballot(hact)) h_phase(std::true_type()); else h_phase(std::false_type());
     wave_lds_sync();
     if (bact) {
-      // the residual of output rows 2q, 2q+1 (32 consecutive bytes of the tile's line in PicDev::resid), in flight during the V pass;
-      // a row crosses two 4x4 quadrants, each with a residual or without
-      // (lanes without one load the buffer's first bytes and select zeros: no register holds a zero across the H pass)
-      uint32_t rsd[2][4];
-      {
-        uint32_t qm = (rmask >> (q & 2)) & 3;                       // quadrants left | right << 1 of the tile half the rows lie in
-        if (BI && pass == 0 && (flags & TM_BI)) qm = 0;
-#ifdef MC_RSD_COND
-        u32x4 r0 = {0, 0, 0, 0}, r1 = {0, 0, 0, 0};
-        if (qm) {
-          const int16_t* rp = a.resid[slot] + ((size_t)(y0 >> 3) * a.rtw + (x0 >> 3)) * 64 + q * 8;
-          r0 = ldg4(rp); r1 = ldg4(rp + 32);
-        }
-#else
-        const int16_t* rp = a.resid[slot] + (qm ? ((size_t)(y0 >> 3) * a.rtw + (x0 >> 3)) * 64 + q * 8 : (size_t)0);   // rows 2q, 2q+1: slots q, q+4
-        const u32x4 r0 = ldg4(rp), r1 = ldg4(rp + 32);
-#endif
         rsd[0][0] = qm & 1 ? r0.x : 0u; rsd[0][1] = qm & 1 ? r0.y : 0u; rsd[1][0] = qm & 1 ? r1.x : 0u; rsd[1][1] = qm & 1 ? r1.y : 0u;
         rsd[0][2] = qm & 2 ? r0.z : 0u; rsd[0][3] = qm & 2 ? r0.w : 0u; rsd[1][2] = qm & 2 ? r1.z : 0u; rsd[1][3] = qm & 2 ? r1.w : 0u;
       }
+#endif
       // output rows 2q, 2q+1 of the tile: window row pairs q .. q+4, the first four of a tile's eight pairs belong to the tile above
       const uint32_t* above = top ? halo_t : body_t - 256;
       const uint32_t* vtap = &S.taps[((fr >> 2) & 3) * 2 * 12];
@@ -457,6 +451,16 @@ __global__ void __launch_bounds__(256, MC_LB_CHROMA) k_mc_chroma(const McArgs a)
   uint32_t* const halo_v = &S.w[wave].halo[r * 128 + hi * 64 + tx * 2];
   WpTile wp = {false, 1, 0, 1, 0, 0};
   if constexpr (WP) wp = wp_tile<WP>(a.slices[slot], flags, tm.w, 1 + hi);
+  // the residual of the plane's rows 2hq, 2hq+1 of the 4x4 block under the tile (8 bytes each, in the 8x8 chroma tile of
+  // PicDev::resid), requested with the tile record in hand: its latency hides behind the whole H pass
+  uint32_t rsd[2][2];
+  {
+    const bool coded = active && (rmask & (hi ? TR_CR : TR_CB));
+    const int xc = x0 >> 1, yc = (y0 >> 1) + 2 * hq;
+    const int16_t* rp = (hi ? a.resid2[slot] : a.resid[slot]) + (coded ? (((size_t)(yc >> 3) * a.rtw + (xc >> 3)) * 8 + resid_slot(yc)) * 8 + (xc & 4) : (size_t)0);
+    const u32x2 r0 = ldg2(rp), r1 = ldg2(rp + 32);
+    rsd[0][0] = coded ? r0.x : 0u; rsd[0][1] = coded ? r0.y : 0u; rsd[1][0] = coded ? r1.x : 0u; rsd[1][1] = coded ? r1.y : 0u;
+  }
   uint32_t park[4] = {0, 0, 0, 0};
 #pragma unroll 1
   for (int pass = 0; pass < npass; pass++) {
@@ -479,15 +483,6 @@ __global__ void __launch_bounds__(256, MC_LB_CHROMA) k_mc_chroma(const McArgs a)
     }
     wave_lds_sync();
     if (vact) {
-      // the residual of the plane's rows 2hq, 2hq+1 of the 4x4 block under the tile: 8 bytes each, 16 apart, in the 8x8 chroma tile
-      uint32_t rsd[2][2];
-      {
-        const bool coded = (rmask & (hi ? TR_CR : TR_CB)) && !(BI && pass == 0 && (flags & TM_BI));
-        const int xc = x0 >> 1, yc = (y0 >> 1) + 2 * hq;
-        const int16_t* rp = (hi ? a.resid2[slot] : a.resid[slot]) + (coded ? (((size_t)(yc >> 3) * a.rtw + (xc >> 3)) * 8 + resid_slot(yc)) * 8 + (xc & 4) : (size_t)0);
-        const u32x2 r0 = ldg2(rp), r1 = ldg2(rp + 32);
-        rsd[0][0] = coded ? r0.x : 0u; rsd[0][1] = coded ? r0.y : 0u; rsd[1][0] = coded ? r1.x : 0u; rsd[1][1] = coded ? r1.y : 0u;
-      }
       const int yf = ((iy & 1) << 2) | ((fr >> 2) & 3);
       const uint32_t* above = top ? halo_v : body_v - 128;
       const uint32_t* vtap = &S.taps[yf * 2 * 8];
