@@ -358,10 +358,6 @@ __global__ void __launch_bounds__(256, (WP || BI) ? 1 : MC_LB_LUMA) k_mc_luma(co
     if (__ballot(hact)) h_phase(std::true_type()); else h_phase(std::false_type());
     wave_lds_sync();
     if (bact) {
-        rsd[0][0] = qm & 1 ? r0.x : 0u; rsd[0][1] = qm & 1 ? r0.y : 0u; rsd[1][0] = qm & 1 ? r1.x : 0u; rsd[1][1] = qm & 1 ? r1.y : 0u;
-        rsd[0][2] = qm & 2 ? r0.z : 0u; rsd[0][3] = qm & 2 ? r0.w : 0u; rsd[1][2] = qm & 2 ? r1.z : 0u; rsd[1][3] = qm & 2 ? r1.w : 0u;
-      }
-#endif
       // output rows 2q, 2q+1 of the tile: window row pairs q .. q+4, the first four of a tile's eight pairs belong to the tile above
       const uint32_t* above = top ? halo_t : body_t - 256;
       const uint32_t* vtap = &S.taps[((fr >> 2) & 3) * 2 * 12];
