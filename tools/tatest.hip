@@ -48,6 +48,7 @@ int main() {
       for (int mis : {0, 4, 8, 2 * 4 + 16}) run<16>(buf, out, G, mis, rows);
     }
   }
+  for (int G : {2, 3, 4}) for (int mis : {0, 4, 40, 104}) run<16>(buf, out, G, mis, 64);   // pairs / triples / quads of lanes per row (104: the group crosses a 128-byte line)
   for (int mis : {0, 4}) { run<8>(buf, out, 8, mis, 16); run<4>(buf, out, 8, mis, 16); run<8>(buf, out, 16, mis, 16); run<4>(buf, out, 32, mis, 16); }
   return 0;
 }
