@@ -17,6 +17,9 @@ LITE = ["ldp_slices_main8_208x120", "ldp_depslices_main10_208x120", "ldp_wpp_mai
         "intra_qp12_main8_208x120", "ra_parmrg4_main8_208x120", "ldp_tudepth1_main10_208x120", "ldp_maxtb16_noamp_main8_208x120",
         "ldp_nots_nosdh_main10_208x120", "ldp_ctu32_mincu16_main8_224x128", "ldp_qpneg_main10_208x120", "ldp_qp48_main8_208x120",
         "ldp_slicedbk_main10_208x120", "ldp_qgctu_main8_208x120", "ldp_tilesexp_main10_832x192", "ldp_bd10_8_208x120", "ldp_bd8_10_208x120"]
+# HM-encoded streams rewritten at the bit level (oracle/make_surgery.py) for syntax HM's encoder never writes; expected pictures = HM's own
+# DECODER on the rewritten stream: pps_scaling_list_data; long-term reference pictures + ref_pic_list_modification
+SURGERY = ["surgery_ppssl_main8_208x120", "surgery_ltr_rplm_main10_208x120"]
 _cache = {}
 
 

@@ -85,7 +85,7 @@ def test_internals_describe_the_picture():
 
 
 @pytest.mark.parametrize("threads", [1, 3])
-@pytest.mark.parametrize("name", gu.LITE)
+@pytest.mark.parametrize("name", gu.LITE + gu.SURGERY)
 def test_syntax_variants_decode_to_the_encoders_reconstruction(name, threads):
     """slices, dependent slice segments, wavefronts, CU-level QP, CRA + leading pictures, 32/16-sample CTUs, conformance window,
     slices of tiles, low-delay B: output == HM's encoder reconstruction (== what HM's decoder must produce), hash SEI check green"""

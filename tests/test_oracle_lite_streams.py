@@ -34,7 +34,7 @@ def _parsed_pictures(stream):
     return pics
 
 
-@pytest.mark.parametrize("name", gu.LITE)
+@pytest.mark.parametrize("name", gu.LITE + gu.SURGERY)
 def test_oracle_reconstructs_the_encoders_pictures(oracle, name):
     z = gu.load("lite_" + name)
     pics = _parsed_pictures(z["bitstream"])

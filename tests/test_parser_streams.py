@@ -136,7 +136,7 @@ def test_errors_are_reported_not_fatal():
 
 
 @pytest.mark.parametrize("threads", [1, 3])
-@pytest.mark.parametrize("name", gu.LITE)
+@pytest.mark.parametrize("name", gu.LITE + gu.SURGERY)
 def test_parser_gets_through_every_syntax_variant(name, threads):
     """slices, dependent slice segments, wavefronts, CU-level QP, CRA with leading pictures, 32/16-sample CTUs, cropping, slices of
     tiles, B low delay: the parser stays in sync to the last bit of every slice (the stop bit check behind end_of_slice_segment_flag),
@@ -151,8 +151,8 @@ def test_parser_gets_through_every_syntax_variant(name, threads):
                                                              depths.update(y=p.geometry()["bd_y"], c=p.geometry()["bd_c"])))
         assert d.pictures_decoded == frames
     assert out == list(range(frames))
-    if "crop" in name:
-        return                                                   # the SEI hashes the uncropped picture, the fixture holds the cropped one
+    if "crop" in name or "surgery" in name:
+        return                                                   # the SEI hashes the uncropped picture, the fixture holds the cropped one; rewritten streams carry no SEI
     for poc in range(frames):
         method, digest = hashes[poc]
         want = b"".join(hashlib.md5(z["poc%02d_%d" % (poc, c)].astype(np.uint8 if depths["c" if c else "y"] <= 8 else "<u2").tobytes()).digest()
