@@ -322,114 +322,96 @@ __device__ inline void intra_stage(const PicDev& P, int comp, int ctu, IntraLds&
   }
 }
 
-// ---- progress between CTUs ----------------------------------------------------------------------------------------------------------
-// PicDev::intra_done[comp][ctu] = number of leading z-order partitions of the CTU whose samples of that component are final (parts =
-// all of it), published whenever the count crosses a multiple of 16 (a 16x16 luma area).  A CTU does not wait for its neighbours
-// as a whole: before a TU on its left / top border it waits until the neighbour has got past the partitions that TU's reference
-// samples lie in, and fetches as much of the neighbour's border as is final by then.  Row lag between CTU rows ~1 CTU time instead of
-// 2, column lag ~0.5 instead of 1: an I picture's critical path halves.
+// ---- order of the TUs of a CTU, progress between CTUs --------------------------------------------------------------------------------
+// Intra prediction fixes WHAT a TU reads (the reconstructed samples of the neighbouring 4x4 units that precede it in z order), not WHEN
+// the TUs run: any order in which every TU comes after the units it reads gives HM's samples.  z order is the order that makes a
+// CTU's right column and bottom row -- what its neighbours wait for -- come last (16x16 areas 5, 7, 13, 15 of 16).  So a wave
+// lists the intra TUs of its CTU, works out for each the units left of and above it that it depends on, and runs, among the TUs whose
+// units are final, the one highest up (raster priority: the picture is wider than high, and the right column of a row of TUs is final two
+// rows of units later).  Finished units are kept as bit masks per row and per column of the CTU's 4x4-unit grid; the neighbouring
+// CTUs' border units come from one published word per CTU and component:
+//   PicDev::intra_done[comp][ctu] = units of the CTU's LAST COLUMN that are final (bit y) | units of its LAST ROW << 16 (bit 16 + x).
+// A CTU no longer waits for its neighbours as a whole, and not in their z order either.
+struct TuRun { uint8_t z, z_cu, log2n, kind; };             // kind 0: transform unit, 1: PCM coding unit (log2n: its size)
+struct IntraSched {
+  TuRun tu[256];
+  uint32_t need_col[256];        // bit y: unit (x4 - 1, y) of the column left of the TU must be final (the left CTU's last column when x4 = 0)
+  uint64_t need_row[256];        // bit c + 1: unit (c, y4 - 1), c = -1 .. 31, of the row above the TU (the row of the CTUs above when y4 = 0)
+  uint16_t done_r[16], done_c[16];   // final units per row (bit x) / per column (bit y)
+};
+
 struct Neighbours {
   uint32_t* prog;            // intra_done of this component
   int ctu[4];                // left, above-left, above, above-right (-1: none)
   bool wait[4];              // the neighbour is reconstructed by this launch and its border towards this CTU holds intra samples
-  int left_rows, top_cols;   // rows of the left columns / columns of the row above (from column 0) already in LDS
-  bool corner;               // columns -2, -1 of the row above fetched
+  uint32_t ext_col;          // final units of the left CTU's last column
+  uint64_t ext_row;          // final units of the row above the CTU: bit 0 above-left CTU's corner unit, 1..16 above, 17..32 above-right
+  uint32_t got_col;          // units whose samples are in LDS already (L.pix columns 0, 1 / L.top)
+  uint64_t got_row;
   bool broken;               // a wait gave up (fault flagged): no further waiting in this block
 };
 
-// number of 4x4 units u in [0, pw) of a CTU's last column (vertical = true: units (pw-1, u)) or last row (units (u, pw-1)) that lie
-// before partition count `prog` in z order; both sequences are increasing in u
-__device__ inline int border_units_done(uint32_t prog, int pw, bool vertical) {
-  int u = 0;
-  while (u < pw) {
-    int z = 0;
-    const int x = vertical ? pw - 1 : u, y = vertical ? u : pw - 1;
+__device__ inline int z_of(int x, int y) {
+  int z = 0;
 #pragma unroll
-    for (int k = 0; k < 4; k++) z |= (((x >> k) & 1) << (2 * k)) | (((y >> k) & 1) << (2 * k + 1));
-    if ((uint32_t)z >= prog) break;
-    u++;
-  }
-  return u;
-}
-
-// waits until pred(progress of CTU n) holds; bounded (a block that gives up flags the picture, see k_intra)
-template <typename F>
-__device__ inline uint32_t wait_progress(const PicDev& P, Neighbours& nb, int n, F enough) {
-  uint32_t spins = 0, v;
-  while (!enough(v = __hip_atomic_load(nb.prog + n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
-    if (nb.broken) return (uint32_t)P.parts;
-    __builtin_amdgcn_s_sleep(16);
-    if (++spins > (1u << 22)) { if ((threadIdx.x & 63) == 0) atomicOr(P.fault, 1u); nb.broken = true; }   // ~2 s
-  }
-  return v;
-}
-
-// reference samples outside the CTU that the TU at (x0, y0), N samples wide, may read: into LDS, after they have become final
-__device__ inline void fetch_neighbours(const PicDev& P, int comp, int ctu, int x0, int y0, int n_tu, Neighbours& nb, IntraLds& L) {
-  const int cs = comp ? 1 : 0, lane = threadIdx.x & 63;
-  const int S = (1 << P.log2ctu) >> cs, us = 4 >> cs, pw = P.pw;
-  const int ctu_x = (ctu % P.ctus_w) << P.log2ctu, ctu_y = (ctu / P.ctus_w) << P.log2ctu;
-  const int16_t* org = P.rec[comp] + (ptrdiff_t)(ctu_y >> cs) * P.pitch[comp] + (ctu_x >> cs);
-  const int rx = x0 - (ctu_x >> cs), ry = y0 - (ctu_y >> cs);
-  bool fetched = false;
-  if (rx == 0) {
-    const int need = min(S, ry + 2 * n_tu);
-    if (need > nb.left_rows) {
-      int avail = S;
-      if (nb.wait[0]) {
-        const uint32_t v = wait_progress(P, nb, nb.ctu[0], [&](uint32_t pr) { return border_units_done(pr, pw, true) * us >= need; });
-        avail = border_units_done(v, pw, true) * us;
-        asm volatile("" ::: "memory");
-      }
-      for (int r = nb.left_rows + lane; r < avail; r += 64)
-        reinterpret_cast<uint32_t*>(&L.pix[r][0])[0] = ld_coh(reinterpret_cast<const uint32_t*>(org + (ptrdiff_t)r * P.pitch[comp] - 2));
-      nb.left_rows = avail; fetched = true;
-    }
-  }
-  if (ry == 0) {
-    const int need = min(2 * S, rx + 2 * n_tu);
-    if (need > nb.top_cols || !nb.corner) {
-      if (!nb.corner) {
-        if (nb.wait[1]) { wait_progress(P, nb, nb.ctu[1], [&](uint32_t pr) { return pr >= (uint32_t)P.parts; }); }
-      }
-      int avail = S;
-      if (nb.wait[2]) {
-        const uint32_t v = wait_progress(P, nb, nb.ctu[2], [&](uint32_t pr) { return border_units_done(pr, pw, false) * us >= min(need, S); });
-        avail = border_units_done(v, pw, false) * us;
-      }
-      if (avail == S) {
-        int more = S;
-        if (nb.wait[3]) {
-          const uint32_t v = wait_progress(P, nb, nb.ctu[3], [&](uint32_t pr) { return border_units_done(pr, pw, false) * us >= need - S; });
-          more = border_units_done(v, pw, false) * us;
-        }
-        avail += more;
-      }
-      asm volatile("" ::: "memory");
-      // dword d of top[] = columns 2d-2, 2d-1
-      const int d0 = nb.corner ? 1 + nb.top_cols / 2 : 0, d1 = 1 + avail / 2;
-      for (int d = d0 + lane; d < d1; d += 64)
-        reinterpret_cast<uint32_t*>(L.top)[d] = ld_coh(reinterpret_cast<const uint32_t*>(org - P.pitch[comp] - 2) + d);
-      nb.top_cols = max(nb.top_cols, avail); nb.corner = true; fetched = true;
-    }
-  }
-  if (fetched) wave_lds_sync();
+  for (int k = 0; k < 4; k++) z |= (((x >> k) & 1) << (2 * k)) | (((y >> k) & 1) << (2 * k + 1));
+  return z;
 }
 
 // Every sample this kernel stores is an agent-scope atomic store (written through to the level all XCDs read from) and every
-// neighbour sample it loads an agent-scope atomic load, so no cache has to be written back or invalidated around the counter: the
-// producer waits until its stores are acknowledged, the consumer issues its loads after it has seen the count.  (Agent-scope
-// release / acquire FENCES also write back / invalidate L2 for ordinary accesses: once per 16x16 area and CTU that cost more than
-// the finer progress gained.)
-__device__ inline void publish_progress(uint32_t* prog, int ctu, uint32_t z) {
+// neighbour sample it loads an agent-scope atomic load, so no cache has to be written back or invalidated around the progress word: the
+// producer waits until its stores are acknowledged, the consumer issues its loads after it has seen the bits.  (Agent-scope
+// release / acquire FENCES also write back / invalidate L2 for ordinary accesses: per publication that cost more than it gained.)
+__device__ inline void publish_progress(uint32_t* prog, int ctu, uint32_t word) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  if ((threadIdx.x & 63) == 0) __hip_atomic_store(prog + ctu, z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if ((threadIdx.x & 63) == 0) __hip_atomic_store(prog + ctu, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// all intra CUs of one CTU, one component, in decoding order (xReconIntraQT per CU, xIntraRecQT over its TU tree)
-__device__ inline void intra_ctu(const PicDev& P, int comp, int ctu, IntraLds& L, Neighbours& nb) {
+// the neighbours' published words -> ext_col / ext_row
+__device__ inline void poll_neighbours(const PicDev& P, Neighbours& nb, int pw) {
+  const uint32_t full = (1u << pw) - 1u;
+  uint32_t w[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) w[k] = nb.wait[k] ? __hip_atomic_load(nb.prog + nb.ctu[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0xffffffffu;
+  asm volatile("" ::: "memory");
+  nb.ext_col = w[0] & full;
+  nb.ext_row = (uint64_t)((w[1] >> (16 + pw - 1)) & 1u) | ((uint64_t)((w[2] >> 16) & full) << 1) | ((uint64_t)((w[3] >> 16) & full) << (1 + pw));
+}
+
+// samples of the neighbouring CTUs' border units the TU needs (all final: the TU was ready) into LDS, unless there already
+__device__ inline void fetch_border(const PicDev& P, int comp, int ctu, uint32_t need_col, uint64_t need_row, Neighbours& nb, IntraLds& L) {
+  const int cs = comp ? 1 : 0, lane = threadIdx.x & 63, us = 4 >> cs;
+  const int ctu_x = (ctu % P.ctus_w) << P.log2ctu, ctu_y = (ctu / P.ctus_w) << P.log2ctu;
+  const int16_t* org = P.rec[comp] + (ptrdiff_t)(ctu_y >> cs) * P.pitch[comp] + (ctu_x >> cs);
+  const uint32_t mc = need_col & ~nb.got_col;
+  const uint64_t mr = need_row & ~nb.got_row;
+  if (!mc && !mr) return;
+  if (mc) {
+    // unit u = rows u * us .. + us - 1 of the two columns left of the CTU: one dword per row
+    const int u = lane >> 2, r = lane & 3;
+    if (((mc >> u) & 1) && r < us) {
+      const int row = u * us + r;
+      reinterpret_cast<uint32_t*>(&L.pix[row][0])[0] = ld_coh(reinterpret_cast<const uint32_t*>(org + (ptrdiff_t)row * P.pitch[comp] - 2));
+    }
+    nb.got_col |= mc;
+  }
+  if (mr) {
+    // dword d of top[] = columns 2d - 2, 2d - 1; unit c (-1 .. 31) = columns c * us .. + us - 1
+    const int dwords = 1 + (33 * us) / 2;
+    for (int d = lane; d < dwords && d < 66; d += 64) {
+      const int col = 2 * d - 2;                            // first column of the dword
+      const int c = col < 0 ? -1 : col / us;
+      if ((mr >> (c + 1)) & 1) reinterpret_cast<uint32_t*>(L.top)[d] = ld_coh(reinterpret_cast<const uint32_t*>(org - P.pitch[comp] - 2) + d);
+    }
+    nb.got_row |= mr;
+  }
+  wave_lds_sync();
+}
+
+// all intra CUs of one CTU, one component (xReconIntraQT per CU, xIntraRecQT over its TU tree), in dependency order
+__device__ inline void intra_ctu(const PicDev& P, int comp, int ctu, IntraLds& L, IntraSched& Q, Neighbours& nb) {
   const bool compact = P.coef_start[0] != nullptr;
-  const int parts = P.parts;
+  const int parts = P.parts, pw = P.pw;
   const int ctu_x = (ctu % P.ctus_w) << P.log2ctu, ctu_y = (ctu / P.ctus_w) << P.log2ctu;
   const int cs = comp ? 1 : 0;
   const int lane = threadIdx.x & 63;
@@ -447,27 +429,129 @@ __device__ inline void intra_ctu(const PicDev& P, int comp, int ctu, IntraLds& L
       if (nbc[k] >= 0 && ldg(P.slice_idx + nbc[k]) == slice && ldg(P.tile_idx + nbc[k]) == tile) nb_same |= 1 << k;
   }
   const int cqo = comp == 1 ? ldg(&sd.cb_qp_offset) : comp == 2 ? ldg(&sd.cr_qp_offset) : 0;
-  wave_lds_sync();
-  int z = 0;
-  uint32_t published = 0;
-  auto progress = [&](int zdone) {                          // all partitions before zdone are final
-    if (((uint32_t)zdone >> 4) != (published >> 4)) { published = (uint32_t)zdone; publish_progress(nb.prog, ctu, published); }
+  // ---- 1. the list, in raster order of the TU origins (= the priority they run in), lane-parallel over the 4x4 units of the CTU: a unit
+  // starts a TU when its z index is aligned to the TU's size.  Units that are not reconstructed here (inter CUs, outside the picture)
+  // are final from the start.
+  int n_tus = 0;
+  auto mark_done = [&](int x4, int y4, int U) {           // units [x4, x4 + U) x [y4, y4 + U) are final
+    if (lane < 16) {
+      if (lane >= y4 && lane < y4 + U) Q.done_r[lane] |= (uint16_t)(((1u << U) - 1u) << x4);
+    } else if (lane < 32) {
+      const int c = lane - 16;
+      if (c >= x4 && c < x4 + U) Q.done_c[c] |= (uint16_t)(((1u << U) - 1u) << y4);
+    }
   };
-  while (z < parts) {
-    progress(z);
-    const int px = ctu_x + 4 * zscan_x(z), py = ctu_y + 4 * zscan_y(z);
-    const int ps = (int8_t)L.m_part[z];
-    if (px >= P.width || py >= P.height || ps == HMGPU_SIZE_NONE) { z++; continue; }
-    const int depth = L.m_depth[z];
-    const int cu_parts = parts >> (2 * depth);
-    if ((int8_t)L.m_pred[z] != HMGPU_MODE_INTRA) { z += cu_parts; continue; }
-    const int log2cu = P.log2ctu - depth;
-    const int qp_cu = (int8_t)L.m_qp[z];
-    const int cu_end = z + cu_parts;
-    if (L.m_pcm[z] && P.pcm[comp] != nullptr) {
+  const int units = pw * pw, log2pw = P.log2ctu - 2;
+  for (int base = 0; base < units; base += 64) {
+    const int u = base + lane;
+    bool preset[2] = {false, false};                          // raster pass (x fastest) and transposed pass (y fastest): final from the start
+    TuRun e = {0, 0, 0, 0};
+    bool origin = false;
+#pragma unroll
+    for (int pass = 0; pass < 2; pass++) {
+      const int a0 = u & (pw - 1), a1 = u >> log2pw;
+      const int x4 = pass ? a1 : a0, y4 = pass ? a0 : a1;
+      if (u >= units) continue;
+      const int z = z_of(x4, y4);
+      const int px = ctu_x + 4 * x4, py = ctu_y + 4 * y4;
+      if (px >= P.width || py >= P.height || (int8_t)L.m_part[z] == HMGPU_SIZE_NONE || (int8_t)L.m_pred[z] != HMGPU_MODE_INTRA) { preset[pass] = true; continue; }
+      if (pass) continue;
+      const int depth = L.m_depth[z];
+      const int cu_parts = parts >> (2 * depth), log2cu = P.log2ctu - depth;
+      const int z_cu = z & ~(cu_parts - 1);
+      if (L.m_pcm[z_cu] && P.pcm[comp] != nullptr) {
+        origin = z == z_cu;
+        e = TuRun{(uint8_t)z, (uint8_t)z_cu, (uint8_t)log2cu, 1};
+      } else {
+        const int log2tu = log2cu - L.m_tr[z];
+        const int tu_parts = 1 << (2 * (log2tu - 2));
+        // chroma: four 4x4 luma TUs share one 4x4 chroma TU, with the first of them (TComTU.cpp:141-171)
+        origin = (z & (tu_parts - 1)) == 0 && (comp == 0 || log2tu >= 3 || (z & 3) == 0);
+        e = TuRun{(uint8_t)z, (uint8_t)z_cu, (uint8_t)(comp == 0 ? log2tu : max(2, log2tu - 1)), 0};
+      }
+    }
+    // rows / columns of the done masks covered by this group of 64 units
+    const unsigned long long m0 = __builtin_amdgcn_ballot_w64(preset[0]), m1 = __builtin_amdgcn_ballot_w64(preset[1]);
+    const int per = 64 >> log2pw;                              // rows (columns) per group
+    if (lane < per && (base >> log2pw) + lane < pw) {
+      Q.done_r[(base >> log2pw) + lane] = (uint16_t)((m0 >> (lane * pw)) & ((1u << pw) - 1u));
+      Q.done_c[(base >> log2pw) + lane] = (uint16_t)((m1 >> (lane * pw)) & ((1u << pw) - 1u));
+    }
+    const unsigned long long mo = __builtin_amdgcn_ballot_w64(origin);
+    if (origin) Q.tu[n_tus + __popcll(mo & ((1ull << lane) - 1ull))] = e;
+    n_tus += __popcll(mo);
+  }
+  wave_lds_sync();
+  // ---- 2. what each TU depends on (lane-parallel over the list)
+  auto footprint = [&](const TuRun& e, int& x4, int& y4, int& U) {     // in 4x4 luma units of the CTU
+    x4 = zscan_x(e.z); y4 = zscan_y(e.z);
+    U = e.kind ? (1 << (e.log2n - 2)) : max(1, ((1 << e.log2n) << cs) >> 2);
+  };
+  for (int i = lane; i < n_tus; i += 64) {
+    const TuRun e = Q.tu[i];
+    int x4, y4, U;
+    footprint(e, x4, y4, U);
+    uint32_t nc = 0;
+    uint64_t nr = 0;
+    if (!e.kind) {
+      // left column and below-left: units (x4 - 1, y4 .. y4 + 2U - 1); the corner (x4 - 1, y4 - 1) belongs to this column too when y4 > 0
+      for (int y = (y4 > 0 ? y4 - 1 : 0); y < min(pw, y4 + 2 * U); y++)
+        if (x4 == 0 || z_of(x4 - 1, y) < e.z) nc |= 1u << y;
+      // row above and above-right: units (x4 - 1 .. x4 + 2U - 1, y4 - 1); for y4 = 0 the row of the CTUs above, corner included
+      if (y4 == 0) { for (int c = x4 - 1; c < x4 + 2 * U; c++) nr |= 1ull << (c + 1); }
+      else for (int c = x4; c < min(pw, x4 + 2 * U); c++) if (z_of(c, y4 - 1) < e.z) nr |= 1ull << (c + 1);
+    }
+    Q.need_col[i] = nc; Q.need_row[i] = nr;
+  }
+  wave_lds_sync();
+  // ---- 3. publish what is final before anything ran (the neighbours may pass inter areas at once), then run
+  uint32_t word = (uint32_t)Q.done_c[pw - 1] | ((uint32_t)Q.done_r[pw - 1] << 16);
+  publish_progress(nb.prog, ctu, word);
+  // pending TUs: lane l keeps bit k for list entry l + 64 k.  The list is in priority order, so a scan tests the 64 entries from the first
+  // pending one on and takes the first that is ready.
+  unsigned left = 0;
+  for (int k = 0; k < 4; k++) if (lane + 64 * k < n_tus) left |= 1u << k;
+  int remaining = n_tus, first = 0;
+  uint32_t spins = 0;
+  while (remaining > 0) {
+    int i = -1;
+    for (int wbase = first & ~63; wbase < n_tus && i < 0; wbase += 64) {
+      const int c = wbase + lane;
+      bool ready = false;
+      if ((left >> (wbase >> 6)) & 1) {
+        const TuRun e = Q.tu[c];
+        const int x4 = zscan_x(e.z), y4 = zscan_y(e.z);
+        const uint32_t have_c = x4 == 0 ? nb.ext_col : Q.done_c[x4 - 1];
+        const uint64_t have_r = y4 == 0 ? nb.ext_row : ((uint64_t)Q.done_r[y4 - 1] << 1) | 1ull;
+        ready = (Q.need_col[c] & ~have_c) == 0 && (Q.need_row[c] & ~have_r) == 0;
+      }
+      const unsigned long long m = __builtin_amdgcn_ballot_w64(ready);
+      if (m) i = wbase + (int)__builtin_ctzll(m);
+    }
+    if (i < 0) {
+      // nothing can run: the neighbours have to get further
+      if (nb.broken) break;
+      __builtin_amdgcn_s_sleep(8);
+      if (++spins > (1u << 22)) { if (lane == 0) atomicOr(P.fault, 1u); nb.broken = true; }
+      poll_neighbours(P, nb, pw);
+      continue;
+    }
+    if ((i & 63) == lane) left &= ~(1u << (i >> 6));
+    remaining--;
+    {
+      // first pending entry (for the next scan's window): lowest set bit over the lanes' masks
+      const unsigned long long p0 = __builtin_amdgcn_ballot_w64((left & 1u) != 0), p1 = __builtin_amdgcn_ballot_w64((left & 2u) != 0),
+                               p2 = __builtin_amdgcn_ballot_w64((left & 4u) != 0), p3 = __builtin_amdgcn_ballot_w64((left & 8u) != 0);
+      first = p0 ? (int)__builtin_ctzll(p0) : p1 ? 64 + (int)__builtin_ctzll(p1) : p2 ? 128 + (int)__builtin_ctzll(p2) : p3 ? 192 + (int)__builtin_ctzll(p3) : 0;
+    }
+    const TuRun e = Q.tu[i];
+    int x4, y4, U;
+    footprint(e, x4, y4, U);
+    const int z = e.z_cu, zc = e.z;
+    if (e.kind) {
       // PCM CU (TDecCu::xReconPCM, TDecCu.cpp:770-830): the transmitted samples, shifted up to the coding bit depth; lane n = row n
-      const int n_cu = (1 << log2cu) >> cs;
-      const int sx = (ctu_x + 4 * zscan_x(z)) >> cs, sy = (ctu_y + 4 * zscan_y(z)) >> cs;
+      const int n_cu = (1 << e.log2n) >> cs;
+      const int sx = (ctu_x + 4 * x4) >> cs, sy = (ctu_y + 4 * y4) >> cs;
       if (lane < n_cu) {
         const int16_t* src = P.pcm[comp] + (size_t)ctu * ((size_t)(1 << (2 * P.log2ctu)) >> (comp ? 2 : 0)) + (comp ? 4 : 16) * z + lane * n_cu;
         uint32_t* row = reinterpret_cast<uint32_t*>(P.rec[comp] + (ptrdiff_t)(sy + lane) * P.pitch[comp] + sx);
@@ -479,46 +563,42 @@ __device__ inline void intra_ctu(const PicDev& P, int comp, int ctu, IntraLds& L
           st_coh(row + x / 2, o);
         }
       }
-      wave_lds_sync();
-      z = cu_end;
-      continue;
-    }
-    int zc = z;
-    int coded_before = 0;                                  // compact levels: coded 4x4 luma TUs of the current 8x8 area before this one
-    while (zc < cu_end) {
+    } else {
+      const int depth = L.m_depth[z];
+      const int log2cu = P.log2ctu - depth;
       const int tr = L.m_tr[zc];
       const int log2tu = log2cu - tr;
       TuCtx t;
-      t.comp = comp; t.ctu = ctu; t.z_tu = zc; t.qp_cu = qp_cu; t.cip = cip; t.cqo = cqo; t.slice = slice; t.tile = tile; t.nb_same = nb_same;
+      t.comp = comp; t.ctu = ctu; t.z_tu = zc; t.qp_cu = (int8_t)L.m_qp[z]; t.cip = cip; t.cqo = cqo; t.slice = slice; t.tile = tile; t.nb_same = nb_same;
       t.cx0 = ctu_x >> cs; t.cy0 = ctu_y >> cs;
-      t.x0 = (ctu_x + 4 * zscan_x(zc)) >> cs; t.y0 = (ctu_y + 4 * zscan_y(zc)) >> cs;
-      bool run = true;
-      if (comp == 0) t.log2n = log2tu;
-      else if (log2tu >= 3) t.log2n = log2tu - 1;
-      else { t.log2n = 2; run = (zc & 3) == 0; }            // four 4x4 luma TUs share one 4x4 chroma TU, with the first of them (TComTU.cpp:141-171)
-      if (run) {
-        int mode = L.m_dir[zc];
-        if (comp && mode == 36) mode = L.m_dirl[z];      // DM_CHROMA_IDX (TDecCu.cpp:523-524): the luma mode of the CU's first partition (z: the CU's origin)
-        t.mode = mode;
-        t.cbf = (L.m_cbf[zc] >> tr) & 1;
-        t.skip = L.m_ts[zc];
-        t.bypass = L.m_byp[zc];
-        if (compact) {
-          // (HM descends to a TU only through coded ancestors: the cbf chain, as in k_prep's count)
-          const int chain = (1 << (tr + 1)) - 1;
-          if ((zc & 3) == 0) coded_before = 0;
-          t.lev_off = (int)L.qoff[zc >> 2] + ((comp == 0 && log2tu == 2) ? 16 * coded_before : 0);
-          if (comp == 0 && log2tu == 2 && (L.m_cbf[zc] & chain) == chain) coded_before++;
-        } else {
-          t.lev_off = (comp ? 4 : 16) * zc;
-        }
-        fetch_neighbours(P, comp, ctu, t.x0, t.y0, 1 << t.log2n, nb, L);
-        intra_tu_any(P, t, L);
+      t.x0 = (ctu_x + 4 * x4) >> cs; t.y0 = (ctu_y + 4 * y4) >> cs;
+      t.log2n = e.log2n;
+      int mode = L.m_dir[zc];
+      if (comp && mode == 36) mode = L.m_dirl[z];        // DM_CHROMA_IDX (TDecCu.cpp:523-524): the luma mode of the CU's first partition (z: the CU's origin)
+      t.mode = mode;
+      t.cbf = (L.m_cbf[zc] >> tr) & 1;
+      t.skip = L.m_ts[zc];
+      t.bypass = L.m_byp[zc];
+      if (compact) {
+        // (HM descends to a TU only through coded ancestors: the cbf chain, as in k_prep's count); 4x4 luma TUs: the coded ones of the
+        // same 8x8 area before this one lie in front of it
+        const int chain = (1 << (tr + 1)) - 1;
+        int coded_before = 0;
+        if (comp == 0 && log2tu == 2)
+          for (int sib = zc & ~3; sib < zc; sib++) if ((L.m_cbf[sib] & chain) == chain) coded_before++;
+        t.lev_off = (int)L.qoff[zc >> 2] + 16 * coded_before;
+      } else {
+        t.lev_off = (comp ? 4 : 16) * zc;
       }
-      zc += 1 << (2 * (log2tu - 2));
-      progress(zc);
+      fetch_border(P, comp, ctu, x4 == 0 ? Q.need_col[i] : 0u, y4 == 0 ? Q.need_row[i] : 0ull, nb, L);
+      intra_tu_any(P, t, L);
     }
-    z = cu_end;
+    mark_done(x4, y4, U);
+    wave_lds_sync();
+    if (x4 + U == pw || y4 + U == pw) {
+      const uint32_t w2 = (uint32_t)Q.done_c[pw - 1] | ((uint32_t)Q.done_r[pw - 1] << 16);
+      if (w2 != word) { word = w2; publish_progress(nb.prog, ctu, word); }
+    }
   }
 }
 
@@ -532,6 +612,7 @@ __device__ inline void intra_ctu(const PicDev& P, int comp, int ctu, IntraLds& L
 // before it (no deadlock however few blocks are resident), and the blocks resident at any time are the wavefront itself.
 __global__ void __launch_bounds__(64) k_intra(const PicDev* __restrict__ pics, Batch b, const int32_t* __restrict__ order) {
   __shared__ IntraLds L;
+  __shared__ IntraSched Q;
   const int slot = blockIdx.x / 3, comp = blockIdx.x % 3, ctu = ldg(order + blockIdx.y);
   const PicDev& P = pics[b.pic[slot]];
   const int first = b.first_ctu[slot], last = first + b.num_ctus[slot] - 1;
@@ -573,7 +654,7 @@ __global__ void __launch_bounds__(64) k_intra(const PicDev* __restrict__ pics, B
   unsigned my_l, my_r, my_t, my_b;
   border_mask(ctu, my_l, my_r, my_t, my_b);
   Neighbours nbs;
-  nbs.prog = done; nbs.left_rows = 0; nbs.top_cols = 0; nbs.corner = false; nbs.broken = false;
+  nbs.prog = done; nbs.got_col = 0; nbs.got_row = 0; nbs.broken = false;
 #pragma unroll
   for (int k = 0; k < 4; k++) {
     const int n = nb[k];
@@ -584,15 +665,19 @@ __global__ void __launch_bounds__(64) k_intra(const PicDev* __restrict__ pics, B
     // left: my first column against its last column; above-left: the corner (covered by column and row tests, conservatively);
     // above and above-right: my first row against its last row
     nbs.wait[k] = k == 0 ? (my_l && n_r) : k == 1 ? ((my_l || my_t) && n_r && n_b) : (my_t && n_b);
+#ifdef INTRA_NOWAIT
+    nbs.wait[k] = false;                                     // experiment: no CTU waits for another (wrong samples, the time of the work alone)
+#endif
   }
-  // The waits (fetch_neighbours) cannot deadlock as long as workgroups are dispatched in linear order (the neighbours lie on earlier
+  // The waits (intra_ctu's polling) cannot deadlock as long as workgroups are dispatched in linear order (the neighbours lie on earlier
   // anti-diagonals, i.e. at smaller block indices: they are resident or finished when this block runs, and never wait for this one).
   // HIP does not promise that order, so every spin is bounded: a block that gives up flags the picture (the host reports HMGPU_EDEVICE
   // at its next sync) instead of hanging the device.
+  poll_neighbours(P, nbs, P.pw);
   wave_lds_sync();
-  intra_ctu(P, comp, ctu, L, nbs);
+  intra_ctu(P, comp, ctu, L, Q, nbs);
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-  publish_progress(done, ctu, (uint32_t)P.parts);
+  publish_progress(done, ctu, 0xffffffffu);
 }
 
 void launch_intra(const PicDev* pics, const Batch& b, const int32_t* order, int num_ctus, hipStream_t s) {
