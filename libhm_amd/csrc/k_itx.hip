@@ -70,9 +70,10 @@ __device__ inline void itx_class(const ItxPic& P, int bx, int nbx, char* __restr
   uint32_t lv_c[N / 2];
   load_levels(t, rc, lv_c);
   for (uint32_t tw = t - jw; tw < count; tw += stride, t += stride) {   // tw: wave-uniform loop variable
-    uint32_t lv_n[N / 2];
+    constexpr bool AHEAD = N < 32;                            // levels of the next group in flight (32x32: see below)
+    uint32_t lv_n[AHEAD ? N / 2 : 1];
     Rec rnn;
-    load_levels(t + stride, rn, lv_n);
+    if constexpr (AHEAD) load_levels(t + stride, rn, lv_n);
     load_rec(t + 2 * stride, rnn);
     {
       const Rec r = rc;
@@ -96,8 +97,12 @@ __device__ inline void itx_class(const ItxPic& P, int bx, int nbx, char* __restr
       }
     }
     rc = rn; rn = rnn;
+    if constexpr (AHEAD) {
 #pragma unroll
-    for (int i = 0; i < N / 2; i++) lv_c[i] = lv_n[i];
+      for (int i = 0; i < N / 2; i++) lv_c[i] = lv_n[i];
+    } else {
+      load_levels(t + stride, rc, lv_c);                           // 32x32: a second set of levels in registers costs two waves per SIMD (82 -> 69 VGPRs: 5 -> 7; measured 6 % faster)
+    }
   }
 }
 
