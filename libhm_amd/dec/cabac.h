@@ -64,30 +64,28 @@ class Cabac {
     range_ = 510;
     offset_ = get(9);
   }
+  // 9.3.4.3.2, without a data-dependent branch: on coded video the bin is what the branch predictor cannot know, and a
+  // mispredicted branch costs as much as the rest of the bin.  MPS and LPS path are computed together and selected by a mask, the state
+  // transition is one table indexed by (state, MPS, LPS taken), renormalisation shifts by the leading-zero count (0 when none is due).
   int decision(ctx_t& ctx) {
-    const unsigned state = ctx >> 1, mps = ctx & 1;
-    const unsigned lps = kRangeLps[state][(range_ >> 6) & 3];
-    range_ -= lps;
-    int bin;
-    if (offset_ >= range_) {
-      offset_ -= range_;
-      range_ = lps;
-      bin = mps ^ 1;
-      ctx = (ctx_t)((kNextLps[state] << 1) | (state == 0 ? mps ^ 1 : mps));
-    } else {
-      bin = mps;
-      ctx = (ctx_t)((kNextMps[state] << 1) | mps);
-      if (range_ >= 256) return bin;
-    }
-    const int n = __builtin_clz(range_) - 23;       // shifts until bit 8 is set
-    range_ <<= n;
+    const unsigned s = ctx;                                  // (pStateIdx << 1) | valMps
+    const unsigned lps = kRangeLps[s >> 1][(range_ >> 6) & 3];
+    const unsigned rmps = range_ - lps;
+    const unsigned is_lps = offset_ >= rmps ? 1u : 0u;
+    const unsigned mask = 0u - is_lps;
+    offset_ -= rmps & mask;
+    const unsigned r = rmps ^ ((rmps ^ lps) & mask);
+    ctx = kNext[(s << 1) | is_lps];
+    const int n = __builtin_clz(r) - 23;                    // shifts until bit 8 is set (0 for an MPS range >= 256)
+    range_ = r << n;
     offset_ = (offset_ << n) | get(n);
-    return bin;
+    return (int)((s & 1u) ^ is_lps);
   }
   int bypass() {
     offset_ = (offset_ << 1) | get(1);
-    if (offset_ >= range_) { offset_ -= range_; return 1; }
-    return 0;
+    const unsigned b = offset_ >= range_ ? 1u : 0u;
+    offset_ -= range_ & (0u - b);
+    return (int)b;
   }
   // n bypass bins at once (n <= 16): with offset < range before, the n bins are the quotient of (offset << n | new bits) by range
   unsigned bypass_bits(int n) {
@@ -123,26 +121,26 @@ class Cabac {
   unsigned plain_bits(int n) { return get(n); }     // pcm_sample_*: read_bits(n) between finish_to_byte() and start()
 
  private:
-  unsigned get(int n) {                               // n <= 25; bits behind the end of the data read as zero
-    if (n == 0) return 0;
-    if (avail_ < n) {
-      if (avail_ <= 32 && next_byte_ + 4 <= nbytes_) {
-        uint32_t w;
-        memcpy(&w, p_ + next_byte_, 4);
-        res_ = (res_ << 32) | __builtin_bswap32(w);
-        next_byte_ += 4;
-        avail_ += 32;
-      } else {
-        while (avail_ <= 56) {
-          res_ = (res_ << 8) | (next_byte_ < nbytes_ ? p_[next_byte_] : 0u);
-          next_byte_++;
-          avail_ += 8;
-        }
+  unsigned get(int n) {                               // n <= 25 (0 allowed); bits behind the end of the data read as zero
+    if (avail_ < 32) refill();                        // (taken once in 32 bits: the one branch of a bin, and a predictable one)
+    avail_ -= n;
+    return (unsigned)(res_ >> avail_) & ((1u << n) - 1u);
+  }
+  void refill() {
+    if (next_byte_ + 4 <= nbytes_) {
+      uint32_t w;
+      memcpy(&w, p_ + next_byte_, 4);
+      res_ = (res_ << 32) | __builtin_bswap32(w);
+      next_byte_ += 4;
+      avail_ += 32;
+    } else {
+      while (avail_ <= 56) {
+        res_ = (res_ << 8) | (next_byte_ < nbytes_ ? p_[next_byte_] : 0u);
+        next_byte_++;
+        avail_ += 8;
       }
       if (next_byte_ > nbytes_ + 24) throw ParseError("CABAC: read far past the end of the slice data");
     }
-    avail_ -= n;
-    return (unsigned)(res_ >> avail_) & ((1u << n) - 1);
   }
   const uint8_t* p_ = nullptr;
   size_t nbytes_ = 0, next_byte_ = 0;
@@ -151,6 +149,7 @@ class Cabac {
   unsigned range_ = 510, offset_ = 0;
   static const uint8_t kRangeLps[64][4];
   static const uint8_t kNextLps[64], kNextMps[64];
+  static const ctx_t kNext[256];                      // [(state << 1 | mps) << 1 | LPS taken] -> next (state << 1 | mps)
 };
 
 }  // namespace hmdec
