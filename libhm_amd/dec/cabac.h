@@ -87,20 +87,34 @@ class Cabac {
     offset_ -= range_ & (0u - b);
     return (int)b;
   }
-  // n bypass bins at once (n <= 16): with offset < range before, the n bins are the quotient of (offset << n | new bits) by range
+  // n bypass bins at once (n <= 16): with offset < range before, the n bins are the quotient of (offset << n | new bits) by range.
+  // The range only changes in decision(), so the division is a multiplication by a tabulated reciprocal (exact: the numerator has
+  // 25 bits at most, the reciprocal 39 fractional bits).
   unsigned bypass_bits(int n) {
     if (n <= 0) return 0;
-    if (n == 1) return (unsigned)bypass();
     unsigned v = 0;
     while (n > 0) {
       const int k = n > 16 ? 16 : n;
       const unsigned wide = (offset_ << k) | get(k);          // offset < range <= 510: 25 bits at most
-      const unsigned q = wide / range_;
+      const unsigned q = (unsigned)(((uint64_t)wide * kInv[range_]) >> 39);
       offset_ = wide - q * range_;
       v = (v << k) | q;
       n -= k;
     }
     return v;
+  }
+  // The next 16 bypass bins (bit 15 = the first) WITHOUT committing to them: bypass bins are a bit sequence whatever way they are
+  // grouped, so a syntax element of unknown length (coeff_abs_level_remaining) is read as one group and the engine then keeps the
+  // first m bins only -- floor(floor(W / 2^k) / r) = floor(floor(W / r) / 2^k), i.e. the state after m bins follows from the group's
+  // numerator and quotient, and the bit position steps back by the rest.
+  unsigned bypass_peek16(unsigned& wide) {
+    wide = (offset_ << 16) | get(16);
+    return (unsigned)(((uint64_t)wide * kInv[range_]) >> 39);
+  }
+  void bypass_keep(unsigned wide, unsigned q, int m) {         // after bypass_peek16: m <= 16 of the bins are consumed
+    const int back = 16 - m;
+    offset_ = (wide >> back) - (q >> back) * range_;
+    avail_ += back;
   }
   // 9.3.4.3.5; when the result is 1 the engine is finished: call finish_to_byte() before reading plain bits or restarting
   int terminate() {
@@ -149,7 +163,8 @@ class Cabac {
   unsigned range_ = 510, offset_ = 0;
   static const uint8_t kRangeLps[64][4];
   static const uint8_t kNextLps[64], kNextMps[64];
-  static const ctx_t kNext[256];                      // [(state << 1 | mps) << 1 | LPS taken] -> next (state << 1 | mps)
+  static const ctx_t kNext[256];
+  static const uint32_t kInv[512];                    // [range]: floor(2^39 / range) + 1 for range >= 256 (bypass_bits)                      // [(state << 1 | mps) << 1 | LPS taken] -> next (state << 1 | mps)
 };
 
 }  // namespace hmdec

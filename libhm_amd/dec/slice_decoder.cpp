@@ -918,7 +918,7 @@ void SliceDecoder::residual_coding(int x0, int y0, int log2, int c) {
     csbf[ys][xs] = coded;
     if (!coded) continue;
     // significance map (9.3.4.2.5)
-    int pos[16], nsig = 0;
+    int pos[17], nsig = 0;
     int n = 15;
     if (i == last_sb) { pos[nsig++] = last_pos; n = last_pos - 1; }
     const int prev_csbf = right | (below << 1);
@@ -936,11 +936,12 @@ void SliceDecoder::residual_coding(int x0, int y0, int log2, int c) {
       if (n > 0 || !infer_dc) {
         const int sc = (n == 0 && i == 0 && log2 > 2) ? (c ? 27 : 0) : sig_base + sig_tab[in_order[n]];
         sig = eng.decision(ctx_.s[CTX_SIG + sc]);
-        if (sig) infer_dc = false;
+        infer_dc = infer_dc && !sig;
       } else {
         sig = true;                                      // the only coefficient a coded sub-block can still have
       }
-      if (sig) pos[nsig++] = n;
+      pos[nsig] = n;                                       // (kept only when significant: no branch on the bin)
+      nsig += sig ? 1 : 0;
     }
     if (nsig == 0) continue;
     // greater-than-1 / greater-than-2 flags (9.3.4.2.6, 9.3.4.2.7)
@@ -966,12 +967,28 @@ void SliceDecoder::residual_coding(int x0, int y0, int log2, int c) {
       int level = 1 + g1[k] + (k == first_g1 ? g2 : 0);
       const int thresh = k < 8 ? (k == first_g1 ? 3 : 2) : 1;
       if (level == thresh) {
-        int prefix = 0;
-        while (prefix < 32 && eng.bypass()) prefix++;
-        if (prefix == 32) throw ParseError("coeff_abs_level_remaining prefix too long");
+        // coeff_abs_level_remaining (9.3.3.11): unary prefix, then rice / escape suffix, all bypass bins: read as one group of 16 bins
+        // (enough for prefixes up to 7 at any rice parameter), the engine keeps what the element used
+        unsigned wide;
+        const unsigned q = eng.bypass_peek16(wide);
+        const unsigned zeros = ~q & 0xffffu;
+        int prefix = zeros ? __builtin_clz(zeros) - 16 : 16;
         int rem;
-        if (prefix <= 3) rem = (prefix << rice) + (int)eng.bypass_bits(rice);
-        else rem = (((1 << (prefix - 3)) + 3 - 1) << rice) + (int)eng.bypass_bits(prefix - 3 + rice);
+        if (prefix <= 3) {
+          const int nb = prefix + 1 + rice;
+          rem = (prefix << rice) + (int)((q >> (16 - nb)) & ((1u << rice) - 1u));
+          eng.bypass_keep(wide, q, nb);
+        } else if (prefix <= 7) {
+          const int sl = prefix - 3 + rice, nb = prefix + 1 + sl;
+          rem = (((1 << (prefix - 3)) + 3 - 1) << rice) + (int)((q >> (16 - nb)) & ((1u << sl) - 1u));
+          eng.bypass_keep(wide, q, nb);
+        } else {
+          eng.bypass_keep(wide, q, 8);                       // eight 1 bins so far
+          prefix = 8;
+          while (prefix < 32 && eng.bypass()) prefix++;
+          if (prefix == 32) throw ParseError("coeff_abs_level_remaining prefix too long");
+          rem = (((1 << (prefix - 3)) + 3 - 1) << rice) + (int)eng.bypass_bits(prefix - 3 + rice);
+        }
         level += rem;
         if (level > 3 * (1 << rice)) rice = std::min(rice + 1, 4);
       }
