@@ -63,7 +63,7 @@ def build_decoder(force=False, verbose=False):
     deps = srcs + [os.path.join(DEC, f) for f in os.listdir(DEC) if f.endswith(".h")] + [
         os.path.join(os.path.dirname(HERE), "include", "hmgpu.h"), os.path.join(os.path.dirname(HERE), "include", "hmdec.h"), gpu]
     if force or _stale(DEC_OUT, deps):
-        cmd = [cxx, "-std=c++17", "-O2", "-fPIC", "-shared", "-pthread", "-Wall", "-o", DEC_OUT] + srcs + [
+        cmd = [cxx, "-std=c++17", "-O3", "-fPIC", "-shared", "-pthread", "-Wall", "-o", DEC_OUT] + srcs + [
             "-L" + HERE, "-lhmgpu", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath,/opt/rocm/lib"]
         if verbose:
             print(" ".join(cmd))
