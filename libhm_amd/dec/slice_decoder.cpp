@@ -969,20 +969,21 @@ void SliceDecoder::residual_coding(int x0, int y0, int log2, int c) {
       if (level == thresh) {
         // coeff_abs_level_remaining (9.3.3.11): unary prefix, then rice / escape suffix, all bypass bins: read as one group of 16 bins
         // (enough for prefixes up to 7 at any rice parameter), the engine keeps what the element used
-        const unsigned q = eng.bypass_peek16();
+        unsigned wide;
+        const unsigned q = eng.bypass_peek16(wide);
         const unsigned zeros = ~q & 0xffffu;
         int prefix = zeros ? __builtin_clz(zeros) - 16 : 16;
         int rem;
         if (prefix <= 3) {
           const int nb = prefix + 1 + rice;
           rem = (prefix << rice) + (int)((q >> (16 - nb)) & ((1u << rice) - 1u));
-          eng.bypass_keep(q, nb);
+          eng.bypass_keep(wide, q, nb);
         } else if (prefix <= 7) {
           const int sl = prefix - 3 + rice, nb = prefix + 1 + sl;
           rem = (((1 << (prefix - 3)) + 3 - 1) << rice) + (int)((q >> (16 - nb)) & ((1u << sl) - 1u));
-          eng.bypass_keep(q, nb);
+          eng.bypass_keep(wide, q, nb);
         } else {
-          eng.bypass_keep(q, 8);                       // eight 1 bins so far
+          eng.bypass_keep(wide, q, 8);                       // eight 1 bins so far
           prefix = 8;
           while (prefix < 32 && eng.bypass()) prefix++;
           if (prefix == 32) throw ParseError("coeff_abs_level_remaining prefix too long");
