@@ -8,7 +8,7 @@ cp libhm_amd/libhmdec.so /tmp/libhmdec_base.so
 for v in "$@"; do
   if [ $v = base ]; then cp /tmp/libhmdec_base.so libhm_amd/libhmdec.so; else cp libhm_amd/variants/$v/libhmdec.so libhm_amd/libhmdec.so; fi
   for s in ra_main10_1920x1080 ldp_main10_3840x2160 ldp_wpp_main10_3840x2160; do
-    python3 bench.py --workload decode --stream tests/golden/bench_$s.bin --steps 4 --warmup 1 --no-cpu-baseline > $out/${v}_$s.json 2> $out/${v}_$s.err
+    python3 bench.py --workload decode --stream tests/golden/bench_$s.bin --steps 5 --warmup 1 --no-cpu-baseline > $out/${v}_$s.json 2> $out/${v}_$s.err
     python3 - $out/${v}_$s.json ${v}_$s <<'PY'
 import json,sys
 try:
