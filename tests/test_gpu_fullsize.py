@@ -20,6 +20,42 @@ def _oracle_chain(oracle, p, cur, refs):
     return rec, dbk, fin
 
 
+@pytest.mark.parametrize("bi", [False, True])
+def test_explicit_weighted_prediction_matches_oracle(oracle, bi):
+    """explicit weighted prediction (TComWeightPrediction.cpp: weightUnidir / weightBidir, per reference index and component) on a picture
+    large enough for every PU shape and every residual mask: the k_mc_*<WP, BI> variants, which also add the residual, against the
+    oracle.  (The HM-made weighted-prediction streams are 208x120.)"""
+    import libhm_amd
+    width, height, bd = 1280, 704, 10
+    p = synth.make_picture(width, height, bd, seed=77 + int(bi), bi=bi, intra_frac=0.1, ref_handles=([0], [1]))
+    sl = p.slice
+    sl.weighted_pred = 1
+    sl.wp_log2_denom[0], sl.wp_log2_denom[1] = 5, 4
+    rng = np.random.RandomState(5)
+    for l in range(2):
+        for r in range(1):
+            for c in range(3):
+                sl.wp_weight[l][r][c] = int((1 << sl.wp_log2_denom[1 if c else 0]) + rng.randint(-12, 13))
+                sl.wp_offset[l][r][c] = int(rng.randint(-20, 21))
+    ref0 = synth.noise_planes(width, height, bd, 21)
+    ref1 = synth.blocky_planes(width, height, bd, 22)
+    cur = synth.blocky_planes(width, height, bd, 23)
+    want_rec, want_dbk, want_fin = _oracle_chain(oracle, p, cur, [ref0, ref1])
+    with libhm_amd.Context(p.seq) as ctx:
+        h0, h1, hc = ctx.acquire(), ctx.acquire(), ctx.acquire()
+        ctx.upload(h0, ref0)
+        ctx.upload(h1, ref1)
+        ctx.upload(hc, cur)
+        ctx.decompress_slice(hc, 0, sl, p.meta, p.coeffs)
+        got = ctx.download(hc)
+        for c in range(3):
+            assert np.array_equal(got[c], want_rec[c]), "reconstruction comp %d" % c
+        ctx.filter_picture(hc, p.pp, p.sao_raw)
+        got = ctx.download(hc)
+        for c in range(3):
+            assert np.array_equal(got[c], want_fin[c]), "filtered comp %d" % c
+
+
 @pytest.mark.parametrize("width,height,bd,bi,intra", [(3840, 2160, 10, False, 0.1), (3840, 2160, 10, True, 0.0),
                                                       (3840, 2160, 10, True, 0.25),      # the slowest filter configuration: bi-pred + Bs 2 edges
                                                       (1920, 1080, 10, False, 0.05), (416, 240, 8, True, 0.1),
