@@ -194,7 +194,9 @@ void Decoder::activate(const SliceHeader& sh) {
   pps_ = pps;
   // (a PPS object is shared with the parser threads of earlier pictures: its tables are derived once per picture geometry)
   if (pps_->derived_w != sps_->pic_w_ctbs() || pps_->derived_h != sps_->pic_h_ctbs()) {
-    if (threaded()) { close_current(); retire_ready(true); }
+    // a PPS object whose tables were derived for another geometry may be in use by pictures still being parsed: wait for them.  A PPS
+    // that has just arrived (parameter sets are commonly repeated in front of every IRAP picture) is not shared with anybody yet.
+    if (threaded() && pps_->derived_w >= 0) { close_current(); retire_ready(true); }
     pps_->derive_tiles(*sps_);
     pps_->derived_w = sps_->pic_w_ctbs();
     pps_->derived_h = sps_->pic_h_ctbs();
