@@ -49,11 +49,16 @@ __device__ inline int ld_sample(const int16_t* p) {
   return (int)(int16_t)((a & 2) ? (w >> 16) : (w & 0xffffu));
 }
 
-struct IntraLds {
+#ifndef INTRA_WAVES
+#define INTRA_WAVES 4                    // waves per CTU and component: they run the CTU's ready TUs side by side (intra_ctu)
+#endif
+struct IntraScratch {                    // what ONE TU in flight needs: one per wave
   int line[4 * 32 + 4];                  // reference line: [0,2N) left column bottom-up, [2N] corner, (2N,4N] row above
   int filt[4 * 32 + 4];                  // the same after smoothing
   int proj[3 * 32 + 4];                  // angular modes: main reference incl. the projected side samples, index k + 32
   __attribute__((aligned(16))) int16_t tile[PkCfg<5>::TU_ELEMS];   // itx_tu_pk scratch: one TU at a time, the largest is 32x32
+};
+struct IntraLds {
   // the CTU's samples of this component (columns -2..63 at index x + 2) and the row above it (columns -2..127): references
   // inside the CTU never leave the chip, and a TU does not wait for its stores before the next one starts
   __attribute__((aligned(4))) int16_t pix[64][66];
@@ -104,7 +109,7 @@ __device__ inline int wave_sum(int v) {
 
 // one TU: everything between "the neighbours are reconstructed" and "this TU is reconstructed"
 template <int LOG2N>
-__device__ inline void intra_tu(const PicDev& P, const TuCtx& t, IntraLds& L) {
+__device__ inline void intra_tu(const PicDev& P, const TuCtx& t, IntraLds& L, IntraScratch& W) {
   constexpr int N = 1 << LOG2N;
   const int lane = threadIdx.x & 63;
   const int comp = t.comp, cs = comp ? 1 : 0;
@@ -161,7 +166,7 @@ __device__ inline void intra_tu(const PicDev& P, const TuCtx& t, IntraLds& L) {
       sx -= t.cx0; sy -= t.cy0;
       v = sy < 0 ? L.top[sx + 2] : L.pix[sy][sx + 2];
     }
-    L.line[i] = v;
+    W.line[i] = v;
   }
   wave_lds_sync();
 
@@ -173,28 +178,28 @@ __device__ inline void intra_tu(const PicDev& P, const TuCtx& t, IntraLds& L) {
     bool strong = false;
     int bl = 0, tl = 0, tr = 0;
     if (N == 32 && P.strong_intra_smoothing) {
-      bl = L.line[0]; tl = L.line[corner]; tr = L.line[total - 1];
+      bl = W.line[0]; tl = W.line[corner]; tr = W.line[total - 1];
       const int th = 1 << (bd - 5);
-      strong = abs(bl + tl - 2 * L.line[N]) < th && abs(tl + tr - 2 * L.line[corner + N]) < th;
+      strong = abs(bl + tl - 2 * W.line[N]) < th && abs(tl + tr - 2 * W.line[corner + N]) < th;
     }
     for (int i = lane; i < total; i += 64) {
-      int v = L.line[i];
+      int v = W.line[i];
       if (i > 0 && i < total - 1) {
         if (strong) {
           // (24-bit multiplies throughout the prediction: samples and weights are small, v_mul_lo_u32 runs at quarter rate)
           if (i < corner) v = (__mul24(2 * N - i, bl) + __mul24(i, tl) + N) >> (LOG2N + 1);
           else if (i > corner) v = (__mul24(2 * N - (i - corner), tl) + __mul24(i - corner, tr) + N) >> (LOG2N + 1);
         } else {
-          v = (L.line[i - 1] + 2 * v + L.line[i + 1] + 2) >> 2;
+          v = (W.line[i - 1] + 2 * v + W.line[i + 1] + 2) >> 2;
         }
       }
-      L.filt[i] = v;
+      W.filt[i] = v;
     }
     wave_lds_sync();
   }
 
   // ---- C. prediction of row n by lane n
-  const int* f = filt ? L.filt : L.line;
+  const int* f = filt ? W.filt : W.line;
   const bool edge = comp == 0 && N <= 16;                   // MAXIMUM_INTRA_FILTERED_WIDTH (TypeDef.h:117)
   int p[N];
   if (t.mode == 0) {
@@ -242,10 +247,10 @@ __device__ inline void intra_tu(const PicDev& P, const TuCtx& t, IntraLds& L) {
         int v = 0;
         if (k >= 0) v = f[corner + sgn * k];
         else if (k > ((N * ang) >> 5)) v = f[corner - sgn * ((128 + __mul24(-k, inv)) >> 8)];
-        L.proj[k + 32] = v;
+        W.proj[k + 32] = v;
       }
       wave_lds_sync();
-      const int* r = L.proj + 32;
+      const int* r = W.proj + 32;
 #pragma unroll
       for (int x = 0; x < N; x++) {
         const int a_ = ver ? n : x, b_ = ver ? x : n;
@@ -263,7 +268,7 @@ __device__ inline void intra_tu(const PicDev& P, const TuCtx& t, IntraLds& L) {
     int per, rem;
     qp_param_tu(t.qp_cu, comp, bd, t.cqo, per, rem);
     const uint8_t* mrow = (P.sl_m != nullptr && (!t.skip || N == 4)) ? P.sl_m + (((LOG2N - 2) * 6 + comp) << 10) + n * N : nullptr;   // intra lists: 0 + component
-    itx_tu_pk<LOG2N>(lv, n, per, rem, t.skip != 0, bd, L.tile, res, comp == 0 && LOG2N == 2, mrow, t.bypass != 0);   // DST: 4x4 intra luma (TComTU::useDST)
+    itx_tu_pk<LOG2N>(lv, n, per, rem, t.skip != 0, bd, W.tile, res, comp == 0 && LOG2N == 2, mrow, t.bypass != 0);   // DST: 4x4 intra luma (TComTU::useDST)
   }
 
   // ---- E. reconstruction of row n: into the LDS copy (what later TUs of this CTU predict from) and, two samples per
@@ -282,12 +287,12 @@ __device__ inline void intra_tu(const PicDev& P, const TuCtx& t, IntraLds& L) {
   wave_lds_sync();
 }
 
-__device__ inline void intra_tu_any(const PicDev& P, const TuCtx& t, IntraLds& L) {
+__device__ inline void intra_tu_any(const PicDev& P, const TuCtx& t, IntraLds& L, IntraScratch& W) {
   switch (t.log2n) {
-    case 2: intra_tu<2>(P, t, L); break;
-    case 3: intra_tu<3>(P, t, L); break;
-    case 4: intra_tu<4>(P, t, L); break;
-    default: intra_tu<5>(P, t, L); break;
+    case 2: intra_tu<2>(P, t, L, W); break;
+    case 3: intra_tu<3>(P, t, L, W); break;
+    case 4: intra_tu<4>(P, t, L, W); break;
+    default: intra_tu<5>(P, t, L, W); break;
   }
 }
 
@@ -337,7 +342,9 @@ struct IntraSched {
   TuRun tu[256];
   uint32_t need_col[256];        // bit y: unit (x4 - 1, y) of the column left of the TU must be final (the left CTU's last column when x4 = 0)
   uint64_t need_row[256];        // bit c + 1: unit (c, y4 - 1), c = -1 .. 31, of the row above the TU (the row of the CTUs above when y4 = 0)
-  uint16_t done_r[16], done_c[16];   // final units per row (bit x) / per column (bit y)
+  uint32_t done_r[16], done_c[16];   // final units per row (bit x) / per column (bit y); set with LDS atomics by the wave that finished a TU
+  uint32_t pend[8];                  // list entries nobody has taken yet (bit i & 31 of pend[i >> 5]); a wave takes one with an atomic AND
+  int32_t n_tus, running;            // list length; waves inside a TU right now
 };
 
 struct Neighbours {
@@ -408,8 +415,12 @@ __device__ inline void fetch_border(const PicDev& P, int comp, int ctu, uint32_t
   wave_lds_sync();
 }
 
-// all intra CUs of one CTU, one component (xReconIntraQT per CU, xIntraRecQT over its TU tree), in dependency order
-__device__ inline void intra_ctu(const PicDev& P, int comp, int ctu, IntraLds& L, IntraSched& Q, Neighbours& nb) {
+// all intra CUs of one CTU, one component (xReconIntraQT per CU, xIntraRecQT over its TU tree), in dependency order, by the INTRA_WAVES
+// waves of the workgroup: wave 0 lists the TUs and what they depend on, then every wave takes, again and again, the first TU of the list
+// that is ready and that nobody has taken (an atomic AND on the pending mask), runs it and marks its units final (atomic ORs).  TUs that
+// do not depend on each other -- the next ones along an anti-diagonal of the CTU -- run side by side; the CTU's samples, the done masks
+// and the list are shared in LDS, the reference line / transform scratch of a TU in flight is the wave's own (IntraScratch).
+__device__ inline void intra_ctu(const PicDev& P, int comp, int ctu, IntraLds& L, IntraSched& Q, IntraScratch& W, Neighbours& nb) {
   const bool compact = P.coef_start[0] != nullptr;
   const int parts = P.parts, pw = P.pw;
   const int ctu_x = (ctu % P.ctus_w) << P.log2ctu, ctu_y = (ctu / P.ctus_w) << P.log2ctu;
@@ -429,18 +440,24 @@ __device__ inline void intra_ctu(const PicDev& P, int comp, int ctu, IntraLds& L
       if (nbc[k] >= 0 && ldg(P.slice_idx + nbc[k]) == slice && ldg(P.tile_idx + nbc[k]) == tile) nb_same |= 1 << k;
   }
   const int cqo = comp == 1 ? ldg(&sd.cb_qp_offset) : comp == 2 ? ldg(&sd.cr_qp_offset) : 0;
+  const int wv = threadIdx.x >> 6;
+  auto mark_done = [&](int x4, int y4, int U) {           // units [x4, x4 + U) x [y4, y4 + U) are final
+    if (lane < 16) {
+      if (lane >= y4 && lane < y4 + U) atomicOr(&Q.done_r[lane], ((1u << U) - 1u) << x4);
+    } else if (lane < 32) {
+      const int c = lane - 16;
+      if (c >= x4 && c < x4 + U) atomicOr(&Q.done_c[c], ((1u << U) - 1u) << y4);
+    }
+  };
+  auto footprint = [&](const TuRun& e, int& x4, int& y4, int& U) {     // in 4x4 luma units of the CTU
+    x4 = zscan_x(e.z); y4 = zscan_y(e.z);
+    U = e.kind ? (1 << (e.log2n - 2)) : max(1, ((1 << e.log2n) << cs) >> 2);
+  };
+  if (wv == 0) {
   // ---- 1. the list, in raster order of the TU origins (= the priority they run in), lane-parallel over the 4x4 units of the CTU: a unit
   // starts a TU when its z index is aligned to the TU's size.  Units that are not reconstructed here (inter CUs, outside the picture)
   // are final from the start.
   int n_tus = 0;
-  auto mark_done = [&](int x4, int y4, int U) {           // units [x4, x4 + U) x [y4, y4 + U) are final
-    if (lane < 16) {
-      if (lane >= y4 && lane < y4 + U) Q.done_r[lane] |= (uint16_t)(((1u << U) - 1u) << x4);
-    } else if (lane < 32) {
-      const int c = lane - 16;
-      if (c >= x4 && c < x4 + U) Q.done_c[c] |= (uint16_t)(((1u << U) - 1u) << y4);
-    }
-  };
   const int units = pw * pw, log2pw = P.log2ctu - 2;
   for (int base = 0; base < units; base += 64) {
     const int u = base + lane;
@@ -474,8 +491,8 @@ __device__ inline void intra_ctu(const PicDev& P, int comp, int ctu, IntraLds& L
     const unsigned long long m0 = __builtin_amdgcn_ballot_w64(preset[0]), m1 = __builtin_amdgcn_ballot_w64(preset[1]);
     const int per = 64 >> log2pw;                              // rows (columns) per group
     if (lane < per && (base >> log2pw) + lane < pw) {
-      Q.done_r[(base >> log2pw) + lane] = (uint16_t)((m0 >> (lane * pw)) & ((1u << pw) - 1u));
-      Q.done_c[(base >> log2pw) + lane] = (uint16_t)((m1 >> (lane * pw)) & ((1u << pw) - 1u));
+      Q.done_r[(base >> log2pw) + lane] = (uint32_t)((m0 >> (lane * pw)) & ((1u << pw) - 1u));
+      Q.done_c[(base >> log2pw) + lane] = (uint32_t)((m1 >> (lane * pw)) & ((1u << pw) - 1u));
     }
     const unsigned long long mo = __builtin_amdgcn_ballot_w64(origin);
     if (origin) Q.tu[n_tus + __popcll(mo & ((1ull << lane) - 1ull))] = e;
@@ -483,10 +500,6 @@ __device__ inline void intra_ctu(const PicDev& P, int comp, int ctu, IntraLds& L
   }
   wave_lds_sync();
   // ---- 2. what each TU depends on (lane-parallel over the list)
-  auto footprint = [&](const TuRun& e, int& x4, int& y4, int& U) {     // in 4x4 luma units of the CTU
-    x4 = zscan_x(e.z); y4 = zscan_y(e.z);
-    U = e.kind ? (1 << (e.log2n - 2)) : max(1, ((1 << e.log2n) << cs) >> 2);
-  };
   for (int i = lane; i < n_tus; i += 64) {
     const TuRun e = Q.tu[i];
     int x4, y4, U;
@@ -504,46 +517,58 @@ __device__ inline void intra_ctu(const PicDev& P, int comp, int ctu, IntraLds& L
     Q.need_col[i] = nc; Q.need_row[i] = nr;
   }
   wave_lds_sync();
-  // ---- 3. publish what is final before anything ran (the neighbours may pass inter areas at once), then run
-  uint32_t word = (uint32_t)Q.done_c[pw - 1] | ((uint32_t)Q.done_r[pw - 1] << 16);
-  publish_progress(nb.prog, ctu, word);
-  // pending TUs: lane l keeps bit k for list entry l + 64 k.  The list is in priority order, so a scan tests the 64 entries from the first
-  // pending one on and takes the first that is ready.
-  unsigned left = 0;
-  for (int k = 0; k < 4; k++) if (lane + 64 * k < n_tus) left |= 1u << k;
-  int remaining = n_tus, first = 0;
+    // ---- 3. what is final before anything ran (the neighbours may pass inter areas at once), the pending mask
+    if (lane < 8) Q.pend[lane] = n_tus >= 32 * (lane + 1) ? 0xffffffffu : (n_tus > 32 * lane ? (1u << (n_tus - 32 * lane)) - 1u : 0u);
+    if (lane == 0) { Q.n_tus = n_tus; Q.running = 0; }
+    wave_lds_sync();
+    const uint32_t word0 = Q.done_c[pw - 1] | (Q.done_r[pw - 1] << 16);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane == 0 && word0) __hip_atomic_fetch_or(nb.prog + ctu, word0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __syncthreads();
+  const int n_tus = Q.n_tus;
   uint32_t spins = 0;
-  while (remaining > 0) {
+  for (;;) {
+    // the first list entry that is pending and ready (the list is in priority order); the pending masks may be stale by the time the
+    // entry is claimed: the atomic AND decides
     int i = -1;
-    for (int wbase = first & ~63; wbase < n_tus && i < 0; wbase += 64) {
+    bool any_pending = false;
+    for (int wbase = 0; wbase < n_tus && i < 0; wbase += 64) {
       const int c = wbase + lane;
+      const uint32_t pm = Q.pend[c >> 5];
+      const bool pending = c < n_tus && ((pm >> (c & 31)) & 1);
       bool ready = false;
-      if ((left >> (wbase >> 6)) & 1) {
+      if (pending) {
         const TuRun e = Q.tu[c];
         const int x4 = zscan_x(e.z), y4 = zscan_y(e.z);
         const uint32_t have_c = x4 == 0 ? nb.ext_col : Q.done_c[x4 - 1];
         const uint64_t have_r = y4 == 0 ? nb.ext_row : ((uint64_t)Q.done_r[y4 - 1] << 1) | 1ull;
         ready = (Q.need_col[c] & ~have_c) == 0 && (Q.need_row[c] & ~have_r) == 0;
       }
+      any_pending |= __builtin_amdgcn_ballot_w64(pending) != 0;
       const unsigned long long m = __builtin_amdgcn_ballot_w64(ready);
       if (m) i = wbase + (int)__builtin_ctzll(m);
     }
     if (i < 0) {
-      // nothing can run: the neighbours have to get further
+      if (!any_pending) break;                               // every TU is taken: the waves that hold one finish it
       if (nb.broken) break;
-      __builtin_amdgcn_s_sleep(8);
-      if (++spins > (1u << 22)) { if (lane == 0) atomicOr(P.fault, 1u); nb.broken = true; }
-      poll_neighbours(P, nb, pw);
+      // nothing this wave can run: either another wave is inside a TU whose units will make one ready, or the neighbours have to get further
+      __builtin_amdgcn_s_sleep(4);
+      ++spins;
+      if (__hip_atomic_load(&Q.running, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0 || (spins & 15) == 0) {
+        if (spins > (1u << 22)) { if (lane == 0) atomicOr(P.fault, 1u); nb.broken = true; }
+        poll_neighbours(P, nb, pw);
+      }
       continue;
     }
-    if ((i & 63) == lane) left &= ~(1u << (i >> 6));
-    remaining--;
-    {
-      // first pending entry (for the next scan's window): lowest set bit over the lanes' masks
-      const unsigned long long p0 = __builtin_amdgcn_ballot_w64((left & 1u) != 0), p1 = __builtin_amdgcn_ballot_w64((left & 2u) != 0),
-                               p2 = __builtin_amdgcn_ballot_w64((left & 4u) != 0), p3 = __builtin_amdgcn_ballot_w64((left & 8u) != 0);
-      first = p0 ? (int)__builtin_ctzll(p0) : p1 ? 64 + (int)__builtin_ctzll(p1) : p2 ? 128 + (int)__builtin_ctzll(p2) : p3 ? 192 + (int)__builtin_ctzll(p3) : 0;
+    // claim it
+    uint32_t old = 0;
+    if (lane == 0) {
+      old = atomicAnd(&Q.pend[i >> 5], ~(1u << (i & 31)));
+      if ((old >> (i & 31)) & 1) atomicAdd(&Q.running, 1);
     }
+    old = (uint32_t)__builtin_amdgcn_readfirstlane((int)old);
+    if (!((old >> (i & 31)) & 1)) continue;                  // another wave was faster
     const TuRun e = Q.tu[i];
     int x4, y4, U;
     footprint(e, x4, y4, U);
@@ -591,15 +616,19 @@ __device__ inline void intra_ctu(const PicDev& P, int comp, int ctu, IntraLds& L
         t.lev_off = (comp ? 4 : 16) * zc;
       }
       fetch_border(P, comp, ctu, x4 == 0 ? Q.need_col[i] : 0u, y4 == 0 ? Q.need_row[i] : 0ull, nb, L);
-      intra_tu_any(P, t, L);
+      intra_tu_any(P, t, L, W);
     }
+    wave_lds_sync();                                         // the TU's samples are in the CTU copy before its units count as final
     mark_done(x4, y4, U);
-    wave_lds_sync();
+    if (lane == 0) atomicSub(&Q.running, 1);
     if (x4 + U == pw || y4 + U == pw) {
-      const uint32_t w2 = (uint32_t)Q.done_c[pw - 1] | ((uint32_t)Q.done_r[pw - 1] << 16);
-      if (w2 != word) { word = w2; publish_progress(nb.prog, ctu, word); }
+      // the neighbours are shown THIS TU's border units, once its stores are acknowledged
+      const uint32_t bits = (x4 + U == pw ? ((1u << U) - 1u) << y4 : 0u) | (y4 + U == pw ? (((1u << U) - 1u) << x4) << 16 : 0u);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (lane == 0) __hip_atomic_fetch_or(nb.prog + ctu, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
 }  // namespace
@@ -610,9 +639,10 @@ __device__ inline void intra_ctu(const PicDev& P, int comp, int ctu, IntraLds& L
 // degenerates into the classic CTU wavefront.  `order` lists the CTUs by anti-diagonal (2*row + column): all four
 // neighbours lie on earlier diagonals, so every block a block can wait for has a smaller linear index and was dispatched
 // before it (no deadlock however few blocks are resident), and the blocks resident at any time are the wavefront itself.
-__global__ void __launch_bounds__(64) k_intra(const PicDev* __restrict__ pics, Batch b, const int32_t* __restrict__ order) {
+__global__ void __launch_bounds__(64 * INTRA_WAVES) k_intra(const PicDev* __restrict__ pics, Batch b, const int32_t* __restrict__ order) {
   __shared__ IntraLds L;
   __shared__ IntraSched Q;
+  __shared__ IntraScratch W[INTRA_WAVES];
   const int slot = blockIdx.x / 3, comp = blockIdx.x % 3, ctu = ldg(order + blockIdx.y);
   const PicDev& P = pics[b.pic[slot]];
   const int first = b.first_ctu[slot], last = first + b.num_ctus[slot] - 1;
@@ -637,7 +667,10 @@ __global__ void __launch_bounds__(64) k_intra(const PicDev* __restrict__ pics, B
     left = __builtin_amdgcn_ballot_w64(l) != 0; right = __builtin_amdgcn_ballot_w64(r) != 0;
     top = __builtin_amdgcn_ballot_w64(t) != 0; bottom = __builtin_amdgcn_ballot_w64(bm) != 0;
   };
-  // the levels of this CTU do not depend on anybody: on their way into LDS while the neighbours finish
+  // the levels of this CTU do not depend on anybody: on their way into LDS while the neighbours finish (wave 0 stages; the others
+  // join at the barrier in front of the TU loop)
+  const int wv = threadIdx.x >> 6;
+  if (wv == 0) {
   if (P.coef_start[0] != nullptr) {
     // compact levels: the CTU's coded TUs are one contiguous piece of the stream; where each 8x8 area's TUs start in it (k_prep)
     const uint32_t s0 = ldg(P.coef_start[comp] + ctu), s1 = ldg(P.coef_start[comp] + ctu + 1);
@@ -651,6 +684,7 @@ __global__ void __launch_bounds__(64) k_intra(const PicDev* __restrict__ pics, B
     for (int i = lane * 8; i < n_lev; i += 64 * 8) *reinterpret_cast<u32x4*>(&L.lev[i]) = ldg4(src + i);
   }
   intra_stage(P, comp, ctu, L);
+  }
   unsigned my_l, my_r, my_t, my_b;
   border_mask(ctu, my_l, my_r, my_t, my_b);
   Neighbours nbs;
@@ -675,13 +709,16 @@ __global__ void __launch_bounds__(64) k_intra(const PicDev* __restrict__ pics, B
   // at its next sync) instead of hanging the device.
   poll_neighbours(P, nbs, P.pw);
   wave_lds_sync();
-  intra_ctu(P, comp, ctu, L, Q, nbs);
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-  publish_progress(done, ctu, 0xffffffffu);
+  intra_ctu(P, comp, ctu, L, Q, W[wv], nbs);
+  __syncthreads();                                           // every wave's stores are acknowledged (intra_ctu ends with the wait)
+  if (wv == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    publish_progress(done, ctu, 0xffffffffu);
+  }
 }
 
 void launch_intra(const PicDev* pics, const Batch& b, const int32_t* order, int num_ctus, hipStream_t s) {
-  hipLaunchKernelGGL(k_intra, dim3((unsigned)b.n * 3, (unsigned)num_ctus), dim3(64), 0, s, pics, b, order);
+  hipLaunchKernelGGL(k_intra, dim3((unsigned)b.n * 3, (unsigned)num_ctus), dim3(64 * INTRA_WAVES), 0, s, pics, b, order);
 }
 
 }  // namespace hmgpu
