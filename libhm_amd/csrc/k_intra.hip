@@ -49,9 +49,6 @@ __device__ inline int ld_sample(const int16_t* p) {
   return (int)(int16_t)((a & 2) ? (w >> 16) : (w & 0xffffu));
 }
 
-#ifndef INTRA_WAVES
-#define INTRA_WAVES 4                    // waves per CTU and component: they run the CTU's ready TUs side by side (intra_ctu)
-#endif
 struct IntraScratch {                    // what ONE TU in flight needs: one per wave
   int line[4 * 32 + 4];                  // reference line: [0,2N) left column bottom-up, [2N] corner, (2N,4N] row above
   int filt[4 * 32 + 4];                  // the same after smoothing
@@ -82,7 +79,7 @@ struct TuCtx {
 // availability of the 4x4 luma partition at luma sample (px, py) as intra reference of the TU at (ctu, z_tu)
 // nb_same: bit k set = neighbouring CTU k (0 left, 1 above-left, 2 above, 3 above-right) lies in the same slice and tile, worked out
 // once per CTU; m_pred: the CTU's own prediction modes in LDS (constrained intra prediction)
-__device__ inline bool intra_avail(const PicDev& P, int ctu, int z_tu, int px, int py, bool cip, unsigned nb_same, const uint8_t* m_pred) {
+__device__ __attribute__((always_inline)) inline bool intra_avail(const PicDev& P, int ctu, int z_tu, int px, int py, bool cip, unsigned nb_same, const uint8_t* m_pred) {
   if (px < 0 || py < 0 || px >= P.width || py >= P.height) return false;
   const int ctu_mask = (1 << P.log2ctu) - 1;
   const int nctu = (py >> P.log2ctu) * P.ctus_w + (px >> P.log2ctu);
@@ -109,7 +106,7 @@ __device__ inline int wave_sum(int v) {
 
 // one TU: everything between "the neighbours are reconstructed" and "this TU is reconstructed"
 template <int LOG2N>
-__device__ inline void intra_tu(const PicDev& P, const TuCtx& t, IntraLds& L, IntraScratch& W) {
+__device__ __attribute__((always_inline)) inline void intra_tu(const PicDev& P, const TuCtx& t, IntraLds& L, IntraScratch& W) {
   constexpr int N = 1 << LOG2N;
   const int lane = threadIdx.x & 63;
   const int comp = t.comp, cs = comp ? 1 : 0;
@@ -287,7 +284,7 @@ __device__ inline void intra_tu(const PicDev& P, const TuCtx& t, IntraLds& L, In
   wave_lds_sync();
 }
 
-__device__ inline void intra_tu_any(const PicDev& P, const TuCtx& t, IntraLds& L, IntraScratch& W) {
+__device__ __attribute__((always_inline)) inline void intra_tu_any(const PicDev& P, const TuCtx& t, IntraLds& L, IntraScratch& W) {
   switch (t.log2n) {
     case 2: intra_tu<2>(P, t, L, W); break;
     case 3: intra_tu<3>(P, t, L, W); break;
@@ -298,7 +295,7 @@ __device__ inline void intra_tu_any(const PicDev& P, const TuCtx& t, IntraLds& L
 
 // what a CTU can fetch before its neighbours are finished: its TComDataCU arrays and its own samples (inter CUs are final --
 // written by earlier launches --, intra ones get overwritten below)
-__device__ inline void intra_stage(const PicDev& P, int comp, int ctu, IntraLds& L) {
+__device__ __attribute__((always_inline)) inline void intra_stage(const PicDev& P, int comp, int ctu, IntraLds& L) {
   const int parts = P.parts;
   const size_t base = (size_t)ctu * parts;
   const int ctu_x = (ctu % P.ctus_w) << P.log2ctu, ctu_y = (ctu / P.ctus_w) << P.log2ctu;
@@ -369,13 +366,13 @@ __device__ inline int z_of(int x, int y) {
 // neighbour sample it loads an agent-scope atomic load, so no cache has to be written back or invalidated around the progress word: the
 // producer waits until its stores are acknowledged, the consumer issues its loads after it has seen the bits.  (Agent-scope
 // release / acquire FENCES also write back / invalidate L2 for ordinary accesses: per publication that cost more than it gained.)
-__device__ inline void publish_progress(uint32_t* prog, int ctu, uint32_t word) {
+__device__ __attribute__((always_inline)) inline void publish_progress(uint32_t* prog, int ctu, uint32_t word) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   if ((threadIdx.x & 63) == 0) __hip_atomic_store(prog + ctu, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // the neighbours' published words -> ext_col / ext_row
-__device__ inline void poll_neighbours(const PicDev& P, Neighbours& nb, int pw) {
+__device__ __attribute__((always_inline)) inline void poll_neighbours(const PicDev& P, Neighbours& nb, int pw) {
   const uint32_t full = (1u << pw) - 1u;
   uint32_t w[4];
 #pragma unroll
@@ -386,7 +383,7 @@ __device__ inline void poll_neighbours(const PicDev& P, Neighbours& nb, int pw) 
 }
 
 // samples of the neighbouring CTUs' border units the TU needs (all final: the TU was ready) into LDS, unless there already
-__device__ inline void fetch_border(const PicDev& P, int comp, int ctu, uint32_t need_col, uint64_t need_row, Neighbours& nb, IntraLds& L) {
+__device__ __attribute__((always_inline)) inline void fetch_border(const PicDev& P, int comp, int ctu, uint32_t need_col, uint64_t need_row, Neighbours& nb, IntraLds& L) {
   const int cs = comp ? 1 : 0, lane = threadIdx.x & 63, us = 4 >> cs;
   const int ctu_x = (ctu % P.ctus_w) << P.log2ctu, ctu_y = (ctu / P.ctus_w) << P.log2ctu;
   const int16_t* org = P.rec[comp] + (ptrdiff_t)(ctu_y >> cs) * P.pitch[comp] + (ctu_x >> cs);
@@ -415,12 +412,12 @@ __device__ inline void fetch_border(const PicDev& P, int comp, int ctu, uint32_t
   wave_lds_sync();
 }
 
-// all intra CUs of one CTU, one component (xReconIntraQT per CU, xIntraRecQT over its TU tree), in dependency order, by the INTRA_WAVES
+// all intra CUs of one CTU, one component (xReconIntraQT per CU, xIntraRecQT over its TU tree), in dependency order, by the
 // waves of the workgroup: wave 0 lists the TUs and what they depend on, then every wave takes, again and again, the first TU of the list
 // that is ready and that nobody has taken (an atomic AND on the pending mask), runs it and marks its units final (atomic ORs).  TUs that
 // do not depend on each other -- the next ones along an anti-diagonal of the CTU -- run side by side; the CTU's samples, the done masks
 // and the list are shared in LDS, the reference line / transform scratch of a TU in flight is the wave's own (IntraScratch).
-__device__ inline void intra_ctu(const PicDev& P, int comp, int ctu, IntraLds& L, IntraSched& Q, IntraScratch& W, Neighbours& nb) {
+__device__ __attribute__((always_inline)) inline void intra_ctu(const PicDev& P, int comp, int ctu, IntraLds& L, IntraSched& Q, IntraScratch& W, Neighbours& nb) {
   const bool compact = P.coef_start[0] != nullptr;
   const int parts = P.parts, pw = P.pw;
   const int ctu_x = (ctu % P.ctus_w) << P.log2ctu, ctu_y = (ctu / P.ctus_w) << P.log2ctu;
@@ -639,10 +636,11 @@ __device__ inline void intra_ctu(const PicDev& P, int comp, int ctu, IntraLds& L
 // degenerates into the classic CTU wavefront.  `order` lists the CTUs by anti-diagonal (2*row + column): all four
 // neighbours lie on earlier diagonals, so every block a block can wait for has a smaller linear index and was dispatched
 // before it (no deadlock however few blocks are resident), and the blocks resident at any time are the wavefront itself.
-__global__ void __launch_bounds__(64 * INTRA_WAVES) k_intra(const PicDev* __restrict__ pics, Batch b, const int32_t* __restrict__ order) {
+template <int WAVES>                     // waves per CTU and component: they run the CTU's ready TUs side by side (intra_ctu)
+__global__ void __launch_bounds__(64 * WAVES) k_intra(const PicDev* __restrict__ pics, Batch b, const int32_t* __restrict__ order) {
   __shared__ IntraLds L;
   __shared__ IntraSched Q;
-  __shared__ IntraScratch W[INTRA_WAVES];
+  __shared__ IntraScratch W[WAVES];
   const int slot = blockIdx.x / 3, comp = blockIdx.x % 3, ctu = ldg(order + blockIdx.y);
   const PicDev& P = pics[b.pic[slot]];
   const int first = b.first_ctu[slot], last = first + b.num_ctus[slot] - 1;
@@ -718,7 +716,13 @@ __global__ void __launch_bounds__(64 * INTRA_WAVES) k_intra(const PicDev* __rest
 }
 
 void launch_intra(const PicDev* pics, const Batch& b, const int32_t* order, int num_ctus, hipStream_t s) {
-  hipLaunchKernelGGL(k_intra, dim3((unsigned)b.n * 3, (unsigned)num_ctus), dim3(64 * INTRA_WAVES), 0, s, pics, b, order);
+  // measured on 2160p I pictures: one picture 17.9 / 11.6 / 9.7 ms with 1 / 2 / 4 waves per CTU, sixteen at once 19.4 / 13.5 / 17.7
+#ifndef INTRA_WAVES_ONE
+#define INTRA_WAVES_ONE 4
+#define INTRA_WAVES_MANY 2
+#endif
+  if (b.n >= 4) hipLaunchKernelGGL(k_intra<INTRA_WAVES_MANY>, dim3((unsigned)b.n * 3, (unsigned)num_ctus), dim3(64 * INTRA_WAVES_MANY), 0, s, pics, b, order);
+  else hipLaunchKernelGGL(k_intra<INTRA_WAVES_ONE>, dim3((unsigned)b.n * 3, (unsigned)num_ctus), dim3(64 * INTRA_WAVES_ONE), 0, s, pics, b, order);
 }
 
 }  // namespace hmgpu
