@@ -301,7 +301,7 @@ __device__ __attribute__((always_inline)) inline void intra_stage(const PicDev& 
   const int ctu_x = (ctu % P.ctus_w) << P.log2ctu, ctu_y = (ctu / P.ctus_w) << P.log2ctu;
   const int cs = comp ? 1 : 0;
   const int lane = threadIdx.x & 63;
-  if (4 * lane < parts) {
+  if (threadIdx.x < 64 && 4 * lane < parts) {
     const size_t o = base + 4 * lane;
     auto dw = [&](const void* p) { return ldg(reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint8_t*>(p) + o)); };
     const uint32_t a0 = dw(P.depth), a1 = dw(P.part_size), a2 = dw(P.pred_mode), a3 = dw(P.tr_idx), a4 = dw(P.qp), a5 = dw(P.cbf[comp]),
@@ -315,7 +315,7 @@ __device__ __attribute__((always_inline)) inline void intra_stage(const PicDev& 
     const int16_t* org = P.rec[comp] + (ptrdiff_t)(ctu_y >> cs) * P.pitch[comp] + (ctu_x >> cs);
     // the interior was written by the MC / residual kernels (earlier launches): plain 16-byte loads
     const int vpr = S / 8;                                  // 16-byte vectors per row
-    for (int i = lane; i < S * vpr; i += 64) {
+    for (int i = threadIdx.x; i < S * vpr; i += blockDim.x) {
       const int r = i / vpr, v = i % vpr;
       const u32x4 q = ldg4(org + (ptrdiff_t)r * P.pitch[comp] + 8 * v);
       uint32_t* d = reinterpret_cast<uint32_t*>(&L.pix[r][2 + 8 * v]);
@@ -665,21 +665,21 @@ __global__ void __launch_bounds__(64 * WAVES) k_intra(const PicDev* __restrict__
     left = __builtin_amdgcn_ballot_w64(l) != 0; right = __builtin_amdgcn_ballot_w64(r) != 0;
     top = __builtin_amdgcn_ballot_w64(t) != 0; bottom = __builtin_amdgcn_ballot_w64(bm) != 0;
   };
-  // the levels of this CTU do not depend on anybody: on their way into LDS while the neighbours finish (wave 0 stages; the others
-  // join at the barrier in front of the TU loop)
+  // the levels of this CTU do not depend on anybody: on their way into LDS while the neighbours finish (all threads of the workgroup stage; the
+  // barrier in front of the TU loop orders it)
   const int wv = threadIdx.x >> 6;
-  if (wv == 0) {
+  {
   if (P.coef_start[0] != nullptr) {
     // compact levels: the CTU's coded TUs are one contiguous piece of the stream; where each 8x8 area's TUs start in it (k_prep)
     const uint32_t s0 = ldg(P.coef_start[comp] + ctu), s1 = ldg(P.coef_start[comp] + ctu + 1);
     const int16_t* src = P.coef[comp] + s0;
-    for (uint32_t i = (uint32_t)lane * 8; i < s1 - s0; i += 64 * 8) *reinterpret_cast<u32x4*>(&L.lev[i]) = ldg4(src + i);
+    for (uint32_t i = threadIdx.x * 8u; i < s1 - s0; i += blockDim.x * 8u) *reinterpret_cast<u32x4*>(&L.lev[i]) = ldg4(src + i);
     const int qpc = P.parts >> 2;
-    if (lane < qpc) L.qoff[lane] = ldg(P.quad_off[comp] + (size_t)ctu * qpc + lane) - s0;
+    if ((int)threadIdx.x < qpc) L.qoff[threadIdx.x] = ldg(P.quad_off[comp] + (size_t)ctu * qpc + threadIdx.x) - s0;
   } else {
     const int n_lev = (1 << (2 * P.log2ctu)) >> (comp ? 2 : 0);
     const int16_t* src = P.coef[comp] + (size_t)ctu * n_lev;
-    for (int i = lane * 8; i < n_lev; i += 64 * 8) *reinterpret_cast<u32x4*>(&L.lev[i]) = ldg4(src + i);
+    for (int i = threadIdx.x * 8; i < n_lev; i += blockDim.x * 8) *reinterpret_cast<u32x4*>(&L.lev[i]) = ldg4(src + i);
   }
   intra_stage(P, comp, ctu, L);
   }
