@@ -340,6 +340,7 @@ struct IntraSched {
   uint32_t need_col[256];        // bit y: unit (x4 - 1, y) of the column left of the TU must be final (the left CTU's last column when x4 = 0)
   uint64_t need_row[256];        // bit c + 1: unit (c, y4 - 1), c = -1 .. 31, of the row above the TU (the row of the CTUs above when y4 = 0)
   uint32_t done_r[16], done_c[16];   // final units per row (bit x) / per column (bit y); set with LDS atomics by the wave that finished a TU
+  uint32_t got[3];                   // border units of the neighbouring CTUs whose samples are in LDS (L.pix columns 0, 1 / L.top): column | row lo | row hi
   uint32_t pend[8];                  // list entries nobody has taken yet (bit i & 31 of pend[i >> 5]); a wave takes one with an atomic AND
   int32_t n_tus, running;            // list length; waves inside a TU right now
 };
@@ -350,8 +351,6 @@ struct Neighbours {
   bool wait[4];              // the neighbour is reconstructed by this launch and its border towards this CTU holds intra samples
   uint32_t ext_col;          // final units of the left CTU's last column
   uint64_t ext_row;          // final units of the row above the CTU: bit 0 above-left CTU's corner unit, 1..16 above, 17..32 above-right
-  uint32_t got_col;          // units whose samples are in LDS already (L.pix columns 0, 1 / L.top)
-  uint64_t got_row;
   bool broken;               // a wait gave up (fault flagged): no further waiting in this block
 };
 
@@ -383,12 +382,14 @@ __device__ __attribute__((always_inline)) inline void poll_neighbours(const PicD
 }
 
 // samples of the neighbouring CTUs' border units the TU needs (all final: the TU was ready) into LDS, unless there already
-__device__ __attribute__((always_inline)) inline void fetch_border(const PicDev& P, int comp, int ctu, uint32_t need_col, uint64_t need_row, Neighbours& nb, IntraLds& L) {
+// (the masks of what has been fetched are shared by the waves of the workgroup: a wave with nothing to run fetches what has become final
+// next door, so that the TUs along the CTU's left and top border find their reference samples in LDS)
+__device__ __attribute__((always_inline)) inline void fetch_border(const PicDev& P, int comp, int ctu, uint32_t need_col, uint64_t need_row, IntraSched& Q, IntraLds& L) {
   const int cs = comp ? 1 : 0, lane = threadIdx.x & 63, us = 4 >> cs;
   const int ctu_x = (ctu % P.ctus_w) << P.log2ctu, ctu_y = (ctu / P.ctus_w) << P.log2ctu;
   const int16_t* org = P.rec[comp] + (ptrdiff_t)(ctu_y >> cs) * P.pitch[comp] + (ctu_x >> cs);
-  const uint32_t mc = need_col & ~nb.got_col;
-  const uint64_t mr = need_row & ~nb.got_row;
+  const uint32_t mc = need_col & ~Q.got[0];
+  const uint64_t mr = need_row & ~((uint64_t)Q.got[1] | ((uint64_t)Q.got[2] << 32));
   if (!mc && !mr) return;
   if (mc) {
     // unit u = rows u * us .. + us - 1 of the two columns left of the CTU: one dword per row
@@ -397,7 +398,6 @@ __device__ __attribute__((always_inline)) inline void fetch_border(const PicDev&
       const int row = u * us + r;
       reinterpret_cast<uint32_t*>(&L.pix[row][0])[0] = ld_coh(reinterpret_cast<const uint32_t*>(org + (ptrdiff_t)row * P.pitch[comp] - 2));
     }
-    nb.got_col |= mc;
   }
   if (mr) {
     // dword d of top[] = columns 2d - 2, 2d - 1; unit c (-1 .. 31) = columns c * us .. + us - 1
@@ -407,9 +407,12 @@ __device__ __attribute__((always_inline)) inline void fetch_border(const PicDev&
       const int c = col < 0 ? -1 : col / us;
       if ((mr >> (c + 1)) & 1) reinterpret_cast<uint32_t*>(L.top)[d] = ld_coh(reinterpret_cast<const uint32_t*>(org - P.pitch[comp] - 2) + d);
     }
-    nb.got_row |= mr;
   }
   wave_lds_sync();
+  if (lane == 0) {
+    if (mc) atomicOr(&Q.got[0], mc);
+    if (mr) { atomicOr(&Q.got[1], (uint32_t)mr); atomicOr(&Q.got[2], (uint32_t)(mr >> 32)); }
+  }
 }
 
 // all intra CUs of one CTU, one component (xReconIntraQT per CU, xIntraRecQT over its TU tree), in dependency order, by the
@@ -517,6 +520,7 @@ __device__ __attribute__((always_inline)) inline void intra_ctu(const PicDev& P,
     // ---- 3. what is final before anything ran (the neighbours may pass inter areas at once), the pending mask
     if (lane < 8) Q.pend[lane] = n_tus >= 32 * (lane + 1) ? 0xffffffffu : (n_tus > 32 * lane ? (1u << (n_tus - 32 * lane)) - 1u : 0u);
     if (lane == 0) { Q.n_tus = n_tus; Q.running = 0; }
+    if (lane < 3) Q.got[lane] = 0;
     wave_lds_sync();
     const uint32_t word0 = Q.done_c[pw - 1] | (Q.done_r[pw - 1] << 16);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -525,6 +529,7 @@ __device__ __attribute__((always_inline)) inline void intra_ctu(const PicDev& P,
   __syncthreads();
   const int n_tus = Q.n_tus;
   uint32_t spins = 0;
+  if (wv == (int)(blockDim.x >> 6) - 1) fetch_border(P, comp, ctu, nb.ext_col, nb.ext_row, Q, L);   // what is final next door already
   for (;;) {
     // the first list entry that is pending and ready (the list is in priority order); the pending masks may be stale by the time the
     // entry is claimed: the atomic AND decides
@@ -555,6 +560,7 @@ __device__ __attribute__((always_inline)) inline void intra_ctu(const PicDev& P,
       if (__hip_atomic_load(&Q.running, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0 || (spins & 15) == 0) {
         if (spins > (1u << 22)) { if (lane == 0) atomicOr(P.fault, 1u); nb.broken = true; }
         poll_neighbours(P, nb, pw);
+        fetch_border(P, comp, ctu, nb.ext_col, nb.ext_row, Q, L);   // whatever has become final next door
       }
       continue;
     }
@@ -612,7 +618,7 @@ __device__ __attribute__((always_inline)) inline void intra_ctu(const PicDev& P,
       } else {
         t.lev_off = (comp ? 4 : 16) * zc;
       }
-      fetch_border(P, comp, ctu, x4 == 0 ? Q.need_col[i] : 0u, y4 == 0 ? Q.need_row[i] : 0ull, nb, L);
+      fetch_border(P, comp, ctu, x4 == 0 ? Q.need_col[i] : 0u, y4 == 0 ? Q.need_row[i] : 0ull, Q, L);
       intra_tu_any(P, t, L, W);
     }
     wave_lds_sync();                                         // the TU's samples are in the CTU copy before its units count as final
@@ -686,7 +692,7 @@ __global__ void __launch_bounds__(64 * WAVES) k_intra(const PicDev* __restrict__
   unsigned my_l, my_r, my_t, my_b;
   border_mask(ctu, my_l, my_r, my_t, my_b);
   Neighbours nbs;
-  nbs.prog = done; nbs.got_col = 0; nbs.got_row = 0; nbs.broken = false;
+  nbs.prog = done; nbs.broken = false;
 #pragma unroll
   for (int k = 0; k < 4; k++) {
     const int n = nb[k];
