@@ -63,13 +63,14 @@ __device__ inline uint32_t pk_sub(uint32_t a, uint32_t b) {                     
 // ---- tap tables: entry (fraction f, parity p) of an N-tap filter c[]: with A = (c0,c1)(c2,c3).. and B = (0,c0)(c1,c2)..(c[N-1],0)
 //   p = 0: even columns A,0   odd columns B        p = 1: even columns B   odd columns 0,A
 // (column x of a window that starts in the high half of its first dword begins one sample later than its dword)
-struct alignas(16) TapsLuma { uint32_t e[8][12]; };
+struct alignas(16) TapsLuma { uint32_t e[12][12]; };   // fractions 0..3, then the identity at tap 0 (4) and at tap 4 (5)
 struct alignas(16) TapsChroma { uint32_t e[16][8]; };
 constexpr uint32_t pk16(int a, int b) { return ((uint32_t)a & 0xffffu) | ((uint32_t)b << 16); }
 constexpr TapsLuma make_taps_luma() {
-  constexpr int c[4][8] = {{0, 0, 0, 64, 0, 0, 0, 0}, {-1, 4, -10, 58, 17, -5, 1, 0}, {-1, 4, -11, 40, 40, -11, 4, -1}, {0, 1, -5, 17, 58, -10, 4, -1}};
+  constexpr int c[6][8] = {{0, 0, 0, 64, 0, 0, 0, 0}, {-1, 4, -10, 58, 17, -5, 1, 0}, {-1, 4, -11, 40, 40, -11, 4, -1}, {0, 1, -5, 17, 58, -10, 4, -1},
+                           {64, 0, 0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 64, 0, 0, 0}};
   TapsLuma t = {};
-  for (int f = 0; f < 4; f++)
+  for (int f = 0; f < 6; f++)
     for (int p = 0; p < 2; p++) {
       uint32_t A[5] = {}, B[5] = {};
       for (int j = 0; j < 4; j++) A[j] = pk16(c[f][2 * j], c[f][2 * j + 1]);
@@ -123,7 +124,7 @@ __device__ inline uint32_t pack_shr(int lo, int hi, int sh) {
 template <bool CHROMA> struct McLds {
   static constexpr int ROW_DW = CHROMA ? 128 : 256;           // dwords per tile row
   struct { uint32_t body[2 * ROW_DW], halo[2 * ROW_DW]; } w[4];   // halo: the first 8 (4) window rows of run tops, at the top tile's position
-  uint32_t taps[CHROMA ? 128 : 96];                           // the tap table (every wave writes the same values, reads its own)
+  uint32_t taps[CHROMA ? 128 : 144];                           // the tap table (every wave writes the same values, reads its own)
 #ifdef MC_LDS_PAD
   uint32_t pad[MC_LDS_PAD / 4];                               // experiment: fewer workgroups per CU
 #endif
@@ -244,10 +245,32 @@ __device__ inline bool tile_is_top(const u32x4 tm, int r, int partner_lane) {
 
 // address of sample (0,0) of the final luma / Cb plane of device picture `ref` (all pictures of a context live in one slab, a
 // finished picture is its SAO output or, without SAO, its reconstruction)
-__device__ inline const char* final_plane(const McArgs& a, int ref) {
+#ifdef MC_BUF
+// window loads as buffer loads: 32-bit byte offsets from the slab, and a lane without a work item gets an offset past the end
+// of the buffer -- the range check answers it with zeros and nothing goes to memory (slabs under kWinLimit bytes)
+constexpr uint32_t kWinLimit = 0xf0000000u;
+typedef uint32_t wref;
+typedef __amdgpu_buffer_rsrc_t wbase;
+__device__ inline wbase win_base(const McArgs& a) { return __builtin_amdgcn_make_buffer_rsrc((void*)a.slab, 0, kWinLimit, 0x00020000); }
+__device__ inline wref win_nowhere(const McArgs& a, int slot) { return kWinLimit; }
+__device__ inline wref final_plane(const McArgs& a, int ref) {
+  const uint32_t m = ref & 32 ? a.sao_mask_hi : a.sao_mask_lo;
+  return (uint32_t)ref * (uint32_t)a.pic_stride + (__builtin_amdgcn_ubfe(m, (uint32_t)ref & 31u, 1u) ? a.sao_off : 0u) + a.origin_off;
+}
+__device__ inline wref win_at(wref plane, int row, int pitch, int x) { return plane + (uint32_t)((row * pitch + x) * 2); }
+__device__ inline u32x4 win_load(wbase b, wref o) { return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(b, o, 0, 0)); }
+#else
+typedef const char* wref;
+typedef int wbase;
+__device__ inline wbase win_base(const McArgs& a) { return 0; }
+__device__ inline wref win_nowhere(const McArgs& a, int slot) { return reinterpret_cast<const char*>(a.tmv[slot]); }   // valid memory
+__device__ inline wref final_plane(const McArgs& a, int ref) {
   const uint32_t m = ref & 32 ? a.sao_mask_hi : a.sao_mask_lo;
   return a.slab + (size_t)(uint32_t)ref * a.pic_stride + (__builtin_amdgcn_ubfe(m, (uint32_t)ref & 31u, 1u) ? a.sao_off : 0u) + a.origin_off;
 }
+__device__ inline wref win_at(wref plane, int row, int pitch, int x) { return plane + ((ptrdiff_t)row * pitch + x) * 2; }
+__device__ inline u32x4 win_load(wbase, wref p) { return ldg4_a4(p); }
+#endif
 
 // ======================================================================================================== luma
 // H pass work item: window rows (2i, 2i+1) x 8 columns.  r[0..1] = first row (8 dwords = 16 samples), r[2..3] = second row;
@@ -294,7 +317,7 @@ __global__ void __launch_bounds__(256, (WP || BI) ? 1 : MC_LB_LUMA) k_mc_luma(co
   const int x0 = g.sx + tx * 8, y0 = g.sy + wave * 16 + r * 8;
   // ---- prologue: the lane's tile record, the tap table
   const u32x4 tm = load_tile_rec(a, slot, g, x0, y0);
-  if (lane < 48) *reinterpret_cast<u32x2*>(&S.taps[2 * lane]) = ldg2(&g_taps_luma.e[0][0] + 2 * lane);
+  if (lane < 36) *reinterpret_cast<u32x4*>(&S.taps[4 * lane]) = ldg4(&g_taps_luma.e[0][0] + 4 * lane);
   const uint32_t flags = tm.z >> 24, rmask = (tm.w >> 8) & 0xff;
   const bool active = (flags & TM_ACTIVE) != 0;
   if (!__ballot(active)) return;
@@ -309,7 +332,8 @@ __global__ void __launch_bounds__(256, (WP || BI) ? 1 : MC_LB_LUMA) k_mc_luma(co
   const int sh1 = 6 - head;
   uint32_t* const body_t = &S.w[wave].body[r * 256 + tx * 2];              // (r, piece 0, row pair 0, tx)
   uint32_t* const halo_t = &S.w[wave].halo[r * 256 + tx * 2];
-  const char* const dummy = reinterpret_cast<const char*>(a.tmv[slot]);   // where lanes without a work item load from (valid memory)
+  const wbase wb = win_base(a);
+  const wref nowhere = win_nowhere(a, slot);               // what lanes without a work item load from
   WpTile wp = {false, 1, 0, 1, 0, 0};
   if constexpr (WP) wp = wp_tile<WP>(a.slices[slot], flags, tm.w, 0);
   // the residual of output rows 2q, 2q+1 (two 16-byte slots of the tile's line in PicDev::resid; a row crosses two 4x4 quadrants, each
@@ -328,39 +352,80 @@ __global__ void __launch_bounds__(256, (WP || BI) ? 1 : MC_LB_LUMA) k_mc_luma(co
 #pragma unroll 1
   for (int pass = 0; pass < npass; pass++) {
     const bool bact = active && (pass == 0 || (flags & TM_BI));
-    const bool hact = bact && top;
     const uint32_t mv = pass ? tm.y : tm.x;
     const uint32_t fr = (tm.z >> (4 * pass)) & 15;
+#ifdef MC_F0
+    // no interpolation in a direction (a quarter of the vectors each): only the 8 rows / 8 columns of the block itself are read.
+    //   vertical: the window starts one row higher (identity tap 4 instead of 3), so the block's rows are window rows 4..11 -- the
+    //   second half of the halo item's rows and the first half of the body item's; the tile shares nothing with its neighbours and is
+    //   its own run.   horizontal: the window starts at the block's first column (identity tap 0): one 16-byte piece per row if that
+    //   column is even.  Rows and pieces that are not read meet zero taps only.
+    const bool yz = (fr & 12) == 0, xz = (fr & 3) == 0;
+    const bool ptop = top || yz;
+    const bool bon = bact && (!yz || q < 2), hon = bact && ptop && (!yz || q >= 2);
+    const int xs = x0 + (int)(int16_t)(mv & 0xffff) - (xz ? 0 : 3);
+    const bool two = !xz || (xs & 1);
+    const uint32_t* const tap = &S.taps[((xz ? 4u : (fr & 3)) * 2 + (xs & 1)) * 12];
+    const wref pw = win_at(final_plane(a, (int)((tm.z >> (8 + 8 * pass)) & (kMaxPics - 1))), y0 + ((int)mv >> 16) - (yz ? 4 : 3) + 2 * q, pitch, xs & ~1);
+    const uint32_t vidx = yz ? 5u : (fr >> 2) & 3;
+#else
+    const bool ptop = top, bon = bact, hon = bact && top, two = true;
     const int xs = x0 + (int)(int16_t)(mv & 0xffff) - 3;
     const uint32_t* const tap = &S.taps[((fr & 3) * 2 + (xs & 1)) * 12];
     // window row 2q of the tile (the halo item's first row; the body item's is 8 rows down)
-    const char* const pw = final_plane(a, (int)((tm.z >> (8 + 8 * pass)) & (kMaxPics - 1))) +
-                           ((ptrdiff_t)(y0 + ((int)mv >> 16) - 3 + 2 * q) * pitch + (xs & ~1)) * 2;
+    const wref pw = win_at(final_plane(a, (int)((tm.z >> (8 + 8 * pass)) & (kMaxPics - 1))), y0 + ((int)mv >> 16) - 3 + 2 * q, pitch, xs & ~1);
+    const uint32_t vidx = (fr >> 2) & 3;
+#endif
+#if defined(MC_EXP) && (MC_EXP & 4)         // experiment: half of the lanes load
+    const bool lon = (q & 1) == 0;
+#else
+    const bool lon = true;
+#endif
     // the H pass of the lane's body item and, in waves that hold run tops, of its halo item.  Loads are unconditional (lanes without
-    // an item read a dummy address): values that are only defined in some lanes would have to be initialised in the others
+    // an item read nowhere): values that are only defined in some lanes would have to be initialised in the others
     auto h_phase = [&](auto with_halo) {
       constexpr bool HALO = decltype(with_halo)::value;
       u32x4 rb[4], rh[4];
       {
-        const char* p0 = bact ? pw + (ptrdiff_t)pitch * 16 : dummy;
-        rb[0] = ldg4_a4(p0); rb[1] = ldg4_a4(p0 + 16); rb[2] = ldg4_a4(p0 + pitch * 2); rb[3] = ldg4_a4(p0 + pitch * 2 + 16);
+#if defined(MC_EXP) && (MC_EXP & 16)        // experiment: no second pieces
+        const wref p0 = bon && lon ? pw + pitch * 16 : nowhere, p1 = nowhere;
+#else
+        const wref p0 = bon && lon ? pw + pitch * 16 : nowhere, p1 = bon && lon && two ? p0 + 16 : nowhere;
+#endif
+        rb[0] = win_load(wb, p0); rb[1] = win_load(wb, p1);
+#if defined(MC_EXP) && (MC_EXP & 8)         // experiment: half of the load instructions
+        rb[2] = rb[0]; rb[3] = rb[1];
+#else
+        rb[2] = win_load(wb, p0 + pitch * 2); rb[3] = win_load(wb, p1 + pitch * 2);
+#endif
       }
       if constexpr (HALO) {
-        const char* p0 = hact ? pw : dummy;
-        rh[0] = ldg4_a4(p0); rh[1] = ldg4_a4(p0 + 16); rh[2] = ldg4_a4(p0 + pitch * 2); rh[3] = ldg4_a4(p0 + pitch * 2 + 16);
+#if defined(MC_EXP) && (MC_EXP & 32)        // experiment: no halo rows
+        const wref p0 = nowhere, p1 = nowhere;
+#elif defined(MC_EXP) && (MC_EXP & 16)
+        const wref p0 = hon && lon ? pw : nowhere, p1 = nowhere;
+#else
+        const wref p0 = hon && lon ? pw : nowhere, p1 = hon && lon && two ? p0 + 16 : nowhere;
+#endif
+        rh[0] = win_load(wb, p0); rh[1] = win_load(wb, p1);
+#if defined(MC_EXP) && (MC_EXP & 8)
+        rh[2] = rh[0]; rh[3] = rh[1];
+#else
+        rh[2] = win_load(wb, p0 + pitch * 2); rh[3] = win_load(wb, p1 + pitch * 2);
+#endif
       }
 #ifdef MC_PRIO
       __builtin_amdgcn_s_setprio(0);
 #endif
-      if (bact) h_item_luma(rb, tap, sh1, body_t + q * 16);
-      if constexpr (HALO) { if (hact) h_item_luma(rh, tap, sh1, halo_t + q * 16); }
+      if (bon) h_item_luma(rb, tap, sh1, body_t + q * 16);
+      if constexpr (HALO) { if (hon) h_item_luma(rh, tap, sh1, halo_t + q * 16); }
     };
-    if (__ballot(hact)) h_phase(std::true_type()); else h_phase(std::false_type());
+    if (__ballot(hon)) h_phase(std::true_type()); else h_phase(std::false_type());
     wave_lds_sync();
     if (bact) {
       // output rows 2q, 2q+1 of the tile: window row pairs q .. q+4, the first four of a tile's eight pairs belong to the tile above
-      const uint32_t* above = top ? halo_t : body_t - 256;
-      const uint32_t* vtap = &S.taps[((fr >> 2) & 3) * 2 * 12];
+      const uint32_t* above = ptop ? halo_t : body_t - 256;
+      const uint32_t* vtap = &S.taps[vidx * 2 * 12];
       const u32x4 t0 = *reinterpret_cast<const u32x4*>(vtap), t1 = *reinterpret_cast<const u32x4*>(vtap + 4);
       const u32x2 t2v = *reinterpret_cast<const u32x2*>(vtap + 8);
       const uint32_t A[4] = {t0.x, t0.y, t0.z, t0.w}, B[5] = {t1.y, t1.z, t1.w, t2v.x, t2v.y};
@@ -458,6 +523,7 @@ __global__ void __launch_bounds__(256, MC_LB_CHROMA) k_mc_chroma(const McArgs a)
     rsd[0][0] = coded ? r0.x : 0u; rsd[0][1] = coded ? r0.y : 0u; rsd[1][0] = coded ? r1.x : 0u; rsd[1][1] = coded ? r1.y : 0u;
   }
   uint32_t park[4] = {0, 0, 0, 0};
+  const wbase wb = win_base(a);
 #pragma unroll 1
   for (int pass = 0; pass < npass; pass++) {
     const bool vact = active && (pass == 0 || (flags & TM_BI));
@@ -468,10 +534,10 @@ __global__ void __launch_bounds__(256, MC_LB_CHROMA) k_mc_chroma(const McArgs a)
       // chroma vector = luma vector in eighth samples: integer part ix >> 1, fraction (ix & 1) * 4 + quarter fraction
       const int xs = (x0 >> 1) + (ix >> 1) - 1, ys = (y0 >> 1) + (iy >> 1) - 1 + (hi ? 0 : 4) + 2 * hq;
       const int xf = ((ix & 1) << 2) | (fr & 3);
-      const char* p0 = final_plane(a, (int)((tm.z >> (8 + 8 * pass)) & (kMaxPics - 1))) + ((ptrdiff_t)ys * pitch + (xs & ~1)) * 2;
-      const char* p1 = p0 + a.cr_off;
+      const wref p0 = win_at(final_plane(a, (int)((tm.z >> (8 + 8 * pass)) & (kMaxPics - 1))), ys, pitch, xs & ~1);
+      const wref p1 = p0 + a.cr_off;
       u32x4 rr[4];
-      rr[0] = ldg4_a4(p0); rr[1] = ldg4_a4(p0 + pitch * 2); rr[2] = ldg4_a4(p1); rr[3] = ldg4_a4(p1 + pitch * 2);
+      rr[0] = win_load(wb, p0); rr[1] = win_load(wb, p0 + pitch * 2); rr[2] = win_load(wb, p1); rr[3] = win_load(wb, p1 + pitch * 2);
 #ifdef MC_PRIO
       __builtin_amdgcn_s_setprio(0);
 #endif

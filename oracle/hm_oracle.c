@@ -105,6 +105,8 @@ static void tmat_init(void)
   for (l = 0; l < 4; l++) for (k = 0; k < (4 << l); k++) for (n = 0; n < (4 << l); n++) g_tmat[l][k][n] = dct_coef(4 << l, k, n);
   g_tmat_ready = 1;
 }
+/* filled when the library is loaded, so that concurrent callers (bench.py's all-cores leg) only ever read the tables */
+__attribute__((constructor)) static void tmat_ctor(void) { tmat_init(); }
 
 /* N-point inverse DCT of one column by even/odd decomposition, the structure of partialButterflyInverse4/8/16/32
  * (TComTrQuant.cpp:468-828): O[k] from the odd rows, E[] = the N/2-point transform of the even rows, no rounding
@@ -426,6 +428,7 @@ typedef struct
   int ctu_addr, cu_z, cu_x, cu_y, cu_size;        /* CU origin in luma samples, z index of its first partition */
   int16_t pred[3][64 * 64];
   int16_t resi[3][64 * 64];
+  int16_t bi_tmp[2][3][64 * 64];                   /* the two 14-bit predictions of a bi-predicted PU (m_acYuvPred[2]: TComPrediction.h) */
 } cu_ctx;
 
 /* one leaf TU: invRecurTransformNxN leaf branch (TComTrQuant.cpp:1566-1591) */
@@ -529,9 +532,8 @@ static void pred_pu(cu_ctx* c, int z_pu, int xr, int yr, int w, int h)
     /* explicit weighted prediction: xPredInterBi with bi = true for every used list, then xWeightedPredictionBi / Uni
      * (TComPrediction.cpp:596-644; TComWeightPrediction.cpp:44-57 weightBidir / weightUnidir, :211-271 getWpScaling).
      * xCheckIdenticalMotion is off for B slices with weighted_bipred_flag (:499). */
-    static int16_t t0[3][64 * 64], t1[3][64 * 64];
-    int16_t* a[3] = { t0[0], t0[1], t0[2] };
-    int16_t* b[3] = { t1[0], t1[1], t1[2] };
+    int16_t* a[3] = { c->bi_tmp[0][0], c->bi_tmp[0][1], c->bi_tmp[0][2] };
+    int16_t* b[3] = { c->bi_tmp[1][0], c->bi_tmp[1][1], c->bi_tmp[1][2] };
     int comp, x, y;
     if (r0 >= 0) pred_uni(c, 0, z_pu, xr, yr, w, h, 1, a);
     if (r1 >= 0) pred_uni(c, 1, z_pu, xr, yr, w, h, 1, b);
@@ -572,9 +574,8 @@ static void pred_pu(cu_ctx* c, int z_pu, int xr, int yr, int w, int h)
   if (r0 >= 0 && r1 >= 0)
   {
     /* xPredInterBi + xWeightedAverage -> addAvg: :596-644, :700-714 */
-    static int16_t t0[3][64 * 64], t1[3][64 * 64];
-    int16_t* a[3] = { t0[0], t0[1], t0[2] };
-    int16_t* b[3] = { t1[0], t1[1], t1[2] };
+    int16_t* a[3] = { c->bi_tmp[0][0], c->bi_tmp[0][1], c->bi_tmp[0][2] };
+    int16_t* b[3] = { c->bi_tmp[1][0], c->bi_tmp[1][1], c->bi_tmp[1][2] };
     int comp;
     pred_uni(c, 0, z_pu, xr, yr, w, h, 1, a);
     pred_uni(c, 1, z_pu, xr, yr, w, h, 1, b);

@@ -34,7 +34,8 @@ def make_picture(width, height, bit_depth=10, seed=1, bi=False, intra_frac=0.0, 
                  coef_dist="typical", tr_split_prob=0.35, intra_modes=True, num_slices=1, lf_across_slices=1):
     """Returns a SynthPicture with .seq, .slice (abi.SliceParams), .meta (MetaHolder), .coeffs (CoeffHolder),
     .sao_raw [num_ctus,3,35], .pp, .meta_np.  ref_handles: device picture handles of list-0 / list-1 references.
-    coef_dist: "typical" (see above) or "stress" (every level of a coded TU uniform over the full int16 range, SURVEY 8d #2)."""
+    coef_dist: "typical" (see above), "stress" (every level of a coded TU uniform over the full int16 range) or
+    "dense" (every level uniform in -3..3)."""
     rng = np.random.RandomState(seed)
     ctu, pw, parts = 64, 16, 256
     cw, ch = (width + 63) // 64, (height + 63) // 64
@@ -172,6 +173,9 @@ def make_picture(width, height, bit_depth=10, seed=1, bi=False, intra_frac=0.0, 
             if coef_dist == "stress":
                 k = size
                 lev = rng.randint(-32768, 32768, size=(a_idx.size, k, k)).astype(np.int16)
+            elif coef_dist == "dense":       # every position of the TU small and non-zero-ish: all basis functions, few samples reach the final clip
+                k = size
+                lev = rng.randint(-3, 4, size=(a_idx.size, k, k)).astype(np.int16)
             else:
                 k = min(size, 8)
                 lev = np.round(rng.laplace(0, 12, size=(a_idx.size, k, k))) * (rng.rand(a_idx.size, k, k) < 0.35)

@@ -96,6 +96,52 @@ def test_synthetic_picture_matches_oracle(oracle, width, height, bd, bi, intra):
             assert np.array_equal(got[c], want_fin[c]), "fused loop filter comp %d" % c
 
 
+@pytest.mark.parametrize("dist", ["stress", "dense"])
+@pytest.mark.parametrize("mode_probs,tr_split,intra,ts", [
+    ((1.0, 0, 0, 0, 0), 0.35, 0.0, False),      # bench.py --workload idct: 64x64 CUs = four 32x32 luma + 16x16 chroma TUs each
+    ((0, 0, 0, 1.0, 0), 1.0, 0.0, True),        # 8x8 CUs split once: 4x4 luma TUs, the shared 4x4 chroma TU, transform skip on half of them
+    ((0, 0, 0.5, 0.5, 0), 0.5, 0.3, True)])     # 16x16 / 8x8 / 4x4 TUs; intra CUs (DST, k_intra) beside inter CUs
+def test_full_range_levels_through_production_residual_path(oracle, mode_probs, tr_split, intra, ts, dist):
+    """every TU coded with levels uniform over the full int16 range ("stress", what `bench.py --workload idct` times): the two clips of
+    the inverse transform (TComTrQuant.cpp:894-948), the saturating residual tiles and the saturating add + clip of the
+    motion-compensation epilogue (TComYuv.cpp:264-299) through the production kernels k_itx -> residual tiles -> k_mc_*, not
+    through the test-only flat kernel.  "stress" drives ~94 % of the samples into the final clip; "dense" (every position of every TU
+    in -3..3) keeps them off it, so that every basis function of every size is visible in the picture."""
+    import libhm_amd
+    width, height, bd = 1920, 1080, 10
+    p = synth.make_picture(width, height, bd, seed=0x484D3136 + int(10 * mode_probs[3]) + int(ts), mode_probs=mode_probs, cbf_prob=1.0,
+                           coef_dist=dist, sao=False, tr_split_prob=tr_split, intra_frac=intra, ref_handles=([0], [1]))
+    if ts:
+        m = dict(p.meta_np)
+        rng = np.random.RandomState(9)
+        log2tu = 6 - m["depth"] - m["tr_idx"]
+        quad = rng.rand(p.num_ctus, 64) < 0.5                                   # one draw per 8x8 area (four z-consecutive partitions)
+        m["ts_y"] = ((rng.rand(p.num_ctus, 256) < 0.5) & (log2tu == 2)).astype(np.uint8)
+        m["ts_u"] = (np.repeat(quad, 4, axis=1) & (log2tu <= 3)).astype(np.uint8)
+        m["ts_v"] = (np.repeat(~quad, 4, axis=1) & (log2tu <= 3)).astype(np.uint8)
+        p.meta = abi.MetaHolder(m)
+    ref0 = synth.noise_planes(width, height, bd, 11)
+    ref1 = synth.blocky_planes(width, height, bd, 12)
+    cur = synth.blocky_planes(width, height, bd, 13)
+    want = [a.copy() for a in cur]
+    oracle.decompress_ctus(p.seq, [p.slice], p.meta, p.coeffs, want, [ref0, ref1])
+    with libhm_amd.Context(p.seq) as ctx:
+        h0, h1, hc = ctx.acquire(), ctx.acquire(), ctx.acquire()
+        ctx.upload(h0, ref0)
+        ctx.upload(h1, ref1)
+        ctx.upload(hc, cur)
+        ctx.decompress_slice(hc, 0, p.slice, p.meta, p.coeffs)
+        got = ctx.download(hc)
+        for c in range(3):
+            assert np.array_equal(got[c], want[c]), "reconstruction comp %d" % c
+        # the same through the batch entry point with compact levels (what a parser that appends TU after TU hands over)
+        ctx.upload(hc, cur)
+        ctx.decompress_pictures([(hc, [p.slice], p.meta, ctx.pack_levels(p.meta, p.coeffs))])
+        got = ctx.download(hc)
+        for c in range(3):
+            assert np.array_equal(got[c], want[c]), "compact levels, comp %d" % c
+
+
 @pytest.mark.parametrize("mode_probs,intra", [((0, 0, 0, 1, 0), 0.0), ((1, 0, 0, 0, 0), 0.0), ((0, 1, 0, 0, 0), 0.3),
                                               ((0, 0, 0.5, 0, 0.5), 0.1), ((0.25, 0.25, 0.25, 0.25, 0), 0.0)])
 def test_fused_loop_filter_matches_oracle_on_partition_extremes(oracle, mode_probs, intra):

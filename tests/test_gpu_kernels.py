@@ -104,3 +104,28 @@ def test_interpolation_with_border_clamp_matches_oracle(ctx, oracle, bd):
             for b, g in zip(blocks, got):
                 want = oracle.pred_inter_blk(is_chroma, bd, plane, int(b[0]), int(b[1]), int(b[2]), int(b[3]), int(b[4]), int(b[5]), bi)
                 assert np.array_equal(g, want), (is_chroma, bi, tuple(b))
+
+
+
+@pytest.mark.parametrize("bd", [8, 10])
+@pytest.mark.parametrize("is_chroma", [0, 1])
+def test_lds_staged_picture_kernels_match_hm_interpolation_kats(bd, is_chroma):
+    """HM's own interpolation vectors (kats.npz interp_*: TComInterpolationFilter::filterHor / filterVer called on a 96x96 plane, all
+    16 luma and 64 chroma phase pairs, final and 14-bit outputs) through the LDS-staged PICTURE kernels k_mc_luma / k_mc_chroma -- the
+    kernels bench.py times -- instead of the test-only flat kernel (tests/kat_pictures.py: a picture of 8x8 CUs, one tile each, PU k
+    predicting KAT case k).  P picture: the `uni` cases against HM's final samples; B picture: two `bi` cases per PU, expected =
+    addAvg of HM's two 14-bit outputs (the formula itself is checked against HM's addAvg vectors first)."""
+    import libhm_amd
+    from tests import kat_pictures as kp
+    z = gu.load("kats")
+    assert np.array_equal(kp.add_avg(z["addavg_a_bd%d" % bd], z["addavg_b_bd%d" % bd], bd), z["addavg_out_bd%d" % bd])
+    for bi in (0, 1):
+        p, ref, checks = kp.build(bd, is_chroma, bi)
+        with libhm_amd.Context(p.seq) as ctx:
+            h0, h1, hc = ctx.acquire(), ctx.acquire(), ctx.acquire()
+            ctx.upload(h0, ref)
+            ctx.upload(h1, ref)
+            ctx.upload(hc, [np.zeros_like(a) for a in ref])
+            ctx.decompress_slice(hc, 0, p.slice, p.meta, p.coeffs)
+            got = ctx.download(hc)
+        kp.verify(got, checks, (bd, is_chroma, bi))
