@@ -77,6 +77,8 @@ struct hmgpu_ctx {
   std::vector<hmgpu_staging*> stagings;
   hipEvent_t dl_ev[32] = {};           // hmgpu_picture_download_begin tickets: ticket t completes with dl_ev[t % 32]
   std::atomic<uint64_t> dl_seq{0};
+  uint32_t* dl_fault = nullptr;        // [32] page-locked: the picture's fault word (k_intra's bounded spin) as it stood behind the copies of ticket t
+  std::vector<int> touched;            // pictures the entry point under way has enqueued work on, in any role (commit_use)
   std::vector<int> intra_launched;    // pictures whose intra kernel ran since the last fault check (k_intra's bounded spin)
   void* scratch = nullptr;            // device scratch of the output calls (packed download, picture hash): grown on demand, kept
   size_t scratch_bytes = 0;
@@ -148,6 +150,22 @@ hmgpu_status check_faults(hmgpu_ctx* c) {
   }
   c->intra_launched.clear();
   return st;
+}
+
+// Which submission last enqueued work on a picture, in ANY role (decoded, filtered, read as a reference, downloaded, hashed): the copy
+// stream of hmgpu_decompress_pictures may rewrite a picture's descriptors and input arrays only behind that point.  Every entry point
+// names the pictures it touches and ends with commit_use (one event on the context's stream).
+void touch(hmgpu_ctx* c, int pic) { c->touched.push_back(pic); }
+void commit_use(hmgpu_ctx* c) {
+  if (c->touched.empty()) return;
+  c->use_seq++;
+  (void)hipEventRecord(c->use_ev[c->use_seq % 8], c->stream);
+  for (int pic : c->touched) c->pics[pic].last_use = c->use_seq;
+  c->touched.clear();
+}
+static void mark_use(hmgpu_ctx* c, const Batch& b) {
+  for (int i = 0; i < b.n; i++) touch(c, b.pic[i]);
+  commit_use(c);
 }
 
 // profiling: a pair of events around one launch, resolved lazily
@@ -287,6 +305,7 @@ bool valid_pic(const hmgpu_ctx* c, hmgpu_pic pic) { return pic >= 0 && pic < (in
 // lazy border extension, as HM does when a picture first enters a reference list (TComSlice.cpp:350: extendPicBorder)
 hmgpu_status ensure_extended(hmgpu_ctx* c, int pic) {
   Picture& p = c->pics[pic];
+  touch(c, pic);                        // (called for every reference picture of a submission)
   if (p.extended) return HMGPU_OK;
   Batch b; memset(&b, 0, sizeof(b));
   b.n = 1; b.pic[0] = pic;
@@ -316,7 +335,7 @@ hmgpu_status run_recon(hmgpu_ctx* c, const Batch& b, bool any_intra, bool any_wp
   memset(&ma, 0, sizeof(ma));
   ma.n = b.n; ma.width = c->seq.width; ma.height = c->seq.height; ma.log2ctu = c->seq.log2_ctu_size; ma.ctus_w = c->ctus_w;
   ma.tw = c->grid_w / 2; ma.npics = c->seq.max_pictures;
-  ma.slab = c->plane_slab; ma.pic_stride = 2 * c->plane_bytes; ma.sao_off = (uint32_t)c->plane_bytes;
+  ma.slab = c->plane_slab; ma.pic_stride = 2 * c->plane_bytes; ma.slab_bytes = ma.pic_stride * c->pics.size(); ma.sao_off = (uint32_t)c->plane_bytes;
   for (size_t i = 0; i < c->pics.size(); i++)
     if (c->pics[i].sao_applied) (i < 32 ? ma.sao_mask_lo : ma.sao_mask_hi) |= 1u << (i & 31);
   for (int i = 0; i < b.n; i++) {
@@ -502,6 +521,7 @@ hmgpu_status hmgpu_create(const hmgpu_seq_params* seq, int device_ordinal, hmgpu
   for (int k = 0; k < 8 && e == hipSuccess; k++) e = hipEventCreateWithFlags(&c->copy_ev[k], hipEventDisableTiming);
   for (int k = 0; k < 8 && e == hipSuccess; k++) e = hipEventCreateWithFlags(&c->use_ev[k], hipEventDisableTiming);
   for (int k = 0; k < 32 && e == hipSuccess; k++) e = hipEventCreateWithFlags(&c->dl_ev[k], hipEventDisableTiming | hipEventBlockingSync);   // (waited for by helper threads: sleep, do not spin)
+  if (e == hipSuccess) { e = hipHostMalloc((void**)&c->dl_fault, 32 * sizeof(uint32_t), hipHostMallocDefault); if (e == hipSuccess) memset(c->dl_fault, 0, 32 * sizeof(uint32_t)); }
   for (int k = 0; k < 2 && e == hipSuccess; k++) e = hipEventCreateWithFlags(&c->lane_ev[k], hipEventDisableTiming);
   if (e != hipSuccess) { delete c; return HMGPU_EDEVICE; }
   c->ctu = 1 << seq->log2_ctu_size; c->pw = c->ctu / 4; c->parts = c->pw * c->pw;
@@ -572,6 +592,7 @@ void hmgpu_destroy(hmgpu_ctx* c) {
   for (int k = 0; k < 8; k++) { if (c->copy_ev[k]) hipEventDestroy(c->copy_ev[k]); if (c->use_ev[k]) hipEventDestroy(c->use_ev[k]); }
   for (hmgpu_staging* st : c->stagings) { if (st->host) hipHostFree(st->host); delete st; }
   for (int k = 0; k < 32; k++) if (c->dl_ev[k]) hipEventDestroy(c->dl_ev[k]);
+  if (c->dl_fault) (void)hipHostFree(c->dl_fault);
   for (int k = 0; k < 2; k++) if (c->lane_ev[k]) hipEventDestroy(c->lane_ev[k]);
   delete c;
 }
@@ -659,9 +680,13 @@ hmgpu_status hmgpu_picture_download_begin(hmgpu_ctx* c, hmgpu_pic pic, int16_t* 
     HIP_TRY(c, hipMemcpy2DAsync(planes[k], (size_t)strides[k] * 2, src, (size_t)c->pitch[k] * 2, (size_t)w * 2, h, hipMemcpyDeviceToHost, c->stream));
   }
   const uint64_t t = c->dl_seq.load() + 1;
+  // the picture's fault word (an intra wavefront that gave up waiting) as it stands behind these copies: hmgpu_download_wait reports it
+  HIP_TRY(c, hipMemcpyAsync(&c->dl_fault[t % 32], p.dev.fault, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipEventRecord(c->dl_ev[t % 32], c->stream));
   c->dl_seq.store(t);
   *ticket = t;
+  touch(c, pic);
+  commit_use(c);
   return HMGPU_OK;
 }
 
@@ -670,6 +695,8 @@ hmgpu_status hmgpu_download_wait(hmgpu_ctx* c, uint64_t ticket) {
   hipSetDevice(c->device);
   // a ticket whose event has been re-recorded is 32 downloads old: the event now stands for a LATER point of the same stream
   if (hipEventSynchronize(c->dl_ev[ticket % 32]) != hipSuccess) return HMGPU_EDEVICE;
+  // (read-only here: this may be a helper thread; the word on the device stays set until the context's own thread reads it in check_faults)
+  if (c->dl_seq.load() - ticket < 32 && reinterpret_cast<volatile uint32_t*>(c->dl_fault)[ticket % 32]) return HMGPU_EDEVICE;
   return HMGPU_OK;
 }
 
@@ -696,7 +723,8 @@ hmgpu_status hmgpu_picture_download_packed(hmgpu_ctx* c, hmgpu_pic pic, void* co
   }
   if (hipStreamSynchronize(c->stream) != hipSuccess) st = HMGPU_EDEVICE;
   prof_drain(c);
-  return st;
+  const hmgpu_status fs = check_faults(c);
+  return st != HMGPU_OK ? st : fs;
 }
 
 hmgpu_status hmgpu_picture_hash(hmgpu_ctx* c, hmgpu_pic pic, int32_t method, uint8_t digest[3][16], int32_t* digest_len) {
@@ -991,7 +1019,9 @@ static hmgpu_status stage_and_run(hmgpu_ctx* c, hmgpu_pic cur, int32_t slice_idx
   if (st != HMGPU_OK) return st;
   Batch b; memset(&b, 0, sizeof(b));
   b.n = 1; b.pic[0] = cur; b.first_ctu[0] = first_ctu; b.num_ctus[0] = num_ctus;
-  return run_recon(c, b, call.intra, call.wp, call.cells, call.bi);
+  st = run_recon(c, b, call.intra, call.wp, call.cells, call.bi);
+  mark_use(c, b);
+  return st;
 }
 
 static bool meta_complete(const hmgpu_ctu_meta* m, const hmgpu_coeffs* co) {
@@ -1125,11 +1155,6 @@ static void wait_for_last_use(hmgpu_ctx* c, const Picture& p) {
   const uint64_t seq = c->use_seq - p.last_use < 8 ? p.last_use : c->use_seq;
   (void)hipStreamWaitEvent(c->copy_stream, c->use_ev[seq % 8], 0);
 }
-static void mark_use(hmgpu_ctx* c, const Batch& b) {
-  c->use_seq++;
-  (void)hipEventRecord(c->use_ev[c->use_seq % 8], c->stream);
-  for (int i = 0; i < b.n; i++) c->pics[b.pic[i]].last_use = c->use_seq;
-}
 
 hmgpu_status hmgpu_decompress_pictures(hmgpu_ctx* c, int32_t n, const hmgpu_picture_job* jobs) {
   if (!c || !jobs || n < 1 || n > kMaxBatch) return HMGPU_EINVAL;
@@ -1251,7 +1276,9 @@ hmgpu_status hmgpu_filter_picture_stages(hmgpu_ctx* c, hmgpu_pic cur, const hmgp
     if (st != HMGPU_OK) return st;
   }
   p.extended = false;
-  return ensure_extended(c, cur);        // the finished picture is ready to be referenced
+  st = ensure_extended(c, cur);          // the finished picture is ready to be referenced
+  commit_use(c);
+  return st;
 }
 
 hmgpu_status hmgpu_filter_picture(hmgpu_ctx* c, hmgpu_pic cur, const hmgpu_pic_params* pp, const hmgpu_sao_param* sao) {
@@ -1314,6 +1341,8 @@ hmgpu_status hmgpu_replay_batch(hmgpu_ctx* c, const hmgpu_pic* pics, int32_t n, 
     HIP_TRY(c, hipEventRecord(c->lane_ev[1], c->stream2));
     HIP_TRY(c, hipStreamWaitEvent(main_stream, c->lane_ev[1], 0));
   }
+  for (int i = 0; i < n; i++) touch(c, pics[i]);
+  commit_use(c);                          // (the references were named by ensure_refs_extended)
   return result;
 }
 

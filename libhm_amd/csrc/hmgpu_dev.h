@@ -174,7 +174,7 @@ struct McArgs {
   // final planes: every picture of a context lives in one slab, picture i at slab + i * pic_stride; its final luma plane (sample
   // (0,0)) is at + origin_off, or + sao_off + origin_off when bit i of the SAO mask is set (the picture went through SAO)
   const char* slab;
-  uint64_t pic_stride;
+  uint64_t pic_stride, slab_bytes;
   uint32_t sao_off, origin_off, cr_off;        // origin_off: luma launch: Y plane; chroma launch: Cb plane; cr_off: Cb -> Cr
   uint32_t sao_mask_lo, sao_mask_hi;
 };

@@ -531,6 +531,8 @@ __device__ __attribute__((always_inline)) inline void intra_ctu(const PicDev& P,
   uint32_t spins = 0;
   if (wv == (int)(blockDim.x >> 6) - 1) fetch_border(P, comp, ctu, nb.ext_col, nb.ext_row, Q, L);   // what is final next door already
   for (;;) {
+    // the scheduler words in LDS (pend, done_c, done_r, got) are updated by the other waves with atomics: read them afresh in every round
+    asm volatile("" ::: "memory");
     // the first list entry that is pending and ready (the list is in priority order); the pending masks may be stale by the time the
     // entry is claimed: the atomic AND decides
     int i = -1;

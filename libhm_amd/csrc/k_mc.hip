@@ -64,7 +64,7 @@ __device__ inline uint32_t pk_sub(uint32_t a, uint32_t b) {                     
 //   p = 0: even columns A,0   odd columns B        p = 1: even columns B   odd columns 0,A
 // (column x of a window that starts in the high half of its first dword begins one sample later than its dword)
 struct alignas(16) TapsLuma { uint32_t e[12][12]; };   // fractions 0..3, then the identity at tap 0 (4) and at tap 4 (5)
-struct alignas(16) TapsChroma { uint32_t e[16][8]; };
+struct alignas(16) TapsChroma { uint32_t e[18][8]; };   // fractions 0..7, then the identity at tap 2 (8)
 constexpr uint32_t pk16(int a, int b) { return ((uint32_t)a & 0xffffu) | ((uint32_t)b << 16); }
 constexpr TapsLuma make_taps_luma() {
   constexpr int c[6][8] = {{0, 0, 0, 64, 0, 0, 0, 0}, {-1, 4, -10, 58, 17, -5, 1, 0}, {-1, 4, -11, 40, 40, -11, 4, -1}, {0, 1, -5, 17, 58, -10, 4, -1},
@@ -82,9 +82,10 @@ constexpr TapsLuma make_taps_luma() {
   return t;
 }
 constexpr TapsChroma make_taps_chroma() {
-  constexpr int c[8][4] = {{0, 64, 0, 0}, {-2, 58, 10, -2}, {-4, 54, 16, -2}, {-6, 46, 28, -4}, {-4, 36, 36, -4}, {-4, 28, 46, -6}, {-2, 16, 54, -4}, {-2, 10, 58, -2}};
+  constexpr int c[9][4] = {{0, 64, 0, 0}, {-2, 58, 10, -2}, {-4, 54, 16, -2}, {-6, 46, 28, -4}, {-4, 36, 36, -4}, {-4, 28, 46, -6}, {-2, 16, 54, -4}, {-2, 10, 58, -2},
+                           {0, 0, 64, 0}};
   TapsChroma t = {};
-  for (int f = 0; f < 8; f++)
+  for (int f = 0; f < 9; f++)
     for (int p = 0; p < 2; p++) {
       const uint32_t A[3] = {pk16(c[f][0], c[f][1]), pk16(c[f][2], c[f][3]), 0u};
       const uint32_t B[3] = {pk16(0, c[f][0]), pk16(c[f][1], c[f][2]), pk16(c[f][3], 0)};
@@ -124,7 +125,7 @@ __device__ inline uint32_t pack_shr(int lo, int hi, int sh) {
 template <bool CHROMA> struct McLds {
   static constexpr int ROW_DW = CHROMA ? 128 : 256;           // dwords per tile row
   struct { uint32_t body[2 * ROW_DW], halo[2 * ROW_DW]; } w[4];   // halo: the first 8 (4) window rows of run tops, at the top tile's position
-  uint32_t taps[CHROMA ? 128 : 144];                           // the tap table (every wave writes the same values, reads its own)
+  uint32_t taps[144];                           // the tap table (every wave writes the same values, reads its own)
 #ifdef MC_LDS_PAD
   uint32_t pad[MC_LDS_PAD / 4];                               // experiment: fewer workgroups per CU
 #endif
@@ -245,32 +246,46 @@ __device__ inline bool tile_is_top(const u32x4 tm, int r, int partner_lane) {
 
 // address of sample (0,0) of the final luma / Cb plane of device picture `ref` (all pictures of a context live in one slab, a
 // finished picture is its SAO output or, without SAO, its reconstruction)
-#ifdef MC_BUF
-// window loads as buffer loads: 32-bit byte offsets from the slab, and a lane without a work item gets an offset past the end
-// of the buffer -- the range check answers it with zeros and nothing goes to memory (slabs under kWinLimit bytes)
-constexpr uint32_t kWinLimit = 0xf0000000u;
-typedef uint32_t wref;
-typedef __amdgpu_buffer_rsrc_t wbase;
-__device__ inline wbase win_base(const McArgs& a) { return __builtin_amdgcn_make_buffer_rsrc((void*)a.slab, 0, kWinLimit, 0x00020000); }
-__device__ inline wref win_nowhere(const McArgs& a, int slot) { return kWinLimit; }
-__device__ inline wref final_plane(const McArgs& a, int ref) {
-  const uint32_t m = ref & 32 ? a.sao_mask_hi : a.sao_mask_lo;
-  return (uint32_t)ref * (uint32_t)a.pic_stride + (__builtin_amdgcn_ubfe(m, (uint32_t)ref & 31u, 1u) ? a.sao_off : 0u) + a.origin_off;
+// Window loads.  BUF: buffer loads with 32-bit byte offsets from the slab of pictures; a lane without a work item gets an offset past
+// the end of the buffer -- the range check answers it with zeros and nothing goes to memory (slabs under kWinLimit bytes: launch_mc).
+// !BUF: plain 64-bit addresses; lanes without a work item read valid memory nobody looks at.
+constexpr uint32_t kWinLimit = 0xffff0000u;
+template <bool BUF> struct Win;
+template <> struct Win<true> {
+  typedef uint32_t ref;
+  __amdgpu_buffer_rsrc_t rs;
+  uint32_t stride;
+  __device__ inline Win(const McArgs& a, int) : rs(__builtin_amdgcn_make_buffer_rsrc((void*)a.slab, 0, kWinLimit, 0x00020000)), stride((uint32_t)a.pic_stride) {}
+  __device__ inline ref nowhere() const { return kWinLimit; }
+  __device__ inline ref plane(const McArgs& a, int pic) const {
+    const uint32_t m = pic & 32 ? a.sao_mask_hi : a.sao_mask_lo;
+    return (uint32_t)pic * stride + (__builtin_amdgcn_ubfe(m, (uint32_t)pic & 31u, 1u) ? a.sao_off : 0u) + a.origin_off;
+  }
+  __device__ inline ref at(ref pl, int row, int pitch, int x) const { return pl + (uint32_t)((row * pitch + x) * 2); }
+  __device__ inline u32x4 load(ref o) const { return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, o, 0, 0)); }
+};
+template <> struct Win<false> {
+  typedef const char* ref;
+  const char* dummy;
+  __device__ inline Win(const McArgs& a, int slot) : dummy(reinterpret_cast<const char*>(a.tmv[slot])) {}
+  __device__ inline ref nowhere() const { return dummy; }
+  __device__ inline ref plane(const McArgs& a, int pic) const {
+    const uint32_t m = pic & 32 ? a.sao_mask_hi : a.sao_mask_lo;
+    return a.slab + (size_t)(uint32_t)pic * a.pic_stride + (__builtin_amdgcn_ubfe(m, (uint32_t)pic & 31u, 1u) ? a.sao_off : 0u) + a.origin_off;
+  }
+  __device__ inline ref at(ref pl, int row, int pitch, int x) const { return pl + ((ptrdiff_t)row * pitch + x) * 2; }
+  __device__ inline u32x4 load(ref p) const { return ldg4_a4(p); }
+};
+
+// second piece of a window row from the lane to the right (its first piece) in the lanes where `take` holds: a DPP move (row_shl:1 =
+// the value of lane + 1; lanes without one, the last of a row of 16, read 0) that the compiler folds into the select (v_cndmask_b32_dpp)
+__device__ inline uint32_t from_right(uint32_t own, uint32_t first, bool take) {
+  const uint32_t t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)first, 0x101, 0xf, 0xf, true);
+  return take ? t : own;
 }
-__device__ inline wref win_at(wref plane, int row, int pitch, int x) { return plane + (uint32_t)((row * pitch + x) * 2); }
-__device__ inline u32x4 win_load(wbase b, wref o) { return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(b, o, 0, 0)); }
-#else
-typedef const char* wref;
-typedef int wbase;
-__device__ inline wbase win_base(const McArgs& a) { return 0; }
-__device__ inline wref win_nowhere(const McArgs& a, int slot) { return reinterpret_cast<const char*>(a.tmv[slot]); }   // valid memory
-__device__ inline wref final_plane(const McArgs& a, int ref) {
-  const uint32_t m = ref & 32 ? a.sao_mask_hi : a.sao_mask_lo;
-  return a.slab + (size_t)(uint32_t)ref * a.pic_stride + (__builtin_amdgcn_ubfe(m, (uint32_t)ref & 31u, 1u) ? a.sao_off : 0u) + a.origin_off;
+__device__ inline u32x4 from_right(const u32x4 own, const u32x4 first, bool take) {
+  return u32x4{from_right(own.x, first.x, take), from_right(own.y, first.y, take), from_right(own.z, first.z, take), from_right(own.w, first.w, take)};
 }
-__device__ inline wref win_at(wref plane, int row, int pitch, int x) { return plane + ((ptrdiff_t)row * pitch + x) * 2; }
-__device__ inline u32x4 win_load(wbase, wref p) { return ldg4_a4(p); }
-#endif
 
 // ======================================================================================================== luma
 // H pass work item: window rows (2i, 2i+1) x 8 columns.  r[0..1] = first row (8 dwords = 16 samples), r[2..3] = second row;
@@ -302,13 +317,27 @@ __device__ inline void h_item_luma(const u32x4 (&r)[4], const uint32_t* __restri
 // ("halo") of THAT tile; its V item is output rows 2q, 2q+1 of the same tile.  The first tile row of a strip always starts a run
 // (the strip above belongs to another wave), so the waves of a workgroup never wait for each other: no barrier, no shared state
 // but the tap table, whose copies are identical.
-template <bool WP, bool BI>
+//
+// What is NOT loaded (round 3: the kernel is bound by the reference lines its waves pull into L1):
+//   * no interpolation in a direction (a quarter of the vectors each): only the 8 rows / 8 columns of the block itself.  Vertical:
+//     the window starts one row higher (identity at tap 4 instead of 3), so the block's rows are window rows 4..11 -- the second half
+//     of the halo item's rows and the first half of the body item's; the tile shares nothing with its neighbours and is its own run.
+//     Horizontal: the window starts at the block's first column (identity at tap 0): one 16-byte piece per row if that column is even.
+//   * (experiment MC_DEDUP) the second 16-byte piece of a row when the tile to the right has the same motion and loads the same rows:
+//     it IS that lane's first piece (from_right).
+//   * window row 15 of a tile that no tile of the strip continues (a tile needs rows 0..14, row 15 is the first row of the next tile's share).
+// Rows and pieces that are not loaded only ever meet zero taps.
+#ifndef MC_NO_F0
+#define MC_F0 1
+#endif
+// (MC_DEDUP, off: see DESIGN.md -- the move + select per dword cost the arithmetic-bound large PUs what the loads saved)
+#ifndef MC_NO_R15
+#define MC_R15 1
+#endif
+template <bool WP, bool BI, bool BUF>
 __global__ void __launch_bounds__(256, (WP || BI) ? 1 : MC_LB_LUMA) k_mc_luma(const McArgs a) {
   __shared__ __attribute__((aligned(16))) McLds<false> S;
   int slot; Square g;
-#ifdef MC_PRIO
-  __builtin_amdgcn_s_setprio(3);
-#endif
   if (!square_of_block(a, slot, g)) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   if (wave * 16 >= g.ext) return;
@@ -322,6 +351,11 @@ __global__ void __launch_bounds__(256, (WP || BI) ? 1 : MC_LB_LUMA) k_mc_luma(co
   const bool active = (flags & TM_ACTIVE) != 0;
   if (!__ballot(active)) return;
   const bool top = tile_is_top(tm, r, lane ^ 32);
+#ifdef MC_DEDUP
+  const bool same_right = tx < 7 && !tile_is_top(tm, 1, lane + 1);          // the tile to the right: same lists, pictures, vectors
+#else
+  const bool same_right = false;
+#endif
   const bool any_bi = BI && __ballot((flags & TM_BI) != 0) != 0;
   wave_lds_sync();
 #ifdef MC_LDS_PAD
@@ -332,8 +366,9 @@ __global__ void __launch_bounds__(256, (WP || BI) ? 1 : MC_LB_LUMA) k_mc_luma(co
   const int sh1 = 6 - head;
   uint32_t* const body_t = &S.w[wave].body[r * 256 + tx * 2];              // (r, piece 0, row pair 0, tx)
   uint32_t* const halo_t = &S.w[wave].halo[r * 256 + tx * 2];
-  const wbase wb = win_base(a);
-  const wref nowhere = win_nowhere(a, slot);               // what lanes without a work item load from
+  const Win<BUF> win(a, slot);
+  typedef typename Win<BUF>::ref wref;
+  const wref nowhere = win.nowhere();                      // what lanes without a work item load from
   WpTile wp = {false, 1, 0, 1, 0, 0};
   if constexpr (WP) wp = wp_tile<WP>(a.slices[slot], flags, tm.w, 0);
   // the residual of output rows 2q, 2q+1 (two 16-byte slots of the tile's line in PicDev::resid; a row crosses two 4x4 quadrants, each
@@ -355,72 +390,56 @@ __global__ void __launch_bounds__(256, (WP || BI) ? 1 : MC_LB_LUMA) k_mc_luma(co
     const uint32_t mv = pass ? tm.y : tm.x;
     const uint32_t fr = (tm.z >> (4 * pass)) & 15;
 #ifdef MC_F0
-    // no interpolation in a direction (a quarter of the vectors each): only the 8 rows / 8 columns of the block itself are read.
-    //   vertical: the window starts one row higher (identity tap 4 instead of 3), so the block's rows are window rows 4..11 -- the
-    //   second half of the halo item's rows and the first half of the body item's; the tile shares nothing with its neighbours and is
-    //   its own run.   horizontal: the window starts at the block's first column (identity tap 0): one 16-byte piece per row if that
-    //   column is even.  Rows and pieces that are not read meet zero taps only.
     const bool yz = (fr & 12) == 0, xz = (fr & 3) == 0;
+#else
+    const bool yz = false, xz = false;
+#endif
     const bool ptop = top || yz;
     const bool bon = bact && (!yz || q < 2), hon = bact && ptop && (!yz || q >= 2);
     const int xs = x0 + (int)(int16_t)(mv & 0xffff) - (xz ? 0 : 3);
     const bool two = !xz || (xs & 1);
     const uint32_t* const tap = &S.taps[((xz ? 4u : (fr & 3)) * 2 + (xs & 1)) * 12];
-    const wref pw = win_at(final_plane(a, (int)((tm.z >> (8 + 8 * pass)) & (kMaxPics - 1))), y0 + ((int)mv >> 16) - (yz ? 4 : 3) + 2 * q, pitch, xs & ~1);
-    const uint32_t vidx = yz ? 5u : (fr >> 2) & 3;
-#else
-    const bool ptop = top, bon = bact, hon = bact && top, two = true;
-    const int xs = x0 + (int)(int16_t)(mv & 0xffff) - 3;
-    const uint32_t* const tap = &S.taps[((fr & 3) * 2 + (xs & 1)) * 12];
     // window row 2q of the tile (the halo item's first row; the body item's is 8 rows down)
-    const wref pw = win_at(final_plane(a, (int)((tm.z >> (8 + 8 * pass)) & (kMaxPics - 1))), y0 + ((int)mv >> 16) - 3 + 2 * q, pitch, xs & ~1);
-    const uint32_t vidx = (fr >> 2) & 3;
-#endif
-#if defined(MC_EXP) && (MC_EXP & 4)         // experiment: half of the lanes load
-    const bool lon = (q & 1) == 0;
+    const wref pw = win.at(win.plane(a, (int)((tm.z >> (8 + 8 * pass)) & (kMaxPics - 1))), y0 + ((int)mv >> 16) - (yz ? 4 : 3) + 2 * q, pitch, xs & ~1);
+    const uint32_t vidx = yz ? 5u : (fr >> 2) & 3;
+    const uint64_t bon_m = __ballot(bon), hon_m = __ballot(hon);
+    // the lane to the right loads the same rows of the same window, 16 bytes on: its first piece is this lane's second
+#ifdef MC_R15
+    // window row 15 (the body item's second row in lanes with q == 3) is only ever read by a tile of the second strip row that continues this one
+    const bool b2on = bon && (q != 3 || (r == 0 && !((__ballot(ptop) >> (lane + 32)) & 1)));
 #else
-    const bool lon = true;
+    const bool b2on = bon;
 #endif
+    const uint64_t b2on_m = __ballot(b2on);
+    const bool rb_shared = same_right && ((bon_m >> (lane + 1)) & 1), rb2_shared = same_right && ((b2on_m >> (lane + 1)) & 1);
+    const bool rh_shared = same_right && ((hon_m >> (lane + 1)) & 1);
     // the H pass of the lane's body item and, in waves that hold run tops, of its halo item.  Loads are unconditional (lanes without
     // an item read nowhere): values that are only defined in some lanes would have to be initialised in the others
     auto h_phase = [&](auto with_halo) {
       constexpr bool HALO = decltype(with_halo)::value;
       u32x4 rb[4], rh[4];
       {
-#if defined(MC_EXP) && (MC_EXP & 16)        // experiment: no second pieces
-        const wref p0 = bon && lon ? pw + pitch * 16 : nowhere, p1 = nowhere;
-#else
-        const wref p0 = bon && lon ? pw + pitch * 16 : nowhere, p1 = bon && lon && two ? p0 + 16 : nowhere;
-#endif
-        rb[0] = win_load(wb, p0); rb[1] = win_load(wb, p1);
-#if defined(MC_EXP) && (MC_EXP & 8)         // experiment: half of the load instructions
-        rb[2] = rb[0]; rb[3] = rb[1];
-#else
-        rb[2] = win_load(wb, p0 + pitch * 2); rb[3] = win_load(wb, p1 + pitch * 2);
-#endif
+        const wref p0 = bon ? pw + pitch * 16 : nowhere, p1 = bon && two && !rb_shared ? p0 + 16 : nowhere;
+        rb[0] = win.load(p0); rb[1] = win.load(p1);
+        rb[2] = win.load(b2on ? p0 + pitch * 2 : nowhere); rb[3] = win.load(b2on && two && !rb2_shared ? p0 + pitch * 2 + 16 : nowhere);
       }
       if constexpr (HALO) {
-#if defined(MC_EXP) && (MC_EXP & 32)        // experiment: no halo rows
-        const wref p0 = nowhere, p1 = nowhere;
-#elif defined(MC_EXP) && (MC_EXP & 16)
-        const wref p0 = hon && lon ? pw : nowhere, p1 = nowhere;
-#else
-        const wref p0 = hon && lon ? pw : nowhere, p1 = hon && lon && two ? p0 + 16 : nowhere;
-#endif
-        rh[0] = win_load(wb, p0); rh[1] = win_load(wb, p1);
-#if defined(MC_EXP) && (MC_EXP & 8)
-        rh[2] = rh[0]; rh[3] = rh[1];
-#else
-        rh[2] = win_load(wb, p0 + pitch * 2); rh[3] = win_load(wb, p1 + pitch * 2);
-#endif
+        const wref p0 = hon ? pw : nowhere, p1 = hon && two && !rh_shared ? p0 + 16 : nowhere;
+        rh[0] = win.load(p0); rh[1] = win.load(p1);
+        rh[2] = win.load(hon ? p0 + pitch * 2 : nowhere); rh[3] = win.load(hon && two && !rh_shared ? p0 + pitch * 2 + 16 : nowhere);
       }
-#ifdef MC_PRIO
-      __builtin_amdgcn_s_setprio(0);
+#ifdef MC_DEDUP
+      {
+        rb[1] = from_right(rb[1], rb[0], rb_shared); rb[3] = from_right(rb[3], rb[2], rb2_shared);
+      }
+      if constexpr (HALO) {
+        rh[1] = from_right(rh[1], rh[0], rh_shared); rh[3] = from_right(rh[3], rh[2], rh_shared);
+      }
 #endif
       if (bon) h_item_luma(rb, tap, sh1, body_t + q * 16);
       if constexpr (HALO) { if (hon) h_item_luma(rh, tap, sh1, halo_t + q * 16); }
     };
-    if (__ballot(hon)) h_phase(std::true_type()); else h_phase(std::false_type());
+    if (hon_m) h_phase(std::true_type()); else h_phase(std::false_type());
     wave_lds_sync();
     if (bact) {
       // output rows 2q, 2q+1 of the tile: window row pairs q .. q+4, the first four of a tile's eight pairs belong to the tile above
@@ -483,13 +502,10 @@ __device__ inline void h_item_chroma(const u32x4 (&r)[4], const uint32_t* __rest
 // One wave = one strip (tile rows 2w, 2w+1) as in k_mc_luma.  Lane -> tile (tx = lane & 7, strip row r = (lane >> 4) & 1) for both
 // passes.  H item: lanes 0..31 window rows 4+2hq, 5+2hq ("body"), lanes 32..63 rows 2hq, 2hq+1 ("halo", tiles that start a run) of
 // both planes, hq = (lane >> 3) & 1.  V item: plane vp = lane >> 5, output rows 2k, 2k+1 with k = (lane >> 3) & 1.
-template <bool WP, bool BI>
-__global__ void __launch_bounds__(256, MC_LB_CHROMA) k_mc_chroma(const McArgs a) {
+template <bool WP, bool BI, bool BUF>
+__global__ void __launch_bounds__(256, (WP && BI) ? 6 : MC_LB_CHROMA) k_mc_chroma(const McArgs a) {
   __shared__ __attribute__((aligned(16))) McLds<true> S;
   int slot; Square g;
-#ifdef MC_PRIO
-  __builtin_amdgcn_s_setprio(3);
-#endif
   if (!square_of_block(a, slot, g)) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   if (wave * 16 >= g.ext) return;
@@ -497,7 +513,7 @@ __global__ void __launch_bounds__(256, MC_LB_CHROMA) k_mc_chroma(const McArgs a)
   const int tx = lane & 7, hq = (lane >> 3) & 1, r = (lane >> 4) & 1, hi = lane >> 5;     // hi: H pass halo item / V pass plane
   const int x0 = g.sx + tx * 8, y0 = g.sy + wave * 16 + r * 8;                            // luma position of the tile
   const u32x4 tm = load_tile_rec(a, slot, g, x0, y0);
-  *reinterpret_cast<u32x2*>(&S.taps[2 * lane]) = ldg2(&g_taps_chroma.e[0][0] + 2 * lane);
+  if (lane < 36) *reinterpret_cast<u32x4*>(&S.taps[4 * lane]) = ldg4(&g_taps_chroma.e[0][0] + 4 * lane);
   const uint32_t flags = tm.z >> 24, rmask = (tm.w >> 8) & 0xff;
   const bool active = (flags & TM_ACTIVE) != 0;
   if (!__ballot(active)) return;
@@ -523,31 +539,43 @@ __global__ void __launch_bounds__(256, MC_LB_CHROMA) k_mc_chroma(const McArgs a)
     rsd[0][0] = coded ? r0.x : 0u; rsd[0][1] = coded ? r0.y : 0u; rsd[1][0] = coded ? r1.x : 0u; rsd[1][1] = coded ? r1.y : 0u;
   }
   uint32_t park[4] = {0, 0, 0, 0};
-  const wbase wb = win_base(a);
+  const Win<BUF> win(a, slot);
+  typedef typename Win<BUF>::ref wref;
 #pragma unroll 1
   for (int pass = 0; pass < npass; pass++) {
     const bool vact = active && (pass == 0 || (flags & TM_BI));
-    const bool hact = vact && (hi == 0 || top);
     const uint32_t mv = pass ? tm.y : tm.x, fr = (tm.z >> (4 * pass)) & 15;
     const int ix = (int)(int16_t)(mv & 0xffff), iy = (int)mv >> 16;
+    // chroma vector = luma vector in eighth samples: integer part ix >> 1, fraction (ix & 1) * 4 + quarter fraction
+    const int yf = ((iy & 1) << 2) | ((fr >> 2) & 3);
+#ifdef MC_F0
+    // no vertical interpolation (an eighth of the vectors): the window starts one row higher (identity at tap 2), the block's four rows are
+    // window rows 2..5 -- the halo item's second row pair and the body item's first; the tile is its own run (as in k_mc_luma)
+    const bool yz = yf == 0;
+#else
+    const bool yz = false;
+#endif
+    const bool ptop = top || yz;
+    const bool hact = vact && (hi == 0 ? (!yz || hq == 0) : (ptop && (!yz || hq == 1)));
+#ifdef MC_R15
+    // window row 7 (the second row of the body item with hq == 1) is only ever read by a tile of the second strip row that continues this one
+    const bool row2 = hi != 0 || hq == 0 || (r == 0 && !((__ballot(ptop) >> (lane | 16)) & 1));
+#else
+    const bool row2 = true;
+#endif
     if (hact) {
-      // chroma vector = luma vector in eighth samples: integer part ix >> 1, fraction (ix & 1) * 4 + quarter fraction
-      const int xs = (x0 >> 1) + (ix >> 1) - 1, ys = (y0 >> 1) + (iy >> 1) - 1 + (hi ? 0 : 4) + 2 * hq;
+      const int xs = (x0 >> 1) + (ix >> 1) - 1, ys = (y0 >> 1) + (iy >> 1) - (yz ? 2 : 1) + (hi ? 0 : 4) + 2 * hq;
       const int xf = ((ix & 1) << 2) | (fr & 3);
-      const wref p0 = win_at(final_plane(a, (int)((tm.z >> (8 + 8 * pass)) & (kMaxPics - 1))), ys, pitch, xs & ~1);
+      const wref p0 = win.at(win.plane(a, (int)((tm.z >> (8 + 8 * pass)) & (kMaxPics - 1))), ys, pitch, xs & ~1);
       const wref p1 = p0 + a.cr_off;
       u32x4 rr[4];
-      rr[0] = win_load(wb, p0); rr[1] = win_load(wb, p0 + pitch * 2); rr[2] = win_load(wb, p1); rr[3] = win_load(wb, p1 + pitch * 2);
-#ifdef MC_PRIO
-      __builtin_amdgcn_s_setprio(0);
-#endif
+      rr[0] = win.load(p0); rr[1] = win.load(row2 ? p0 + pitch * 2 : win.nowhere()); rr[2] = win.load(p1); rr[3] = win.load(row2 ? p1 + pitch * 2 : win.nowhere());
       h_item_chroma(rr, &S.taps[(xf * 2 + (xs & 1)) * 8], sh1, hout);
     }
     wave_lds_sync();
     if (vact) {
-      const int yf = ((iy & 1) << 2) | ((fr >> 2) & 3);
-      const uint32_t* above = top ? halo_v : body_v - 128;
-      const uint32_t* vtap = &S.taps[yf * 2 * 8];
+      const uint32_t* above = ptop ? halo_v : body_v - 128;
+      const uint32_t* vtap = &S.taps[(yz ? 8 : yf) * 2 * 8];
       const u32x4 t0 = *reinterpret_cast<const u32x4*>(vtap);
       const u32x2 t1 = *reinterpret_cast<const u32x2*>(vtap + 4);
       const uint32_t A[2] = {t0.x, t0.y}, B[3] = {t0.w, t1.x, t1.y};
@@ -590,13 +618,29 @@ static void launch_mc(K kernel, McArgs& a, int max_ctus, hipStream_t s) {
   }
   hipLaunchKernelGGL(kernel, grid, dim3(256), 0, s, a);
 }
+// buffer-load windows while every byte of the slab of pictures has a 32-bit offset below kWinLimit (57 pictures of 3840x2160), plain addresses beyond
+#ifdef MC_FORCE_PTR
+static bool win_buf(const McArgs& a) { return false; }
+#else
+static bool win_buf(const McArgs& a) { return a.slab_bytes < (uint64_t)kWinLimit; }
+#endif
 void launch_mc_luma(McArgs& a, int max_ctus, bool wp, bool bi, hipStream_t s) {
-  if (wp) { if (bi) launch_mc(k_mc_luma<true, true>, a, max_ctus, s); else launch_mc(k_mc_luma<true, false>, a, max_ctus, s); }
-  else { if (bi) launch_mc(k_mc_luma<false, true>, a, max_ctus, s); else launch_mc(k_mc_luma<false, false>, a, max_ctus, s); }
+  if (win_buf(a)) {
+    if (wp) { if (bi) launch_mc(k_mc_luma<true, true, true>, a, max_ctus, s); else launch_mc(k_mc_luma<true, false, true>, a, max_ctus, s); }
+    else { if (bi) launch_mc(k_mc_luma<false, true, true>, a, max_ctus, s); else launch_mc(k_mc_luma<false, false, true>, a, max_ctus, s); }
+  } else {
+    if (wp) { if (bi) launch_mc(k_mc_luma<true, true, false>, a, max_ctus, s); else launch_mc(k_mc_luma<true, false, false>, a, max_ctus, s); }
+    else { if (bi) launch_mc(k_mc_luma<false, true, false>, a, max_ctus, s); else launch_mc(k_mc_luma<false, false, false>, a, max_ctus, s); }
+  }
 }
 void launch_mc_chroma(McArgs& a, int max_ctus, bool wp, bool bi, hipStream_t s) {
-  if (wp) { if (bi) launch_mc(k_mc_chroma<true, true>, a, max_ctus, s); else launch_mc(k_mc_chroma<true, false>, a, max_ctus, s); }
-  else { if (bi) launch_mc(k_mc_chroma<false, true>, a, max_ctus, s); else launch_mc(k_mc_chroma<false, false>, a, max_ctus, s); }
+  if (win_buf(a)) {
+    if (wp) { if (bi) launch_mc(k_mc_chroma<true, true, true>, a, max_ctus, s); else launch_mc(k_mc_chroma<true, false, true>, a, max_ctus, s); }
+    else { if (bi) launch_mc(k_mc_chroma<false, true, true>, a, max_ctus, s); else launch_mc(k_mc_chroma<false, false, true>, a, max_ctus, s); }
+  } else {
+    if (wp) { if (bi) launch_mc(k_mc_chroma<true, true, false>, a, max_ctus, s); else launch_mc(k_mc_chroma<true, false, false>, a, max_ctus, s); }
+    else { if (bi) launch_mc(k_mc_chroma<false, true, false>, a, max_ctus, s); else launch_mc(k_mc_chroma<false, false, false>, a, max_ctus, s); }
+  }
 }
 
 }  // namespace hmgpu

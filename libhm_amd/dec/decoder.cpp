@@ -239,20 +239,33 @@ void Decoder::activate(const SliceHeader& sh) {
 }
 
 PicData* Decoder::acquire_buffer() {
-  for (int attempt = 0; threaded() && attempt < 64; attempt++) {
-    bool free_one = (int)pool_.size() < seq_.max_pictures;
-    for (auto& p : pool_)
-      if (p.get() != cur_ && !p->is_reference && !p->needed_for_output && !p->lent && !p->in_flight && p->users.load() == 0) free_one = true;
-    if (free_one || inflight_.empty()) break;
-    // every buffer is held by a picture still in flight: wait for the oldest one, hand it on, look again
-    { std::unique_lock<std::mutex> lk(mu_); PicData* head = inflight_.front()->pic; cv_progress_.wait(lk, [&] { return head->parse_done.load(); }); }
-    retire_ready(false);
+  // a buffer nobody needs any more; `pinned_too`: also one whose only holders are readers that let go by themselves (parser tasks
+  // that predict from it, hash jobs that read its planes)
+  auto reusable = [&](const PicData* p, bool pinned_too) {
+    return p != cur_ && !p->is_reference && !p->needed_for_output && !p->lent && !p->in_flight && (pinned_too || p->users.load() == 0);
+  };
+  for (int attempt = 0; threaded() && attempt < 4096; attempt++) {
+    bool free_one = (int)pool_.size() < seq_.max_pictures, pinned_one = false;
+    for (auto& p : pool_) { free_one |= reusable(p.get(), false); pinned_one |= reusable(p.get(), true); }
+    if (free_one) break;
+    if (!inflight_.empty()) {
+      // every buffer is held by a picture still in flight: wait for the oldest one, hand it on, look again
+      { std::unique_lock<std::mutex> lk(mu_); PicData* head = inflight_.front()->pic; cv_progress_.wait(lk, [&] { return head->parse_done.load(); }); }
+      retire_ready(false);
+      continue;
+    }
+    if (!pinned_one || hash_threads_.empty()) break;     // nothing will come free by itself: the stream holds more pictures than the SPS allows
+    // the pipeline is empty and the only reusable buffers are still being hashed (MD5 behind decoding: few cores, large pictures):
+    // throttle instead of failing.  The hash threads release a picture (users) before they take hash_mu_ and notify.
+    std::unique_lock<std::mutex> lk(hash_mu_);
+    hash_idle_cv_.wait(lk, [&] { for (auto& p : pool_) if (reusable(p.get(), false)) return true; return hash_jobs_.empty() && hash_busy_ == 0; });
   }
   for (auto& p : pool_)
-    if (p.get() != cur_ && !p->is_reference && !p->needed_for_output && !p->lent && !p->in_flight && p->users.load() == 0) {
+    if (reusable(p.get(), false)) {
       if (gpu_ && p->submit_seq > synced_seq_) {          // the device may still be reading the arrays of the picture that lived here
-        hmgpu_sync(gpu_);
+        const hmgpu_status st = hmgpu_sync(gpu_);
         synced_seq_ = submitted_seq_;
+        if (st != HMGPU_OK) throw std::runtime_error(std::string("hmgpu_sync: ") + hmgpu_status_string(st));   // e.g. an intra wavefront that gave up
       }
       return p.get();
     }
@@ -820,10 +833,10 @@ void Decoder::hash_main() {
     }
     bool landed = true;
     if (const uint64_t t = j.pic->dl_ticket.load()) landed = hmgpu_download_wait(gpu_, t) == HMGPU_OK;
-    if (landed && !md5_plane_matches(j.pic, j.comp, j.bd, j.want)) {
+    if (!landed || !md5_plane_matches(j.pic, j.comp, j.bd, j.want)) {
       if (!j.pic->hash_mismatch.exchange(true)) {
         hash_mismatches_++;
-        fprintf(stderr, "hmdec: ***ERROR*** decoded picture hash mismatch, POC %d\n", j.pic->poc);
+        fprintf(stderr, landed ? "hmdec: ***ERROR*** decoded picture hash mismatch, POC %d\n" : "hmdec: ***ERROR*** device error behind the picture of POC %d (not checked)\n", j.pic->poc);
       }
     }
     j.pic->users.fetch_sub(1);

@@ -26,10 +26,11 @@ def build(bd, is_chroma, bi):
     p = synth.make_picture(size, size, bd, seed=3, bi=bool(bi), mode_probs=(0, 0, 0, 1.0, 0), cbf_prob=0.0, sao=False, ref_handles=([0], [1]))
     m = dict(p.meta_np)
     cu = (p.py >> 3) * (size >> 3) + (p.px >> 3)           # index of the 8x8 CU of every partition
+    pux, puy = (p.px & ~7) >> cs, (p.py & ~7) >> cs        # origin of the partition's PU in the component (one vector per PU: TComDataCU)
     for name, ks in (("mv0", sel[cu % len(sel)]), ("mv1", sel[(cu * 7 + 3) % len(sel)])):
         # integer part: from the PU to the KAT block; fraction in the component's own units = quarter luma samples either way
-        mvx = ((cases[ks, 4] - (p.px >> cs)) << (2 + cs)) + cases[ks, 2]
-        mvy = ((cases[ks, 5] - (p.py >> cs)) << (2 + cs)) + cases[ks, 3]
+        mvx = ((cases[ks, 4] - pux) << (2 + cs)) + cases[ks, 2]
+        mvy = ((cases[ks, 5] - puy) << (2 + cs)) + cases[ks, 3]
         m[name] = np.stack([mvx, mvy], axis=2).astype(np.int16)
     m["ref_idx0"] = np.where(p.inside, 0, -1)
     m["ref_idx1"] = np.where(p.inside, 0 if bi else -1, -1)
