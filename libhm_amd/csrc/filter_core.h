@@ -16,6 +16,14 @@ static __constant__ uint8_t c_chroma_scale_420_dbk[58] = {
     29, 30, 31, 32, 33, 33, 34, 34, 35, 35, 36, 36, 37, 37, 38, 39, 40, 41, 42, 43, 44, 45, 46, 47, 48, 49, 50, 51};
 
 __device__ inline bool mvd4(const int16_t* a, const int16_t* b) { return abs(a[0] - b[0]) >= 4 || abs(a[1] - b[1]) >= 4; }
+// the same on packed vectors (hor | ver << 16): some component differs by 4 or more quarter samples.  The differences of two 16-bit
+// vector components fit 17 bits: saturating subtraction keeps the comparison exact (|d| >= 4 survives the clamp)
+typedef short mv2 __attribute__((ext_vector_type(2)));
+__device__ inline bool mvd4(uint32_t a, uint32_t b) {
+  const mv2 d = __builtin_elementwise_sub_sat(__builtin_bit_cast(mv2, a), __builtin_bit_cast(mv2, b));
+  const mv2 m = __builtin_elementwise_max(d, __builtin_elementwise_sub_sat((mv2){0, 0}, d));       // |d| (saturated)
+  return (__builtin_bit_cast(uint32_t, m) & 0xfffcfffcu) != 0u;
+}
 
 // xGetBoundaryStrengthSingle (TComLoopFilter.cpp:411-537).  `transform_edge` is the m_aapucBS marker.  The P-slice
 // branch (:515-532) is the B-slice branch with list 1 absent on both sides, so one formula serves both.
@@ -24,11 +32,11 @@ __device__ inline int boundary_strength(const BlkInfo& p, const BlkInfo& q, bool
   if (transform_edge && ((p.flags | q.flags) & BF_CBFY)) return 1;
   const int p0 = p.ref[0], p1 = p.ref[1], q0 = q.ref[0], q1 = q.ref[1];
   if ((p0 == q0 && p1 == q1) || (p0 == q1 && p1 == q0)) {
-    if (p0 != p1) {
-      if (p0 == q0) return (mvd4(q.mv[0], p.mv[0]) || mvd4(q.mv[1], p.mv[1])) ? 1 : 0;
-      return (mvd4(q.mv[1], p.mv[0]) || mvd4(q.mv[0], p.mv[1])) ? 1 : 0;
-    }
-    return ((mvd4(q.mv[0], p.mv[0]) || mvd4(q.mv[1], p.mv[1])) && (mvd4(q.mv[1], p.mv[0]) || mvd4(q.mv[0], p.mv[1]))) ? 1 : 0;
+    const uint32_t pm0 = __builtin_bit_cast(uint32_t, *reinterpret_cast<const mv2*>(p.mv[0])), pm1 = __builtin_bit_cast(uint32_t, *reinterpret_cast<const mv2*>(p.mv[1]));
+    const uint32_t qm0 = __builtin_bit_cast(uint32_t, *reinterpret_cast<const mv2*>(q.mv[0])), qm1 = __builtin_bit_cast(uint32_t, *reinterpret_cast<const mv2*>(q.mv[1]));
+    const bool straight = mvd4(qm0, pm0) || mvd4(qm1, pm1), crossed = mvd4(qm1, pm0) || mvd4(qm0, pm1);
+    if (p0 != p1) return (p0 == q0 ? straight : crossed) ? 1 : 0;
+    return (straight && crossed) ? 1 : 0;
   }
   return 1;
 }

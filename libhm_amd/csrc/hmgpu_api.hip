@@ -243,6 +243,7 @@ hmgpu_status alloc_picture(hmgpu_ctx* c, Picture& p) {
     Carver m(pass ? p.derived : nullptr);
     PicDev& d = p.dev;
     d.blk = m.take<BlkInfo>((size_t)c->grid_w * c->grid_h);
+    d.edges = m.take<EdgeRec>((size_t)(c->grid_w / 2) * (c->grid_h / 2));
     d.tmv = m.take<TileMv>((size_t)(c->grid_w / 2) * (c->grid_h / 2));
     for (int k = 0; k < 3; k++) d.resid[k] = m.take<int16_t>(c->coef_elems[k]);
     for (int k = 0; k < 3; k++) d.quad_off[k] = m.take<uint32_t>((size_t)c->num_ctus * (c->parts / 4));
@@ -330,7 +331,7 @@ hmgpu_status ensure_refs_extended(hmgpu_ctx* c, const Batch& b, size_t call_idx)
 hmgpu_status run_recon(hmgpu_ctx* c, const Batch& b, bool any_intra, bool any_wp, bool any_cells, bool any_bi) {
   int max_ctus = 0;
   for (int i = 0; i < b.n; i++) max_ctus = std::max(max_ctus, b.num_ctus[i]);
-  { ProfScope ps(c, K_PREP); launch_prep(c->d_pics, b, max_ctus, c->parts, any_intra, c->stream); }
+  { ProfScope ps(c, K_PREP); launch_prep(c->d_pics, b, max_ctus, c->parts, any_intra, any_cells, c->stream); }
   McArgs ma;
   memset(&ma, 0, sizeof(ma));
   ma.n = b.n; ma.width = c->seq.width; ma.height = c->seq.height; ma.log2ctu = c->seq.log2_ctu_size; ma.ctus_w = c->ctus_w;

@@ -44,6 +44,20 @@ enum : uint8_t {
   BE_HOR_TRANSFORM = 8,
 };
 
+// ---- deblocking decisions of one 8x8 luma area (raster grid, grid_w/2 x grid_h/2), written by k_prep for the loop-filter kernels ----
+// The four 4-sample edge units on the area's left border (v[k]: rows 4k .. 4k+3) and top border (h[k]: columns 4k .. 4k+3), 2 bytes
+// each: what xGetBoundaryStrengthSingle, xEdgeFilterLuma and xEdgeFilterChroma take from the two blocks that face each other
+// across the unit (TComLoopFilter.cpp:411-537, 587-600, 629-634) -- SURVEY.md a-12.  The slice constants of a unit are those of the
+// CTU its Q side lies in (slices are whole CTUs).
+//   bits 0-1  Bs; 0 = the unit is not filtered (no edge, deblocking disabled, unavailable neighbour or Bs 0)
+//   bits 2-8  ((QP_P + QP_Q + 1) >> 1) + 32
+//   bit 9/10  the P / Q side is exempt from the loop filters (lossless CU, PCM CU with pcm_loop_filter_disabled)
+struct __attribute__((aligned(8))) EdgeRec { uint16_t v[2], h[2]; };
+static_assert(sizeof(EdgeRec) == 8, "EdgeRec must be 8 bytes");
+__host__ __device__ constexpr uint32_t edge_unit_pack(int bs, int qp, bool p_nf, bool q_nf) {
+  return (uint32_t)bs | ((uint32_t)(qp + 32) << 2) | ((p_nf ? 1u : 0u) << 9) | ((q_nf ? 1u : 0u) << 10);
+}
+
 // ---- motion of one 8x8 luma tile (raster grid, grid_w/2 x grid_h/2), written by k_prep for the motion-compensation kernels --
 // A tile is ACTIVE when its four 4x4 cells are inter-predicted with identical motion (k_mc.hip predicts those); slot 0 is
 // the first list the tile predicts from, slot 1 is list 1 of a bi-predicted tile.  The vectors are CLIPPED (TComDataCU::clipMv)
@@ -132,7 +146,8 @@ struct PicDev {
   uint32_t* quad_off[3];           // compact levels: offset of the first TU that starts in every 8x8 luma area (z-order), written by k_prep
   const SliceDev* slices;
   // derived
-  BlkInfo* blk;
+  BlkInfo* blk;                    // written only for calls that run kernels which read it (mixed-motion tiles, exempt CUs): launch_prep
+  EdgeRec* edges;                  // [grid_h / 2][grid_w / 2]
   TileMv* tmv;                     // [grid_h / 2][grid_w / 2]
   TuRec* tu[4];                    // by log2 size - 2: kTuShards shards of tu_cap[] records each
   uint32_t* tu_count;              // [4][kTuShards]
@@ -240,7 +255,7 @@ __host__ inline int xcd_grid(int n, int nb) {
 }
 
 // ---- launchers (one per kernel family; defined in the .hip files) ---------------------------------------------------
-void launch_prep(const PicDev* pics, const Batch& b, int max_ctus, int parts, bool intra, hipStream_t s);
+void launch_prep(const PicDev* pics, const Batch& b, int max_ctus, int parts, bool intra, bool write_blk, hipStream_t s);
 // npics = entries of the finals table (device pictures of the context, <= kMaxPics)
 // bi: the batch holds B slices (the variants that run the H and V passes once per list)
 void launch_mc_luma(McArgs& a, int max_ctus, bool wp, bool bi, hipStream_t s);

@@ -2,10 +2,9 @@
 // edges of the picture, one for all horizontal edges (the second consumes the first's output, as in HM).
 //
 // One thread per 4-sample edge unit on the 8x8 grid, the unit at which HM takes every decision (xEdgeFilterLuma,
-// :540-653).  The thread derives the boundary strength from the two BlkInfo records that face each other across the
-// edge (xGetBoundaryStrengthSingle, :411-537 -- reference pictures are compared by device picture handle, the
-// counterpart of HM's TComPic* comparison), evaluates dE / side / strong-weak on lines 0 and 3 and filters its four
-// lines in registers.  Where the unit also lies on the 8x8 chroma grid and Bs == 2 the same thread filters the two
+// :540-653).  The thread takes the unit's boundary strength, mean QP and exemptions from its EdgeRec entry (k_prep.hip:
+// xGetBoundaryStrengthSingle, :411-537 -- reference pictures are compared by device picture handle, the counterpart of
+// HM's TComPic* comparison), evaluates dE / side / strong-weak on lines 0 and 3 and filters its four lines in registers.  Where the unit also lies on the 8x8 chroma grid and Bs == 2 the same thread filters the two
 // chroma lines of Cb and Cr (xEdgeFilterChroma, :656-785).  Filtering is in place: units on the 8x8 grid read and
 // write disjoint samples (4 read / 3 written per side), so no two threads of one launch touch the same sample.
 #include "hmgpu_dev.h"
@@ -23,15 +22,14 @@ __global__ void __launch_bounds__(256) k_deblock(const PicDev* __restrict__ pics
   const int gy = DIR == 0 ? ty : ty * 2;
   const int x = gx * 4, y = gy * 4;
   if (x >= P.width || y >= P.height) return;
-  if (DIR == 0 ? gx == 0 : gy == 0) return;
-  const BlkInfo q = ld_blk(P.blk + (size_t)gy * P.grid_w + gx);
-  if (!(q.edge & (DIR == 0 ? BE_VER_FILTER : BE_HOR_FILTER))) return;
-  const BlkInfo p = ld_blk(DIR == 0 ? P.blk + (size_t)gy * P.grid_w + gx - 1 : P.blk + (size_t)(gy - 1) * P.grid_w + gx);
-  const int bs = boundary_strength(p, q, (q.edge & (DIR == 0 ? BE_VER_TRANSFORM : BE_HOR_TRANSFORM)) != 0);
+  // the unit's EdgeRec entry (k_prep): Bs, mean QP, exemptions of the two blocks that face each other
+  const uint32_t rec = ldg(reinterpret_cast<const uint16_t*>(P.edges + (size_t)(y >> 3) * (P.grid_w >> 1) + (x >> 3)) + (DIR == 0 ? ((y >> 2) & 1) : 2 + ((x >> 2) & 1)));
+  const int bs = rec & 3;
   if (bs == 0) return;
-  const SliceDev* slp = P.slices + q.slice;                         // offsets come from the Q side's slice (:565-566)
+  const int sidx = P.slice_idx ? ldg(P.slice_idx + (size_t)(y >> P.log2ctu) * P.ctus_w + (x >> P.log2ctu)) : 0;
+  const SliceDev* slp = P.slices + sidx;                            // offsets come from the Q side's slice (:565-566)
   const int tc_off = ldg(&slp->tc_offset_div2), beta_off = ldg(&slp->beta_offset_div2);
-  const int qp = ((int)p.qp + (int)q.qp + 1) >> 1;
+  const int qp = (int)((rec >> 2) & 127) - 32;
   const int pitch = P.pitch[0];
   int16_t* base = P.rec[0] + (size_t)y * pitch + x;
   // the unit as line pairs (filter_core.h): la = lines 0|1, lb = lines 2|3, index = position across the edge
@@ -52,7 +50,7 @@ __global__ void __launch_bounds__(256) k_deblock(const PicDev* __restrict__ pics
       la[k] = v.x; lb[k] = v.y;
     }
   }
-  const bool p_nf = (p.flags & BF_NOFILT) != 0, q_nf = (q.flags & BF_NOFILT) != 0;
+  const bool p_nf = (rec >> 9) & 1, q_nf = (rec >> 10) & 1;
   filter_luma_unit(la, lb, bs, qp, tc_off, beta_off, P.bd[0], p_nf, q_nf);
   if (DIR == 0) {
     uint32_t r[4][4];

@@ -113,21 +113,13 @@ __device__ inline void sao_group(const PicDev& P, int comp, const int16_t (*t)[W
   stg4(dst, res);
 }
 
-// the two BlkInfo records facing each other across an edge unit of direction DIR whose Q block is at luma (x, y); requested
-// at kernel entry, long before the unit is filtered (their latency hides behind the tile load)
-struct EdgeBlk { u32x4 q, p; bool on; };
+// the EdgeRec unit (k_prep: Bs, mean QP, exemptions) of the edge unit of direction DIR whose Q block is at luma (x, y); requested at
+// kernel entry, long before the unit is filtered (its latency hides behind the tile load)
 template <int DIR>
-__device__ inline EdgeBlk edge_fetch(const PicDev& P, int x, int y, bool mine) {
-  EdgeBlk e;
-  e.q = e.p = (u32x4){0, 0, 0, 0};
-  const int gx = x >> 2, gy = y >> 2;
-  e.on = mine && x >= 0 && y >= 0 && x < P.width && y < P.height && (DIR == 0 ? gx != 0 : gy != 0);
-  if (e.on) {
-    const BlkInfo* g = P.blk + (size_t)gy * P.grid_w + gx;
-    e.q = ldg4(g);
-    e.p = ldg4(DIR == 0 ? g - 1 : g - P.grid_w);
-  }
-  return e;
+__device__ inline uint32_t edge_fetch(const PicDev& P, int x, int y, bool mine) {
+  if (!(mine && x >= 0 && y >= 0 && x < P.width && y < P.height)) return 0u;
+  const uint16_t* rec = reinterpret_cast<const uint16_t*>(P.edges + (size_t)(y >> 3) * (P.grid_w >> 1) + (x >> 3));
+  return ldg(rec + (DIR == 0 ? ((y >> 2) & 1) : 2 + ((x >> 2) & 1)));
 }
 
 // Deblocking runs in two steps so that lanes are spent on real work only: every edge unit of the tile is CLASSIFIED by its
@@ -141,16 +133,15 @@ __device__ inline SliceLf slice_lf(const SliceDev* s) {
 }
 static_assert(HMGPU_MAX_SLICES <= 4096, "slice index must fit the 12 bits of a list entry");
 
-template <int DIR, bool NF>
-__device__ inline uint32_t edge_classify(const EdgeBlk& e, int u) {
-  if (!e.on) return 0u;
-  const BlkInfo q = __builtin_bit_cast(BlkInfo, e.q), p = __builtin_bit_cast(BlkInfo, e.p);
-  if (!(q.edge & (DIR == 0 ? BE_VER_FILTER : BE_HOR_FILTER))) return 0u;
-  const int bs = boundary_strength(p, q, (q.edge & (DIR == 0 ? BE_VER_TRANSFORM : BE_HOR_TRANSFORM)) != 0);
-  if (bs == 0) return 0u;
-  const int qp = ((int)p.qp + (int)q.qp + 1) >> 1;
-  const uint32_t p_nf = NF && (p.flags & BF_NOFILT) != 0, q_nf = NF && (q.flags & BF_NOFILT) != 0;
-  return (uint32_t)u | ((uint32_t)bs << 8) | (p_nf << 10) | (q_nf << 11) | ((uint32_t)(qp + 64) << 12) | ((uint32_t)q.slice << 20);
+// unit u of the tile with EdgeRec unit `rec` (0: not filtered) at luma (x, y) -> list entry
+template <bool NF>
+__device__ inline uint32_t edge_classify(const PicDev& P, uint32_t rec, int u, int x, int y) {
+  if ((rec & 3u) == 0u) return 0u;
+  const uint32_t bs = rec & 3u, qp = (rec >> 2) & 127u;                 // QP + 32
+  const uint32_t p_nf = NF ? (rec >> 9) & 1u : 0u, q_nf = NF ? (rec >> 10) & 1u : 0u;
+  // the slice whose deblocking constants apply: the one of the Q side's CTU (TComLoopFilter.cpp:565-566)
+  const uint32_t slice = P.slice_idx ? (uint32_t)ldg(P.slice_idx + (size_t)(y >> P.log2ctu) * P.ctus_w + (x >> P.log2ctu)) : 0u;
+  return (uint32_t)u | (bs << 8) | (p_nf << 10) | (q_nf << 11) | ((qp + 32u) << 12) | (slice << 20);
 }
 
 // append the wave's active units to its list; called by the three waves that classify
@@ -251,7 +242,7 @@ __global__ void __launch_bounds__(256) k_filter_fused(const PicDev* __restrict__
   // edge units of this thread: vertical edges x0, x0+8 .. x0+64 over the rows [y0-4, y0+68) (9 edges x 18 units), horizontal
   // edges y0 .. y0+64 over the columns [x0-4, x0+68)
   const int vx = x0 + 8 * (t % 9), vy = y0 - 4 + 4 * (t / 9), hx = x0 - 4 + 4 * (t % 18), hy = y0 + 8 * (t / 18);
-  const EdgeBlk ev = edge_fetch<0>(P, vx, vy, t < kUnits), eh = edge_fetch<1>(P, hx, hy, t < kUnits);
+  const uint32_t ev = edge_fetch<0>(P, vx, vy, t < kUnits), eh = edge_fetch<1>(P, hx, hy, t < kUnits);
   const SliceLf s0 = slice_lf(P.slices);
   // SAO groups of this thread (8 samples each): two of luma (64 rows x 8 groups), one of Cb or Cr (32 rows x 4 groups each);
   // their parameters are requested now as well
@@ -283,8 +274,8 @@ __global__ void __launch_bounds__(256) k_filter_fused(const PicDev* __restrict__
     }
   }
   if (t < 192) {
-    push_units(L.unit[0], L.units[0], edge_classify<0, NF>(ev, t), t);
-    push_units(L.unit[1], L.units[1], edge_classify<1, NF>(eh, t), t);
+    push_units(L.unit[0], L.units[0], edge_classify<NF>(P, ev, t, vx, vy), t);
+    push_units(L.unit[1], L.units[1], edge_classify<NF>(P, eh, t, hx, hy), t);
   }
 #pragma unroll
   for (int k = 0; k < NY; k++) {

@@ -250,6 +250,7 @@ __device__ inline bool tile_is_top(const u32x4 tm, int r, int partner_lane) {
 // the end of the buffer -- the range check answers it with zeros and nothing goes to memory (slabs under kWinLimit bytes: launch_mc).
 // !BUF: plain 64-bit addresses; lanes without a work item read valid memory nobody looks at.
 constexpr uint32_t kWinLimit = 0xffff0000u;
+constexpr uint32_t kResidLimit = 0x7fffff00u;   // residual tiles of a picture: far below 2 GB
 template <bool BUF> struct Win;
 template <> struct Win<true> {
   typedef uint32_t ref;
@@ -376,8 +377,11 @@ __global__ void __launch_bounds__(256, (WP || BI) ? 1 : MC_LB_LUMA) k_mc_luma(co
   uint32_t rsd[2][4];
   {
     const uint32_t qm = active ? (rmask >> (q & 2)) & 3 : 0u;
-    const int16_t* rp = a.resid[slot] + (qm ? ((size_t)(y0 >> 3) * a.rtw + (x0 >> 3)) * 64 + q * 8 : (size_t)0);
-    const u32x4 r0 = ldg4(rp), r1 = ldg4(rp + 32);
+    // (buffer loads: lanes whose tile carries no residual ask past the end of the buffer and get zeros without a memory access)
+    const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc((void*)a.resid[slot], 0, kResidLimit, 0x00020000);
+    const uint32_t ro = qm ? (uint32_t)((((y0 >> 3) * a.rtw + (x0 >> 3)) * 64 + q * 8) * 2) : kResidLimit;
+    const u32x4 r0 = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rr, ro, 0, 0));
+    const u32x4 r1 = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rr, ro + 64, 0, 0));
     rsd[0][0] = qm & 1 ? r0.x : 0u; rsd[0][1] = qm & 1 ? r0.y : 0u; rsd[1][0] = qm & 1 ? r1.x : 0u; rsd[1][1] = qm & 1 ? r1.y : 0u;
     rsd[0][2] = qm & 2 ? r0.z : 0u; rsd[0][3] = qm & 2 ? r0.w : 0u; rsd[1][2] = qm & 2 ? r1.z : 0u; rsd[1][3] = qm & 2 ? r1.w : 0u;
   }
@@ -534,8 +538,11 @@ __global__ void __launch_bounds__(256, (WP && BI) ? 6 : MC_LB_CHROMA) k_mc_chrom
   {
     const bool coded = active && (rmask & (hi ? TR_CR : TR_CB));
     const int xc = x0 >> 1, yc = (y0 >> 1) + 2 * hq;
-    const int16_t* rp = (hi ? a.resid2[slot] : a.resid[slot]) + (coded ? (((size_t)(yc >> 3) * a.rtw + (xc >> 3)) * 8 + resid_slot(yc)) * 8 + (xc & 4) : (size_t)0);
-    const u32x2 r0 = ldg2(rp), r1 = ldg2(rp + 32);
+    // (both planes' residual tiles lie in one allocation, Cb before Cr: one buffer, the plane is part of the offset)
+    const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc((void*)a.resid[slot], 0, kResidLimit, 0x00020000);
+    const uint32_t ro = coded ? (uint32_t)(((((yc >> 3) * a.rtw + (xc >> 3)) * 8 + resid_slot(yc)) * 8 + (xc & 4)) * 2) + (hi ? (uint32_t)((const char*)a.resid2[slot] - (const char*)a.resid[slot]) : 0u) : kResidLimit;
+    const u32x2 r0 = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rr, ro, 0, 0));
+    const u32x2 r1 = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rr, ro + 64, 0, 0));
     rsd[0][0] = coded ? r0.x : 0u; rsd[0][1] = coded ? r0.y : 0u; rsd[1][0] = coded ? r1.x : 0u; rsd[1][1] = coded ? r1.y : 0u;
   }
   uint32_t park[4] = {0, 0, 0, 0};
@@ -569,7 +576,15 @@ __global__ void __launch_bounds__(256, (WP && BI) ? 6 : MC_LB_CHROMA) k_mc_chrom
       const wref p0 = win.at(win.plane(a, (int)((tm.z >> (8 + 8 * pass)) & (kMaxPics - 1))), ys, pitch, xs & ~1);
       const wref p1 = p0 + a.cr_off;
       u32x4 rr[4];
-      rr[0] = win.load(p0); rr[1] = win.load(row2 ? p0 + pitch * 2 : win.nowhere()); rr[2] = win.load(p1); rr[3] = win.load(row2 ? p1 + pitch * 2 : win.nowhere());
+#if defined(MC_CEXP) && (MC_CEXP & 1)       // experiment: no halo rows
+      const bool ld = hi == 0;
+#elif defined(MC_CEXP) && (MC_CEXP & 2)     // experiment: no window loads at all
+      const bool ld = false;
+#else
+      const bool ld = true;
+#endif
+      rr[0] = win.load(ld ? p0 : win.nowhere()); rr[1] = win.load(ld && row2 ? p0 + pitch * 2 : win.nowhere());
+      rr[2] = win.load(ld ? p1 : win.nowhere()); rr[3] = win.load(ld && row2 ? p1 + pitch * 2 : win.nowhere());
       h_item_chroma(rr, &S.taps[(xf * 2 + (xs & 1)) * 8], sh1, hout);
     }
     wave_lds_sync();

@@ -11,6 +11,7 @@
 //   * TComLoopFilter::xSetLoopfilterParam / xSetEdgefilterTU / xSetEdgefilterPU (TComLoopFilter.cpp:269-409):
 //     whether the left/top border of a partition is a CU, TU or PU edge follows from depth, tr_idx and part_size.
 #include "hmgpu_dev.h"
+#include "filter_core.h"
 
 namespace hmgpu {
 
@@ -57,8 +58,56 @@ __device__ inline TuRec make_tu(const PicDev& P, const Quad& q, const SliceDev* 
   return r;
 }
 
-__global__ void __launch_bounds__(256) k_prep(const PicDev* __restrict__ pics, Batch b) {
+// z index of the partition at column x, row y of a CTU (inverse of zscan_x / zscan_y)
+__device__ inline int z_of(int x, int y) {
+  int z = 0;
+#pragma unroll
+  for (int k = 0; k < 4; k++) z |= (((x >> k) & 1) << (2 * k)) | (((y >> k) & 1) << (2 * k + 1));
+  return z;
+}
+
+// what the boundary strength and the filter decisions need to know about partition z of CTU `ctu`, straight from HM's arrays:
+// for the few edge units whose P side lies in a CTU that another workgroup flattens (the CTU row above, the CTU left of a
+// workgroup's first).  The same fields the main path derives for its own cells.
+__device__ inline BlkInfo cell_from_arrays(const PicDev& P, int ctu, int z) {
+  BlkInfo bi;
+  bi.mv[0][0] = bi.mv[0][1] = bi.mv[1][0] = bi.mv[1][1] = 0;
+  bi.ref[0] = bi.ref[1] = -1;
+  bi.qp = 0; bi.flags = 0; bi.edge = 0; bi.log2cu = 3; bi.slice = 0;
+  const size_t i = (size_t)ctu * P.parts + z;
+  if ((int)ldg(P.part_size + i) == HMGPU_SIZE_NONE) return bi;
+  const int sidx = P.slice_idx ? ldg(P.slice_idx + ctu) : 0;
+  const SliceDev* sl = P.slices + sidx;
+  const int tr = ldg(P.tr_idx + i);
+  const bool intra = ldg(P.pred_mode + i) == HMGPU_MODE_INTRA;
+  bi.flags = BF_VALID | (intra ? BF_INTRA : 0) | (((ldg(P.cbf[0] + i) >> tr) & 1) ? BF_CBFY : 0);
+  if (ldg(P.bypass + i) || (P.pcm_lf_disable && ldg(P.ipcm + i))) bi.flags |= BF_NOFILT;
+  bi.qp = ldg(P.qp + i);
+  bi.log2cu = (uint8_t)(P.log2ctu - ldg(P.depth + i));
+  bi.slice = (uint16_t)sidx;
+  if (!intra) {
+    const int r0 = ldg(P.ref_idx[0] + i), r1 = ldg(P.ref_idx[1] + i);
+    if (r0 >= 0) { const uint32_t w = ldg(reinterpret_cast<const uint32_t*>(P.mv[0]) + i); bi.mv[0][0] = (int16_t)(w & 0xffff); bi.mv[0][1] = (int16_t)(w >> 16); bi.ref[0] = ldg(&sl->ref_pic[0][r0]); }
+    if (r1 >= 0 && ldg(&sl->slice_type) == HMGPU_B_SLICE) { const uint32_t w = ldg(reinterpret_cast<const uint32_t*>(P.mv[1]) + i); bi.mv[1][0] = (int16_t)(w & 0xffff); bi.mv[1][1] = (int16_t)(w >> 16); bi.ref[1] = ldg(&sl->ref_pic[1][r1]); }
+  }
+  return bi;
+}
+
+// one edge unit: Bs of the two cells that face each other, their mean QP and their exemptions (EdgeRec, hmgpu_dev.h)
+__device__ inline uint16_t edge_unit(const BlkInfo& p, const BlkInfo& q, bool transform_edge) {
+  const int bs = boundary_strength(p, q, transform_edge);
+  if (bs == 0) return 0;
+  return (uint16_t)edge_unit_pack(bs, ((int)p.qp + (int)q.qp + 1) >> 1, (p.flags & BF_NOFILT) != 0, (q.flags & BF_NOFILT) != 0);
+}
+
+__global__ void __launch_bounds__(256) k_prep(const PicDev* __restrict__ pics, Batch b, int write_blk) {
   __shared__ uint32_t lds_cnt[4], lds_base[4], lds_stat[2];
+  // the cells of the workgroup's areas, for the edge units of their right and lower neighbours (boundary strength needs both sides)
+  __shared__ __attribute__((aligned(16))) u32x4 lds_cell[256 * 4];
+  // ... and the P sides that lie in CTUs other workgroups flatten: the two cells above every area of a CTU's top row (128 slots cover
+  // 64 CTUs of 2 areas), the two cells left of the areas in the first column of the workgroup's first CTU.  Fetched from HM's arrays at
+  // the very start (cell_from_arrays), so that their latency runs beside the thread's own loads
+  __shared__ __attribute__((aligned(16))) u32x4 lds_above[256], lds_left[16];
   const PicDev& P = pics[b.pic[blockIdx.z]];
   if (threadIdx.x < 4) lds_cnt[threadIdx.x] = 0;
   if (threadIdx.x < 2) lds_stat[threadIdx.x] = 0;
@@ -73,6 +122,8 @@ __global__ void __launch_bounds__(256) k_prep(const PicDev* __restrict__ pics, B
   int cls[6] = {0, 0, 0, 0, 0, 0};
   uint32_t loc[6] = {0, 0, 0, 0, 0, 0};
   const SliceDev* sl = P.slices;
+  u32x4 cells[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+  write_blk |= P.any_nofilt;                                     // SAO reads the exemption flags back (sao_exempt_mask)
   if (active) {
     q.ctu = b.first_ctu[blockIdx.z] + gq / (parts >> 2);
     q.z0 = (gq % (parts >> 2)) * 4;
@@ -80,6 +131,21 @@ __global__ void __launch_bounds__(256) k_prep(const PicDev* __restrict__ pics, B
     const int cx = q.ctu % P.ctus_w, cy = q.ctu / P.ctus_w;
     const int x4 = zscan_x(q.z0), y4 = zscan_y(q.z0);            // partition 0 inside the CTU; partitions 1..3 are (+1,0),(0,+1),(+1,+1)
     q.gx0 = cx * P.pw + x4; q.gy0 = cy * P.pw + y4;
+    {
+      // the cells this CTU's edge units need from CTUs that other workgroups flatten: the pw cells above the CTU (if the CTU above is not
+      // in this workgroup) and the pw cells left of it (first CTU of the workgroup), one cell per lane of the CTU's first lanes
+      const int qpc = parts >> 2, lane_c = q.z0 >> 2, t0 = (int)threadIdx.x - lane_c, cl = t0 / qpc, pw = P.pw;
+      const bool need_above = cy > 0 && t0 - P.ctus_w * qpc < 0, need_left = cx > 0 && t0 - qpc < 0;
+#pragma unroll 1
+      for (int r = lane_c; r < 2 * pw; r += qpc) {
+        const bool left = r >= pw;
+        const int i = left ? r - pw : r;
+        if (left ? need_left : need_above) {
+          const u32x4 v = __builtin_bit_cast(u32x4, cell_from_arrays(P, left ? q.ctu - 1 : q.ctu - P.ctus_w, left ? z_of(pw - 1, i) : z_of(i, pw - 1)));
+          if (left) lds_left[i] = v; else lds_above[cl * pw + i] = v;
+        }
+      }
+    }
     // ---- the quad's share of HM's arrays
     const uint32_t part4 = ldg(reinterpret_cast<const uint32_t*>(P.part_size + idx));
     const uint32_t depth4 = ldg(reinterpret_cast<const uint32_t*>(P.depth + idx));
@@ -198,7 +264,8 @@ __global__ void __launch_bounds__(256) k_prep(const PicDev* __restrict__ pics, B
           }
         }
       }
-      stg4(&P.blk[(size_t)gy * P.grid_w + gx], __builtin_bit_cast(u32x4, bi));
+      cells[j] = __builtin_bit_cast(u32x4, bi);
+      if (write_blk) stg4(&P.blk[(size_t)gy * P.grid_w + gx], cells[j]);
       if (!q.valid) { tm_mv[j][0] = tm_mv[j][1] = 0; tm_key[j] = 0; }
     }
     {
@@ -311,7 +378,51 @@ __global__ void __launch_bounds__(256) k_prep(const PicDev* __restrict__ pics, B
       }
     }
   }
+  if (active) {
+#pragma unroll
+    for (int j = 0; j < 4; j++) lds_cell[threadIdx.x * 4 + j] = cells[j];
+  }
   __syncthreads();
+  // ---- the area's four edge units (xGetBoundaryStrengthSingle, TComLoopFilter.cpp:411-537): the Q side is one of its own cells, the P side
+  // the cell to the left / above -- another thread's, through LDS where that thread belongs to this workgroup (the areas of a CTU are 64,
+  // 16 or 4 consecutive threads in z-order, consecutive CTUs follow each other)
+  if (active) {
+    EdgeRec er; er.v[0] = er.v[1] = er.h[0] = er.h[1] = 0;
+    if (q.valid) {
+      const int x4 = zscan_x(q.z0), y4 = zscan_y(q.z0), qpc = parts >> 2;
+      const int t0 = (int)threadIdx.x - (q.z0 >> 2);             // the thread of the CTU's first area
+#pragma unroll
+      for (int k = 0; k < 2; k++) {
+        {
+          const BlkInfo Q = __builtin_bit_cast(BlkInfo, cells[2 * k]);
+          if (Q.edge & BE_VER_FILTER) {
+            BlkInfo Pn;
+            if (x4 > 0) Pn = __builtin_bit_cast(BlkInfo, lds_cell[(t0 + (z_of(x4 - 2, y4) >> 2)) * 4 + 2 * k + 1]);
+            else {
+              const int tn = t0 - qpc + (z_of(P.pw - 2, y4) >> 2);
+              if (tn >= 0) Pn = __builtin_bit_cast(BlkInfo, lds_cell[tn * 4 + 2 * k + 1]);
+              else Pn = __builtin_bit_cast(BlkInfo, lds_left[y4 + k]);
+            }
+            er.v[k] = edge_unit(Pn, Q, (Q.edge & BE_VER_TRANSFORM) != 0);
+          }
+        }
+        {
+          const BlkInfo Q = __builtin_bit_cast(BlkInfo, cells[k]);
+          if (Q.edge & BE_HOR_FILTER) {
+            BlkInfo Pn;
+            if (y4 > 0) Pn = __builtin_bit_cast(BlkInfo, lds_cell[(t0 + (z_of(x4, y4 - 2) >> 2)) * 4 + 2 + k]);
+            else {
+              const int tn = t0 - P.ctus_w * qpc + (z_of(x4, P.pw - 2) >> 2);
+              if (tn >= 0) Pn = __builtin_bit_cast(BlkInfo, lds_cell[tn * 4 + 2 + k]);
+              else Pn = __builtin_bit_cast(BlkInfo, lds_above[(t0 / qpc) * P.pw + x4 + k]);
+            }
+            er.h[k] = edge_unit(Pn, Q, (Q.edge & BE_HOR_TRANSFORM) != 0);
+          }
+        }
+      }
+    }
+    stg2(reinterpret_cast<uint32_t*>(P.edges + (size_t)(q.gy0 >> 1) * (P.grid_w >> 1) + (q.gx0 >> 1)), __builtin_bit_cast(u32x2, er));
+  }
   const int shard = blockIdx.x & (kTuShards - 1);
   if (threadIdx.x < 4) {
     const uint32_t n = lds_cnt[threadIdx.x];
@@ -351,10 +462,12 @@ __global__ void k_zero_counts(const PicDev* __restrict__ pics, Batch b, int intr
   if (intra) for (int i = threadIdx.x; i < 3 * P.num_ctus; i += blockDim.x) stg(P.intra_done + i, 0u);
 }
 
-void launch_prep(const PicDev* pics, const Batch& b, int max_ctus, int parts, bool intra, hipStream_t s) {
+// write_blk: the call runs kernels that read the BlkInfo grid (the cells kernels of mixed-motion tiles); pictures with exempt CUs add
+// themselves (SAO's exemption mask).  Everything else reads TileMv and EdgeRec only.
+void launch_prep(const PicDev* pics, const Batch& b, int max_ctus, int parts, bool intra, bool write_blk, hipStream_t s) {
   hipLaunchKernelGGL(k_zero_counts, dim3((unsigned)b.n), dim3(256), 0, s, pics, b, intra ? 1 : 0);
   dim3 grid((unsigned)(((size_t)max_ctus * (parts / 4) + 255) / 256), 1, (unsigned)b.n);
-  hipLaunchKernelGGL(k_prep, grid, dim3(256), 0, s, pics, b);
+  hipLaunchKernelGGL(k_prep, grid, dim3(256), 0, s, pics, b, write_blk ? 1 : 0);
 }
 
 }  // namespace hmgpu
