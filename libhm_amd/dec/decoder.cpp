@@ -62,6 +62,9 @@ Decoder::~Decoder() {
       for (int k = 0; k < HMGPU_NUM_KERNELS; k++)
         if (st.kernel_launches[k]) fprintf(stderr, "hmdec: %-14s %8.3f ms in %llu launches\n", hmgpu_kernel_name(k), st.kernel_ms[k], (unsigned long long)st.kernel_launches[k]);
   }
+  batch_.clear();
+  pool_.clear();                            // (the pictures' staging blocks belong to the context)
+  retired_.clear();
   if (gpu_) hmgpu_destroy(gpu_);
 }
 
@@ -206,12 +209,13 @@ void Decoder::activate(const SliceHeader& sh) {
   // a new coded video sequence with another geometry: the picture store starts over.  Pictures the application holds or has still
   // to fetch from the output queue stay alive (retired_, samples on the host) until the next change of sequence; pictures that were
   // never put out are dropped, as in HM.
+  flush_batch();
   drain_hash_jobs();                       // (the hash threads read the planes of the pictures that go away here)
   retired_.clear();
   for (auto& p : pool_) {
     const bool queued = std::find(out_queue_.begin(), out_queue_.end(), p.get()) != out_queue_.end();
     if (queued) fetch_planes(p.get());     // (the device context that holds the samples goes away below)
-    if (queued || p->lent) retired_.push_back(std::move(p));
+    if (queued || p->lent) { p->detach_from_device(); retired_.push_back(std::move(p)); }
   }
   pool_.clear();
   scan_.clear();
@@ -262,6 +266,7 @@ PicData* Decoder::acquire_buffer() {
   }
   for (auto& p : pool_)
     if (reusable(p.get(), false)) {
+      flush_batch();                                      // (nothing that names the buffer may still be waiting to be submitted)
       if (gpu_ && p->submit_seq > synced_seq_) {          // the device may still be reading the arrays of the picture that lived here
         const hmgpu_status st = hmgpu_sync(gpu_);
         synced_seq_ = submitted_seq_;
@@ -273,7 +278,7 @@ PicData* Decoder::acquire_buffer() {
   pool_.emplace_back(new PicData());
   PicData* p = pool_.back().get();
   host_alloc_use_pinned(gpu_ != nullptr);
-  p->allocate(*sps_, &zscan_);
+  p->allocate(*sps_, &zscan_, gpu_);
   if (gpu_) for (int c = 0; c < 3; c++) p->plane[c].resize((size_t)(p->width >> (c ? 1 : 0)) * (p->height >> (c ? 1 : 0)));
   host_alloc_use_pinned(false);
   if (gpu_) {
@@ -423,6 +428,8 @@ void Decoder::build_slice_params(const SliceHeader& sh, SliceInfo& si) {
 void Decoder::start_picture(const SliceHeader& sh) {
   cur_ = acquire_buffer();
   cur_->reset();
+  // levels in the compact form when one parser walks the picture from front to back (wavefront rows / tiles may be shared out among threads)
+  cur_->compact = gpu_ && cur_->stg && !pps_->entropy_coding_sync && !pps_->tiles_enabled && !getenv("HMDEC_DENSE_LEVELS");
   cur_->poc = sh.poc;
   cur_->nal_type = sh.nal_type;
   cur_->temporal_id = sh.temporal_id;
@@ -703,6 +710,7 @@ void Decoder::retire_ready(bool wait_all) {
     begin_output_scan(max_tl_);
     while (PicData* o = next_output(false)) out_queue_.push_back(o);
   }
+  flush_batch();
 }
 
 void Decoder::queue_flush() {
@@ -730,6 +738,7 @@ void Decoder::finish_picture() {
   PicData* p = cur_;
   cur_ = nullptr;
   submit_picture(p, parse_state_.next_ctb_ts);
+  flush_batch();
 }
 
 void Decoder::submit_picture(PicData* p, int parsed_ctbs) {
@@ -747,7 +756,37 @@ void Decoder::submit_picture(PicData* p, int parsed_ctbs) {
   p->rows_done.store(p->ctbs_h, std::memory_order_release);
   for (int rs = 0; rs < p->num_ctbs; rs++) if (p->slice_addr[rs] < 0) p->reset_ctu(rs);     // CTUs no slice delivered
   if (gpu_) {
-    hmgpu_ctu_meta m;
+    // the picture joins the pictures retired with it if it predicts from none of them (the B pictures of one temporal level, pictures of
+    // different sub-GOPs): one set of launches for all of them (hmgpu_decompress_pictures, TDecGop.cpp:105 / TDecTop.cpp:672 per picture)
+    bool dependent = batch_.size() >= 16;
+    for (auto& sl : p->slices)
+      for (int l = 0; l < 2; l++)
+        for (int r = 0; r < 16; r++)
+          for (PicData* b : batch_) if (sl->ref_pics[l][r] == b) dependent = true;
+    if (dependent) flush_batch();
+    batch_.push_back(p);
+  }
+  p->decoded = true;
+  p->filtered = true;
+  p->needed_for_output = p->pic_output;
+  last_decoded_ = p;
+  pictures_decoded_++;
+  if (!gpu_ && check_hash_ && p->sei_hash_method) check_hash(p);
+}
+
+// the device work of the pictures retired together: reconstruction and loop filters of all of them in one batch of launches each
+void Decoder::flush_batch() {
+  if (batch_.empty() || !gpu_) { batch_.clear(); return; }
+  const size_t n = batch_.size();
+  std::vector<hmgpu_ctu_meta> metas(n);
+  std::vector<hmgpu_coeffs> coefs(n);
+  std::vector<std::vector<const hmgpu_slice_params*>> slices(n);
+  std::vector<hmgpu_picture_job> jobs(n);
+  std::vector<hmgpu_pic_params> pps(n);
+  std::vector<hmgpu_filter_job> fjobs(n);
+  for (size_t i = 0; i < n; i++) {
+    PicData* p = batch_[i];
+    hmgpu_ctu_meta& m = metas[i];
     memset(&m, 0, sizeof(m));
     m.depth = p->depth.data(); m.part_size = p->part_size.data(); m.pred_mode = p->pred_mode.data(); m.qp = p->qp.data();
     m.tr_idx = p->tr_idx.data();
@@ -758,32 +797,41 @@ void Decoder::submit_picture(PicData* p, int parsed_ctbs) {
     m.ipcm = p->has_pcm ? p->ipcm.data() : nullptr;
     m.slice_idx = p->slice_idx.data();
     m.tile_idx = p->tile_idx.data();
-    hmgpu_coeffs co;
+    hmgpu_coeffs& co = coefs[i];
     memset(&co, 0, sizeof(co));
     for (int c = 0; c < 3; c++) { co.level[c] = p->coeff[c].data(); co.pcm_sample[c] = p->has_pcm ? p->pcm[c].data() : nullptr; }
-    std::vector<const hmgpu_slice_params*> sl;
-    for (auto& s : p->slices) sl.push_back(&s->params);
-    hmgpu_status st = hmgpu_decompress_picture(gpu_, p->handle, (int32_t)sl.size(), sl.data(), &m, &co);
-    if (st != HMGPU_OK) throw std::runtime_error(std::string("hmgpu_decompress_picture: ") + hmgpu_status_string(st));
-    hmgpu_pic_params pp;
-    memset(&pp, 0, sizeof(pp));
-    pp.lf_across_tiles = p->lf_across_tiles;
-    pp.sao_enabled = p->sao_enabled;
-    st = hmgpu_filter_picture(gpu_, p->handle, &pp, p->sao_enabled ? p->sao.data() : nullptr);
-    if (st != HMGPU_OK) throw std::runtime_error(std::string("hmgpu_filter_picture: ") + hmgpu_status_string(st));
-    p->submit_seq = ++submitted_seq_;
+    if (p->compact) {
+      // CTUs nobody parsed hold no TUs: their start is the next CTU's; the last entry is the length of the stream
+      for (int c = 0; c < 3; c++) {
+        p->level_start[c][p->num_ctbs] = p->level_cursor[c];
+        for (int rs = p->num_ctbs - 1; rs >= 0; rs--) if (p->slice_addr[rs] < 0) p->level_start[c][rs] = p->level_start[c][rs + 1];
+        co.ctu_level_start[c] = p->level_start[c].data();
+      }
+    }
+    for (auto& s : p->slices) slices[i].push_back(&s->params);
+    jobs[i].pic = p->handle; jobs[i].num_slices = (int32_t)slices[i].size(); jobs[i].slices = slices[i].data();
+    jobs[i].meta = &m; jobs[i].coeffs = &co;
+    memset(&pps[i], 0, sizeof(pps[i]));
+    pps[i].lf_across_tiles = p->lf_across_tiles;
+    pps[i].sao_enabled = p->sao_enabled;
+    fjobs[i].pic = p->handle; fjobs[i].pp = &pps[i]; fjobs[i].sao = p->sao_enabled ? p->sao.data() : nullptr;
   }
-  p->decoded = true;
-  p->filtered = true;
-  p->needed_for_output = p->pic_output;
-  last_decoded_ = p;
-  pictures_decoded_++;
-  if (check_hash_ && p->sei_hash_method) check_hash(p);
+  std::vector<PicData*> pics;
+  pics.swap(batch_);
+  hmgpu_status st = hmgpu_decompress_pictures(gpu_, (int32_t)n, jobs.data());
+  if (st != HMGPU_OK) throw std::runtime_error(std::string("hmgpu_decompress_pictures: ") + hmgpu_status_string(st));
+  st = hmgpu_filter_pictures(gpu_, (int32_t)n, fjobs.data());
+  if (st != HMGPU_OK) throw std::runtime_error(std::string("hmgpu_filter_pictures: ") + hmgpu_status_string(st));
+  ++submitted_seq_;
+  batches_submitted_++;
+  for (PicData* p : pics) p->submit_seq = submitted_seq_;
+  if (check_hash_) for (PicData* p : pics) if (p->sei_hash_method) check_hash(p);
 }
 
 bool Decoder::fetch_planes(PicData* pic) {
   if (!gpu_ || !pic) return false;
   if (pic->planes_valid) return true;
+  flush_batch();
   if (const uint64_t t = pic->dl_ticket.load()) {        // begun for the hash check: wait for it instead of copying again
     if (hmgpu_download_wait(gpu_, t) != HMGPU_OK) return false;
     pic->planes_valid = true;

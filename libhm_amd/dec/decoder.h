@@ -49,6 +49,7 @@ class Decoder {
   PicData* open_picture() const { return cur_; }
   int hash_mismatches() { drain_hash_jobs(); return hash_mismatches_.load(); }   // (waits for the MD5 checks still running on the hash threads)
   int pictures_decoded() const { return pictures_decoded_; }
+  int device_batches() const { return (int)batches_submitted_; }
   const std::string& last_error() const { return last_error_; }
   void set_error(const std::string& s) { last_error_ = s; }
   bool fetch_planes(PicData* pic);                        // device -> host planes of a finished picture (no-op when parse-only)
@@ -65,7 +66,8 @@ class Decoder {
   void build_slice_params(const SliceHeader& sh, SliceInfo& si);
   void parse_sei(const std::vector<uint8_t>& rbsp, bool suffix);
   void check_hash(PicData* pic);
-  void submit_picture(PicData* pic, int parsed_ctbs);     // device work + marks of a completely parsed picture
+  void submit_picture(PicData* pic, int parsed_ctbs);     // marks of a completely parsed picture; its device work joins the batch
+  void flush_batch();                                     // the device work of the pictures retired together (hmgpu_decompress_pictures / hmgpu_filter_pictures)
   void close_current();
   void worker_main();
   static void hook_wait_rows(void* self, const PicData* pic, int rows);
@@ -115,6 +117,8 @@ class Decoder {
   void drain_hash_jobs();
   static bool md5_plane_matches(const PicData* pic, int comp, int bd, const uint8_t want[16]);
   uint64_t submitted_seq_ = 0, synced_seq_ = 0;            // device submissions / the last one known to have completed
+  std::vector<PicData*> batch_;                            // pictures retired and not yet submitted: mutually independent
+  uint64_t batches_submitted_ = 0;
   std::string last_error_;
   std::string deferred_error_;                            // parse error of a picture that left the pipeline while another unit was pushed
   bool push_unit(const uint8_t* data, size_t len, int max_temporal_layer, int* nal_type_out);

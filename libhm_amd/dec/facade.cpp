@@ -174,10 +174,10 @@ static void tu_values(Wrapper* w, const PicData& p, int x, int y, int log2, int 
     default: {
       const int c = type == LIBHMDEC_TU_COEFF_ENERGY_Y ? 0 : type == LIBHMDEC_TU_COEFF_ENERGY_CB ? 1 : 2;
       const size_t ctb = p.ctb_at(x, y), z = part - ctb * p.parts;
-      const int16_t* lv = c == 0 ? &p.coeff[0][(ctb << (2 * p.log2_ctb)) + 16 * z] : &p.coeff[c][(ctb << (2 * p.log2_ctb - 2)) + 4 * z];
+      const int16_t* lv = p.level_src(c, ctb, z);
       const int n = c == 0 ? (1 << (2 * log2)) : (1 << (2 * log2 - 2));
       int64_t e = 0;
-      for (int i = 0; i < n; i++) e += (int64_t)lv[i] * lv[i];
+      for (int i = 0; lv && i < n; i++) e += (int64_t)lv[i] * lv[i];
       b.value = e > 0x7fffffff ? 0x7fffffff : (int)e;
       break;
     }
@@ -285,6 +285,7 @@ void hmdec_set_threads(libHMDec_context* ctx, int n) { if (ctx) static_cast<Wrap
 void hmdec_set_parse_only(libHMDec_context* ctx, int on) { if (ctx) static_cast<Wrapper*>(ctx)->dec.set_parse_only(on != 0); }
 int hmdec_hash_mismatches(libHMDec_context* ctx) { return ctx ? static_cast<Wrapper*>(ctx)->dec.hash_mismatches() : -1; }
 int hmdec_pictures_decoded(libHMDec_context* ctx) { return ctx ? static_cast<Wrapper*>(ctx)->dec.pictures_decoded() : -1; }
+int hmdec_device_batches(libHMDec_context* ctx) { return ctx ? static_cast<Wrapper*>(ctx)->dec.device_batches() : -1; }
 const char* hmdec_last_error(libHMDec_context* ctx) { return ctx ? static_cast<Wrapper*>(ctx)->dec.last_error().c_str() : ""; }
 libHMDec_picture* hmdec_last_decoded_picture(libHMDec_context* ctx) { return ctx ? static_cast<Wrapper*>(ctx)->dec.last_decoded() : nullptr; }
 

@@ -29,6 +29,28 @@ template <class T> struct HostAlloc {
 };
 template <class T> using HostVec = std::vector<T, HostAlloc<T>>;
 
+// An array of the parser that the device reads: either storage of its own (no device: parse-only runs) or a view into the picture's
+// staging block (hmgpu_staging_alloc: ONE page-locked block that mirrors the device's array layout, moved in one DMA).  The subset
+// of std::vector the parser uses.
+template <class T> struct Arr {
+  T* p = nullptr;
+  size_t n = 0;
+  HostVec<T> own;
+  void assign(size_t count, T v) { own.assign(count, v); p = own.data(); n = count; }
+  void bind(const T* ptr, size_t count) { own.clear(); own.shrink_to_fit(); p = const_cast<T*>(ptr); n = count; }
+  void detach() { if (p && own.empty() && n) { own.assign(p, p + n); p = own.data(); } }      // a view becomes a copy of its own
+  bool is_view() const { return p && own.empty() && n; }
+  T* data() { return p; }
+  const T* data() const { return p; }
+  size_t size() const { return n; }
+  T* begin() { return p; }
+  T* end() { return p + n; }
+  const T* begin() const { return p; }
+  const T* end() const { return p + n; }
+  T& operator[](size_t i) { return p[i]; }
+  const T& operator[](size_t i) const { return p[i]; }
+};
+
 struct ZScan {                       // raster (4x4 units inside a CTU) <-> HM z-scan order (g_auiRasterToZscan / g_auiZscanToRaster)
   int log2_ctb = 0, n4 = 0;          // n4: 4x4 units per CTU side
   std::vector<uint16_t> r2z, z2r;
@@ -64,14 +86,28 @@ struct PicData {
   int width = 0, height = 0, log2_ctb = 0, ctbs_w = 0, ctbs_h = 0, num_ctbs = 0, parts = 0;
   const ZScan* zs = nullptr;
   // per partition, [num_ctbs][parts]
-  HostVec<uint8_t> depth, tr_idx, cbf[3], ts[3], intra_dir[2], bypass, ipcm, skip, merge, merge_idx, inter_dir;
-  HostVec<int8_t> part_size, pred_mode, qp, ref_idx[2];
-  HostVec<int16_t> mv[2];        // {hor, ver}
+  Arr<uint8_t> depth, tr_idx, cbf[3], ts[3], intra_dir[2], bypass, ipcm;
+  HostVec<uint8_t> skip, merge, merge_idx, inter_dir;             // (parser-only: merge / AMVP derivation of later CUs and pictures)
+  Arr<int8_t> part_size, pred_mode, qp, ref_idx[2];
+  Arr<int16_t> mv[2];            // {hor, ver}
   // per CTB
-  HostVec<uint16_t> slice_idx, tile_idx;
+  Arr<uint16_t> slice_idx, tile_idx;
   std::vector<int32_t> slice_addr;   // SliceAddrRs of the slice that decoded the CTB, -1 = not (yet) decoded
-  // levels / PCM samples in HM's layout
-  HostVec<int16_t> coeff[3], pcm[3];
+  // levels: HM's dense TU layout (coefficients of the TU at partition z of a CTU at 16 z / 4 z of the CTU's share), or COMPACT
+  // (hmgpu_coeffs::ctu_level_start): only the coded TUs, one after the other in parsing order = z order per component, with the offset
+  // of every CTU's first one -- written that way when the picture is parsed by one thread from front to back (no wavefront / tile
+  // workers) and handed to the device (the transfer shrinks to the coded part)
+  Arr<int16_t> coeff[3];
+  Arr<uint32_t> level_start[3];      // compact: [num_ctbs + 1]
+  bool compact = false;
+  uint32_t level_cursor[3] = {0, 0, 0};
+  std::vector<uint32_t> tu_off[3];   // compact: offset of the TU that starts at a partition (what the dense layout gives by arithmetic)
+  HostVec<int16_t> pcm[3];           // PCM samples in HM's dense layout
+  // the staging block the arrays above are views of (null: they own their storage)
+  hmgpu_ctx* stg_ctx = nullptr;
+  hmgpu_staging* stg = nullptr;
+  hmgpu_ctu_meta stg_meta;
+  hmgpu_coeffs stg_co;
   HostVec<hmgpu_sao_param> sao;      // [num_ctbs][3]
   std::vector<std::unique_ptr<SliceInfo>> slices;
   // picture state (8.3)
@@ -96,23 +132,55 @@ struct PicData {
   int sei_hash_method = 0;           // 0 = none, 1 = MD5, 2 = CRC, 3 = checksum
   std::atomic<bool> hash_mismatch{false};
 
-  void allocate(const Sps& sps, const ZScan* z) {
+  PicData() { memset(&stg_meta, 0, sizeof(stg_meta)); memset(&stg_co, 0, sizeof(stg_co)); }
+  PicData(const PicData&) = delete;
+  PicData& operator=(const PicData&) = delete;
+  ~PicData() { release_staging(); }
+  void release_staging() {
+    if (stg) { hmgpu_staging_free(stg_ctx, stg); stg = nullptr; stg_ctx = nullptr; }
+  }
+  // the device context goes away while the application still holds the picture: the views become copies
+  void detach_from_device() {
+    if (!stg) return;
+    for (auto* v : {&depth, &tr_idx, &cbf[0], &cbf[1], &cbf[2], &ts[0], &ts[1], &ts[2], &intra_dir[0], &intra_dir[1], &bypass, &ipcm}) v->detach();
+    for (auto* v : {&part_size, &pred_mode, &qp, &ref_idx[0], &ref_idx[1]}) v->detach();
+    mv[0].detach(); mv[1].detach(); slice_idx.detach(); tile_idx.detach();
+    for (int c = 0; c < 3; c++) { coeff[c].detach(); level_start[c].detach(); }
+    release_staging();
+  }
+  // gpu: the device context the picture will be handed to (its arrays live in a staging block of that context), or null
+  void allocate(const Sps& sps, const ZScan* z, hmgpu_ctx* gpu = nullptr) {
     width = sps.width; height = sps.height; log2_ctb = sps.log2_ctb;
     ctbs_w = sps.pic_w_ctbs(); ctbs_h = sps.pic_h_ctbs(); num_ctbs = ctbs_w * ctbs_h;
     parts = 1 << (2 * log2_ctb - 4);
     zs = z;
     const size_t n = (size_t)num_ctbs * parts;
-    for (auto* v : {&depth, &tr_idx, &cbf[0], &cbf[1], &cbf[2], &ts[0], &ts[1], &ts[2], &intra_dir[0], &intra_dir[1], &bypass, &ipcm, &skip, &merge, &merge_idx, &inter_dir}) v->assign(n, 0);
-    for (auto* v : {&part_size, &pred_mode, &qp, &ref_idx[0], &ref_idx[1]}) v->assign(n, 0);
-    mv[0].assign(2 * n, 0);
-    mv[1].assign(2 * n, 0);
-    slice_idx.assign(num_ctbs, 0);
-    tile_idx.assign(num_ctbs, 0);
-    slice_addr.assign(num_ctbs, -1);
     const size_t luma = (size_t)num_ctbs << (2 * log2_ctb);
-    coeff[0].assign(luma, 0);
-    coeff[1].assign(luma / 4, 0);
-    coeff[2].assign(luma / 4, 0);
+    if (gpu && hmgpu_staging_alloc(gpu, &stg, &stg_meta, &stg_co) == HMGPU_OK) {
+      stg_ctx = gpu;
+      const hmgpu_ctu_meta& m = stg_meta;
+      depth.bind(m.depth, n); tr_idx.bind(m.tr_idx, n); part_size.bind(m.part_size, n); pred_mode.bind(m.pred_mode, n); qp.bind(m.qp, n);
+      for (int c = 0; c < 3; c++) { cbf[c].bind(m.cbf[c], n); ts[c].bind(m.transform_skip[c], n); }
+      for (int l = 0; l < 2; l++) { mv[l].bind(m.mv[l], 2 * n); ref_idx[l].bind(m.ref_idx[l], n); intra_dir[l].bind(m.intra_dir[l], n); }
+      bypass.bind(m.transquant_bypass, n); ipcm.bind(m.ipcm, n);
+      slice_idx.bind(m.slice_idx, num_ctbs); tile_idx.bind(m.tile_idx, num_ctbs);
+      for (int c = 0; c < 3; c++) { coeff[c].bind(stg_co.level[c], c ? luma / 4 : luma); level_start[c].bind(stg_co.ctu_level_start[c], num_ctbs + 1); }
+      for (int c = 0; c < 3; c++) tu_off[c].assign(n, 0xffffffffu);
+    } else {
+      stg = nullptr;
+      for (auto* v : {&depth, &tr_idx, &cbf[0], &cbf[1], &cbf[2], &ts[0], &ts[1], &ts[2], &intra_dir[0], &intra_dir[1], &bypass, &ipcm}) v->assign(n, 0);
+      for (auto* v : {&part_size, &pred_mode, &qp, &ref_idx[0], &ref_idx[1]}) v->assign(n, 0);
+      mv[0].assign(2 * n, 0);
+      mv[1].assign(2 * n, 0);
+      slice_idx.assign(num_ctbs, 0);
+      tile_idx.assign(num_ctbs, 0);
+      coeff[0].assign(luma, 0);
+      coeff[1].assign(luma / 4, 0);
+      coeff[2].assign(luma / 4, 0);
+      for (int c = 0; c < 3; c++) level_start[c].assign(num_ctbs + 1, 0);
+    }
+    for (auto* v : {&skip, &merge, &merge_idx, &inter_dir}) v->assign(n, 0);
+    slice_addr.assign(num_ctbs, -1);
     if (sps.pcm) { pcm[0].assign(luma, 0); pcm[1].assign(luma / 4, 0); pcm[2].assign(luma / 4, 0); }
     sao.assign((size_t)num_ctbs * 3, hmgpu_sao_param{});
   }
@@ -125,6 +193,7 @@ struct PicData {
     slices.clear();
     slices.reserve(HMGPU_MAX_SLICES);   // entries are added while a parser thread reads earlier ones: the storage must not move
     has_pcm = has_bypass = decoded = filtered = planes_valid = false;
+    level_cursor[0] = level_cursor[1] = level_cursor[2] = 0;
     hash_mismatch = false;
     dl_ticket = 0;
     sei_hash_method = 0;
@@ -146,9 +215,30 @@ struct PicData {
       std::fill(mv[l].begin() + 2 * first, mv[l].begin() + 2 * (first + parts), (int16_t)0);
     }
     const size_t luma = (size_t)1 << (2 * log2_ctb);
-    std::fill(coeff[0].begin() + rs * luma, coeff[0].begin() + (rs + 1) * luma, (int16_t)0);
-    for (int c = 1; c < 3; c++) std::fill(coeff[c].begin() + rs * (luma / 4), coeff[c].begin() + (rs + 1) * (luma / 4), (int16_t)0);
+    if (compact) {
+      // the CTU's coded TUs will follow here (a CTU that is reset again after a parse error keeps no TU: whatever it wrote is dead space)
+      for (int c = 0; c < 3; c++) { level_start[c][rs] = level_cursor[c]; std::fill(tu_off[c].begin() + first, tu_off[c].begin() + first + parts, 0xffffffffu); }
+    } else {
+      std::fill(coeff[0].begin() + rs * luma, coeff[0].begin() + (rs + 1) * luma, (int16_t)0);
+      for (int c = 1; c < 3; c++) std::fill(coeff[c].begin() + rs * (luma / 4), coeff[c].begin() + (rs + 1) * (luma / 4), (int16_t)0);
+    }
     for (int c = 0; c < 3; c++) sao[(size_t)rs * 3 + c] = hmgpu_sao_param{};
+  }
+  // where the levels of the TU of component c that starts at partition z of CTB ctb go (size x size, zeroed): HM's place, or the next free one
+  int16_t* level_dst(int c, size_t ctb, size_t z, int size) {
+    if (!compact) return c == 0 ? &coeff[0][(ctb << (2 * log2_ctb)) + 16 * z] : &coeff[c][(ctb << (2 * log2_ctb - 2)) + 4 * z];
+    const uint32_t off = level_cursor[c];
+    level_cursor[c] += (uint32_t)(size * size);
+    tu_off[c][ctb * parts + z] = off;
+    int16_t* d = &coeff[c][off];
+    memset(d, 0, (size_t)size * size * sizeof(int16_t));
+    return d;
+  }
+  // the levels of the TU that starts at partition z of CTB ctb, or null (compact: no coded TU starts there)
+  const int16_t* level_src(int c, size_t ctb, size_t z) const {
+    if (!compact) return c == 0 ? &coeff[0][(ctb << (2 * log2_ctb)) + 16 * z] : &coeff[c][(ctb << (2 * log2_ctb - 2)) + 4 * z];
+    const uint32_t off = tu_off[c][ctb * parts + z];
+    return off == 0xffffffffu ? nullptr : &coeff[c][off];
   }
   size_t part_at(int x, int y) const {      // partition index of the 4x4 block covering luma sample (x, y)
     const int mask = (1 << log2_ctb) - 1;

@@ -874,7 +874,7 @@ void SliceDecoder::residual_coding(int x0, int y0, int log2, int c) {
   Cabac eng = cabac_;                    // the engine's registers stay in CPU registers for the whole block (written back at the end)
   const int size = 1 << log2;
   const size_t part = pic_.part_at(x0, y0), ctb = pic_.ctb_at(x0, y0), z = part - ctb * pic_.parts;
-  int16_t* dst = c == 0 ? &pic_.coeff[0][(ctb << (2 * sps_.log2_ctb)) + 16 * z] : &pic_.coeff[c][(ctb << (2 * sps_.log2_ctb - 2)) + 4 * z];
+  int16_t* dst = pic_.level_dst(c, ctb, z, size);
   if (pps_.transform_skip_enabled && !cu_bypass_ && log2 == 2 && eng.decision(ctx_.s[CTX_TS_FLAG + (c ? 1 : 0)])) {
     const int span = c ? 2 : 1;                          // a 4x4 chroma block lies over 2x2 luma partitions
     for (int y = 0; y < span; y++) for (int x = 0; x < span; x++) pic_.ts[c][pic_.part_at(x0 + 4 * x, y0 + 4 * y)] = 1;

@@ -42,6 +42,7 @@ def lib():
         L.hmdec_set_threads.argtypes = [C.c_void_p, C.c_int]
         L.hmdec_hash_mismatches.argtypes = [C.c_void_p]
         L.hmdec_pictures_decoded.argtypes = [C.c_void_p]
+        L.hmdec_device_batches.argtypes = [C.c_void_p]
         L.hmdec_last_error.argtypes = [C.c_void_p]
         L.hmdec_last_error.restype = C.c_char_p
         L.hmdec_last_decoded_picture.argtypes = [C.c_void_p]
@@ -213,6 +214,10 @@ class Decoder:
     @property
     def pictures_decoded(self):
         return lib().hmdec_pictures_decoded(self.ctx)
+
+    @property
+    def device_batches(self):
+        return lib().hmdec_device_batches(self.ctx)
 
     def decode_stream(self, stream, on_decoded=None, on_output=None):
         """libHM's documented loop (libHMDecoder.h:36-77) over an Annex B stream"""

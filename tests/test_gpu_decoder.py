@@ -161,3 +161,31 @@ def test_full_size_streams_verify_against_their_hash_sei(stream, pictures, threa
         assert d.pictures_decoded == pictures
         assert d.hash_mismatches == 0
     assert out == sorted(out) and len(out) == pictures
+
+
+
+@pytest.mark.parametrize("name,threads", [("ra_main10_208x120", 4), ("ra_main10_208x120", 1), ("ldp_main10_208x120", 3)])
+def test_decoder_submits_batches_with_compact_levels(name, threads):
+    """libhmdec hands the device whole batches through hmgpu_decompress_pictures / hmgpu_filter_pictures (HM: TDecGop.cpp:105,157 once
+    per picture): pictures retired together that do not predict from each other -- B pictures of one temporal level of the
+    random-access GOP -- share one set of launches; the arrays travel from the pictures' staging blocks, the levels in the compact
+    form the parser writes.  The pictures are HM's with the compact form and with the dense one."""
+    import os
+    z = gu.load("stream_" + name)
+    want = {p.poc: p for p in gu.stream_pictures(name)}
+    for dense in (False, True):
+        os.environ.pop("HMDEC_DENSE_LEVELS", None)
+        if dense:
+            os.environ["HMDEC_DENSE_LEVELS"] = "1"
+        try:
+            got = {}
+            with hmdec.Decoder(threads=threads) as d:
+                d.decode_stream(z["bitstream"], on_output=lambda p: got.update({p.poc: [p.plane(c).copy() for c in range(3)]}))
+                assert d.hash_mismatches == 0
+                n, batches = d.pictures_decoded, d.device_batches
+        finally:
+            os.environ.pop("HMDEC_DENSE_LEVELS", None)
+        assert n == len(want) and 0 < batches <= n
+        for poc, planes in got.items():
+            for c in range(3):
+                assert np.array_equal(planes[c], want[poc].fin[c]), (dense, poc, c)
