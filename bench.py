@@ -411,8 +411,8 @@ def decode_main(args, hdist, dist, rank, world, local_rank):
     # timed: ONE decoder (device context, picture buffers) fed the stream args.steps times, as a player looping a clip would --
     # with the decoded-picture-hash SEI check ON, libHM's default (the MD5s run on the decoder's hash threads), and once more with
     # the check off (what HM's own timing below does)
-    def timed(check):
-        d = hmdec.Decoder(device=local_rank, check_hash=check, threads=args.threads)
+    def timed(check, device_md5=False):
+        d = hmdec.Decoder(device=local_rank, check_hash=check, threads=args.threads, device_md5=device_md5)
         state = {"pixels": 0, "pictures": 0}
         for _ in range(max(1, args.warmup)):
             feed(d, state, False)
@@ -422,14 +422,23 @@ def decode_main(args, hdist, dist, rank, world, local_rank):
             for k in range(args.steps):
                 feed(d, state, k == args.steps - 1)
         t = hdist.timed_region(dist, steps, lambda: None, device=("cuda:%d" % local_rank) if dist is not None else None)
-        bad_now = d.hash_mismatches
+        t_tail = time.perf_counter()
+        bad_now = d.hash_mismatches                          # (waits for the checks still under way: the tail of the last pictures' chains)
+        t_tail = time.perf_counter() - t_tail
+        batches = d.device_batches
         d.close()
+        timed.tail_s, timed.batches = t_tail, batches
         if bad_now:
             raise SystemExit("decode: %d pictures disagree with their hash SEI in the timed passes" % bad_now)
         # the warm-up passes leave pictures in the decoder that the first timed pass puts out: count what actually came out
         return t, state["pixels"], state["pictures"]
     elapsed_off, pixels_off, pictures_off = timed(False)
     elapsed, pixels_timed, pictures_timed = timed(True)
+    batches_timed = timed.batches
+    # the same with the MD5 chains on the device (hmgpu_picture_hash_begin: no download for the check, no hash threads); the chains of the
+    # last pictures finish after the last picture is out -- a GPU lane runs an MD5 chain ~8x slower than a host core -- reported separately
+    elapsed_dev, _, pictures_dev = timed(True, device_md5=True)
+    tail_dev = timed.tail_s
     # host parsing alone (no device work): what bounds the decoder today
     t0 = time.perf_counter()
     with hmdec.Decoder(parse_only=True, threads=args.threads) as d:
@@ -448,6 +457,9 @@ def decode_main(args, hdist, dist, rank, world, local_rank):
             "fps": round(world * pictures_timed / elapsed, 2),
             "hash_sei_check": "on in the timed passes (MD5 of every picture on the decoder's hash threads)",
             "fps_hash_check_off": round(world * pictures_off / elapsed_off, 2),
+            "fps_hash_check_on_device": round(world * pictures_dev / elapsed_dev, 2),
+            "device_md5_tail_s": round(tail_dev, 3),
+            "device_batches_per_step": round(batches_timed / max(1, args.steps + max(1, args.warmup)), 2),
             "host_parse_only_Mpixels_s": round(pixels / t_parse / 1e6, 1),
             "host_parse_only_Mbit_s": round(len(data) * 8 / t_parse / 1e6, 1),
             "hash_sei_verified_pictures": npic,

@@ -193,11 +193,18 @@ hmgpu_status hmgpu_download_wait(hmgpu_ctx* ctx, uint64_t ticket);
  * bytes per sample (TVideoIOYuv::write, TVideoIOYuv.cpp:706-790: 8-bit files take the low byte), cropped to a window given in
  * luma samples (conformance / display window; 0,0,0,0 = the whole picture) -- converted on the device, so an 8-bit picture crosses
  * PCIe in half the bytes.  hmgpu_picture_hash: the decoded-picture-hash SEI check (TDecGop.cpp:199-208) without moving the
- * picture: method 2 = CRC, 3 = checksum (TComPicYuvMD5.cpp:89-170); MD5 (method 1) is a serial chain over the whole plane and
- * stays on the host (HMGPU_EUNSUPPORTED): download the picture for it. */
+ * picture: method 1 = MD5 (TComPicYuvMD5.cpp:183-205; HM's default and the hash its own streams carry), 2 = CRC, 3 = checksum
+ * (:89-170).  MD5 is one serial chain of 64-byte blocks per plane -- about 0.2 s for a 3840x2160 10-bit luma plane on a GPU lane,
+ * eight times what a host core needs -- so hmgpu_picture_hash(.., 1, ..) is for verification and tests.  A decoder uses
+ * hmgpu_picture_hash_begin: it packs the planes behind the picture's filters (the picture buffer is free again at once) and the
+ * chains of up to sixteen pictures at a time run side by side, one LANE per plane, on low-priority streams of their own (several
+ * such batches at once); 48 bytes come back per picture.  hmgpu_hash_wait(ticket, block = 0) polls, (block = 1) waits -- and
+ * launches the batch the ticket belongs to if it is still collecting.  At most 64 tickets may be outstanding. */
 hmgpu_status hmgpu_picture_download_packed(hmgpu_ctx* ctx, hmgpu_pic pic, void* const planes[3], const int32_t stride_bytes[3],
                                            int32_t bytes_per_sample, int32_t crop_left, int32_t crop_right, int32_t crop_top, int32_t crop_bottom);
 hmgpu_status hmgpu_picture_hash(hmgpu_ctx* ctx, hmgpu_pic pic, int32_t method, uint8_t digest[3][16], int32_t* digest_len);
+hmgpu_status hmgpu_picture_hash_begin(hmgpu_ctx* ctx, hmgpu_pic pic, int32_t method /* 1 */, uint64_t* ticket);
+hmgpu_status hmgpu_hash_wait(hmgpu_ctx* ctx, uint64_t ticket, int32_t block, uint8_t digest[3][16], int32_t* digest_len, int32_t* ready);
 
 /* Frame-parallel exchange (BASELINE config #5): a finished picture is ONE contiguous device region (three
  * planes, replicated margins included -- HM's TComPicYuv after extendPicBorder, TComPicYuv.cpp:89-100) that another GPU

@@ -188,7 +188,7 @@ class Context:
         return planes
 
     def picture_hash(self, pic, method):
-        """method 2 = CRC, 3 = checksum (decoded-picture-hash SEI); returns the bytes of Y, Cb, Cr concatenated"""
+        """method 1 = MD5, 2 = CRC, 3 = checksum (decoded-picture-hash SEI); returns the bytes of Y, Cb, Cr concatenated"""
         dig = (C.c_uint8 * 48)()
         n = C.c_int32()
         self._chk(lib().hmgpu_picture_hash(self._h, pic, method, dig, C.byref(n)), "hmgpu_picture_hash")

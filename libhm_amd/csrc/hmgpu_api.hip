@@ -77,6 +77,16 @@ struct hmgpu_ctx {
   std::vector<hmgpu_staging*> stagings;
   hipEvent_t dl_ev[32] = {};           // hmgpu_picture_download_begin tickets: ticket t completes with dl_ev[t % 32]
   std::atomic<uint64_t> dl_seq{0};
+  // hmgpu_picture_hash_begin: MD5 chains of finished pictures over packed copies in a ring of slots; launched in batches (one lane per
+  // plane, k_md5) on low-priority streams of their own
+  static constexpr int kHashSlots = 64, kHashBatch = 16, kHashStreams = 4;
+  hipStream_t hash_stream[kHashStreams] = {};
+  hipEvent_t hash_packed[kHashSlots] = {}, hash_done[kHashSlots] = {};
+  int hash_done_slot[kHashSlots] = {};   // the slot whose hash_done event stands for the batch a slot's chains ran in
+  uint8_t* hash_buf[kHashSlots] = {};    // device: the packed planes, allocated when first used
+  uint32_t* hash_dev = nullptr;          // device: [kHashSlots][12] state words
+  uint32_t* hash_host = nullptr;         // page-locked: the same
+  uint64_t hash_seq = 0, hash_launched = 0, hash_launches = 0;
   uint32_t* dl_fault = nullptr;        // [32] page-locked: the picture's fault word (k_intra's bounded spin) as it stood behind the copies of ticket t
   std::vector<int> touched;            // pictures the entry point under way has enqueued work on, in any role (commit_use)
   std::vector<int> intra_launched;    // pictures whose intra kernel ran since the last fault check (k_intra's bounded spin)
@@ -594,6 +604,14 @@ void hmgpu_destroy(hmgpu_ctx* c) {
   for (hmgpu_staging* st : c->stagings) { if (st->host) hipHostFree(st->host); delete st; }
   for (int k = 0; k < 32; k++) if (c->dl_ev[k]) hipEventDestroy(c->dl_ev[k]);
   if (c->dl_fault) (void)hipHostFree(c->dl_fault);
+  for (int k = 0; k < hmgpu_ctx::kHashStreams; k++) if (c->hash_stream[k]) { (void)hipStreamSynchronize(c->hash_stream[k]); (void)hipStreamDestroy(c->hash_stream[k]); }
+  for (int k = 0; k < hmgpu_ctx::kHashSlots; k++) {
+    if (c->hash_packed[k]) hipEventDestroy(c->hash_packed[k]);
+    if (c->hash_done[k]) hipEventDestroy(c->hash_done[k]);
+    if (c->hash_buf[k]) (void)hipFree(c->hash_buf[k]);
+  }
+  if (c->hash_dev) (void)hipFree(c->hash_dev);
+  if (c->hash_host) (void)hipHostFree(c->hash_host);
   for (int k = 0; k < 2; k++) if (c->lane_ev[k]) hipEventDestroy(c->lane_ev[k]);
   delete c;
 }
@@ -730,7 +748,15 @@ hmgpu_status hmgpu_picture_download_packed(hmgpu_ctx* c, hmgpu_pic pic, void* co
 
 hmgpu_status hmgpu_picture_hash(hmgpu_ctx* c, hmgpu_pic pic, int32_t method, uint8_t digest[3][16], int32_t* digest_len) {
   if (!c || !valid_pic(c, pic) || !digest || !digest_len) return HMGPU_EINVAL;
-  if (method == 1) return HMGPU_EUNSUPPORTED;              // MD5: a serial chain over the plane, host work
+  if (method == 1) {
+    // MD5: one chain per plane (k_md5).  The call waits for it -- ~0.2 s for a 2160p luma plane; a decoder that must not wait uses
+    // hmgpu_picture_hash_begin / hmgpu_hash_wait
+    uint64_t t = 0;
+    hmgpu_status st = hmgpu_picture_hash_begin(c, pic, 1, &t);
+    int32_t ready = 0;
+    if (st == HMGPU_OK) st = hmgpu_hash_wait(c, t, 1, digest, digest_len, &ready);
+    return st;
+  }
   if (method != 2 && method != 3) return HMGPU_EINVAL;
   hipSetDevice(c->device);
   Picture& p = c->pics[pic];
@@ -757,6 +783,122 @@ hmgpu_status hmgpu_picture_hash(hmgpu_ctx* c, hmgpu_pic pic, int32_t method, uin
     else { digest[k][0] = (uint8_t)(r[k] >> 24); digest[k][1] = (uint8_t)(r[k] >> 16); digest[k][2] = (uint8_t)(r[k] >> 8); digest[k][3] = (uint8_t)r[k]; }
   }
   *digest_len = method == 2 ? 2 : 4;
+  return HMGPU_OK;
+}
+
+// the packed planes of a picture (HM's hash input, TComPicYuvMD5.cpp:44-84: rows of the visible area, 1 or 2 little-endian bytes per
+// sample) + the digest words behind them
+static size_t hash_slot_bytes(const hmgpu_ctx* c, size_t off[4]) {
+  size_t total = 0;
+  for (int k = 0; k < 3; k++) {
+    const int bd = k ? c->seq.bit_depth_chroma : c->seq.bit_depth_luma;
+    off[k] = total;
+    total += align_up((size_t)(c->seq.width >> (k ? 1 : 0)) * (c->seq.height >> (k ? 1 : 0)) * (bd > 8 ? 2 : 1), 256);
+  }
+  off[3] = total;
+  return total;
+}
+
+// the chains of the pictures handed over since the last launch: one lane per plane
+static hmgpu_status hash_launch_pending(hmgpu_ctx* c) {
+  if (c->hash_launched == c->hash_seq) return HMGPU_OK;
+  size_t off[4];
+  hash_slot_bytes(c, off);
+  Md5Batch job;
+  memset(&job, 0, sizeof(job));
+  const int S = hmgpu_ctx::kHashSlots;
+  int last_slot = 0;
+  for (uint64_t t = c->hash_launched + 1; t <= c->hash_seq; t++) {
+    const int slot = (int)(t % S);
+    for (int k = 0; k < 3; k++) {
+      const int nb = (k ? c->seq.bit_depth_chroma : c->seq.bit_depth_luma) > 8 ? 2 : 1;
+      job.msg[job.n] = c->hash_buf[slot] + off[k];
+      job.bytes[job.n] = (unsigned long long)(c->seq.width >> (k ? 1 : 0)) * (c->seq.height >> (k ? 1 : 0)) * nb;
+      job.out[job.n] = c->hash_dev + slot * 12 + k * 4;
+      job.n++;
+    }
+    last_slot = slot;
+  }
+  hipStream_t hs = c->hash_stream[c->hash_launches++ % hmgpu_ctx::kHashStreams];
+  HIP_TRY(c, hipStreamWaitEvent(hs, c->hash_packed[last_slot], 0));       // (recorded in ticket order on the context's stream: the newest covers all)
+  launch_md5(job, hs);
+  HIP_TRY(c, hipGetLastError());
+  for (uint64_t t = c->hash_launched + 1; t <= c->hash_seq; t++) {
+    const int slot = (int)(t % S);
+    HIP_TRY(c, hipMemcpyAsync(c->hash_host + slot * 12, c->hash_dev + slot * 12, 12 * sizeof(uint32_t), hipMemcpyDeviceToHost, hs));
+    c->hash_done_slot[slot] = last_slot;
+  }
+  HIP_TRY(c, hipEventRecord(c->hash_done[last_slot], hs));
+  c->hash_launched = c->hash_seq;
+  return HMGPU_OK;
+}
+
+hmgpu_status hmgpu_picture_hash_begin(hmgpu_ctx* c, hmgpu_pic pic, int32_t method, uint64_t* ticket) {
+  if (!c || !valid_pic(c, pic) || !ticket || method != 1) return HMGPU_EINVAL;
+  hipSetDevice(c->device);
+  const int S = hmgpu_ctx::kHashSlots;
+  if (!c->hash_stream[0]) {
+    int lo = 0, hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+    for (int k = 0; k < hmgpu_ctx::kHashStreams; k++) HIP_TRY(c, hipStreamCreateWithPriority(&c->hash_stream[k], hipStreamNonBlocking, lo));   // lowest priority: the chains fill gaps
+    for (int k = 0; k < S; k++) {
+      HIP_TRY(c, hipEventCreateWithFlags(&c->hash_packed[k], hipEventDisableTiming));
+      HIP_TRY(c, hipEventCreateWithFlags(&c->hash_done[k], hipEventDisableTiming | hipEventBlockingSync));
+    }
+    HIP_TRY(c, hipMalloc((void**)&c->hash_dev, (size_t)S * 12 * sizeof(uint32_t)));
+    HIP_TRY(c, hipHostMalloc((void**)&c->hash_host, (size_t)S * 12 * sizeof(uint32_t), hipHostMallocDefault));
+  }
+  const uint64_t t = c->hash_seq + 1;
+  const int slot = (int)(t % S);
+  size_t off[4];
+  const size_t bytes = hash_slot_bytes(c, off);
+  if (t > (uint64_t)S) {
+    // the slot's previous chains (throttle: a caller that never waits is held back here once the ring is full)
+    if (t - S > c->hash_launched) { const hmgpu_status st = hash_launch_pending(c); if (st != HMGPU_OK) return st; }
+    HIP_TRY(c, hipEventSynchronize(c->hash_done[c->hash_done_slot[slot]]));
+  }
+  if (!c->hash_buf[slot]) HIP_TRY(c, hipMalloc((void**)&c->hash_buf[slot], bytes));
+  Picture& p = c->pics[pic];
+  uint8_t* d = c->hash_buf[slot];
+  for (int k = 0; k < 3; k++) {
+    const int cs = k ? 1 : 0, w = c->seq.width >> cs, h = c->seq.height >> cs;
+    const int nb = (k ? c->seq.bit_depth_chroma : c->seq.bit_depth_luma) > 8 ? 2 : 1;
+    const int16_t* src = p.sao_applied ? p.dev.sao[k] : p.dev.rec[k];
+    launch_pack(src, c->pitch[k], 0, 0, w, h, nb, d + off[k], w * nb, c->stream);
+  }
+  HIP_TRY(c, hipGetLastError());
+  // the picture itself is free again behind the packing; the chains run over the copy
+  HIP_TRY(c, hipEventRecord(c->hash_packed[slot], c->stream));
+  c->hash_seq = t;
+  *ticket = t;
+  touch(c, pic);
+  commit_use(c);
+  if (c->hash_seq - c->hash_launched >= (uint64_t)hmgpu_ctx::kHashBatch) return hash_launch_pending(c);
+  return HMGPU_OK;
+}
+
+hmgpu_status hmgpu_hash_wait(hmgpu_ctx* c, uint64_t ticket, int32_t block, uint8_t digest[3][16], int32_t* digest_len, int32_t* ready) {
+  if (!c || !digest || !digest_len || !ready || ticket == 0 || ticket > c->hash_seq || c->hash_seq - ticket >= (uint64_t)hmgpu_ctx::kHashSlots) return HMGPU_EINVAL;
+  hipSetDevice(c->device);
+  const int slot = (int)(ticket % hmgpu_ctx::kHashSlots);
+  *ready = 0;
+  if (ticket > c->hash_launched) {                          // its batch has not been launched yet: a waiting caller closes it
+    if (!block) return HMGPU_OK;
+    const hmgpu_status st = hash_launch_pending(c);
+    if (st != HMGPU_OK) return st;
+  }
+  hipEvent_t ev = c->hash_done[c->hash_done_slot[slot]];
+  if (block) { if (hipEventSynchronize(ev) != hipSuccess) return HMGPU_EDEVICE; }
+  else {
+    const hipError_t e = hipEventQuery(ev);
+    if (e == hipErrorNotReady) { (void)hipGetLastError(); return HMGPU_OK; }
+    if (e != hipSuccess) return HMGPU_EDEVICE;
+  }
+  const uint32_t* w = c->hash_host + slot * 12;
+  for (int k = 0; k < 3; k++)
+    for (int i = 0; i < 16; i++) digest[k][i] = (uint8_t)(w[k * 4 + (i >> 2)] >> (8 * (i & 3)));      // RFC 1321: the state words, low byte first
+  *digest_len = 16;
+  *ready = 1;
   return HMGPU_OK;
 }
 

@@ -62,6 +62,7 @@ Decoder::~Decoder() {
       for (int k = 0; k < HMGPU_NUM_KERNELS; k++)
         if (st.kernel_launches[k]) fprintf(stderr, "hmdec: %-14s %8.3f ms in %llu launches\n", hmgpu_kernel_name(k), st.kernel_ms[k], (unsigned long long)st.kernel_launches[k]);
   }
+  poll_device_hashes(true);
   batch_.clear();
   pool_.clear();                            // (the pictures' staging blocks belong to the context)
   retired_.clear();
@@ -897,7 +898,24 @@ void Decoder::hash_main() {
   }
 }
 
+// device MD5: the oldest outstanding digests, as far as they are there (all of them: block)
+void Decoder::poll_device_hashes(bool block) {
+  while (gpu_ && !dev_hashes_.empty()) {
+    uint8_t got[3][16];
+    int32_t len = 0, ready = 0;
+    if (hmgpu_hash_wait(gpu_, dev_hashes_.front().ticket, block ? 1 : 0, got, &len, &ready) != HMGPU_OK) { ready = 1; len = 0; }
+    if (!ready) return;
+    const DevHash& h = dev_hashes_.front();
+    if (len != 16 || memcmp(got, h.want, sizeof(h.want)) != 0) {
+      hash_mismatches_++;
+      fprintf(stderr, "hmdec: ***ERROR*** decoded picture hash mismatch, POC %d\n", h.poc);
+    }
+    dev_hashes_.pop_front();
+  }
+}
+
 void Decoder::drain_hash_jobs() {
+  poll_device_hashes(true);
   if (hash_threads_.empty()) return;
   std::unique_lock<std::mutex> lk(hash_mu_);
   hash_idle_cv_.wait(lk, [&] { return hash_jobs_.empty() && hash_busy_ == 0; });
@@ -909,6 +927,19 @@ void Decoder::check_hash(PicData* pic) {
   uint8_t got[3][16];
   memset(got, 0, sizeof(got));
   int len = 0;
+  if (pic->sei_hash_method == 1 && device_md5_) {
+    // the chains run on the device (hmgpu_picture_hash_begin): no download, no hash threads, the picture buffer is free at once;
+    // the verdict arrives a fraction of a second later (a GPU lane runs the serial chain ~8x slower than a host core) and is read
+    // when it is there, at the latest when somebody asks (hash_mismatches, flush, end of the sequence)
+    while (dev_hashes_.size() >= 40) poll_device_hashes(true);         // (the device keeps a ring of 64)
+    DevHash h;
+    h.poc = pic->poc;
+    memcpy(h.want, pic->sei_hash, sizeof(h.want));
+    if (hmgpu_picture_hash_begin(gpu_, pic->handle, 1, &h.ticket) != HMGPU_OK) return;
+    dev_hashes_.push_back(h);
+    poll_device_hashes(false);
+    return;
+  }
   if (pic->sei_hash_method == 1) {
     // MD5 is a serial chain over every byte of a plane (~20-30 ms for a 2160p luma plane): with parser threads the three planes
     // go to the hash threads, picture after picture, and the decoding thread carries on; the picture stays pinned meanwhile

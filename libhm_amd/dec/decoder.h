@@ -4,9 +4,9 @@
 // HM counterpart: TDecTop.cpp (decode / xActivateParameterSets / xDecodeSlice / executeLoopFilters), TComSlice.cpp (setRefPicList,
 // applyReferencePictureSet), TDecGop.cpp, SEIread.cpp (decoded picture hash).
 #pragma once
-#include <condition_variable>
 #include <atomic>
 #include <condition_variable>
+#include <cstdlib>
 #include <deque>
 #include <memory>
 #include <mutex>
@@ -50,6 +50,7 @@ class Decoder {
   int hash_mismatches() { drain_hash_jobs(); return hash_mismatches_.load(); }   // (waits for the MD5 checks still running on the hash threads)
   int pictures_decoded() const { return pictures_decoded_; }
   int device_batches() const { return (int)batches_submitted_; }
+  void set_device_md5(bool on) { device_md5_ = on; }        // MD5 hash SEIs are checked on the device instead of on the hash threads
   const std::string& last_error() const { return last_error_; }
   void set_error(const std::string& s) { last_error_ = s; }
   bool fetch_planes(PicData* pic);                        // device -> host planes of a finished picture (no-op when parse-only)
@@ -66,6 +67,7 @@ class Decoder {
   void build_slice_params(const SliceHeader& sh, SliceInfo& si);
   void parse_sei(const std::vector<uint8_t>& rbsp, bool suffix);
   void check_hash(PicData* pic);
+  void poll_device_hashes(bool block);
   void submit_picture(PicData* pic, int parsed_ctbs);     // marks of a completely parsed picture; its device work joins the batch
   void flush_batch();                                     // the device work of the pictures retired together (hmgpu_decompress_pictures / hmgpu_filter_pictures)
   void close_current();
@@ -117,6 +119,9 @@ class Decoder {
   void drain_hash_jobs();
   static bool md5_plane_matches(const PicData* pic, int comp, int bd, const uint8_t want[16]);
   uint64_t submitted_seq_ = 0, synced_seq_ = 0;            // device submissions / the last one known to have completed
+  struct DevHash { uint64_t ticket; int poc; uint8_t want[3][16]; };
+  std::deque<DevHash> dev_hashes_;                         // MD5 chains under way on the device (hmgpu_picture_hash_begin)
+  bool device_md5_ = getenv("HMDEC_DEVICE_MD5") != nullptr && getenv("HMDEC_DEVICE_MD5")[0] == '1';
   std::vector<PicData*> batch_;                            // pictures retired and not yet submitted: mutually independent
   uint64_t batches_submitted_ = 0;
   std::string last_error_;

@@ -285,6 +285,7 @@ void hmdec_set_threads(libHMDec_context* ctx, int n) { if (ctx) static_cast<Wrap
 void hmdec_set_parse_only(libHMDec_context* ctx, int on) { if (ctx) static_cast<Wrapper*>(ctx)->dec.set_parse_only(on != 0); }
 int hmdec_hash_mismatches(libHMDec_context* ctx) { return ctx ? static_cast<Wrapper*>(ctx)->dec.hash_mismatches() : -1; }
 int hmdec_pictures_decoded(libHMDec_context* ctx) { return ctx ? static_cast<Wrapper*>(ctx)->dec.pictures_decoded() : -1; }
+void hmdec_set_device_md5(libHMDec_context* ctx, int on) { if (ctx) static_cast<Wrapper*>(ctx)->dec.set_device_md5(on != 0); }
 int hmdec_device_batches(libHMDec_context* ctx) { return ctx ? static_cast<Wrapper*>(ctx)->dec.device_batches() : -1; }
 const char* hmdec_last_error(libHMDec_context* ctx) { return ctx ? static_cast<Wrapper*>(ctx)->dec.last_error().c_str() : ""; }
 libHMDec_picture* hmdec_last_decoded_picture(libHMDec_context* ctx) { return ctx ? static_cast<Wrapper*>(ctx)->dec.last_decoded() : nullptr; }

@@ -43,6 +43,7 @@ def lib():
         L.hmdec_hash_mismatches.argtypes = [C.c_void_p]
         L.hmdec_pictures_decoded.argtypes = [C.c_void_p]
         L.hmdec_device_batches.argtypes = [C.c_void_p]
+        L.hmdec_set_device_md5.argtypes = [C.c_void_p, C.c_int]
         L.hmdec_last_error.argtypes = [C.c_void_p]
         L.hmdec_last_error.restype = C.c_char_p
         L.hmdec_last_decoded_picture.argtypes = [C.c_void_p]
@@ -161,7 +162,7 @@ class Picture:
 
 
 class Decoder:
-    def __init__(self, parse_only=False, device=0, check_hash=True, max_temporal_layer=-1, threads=1):
+    def __init__(self, parse_only=False, device=0, check_hash=True, max_temporal_layer=-1, threads=1, device_md5=None):
         self.ctx = lib().libHMDec_new_decoder()
         if not self.ctx:
             raise MemoryError("libHMDec_new_decoder")
@@ -170,6 +171,8 @@ class Decoder:
         lib().hmdec_set_threads(self.ctx, threads)
         lib().libHMDec_set_SEI_Check(self.ctx, check_hash)
         lib().libHMDec_set_max_temporal_layer(self.ctx, max_temporal_layer)
+        if device_md5 is not None:                 # MD5 hash SEIs checked on the device (default: the decoder's hash threads / HMDEC_DEVICE_MD5)
+            lib().hmdec_set_device_md5(self.ctx, 1 if device_md5 else 0)
 
     def close(self):
         if self.ctx:

@@ -189,3 +189,28 @@ def test_decoder_submits_batches_with_compact_levels(name, threads):
         for poc, planes in got.items():
             for c in range(3):
                 assert np.array_equal(planes[c], want[poc].fin[c]), (dense, poc, c)
+
+
+@pytest.mark.parametrize("stream, pictures, threads", [("bench_ldp_main10_1920x1080_17.bin", 17, 3), ("bench_ldp_wpp_main10_3840x2160.bin", 5, 8)])
+def test_md5_sei_checked_on_the_device(stream, pictures, threads):
+    """the decoder's check of the MD5 hash SEI with the chains on the device (hmgpu_picture_hash_begin: no download, no hash threads):
+    green on HM's own streams -- more pictures than the ring of hash slots holds -- and red when a picture is wrong"""
+    import os
+    data = open(os.path.join(gu.GOLD, stream), "rb").read()
+    with hmdec.Decoder(threads=threads, device_md5=True) as d:
+        d.decode_stream(data)
+        assert d.pictures_decoded == pictures
+        assert d.hash_mismatches == 0
+    # a hash SEI that belongs to another picture: the last byte of every MD5 SEI payload flipped
+    nals = hmdec.split_nal_units(data)
+    bad, n_sei = [], 0
+    for nal in nals:
+        b = bytearray(nal)
+        if ((b[0] >> 1) & 0x3f) == 40 and len(b) > 20 and b[2] == 132:         # suffix SEI, payload type 132 (decoded picture hash)
+            b[6] ^= 0x55
+            n_sei += 1
+        bad.append(bytes(b))
+    assert pictures - 1 <= n_sei <= pictures
+    with hmdec.Decoder(threads=threads, device_md5=True) as d:
+        d.decode_stream(b"".join(b"\x00\x00\x00\x01" + n for n in bad))
+        assert d.hash_mismatches == n_sei

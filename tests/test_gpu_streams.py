@@ -74,7 +74,7 @@ def test_single_call_filter_picture_matches_hm(name):
 
 @pytest.mark.parametrize("name", gu.STREAMS)
 def test_device_hash_and_packed_output_match_hm(name):
-    """f-4: the decoded-picture-hash check (CRC, checksum) and the output packing (8/16-bit, conformance window) happen on the
+    """f-4: the decoded-picture-hash check (MD5, CRC, checksum) and the output packing (8/16-bit, conformance window) happen on the
     device; the hashes are the ones HM computed, the packed planes are HM's planes cropped (TVideoIOYuv.cpp:706-790)"""
     import libhm_amd
     def check(ctx, h, p):
@@ -83,9 +83,7 @@ def test_device_hash_and_packed_output_match_hm(name):
         ctx.filter_picture(h, p.pp, p.sao_raw)
         assert np.array_equal(ctx.picture_hash(h, 2), p.crc), "%s pic %d CRC" % (name, p.index)
         assert np.array_equal(ctx.picture_hash(h, 3), p.checksum), "%s pic %d checksum" % (name, p.index)
-        with pytest.raises(libhm_amd.HmgpuError) as e:
-            ctx.picture_hash(h, 1)                                   # MD5 stays with the host
-        assert e.value.status == abi.HMGPU_EUNSUPPORTED
+        assert bytes(ctx.picture_hash(h, 1)) == p.md5, "%s pic %d MD5" % (name, p.index)     # the chains of k_md5 (TComPicYuvMD5.cpp:183-205)
         nbytes = 1 if p.bd_y <= 8 else 2
         for crop in [(0, 0, 0, 0), (2, 6, 4, 8)]:
             l, r, t, b = crop
