@@ -342,6 +342,11 @@ def gop_main(args, hdist, dist, rank, world, local_rank, copy_gbps):
     run.step()
     st = ctx.stats(reset=True)
     ctx.set_profiling(False)
+    # every rank says what it moved: a scaling run is self-evidencing (which backend carried the pictures, how many ranks, how many bytes)
+    my_sends = sum(len(s[3]) for lvl in run.plan for s in lvl["sends"] if s[2] == rank)
+    my_recvs = sum(1 for lvl in run.plan for s in lvl["sends"] if rank in s[3])
+    sys.stderr.write("gop rank %d of %d: backend %s, %d pictures sent / %d received per step, %d bytes each (device region to device region)\n" % (
+        rank, world, (dist.get_backend() if dist is not None else "none (one rank)"), my_sends, my_recvs, ctx.device_region(run.handle_of[(0, 0)])[1]))
     if rank == 0:
         plan = run.plan
         sends = sum(len(s[3]) for lvl in plan for s in lvl["sends"])

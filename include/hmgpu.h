@@ -197,9 +197,9 @@ hmgpu_status hmgpu_download_wait(hmgpu_ctx* ctx, uint64_t ticket);
  * (:89-170).  MD5 is one serial chain of 64-byte blocks per plane -- about 0.2 s for a 3840x2160 10-bit luma plane on a GPU lane,
  * eight times what a host core needs -- so hmgpu_picture_hash(.., 1, ..) is for verification and tests.  A decoder uses
  * hmgpu_picture_hash_begin: it packs the planes behind the picture's filters (the picture buffer is free again at once) and the
- * chains of up to sixteen pictures at a time run side by side, one LANE per plane, on low-priority streams of their own (several
- * such batches at once); 48 bytes come back per picture.  hmgpu_hash_wait(ticket, block = 0) polls, (block = 1) waits -- and
- * launches the batch the ticket belongs to if it is still collecting.  At most 64 tickets may be outstanding. */
+ * chains of up to 32 pictures at a time run side by side, one LANE per plane, on a low-priority stream of their own; 48 bytes come
+ * back per picture.  hmgpu_hash_wait(ticket, block = 0) polls, (block = 1) waits -- and launches the batch the ticket belongs to
+ * if it is still collecting.  At most 96 tickets may be outstanding. */
 hmgpu_status hmgpu_picture_download_packed(hmgpu_ctx* ctx, hmgpu_pic pic, void* const planes[3], const int32_t stride_bytes[3],
                                            int32_t bytes_per_sample, int32_t crop_left, int32_t crop_right, int32_t crop_top, int32_t crop_bottom);
 hmgpu_status hmgpu_picture_hash(hmgpu_ctx* ctx, hmgpu_pic pic, int32_t method, uint8_t digest[3][16], int32_t* digest_len);
@@ -215,6 +215,13 @@ hmgpu_status hmgpu_hash_wait(hmgpu_ctx* ctx, uint64_t ticket, int32_t block, uin
  *              hmgpu_picture_commit_received(ctx, pic)        (the picture can now be named in ref_pic[][])
  * Regions of two contexts with equal hmgpu_seq_params have equal size and layout. */
 typedef enum { HMGPU_REGION_FINISHED = 0, HMGPU_REGION_RECEIVE = 1 } hmgpu_region;
+/* Within ONE process that drives several devices (a decoder that places the pictures of one temporal level on different GPUs,
+ * TDecTop.cpp:672 / TDecGop.cpp:105 per picture): hmgpu_picture_transfer copies the finished picture `src_pic` of `src` into
+ * `dst_pic` of `dst` -- a context of the same geometry on another GPU (peer copy over xGMI, hipMemcpyPeerAsync) or on the same one --
+ * ordered behind everything enqueued on both contexts' streams, margins included, and commits it: dst_pic can be named in
+ * ref_pic[][] of dst at once.  hmgpu_transfer_bytes: bytes a context has sent so far. */
+hmgpu_status hmgpu_picture_transfer(hmgpu_ctx* src, hmgpu_pic src_pic, hmgpu_ctx* dst, hmgpu_pic dst_pic);
+uint64_t     hmgpu_transfer_bytes(const hmgpu_ctx* ctx);
 hmgpu_status hmgpu_picture_device_region(hmgpu_ctx* ctx, hmgpu_pic pic, int32_t which, void** base, int64_t* bytes);
 hmgpu_status hmgpu_picture_commit_received(hmgpu_ctx* ctx, hmgpu_pic pic);
 /* the context's HIP stream (a hipStream_t), for callers that order their own device work against the library's */

@@ -75,6 +75,9 @@ def lib():
         L.hmgpu_picture_hash.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.POINTER(C.c_int32)]
         L.hmgpu_picture_device_region.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]
         L.hmgpu_picture_commit_received.argtypes = [C.c_void_p, C.c_int32]
+        L.hmgpu_picture_transfer.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32]
+        L.hmgpu_transfer_bytes.argtypes = [C.c_void_p]
+        L.hmgpu_transfer_bytes.restype = C.c_uint64
         L.hmgpu_stream.argtypes = [C.c_void_p]
         L.hmgpu_stream.restype = C.c_void_p
         L.hmgpu_decompress_slice.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(abi.SliceParams), C.POINTER(abi.CtuMeta),
@@ -204,6 +207,14 @@ class Context:
 
     def commit_received(self, pic):
         self._chk(lib().hmgpu_picture_commit_received(self._h, pic), "hmgpu_picture_commit_received")
+
+    def transfer_to(self, pic, other, other_pic):
+        """the finished picture `pic` into picture `other_pic` of another context (same process; another GPU or this one)"""
+        self._chk(lib().hmgpu_picture_transfer(self._h, pic, other._h, other_pic), "hmgpu_picture_transfer")
+
+    @property
+    def transfer_bytes(self):
+        return int(lib().hmgpu_transfer_bytes(self._h))
 
     def stream_handle(self):
         return int(lib().hmgpu_stream(self._h) or 0)

@@ -79,7 +79,7 @@ struct hmgpu_ctx {
   std::atomic<uint64_t> dl_seq{0};
   // hmgpu_picture_hash_begin: MD5 chains of finished pictures over packed copies in a ring of slots; launched in batches (one lane per
   // plane, k_md5) on low-priority streams of their own
-  static constexpr int kHashSlots = 64, kHashBatch = 16, kHashStreams = 4;
+  static constexpr int kHashSlots = 96, kHashBatch = 32, kHashStreams = 1;   // (a batch: 96 chains = two waves; several streams shared hardware queues with each other and the context's own)
   hipStream_t hash_stream[kHashStreams] = {};
   hipEvent_t hash_packed[kHashSlots] = {}, hash_done[kHashSlots] = {};
   int hash_done_slot[kHashSlots] = {};   // the slot whose hash_done event stands for the batch a slot's chains ran in
@@ -87,6 +87,8 @@ struct hmgpu_ctx {
   uint32_t* hash_dev = nullptr;          // device: [kHashSlots][12] state words
   uint32_t* hash_host = nullptr;         // page-locked: the same
   uint64_t hash_seq = 0, hash_launched = 0, hash_launches = 0;
+  hipEvent_t xfer_ev[2] = {};            // hmgpu_picture_transfer: source ready / copy done
+  uint64_t xfer_bytes = 0;
   uint32_t* dl_fault = nullptr;        // [32] page-locked: the picture's fault word (k_intra's bounded spin) as it stood behind the copies of ticket t
   std::vector<int> touched;            // pictures the entry point under way has enqueued work on, in any role (commit_use)
   std::vector<int> intra_launched;    // pictures whose intra kernel ran since the last fault check (k_intra's bounded spin)
@@ -611,6 +613,7 @@ void hmgpu_destroy(hmgpu_ctx* c) {
     if (c->hash_buf[k]) (void)hipFree(c->hash_buf[k]);
   }
   if (c->hash_dev) (void)hipFree(c->hash_dev);
+  for (int k = 0; k < 2; k++) if (c->xfer_ev[k]) hipEventDestroy(c->xfer_ev[k]);
   if (c->hash_host) (void)hipHostFree(c->hash_host);
   for (int k = 0; k < 2; k++) if (c->lane_ev[k]) hipEventDestroy(c->lane_ev[k]);
   delete c;
@@ -933,6 +936,46 @@ hmgpu_status hmgpu_picture_commit_received(hmgpu_ctx* c, hmgpu_pic pic) {
   p.extended = true;                               // the margins travelled with the planes
   return HMGPU_OK;
 }
+
+// A finished picture of one context into a picture of another context of the same geometry -- on another GPU of the process (a peer
+// copy over xGMI) or on the same one -- ordered behind the work of both contexts' streams: what a decoder that spreads the pictures of
+// one temporal level over several devices does with each reference picture (TComPrediction.cpp:593 reads it on the other device).
+hmgpu_status hmgpu_picture_transfer(hmgpu_ctx* src, hmgpu_pic src_pic, hmgpu_ctx* dst, hmgpu_pic dst_pic) {
+  if (!src || !dst || !valid_pic(src, src_pic) || !valid_pic(dst, dst_pic) || (src == dst && src_pic == dst_pic)) return HMGPU_EINVAL;
+  const hmgpu_seq_params &a = src->seq, &b = dst->seq;
+  if (a.width != b.width || a.height != b.height || a.log2_ctu_size != b.log2_ctu_size || a.bit_depth_luma != b.bit_depth_luma ||
+      a.bit_depth_chroma != b.bit_depth_chroma) return HMGPU_EINVAL;
+  void *from = nullptr, *to = nullptr;
+  int64_t n_from = 0, n_to = 0;
+  hmgpu_status st = hmgpu_picture_device_region(src, src_pic, HMGPU_REGION_FINISHED, &from, &n_from);      // (extends the border if needed)
+  if (st == HMGPU_OK) st = hmgpu_picture_device_region(dst, dst_pic, HMGPU_REGION_RECEIVE, &to, &n_to);
+  if (st != HMGPU_OK) return st;
+  if (n_from != n_to) return HMGPU_EINVAL;
+  if (src->device != dst->device) {
+    int can = 0;
+    if (hipDeviceCanAccessPeer(&can, dst->device, src->device) == hipSuccess && can) {
+      hipSetDevice(dst->device);
+      const hipError_t e = hipDeviceEnablePeerAccess(src->device, 0);
+      if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) return HMGPU_EDEVICE;
+      (void)hipGetLastError();
+    }
+  }
+  // source ready -> copy on the receiver's stream -> the source may be rewritten again
+  hipSetDevice(src->device);
+  if (!src->xfer_ev[0]) for (int k = 0; k < 2; k++) HIP_TRY(src, hipEventCreateWithFlags(&src->xfer_ev[k], hipEventDisableTiming));
+  HIP_TRY(src, hipEventRecord(src->xfer_ev[0], src->stream));
+  hipSetDevice(dst->device);
+  HIP_TRY(dst, hipStreamWaitEvent(dst->stream, src->xfer_ev[0], 0));
+  HIP_TRY(dst, hipMemcpyPeerAsync(to, dst->device, from, src->device, (size_t)n_from, dst->stream));
+  HIP_TRY(dst, hipEventRecord(src->xfer_ev[1], dst->stream));
+  hipSetDevice(src->device);
+  HIP_TRY(src, hipStreamWaitEvent(src->stream, src->xfer_ev[1], 0));
+  src->xfer_bytes += (uint64_t)n_from;
+  touch(src, src_pic); commit_use(src);
+  touch(dst, dst_pic); commit_use(dst);
+  return hmgpu_picture_commit_received(dst, dst_pic);
+}
+uint64_t hmgpu_transfer_bytes(const hmgpu_ctx* c) { return c ? c->xfer_bytes : 0; }
 
 void* hmgpu_stream(hmgpu_ctx* c) { return c ? (void*)c->stream : nullptr; }
 

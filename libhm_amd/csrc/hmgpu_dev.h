@@ -268,7 +268,7 @@ void launch_filter_fused(const PicDev* pics, const Batch& b, int width, int heig
 void launch_pack(const int16_t* src, int pitch, int x0, int y0, int w, int h, int bytes, uint8_t* dst, int dst_stride, hipStream_t s);
 void launch_checksum(const int16_t* src, int pitch, int w, int h, int bd, uint32_t* out, hipStream_t s);
 // MD5 chains, one per lane (k_out.hip): message, length, where the four state words a, b, c, d go
-struct Md5Batch { int32_t n, pad_; const uint8_t* msg[64]; unsigned long long bytes[64]; uint32_t* out[64]; };
+struct Md5Batch { int32_t n, pad_; const uint8_t* msg[128]; unsigned long long bytes[128]; uint32_t* out[128]; };
 void launch_md5(const Md5Batch& job, hipStream_t s);
 void launch_crc(const int16_t* src, int pitch, int w, int h, int bd, uint32_t* rows, uint32_t* out, hipStream_t s);
 void launch_intra(const PicDev* pics, const Batch& b, const int32_t* order, int num_ctus, hipStream_t s);

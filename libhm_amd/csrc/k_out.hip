@@ -85,7 +85,7 @@ __global__ void k_crc_fold(const uint32_t* __restrict__ rows, int h, int row_byt
 // for a 3840x2160 10-bit luma plane, eight times what a host core takes), and nothing inside a chain is parallel.  What the device
 // offers is chains side by side: every LANE of a wave runs the chain of another plane -- same instruction stream, its own message
 // (64 bytes per block straight from its plane, one block ahead) and state -- so one wave hashes the planes of 21 pictures in the
-// time of the longest of them.  hmgpu_picture_hash_begin collects the planes of finished pictures and launches them in batches on
+// time of the longest of them (a batch is up to two such waves).  hmgpu_picture_hash_begin collects the planes of finished pictures and launches them in batches on
 // low-priority streams of their own.  Plane sizes are multiples of 16 bytes (width and height are multiples of 8).
 __device__ inline uint32_t md5_rol(uint32_t v, int s) { return __builtin_amdgcn_alignbit(v, v, 32 - s); }
 __device__ inline void md5_block(const uint32_t (&m)[16], uint32_t& sa, uint32_t& sb, uint32_t& sc, uint32_t& sd) {
@@ -120,19 +120,25 @@ __global__ void __launch_bounds__(64) k_md5(Md5Batch job) {
   const uint32_t* p = reinterpret_cast<const uint32_t*>(live ? job.msg[lane] : job.msg[0]);
   const unsigned long long n = live ? job.bytes[lane] : 0ull, blocks = n >> 6;
   uint32_t sa = 0x67452301u, sb = 0xefcdab89u, sc = 0x98badcfeu, sd = 0x10325476u;
-  // two blocks per round, the next two in flight meanwhile (a lane's loads are its own: ~1.5 us of chain per round cover their latency)
-  uint32_t cur[2][16], nxt[2][16];
+  // four blocks per round, the next four in flight meanwhile (a lane's loads are its own, 48 planes = 48 places: ~3 us of chain per
+  // round cover their latency; one wave per SIMD, registers are free)
+  constexpr int R = 4;
+  uint32_t cur[R][16], nxt[R][16];
 #pragma unroll
-  for (int k = 0; k < 16; k++) cur[0][k] = cur[1][k] = nxt[0][k] = nxt[1][k] = 0;
-  if (blocks > 0) md5_fetch(p, cur[0]);
-  if (blocks > 1) md5_fetch(p + 16, cur[1]);
-  for (unsigned long long b = 0; __any(b < blocks); b += 2) {
-    if (b + 2 < blocks) md5_fetch(p + (b + 2) * 16, nxt[0]);
-    if (b + 3 < blocks) md5_fetch(p + (b + 3) * 16, nxt[1]);
-    if (b < blocks) md5_block(cur[0], sa, sb, sc, sd);
-    if (b + 1 < blocks) md5_block(cur[1], sa, sb, sc, sd);
+  for (int j = 0; j < R; j++)
 #pragma unroll
-    for (int k = 0; k < 16; k++) { cur[0][k] = nxt[0][k]; cur[1][k] = nxt[1][k]; }
+    for (int k = 0; k < 16; k++) cur[j][k] = nxt[j][k] = 0;
+#pragma unroll
+  for (int j = 0; j < R; j++) if ((unsigned long long)j < blocks) md5_fetch(p + j * 16, cur[j]);
+  for (unsigned long long b = 0; __any(b < blocks); b += R) {
+#pragma unroll
+    for (int j = 0; j < R; j++) if (b + R + j < blocks) md5_fetch(p + (b + R + j) * 16, nxt[j]);
+#pragma unroll
+    for (int j = 0; j < R; j++) if (b + j < blocks) md5_block(cur[j], sa, sb, sc, sd);
+#pragma unroll
+    for (int j = 0; j < R; j++)
+#pragma unroll
+      for (int k = 0; k < 16; k++) cur[j][k] = nxt[j][k];
   }
   if (!live) return;
   // the rest of the message (0, 16, 32 or 48 bytes), the 0x80 byte, zeros and the length in bits in the last eight bytes of the last block

@@ -931,7 +931,7 @@ void Decoder::check_hash(PicData* pic) {
     // the chains run on the device (hmgpu_picture_hash_begin): no download, no hash threads, the picture buffer is free at once;
     // the verdict arrives a fraction of a second later (a GPU lane runs the serial chain ~8x slower than a host core) and is read
     // when it is there, at the latest when somebody asks (hash_mismatches, flush, end of the sequence)
-    while (dev_hashes_.size() >= 40) poll_device_hashes(true);         // (the device keeps a ring of 64)
+    while (dev_hashes_.size() >= 64) poll_device_hashes(true);         // (the device keeps a ring of 96)
     DevHash h;
     h.poc = pic->poc;
     memcpy(h.want, pic->sei_hash, sizeof(h.want));

@@ -105,3 +105,43 @@ def test_two_ranks_exchange_reference_pictures_over_rccl():
     if torch.cuda.device_count() < 2:
         pytest.skip("needs two GPUs")
     _run_two_ranks({})
+
+
+def test_picture_transfer_between_contexts(oracle):
+    """hmgpu_picture_transfer: a finished picture of one context becomes a reference picture of another (two contexts of one process --
+    on different GPUs a peer copy over xGMI, here on the same one): the second context predicts from it and must get the oracle's picture"""
+    import libhm_amd
+    w, h, bd = 832, 480, 10
+    p1 = synth.make_picture(w, h, bd, seed=71, intra_frac=0.1, ref_handles=([0], [0]))
+    p2 = synth.make_picture(w, h, bd, seed=72, ref_handles=([0], [0]))
+    ref = synth.noise_planes(w, h, bd, 73)
+    cur = synth.blocky_planes(w, h, bd, 74)
+
+    def chain(p, cur, refs):
+        rec = [a.copy() for a in cur]
+        oracle.decompress_ctus(p.seq, [p.slice], p.meta, p.coeffs, rec, refs)
+        oracle.loop_filter_pic(p.seq, [p.slice], p.meta, p.pp, rec, 3)
+        prm = oracle.sao_reconstruct_params(p.seq, p.pp, p.meta, p.sao_raw)
+        return oracle.sao_process(p.seq, [p.slice], p.pp, p.meta, prm, rec)
+    want1 = chain(p1, cur, [ref])
+    want2 = chain(p2, cur, [want1])
+    with libhm_amd.Context(p1.seq) as a, libhm_amd.Context(p1.seq) as b:
+        ha0, ha1 = a.acquire(), a.acquire()
+        a.upload(ha0, ref)
+        a.upload(ha1, cur)
+        p1.slice.ref_pic[0][0] = ha0
+        a.decompress_slice(ha1, 0, p1.slice, p1.meta, p1.coeffs)
+        a.filter_picture(ha1, p1.pp, p1.sao_raw)
+        hb_junk, hb0, hb1 = b.acquire(), b.acquire(), b.acquire()
+        a.transfer_to(ha1, b, hb0)                       # no sync in between: the copy is ordered behind a's filters
+        assert a.transfer_bytes > 2 * w * h
+        b.upload(hb1, cur)
+        p2.slice.ref_pic[0][0] = hb0
+        b.decompress_slice(hb1, 0, p2.slice, p2.meta, p2.coeffs)
+        b.filter_picture(hb1, p2.pp, p2.sao_raw)
+        got1, got2 = b.download(hb0), b.download(hb1)
+        for c in range(3):
+            assert np.array_equal(got1[c], want1[c]), "transferred picture comp %d" % c
+            assert np.array_equal(got2[c], want2[c]), "picture predicted from it, comp %d" % c
+        with pytest.raises(libhm_amd.HmgpuError):
+            a.transfer_to(ha1, a, ha1)
