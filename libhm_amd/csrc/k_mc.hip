@@ -313,6 +313,28 @@ __device__ inline void h_item_luma(const u32x4 (&r)[4], const uint32_t* __restri
     *reinterpret_cast<u32x2*>(out + c * 64) = u32x2{pack_shr(sum[0][2 * c], sum[1][2 * c], sh1), pack_shr(sum[0][2 * c + 1], sum[1][2 * c + 1], sh1)};
 }
 
+// one window row x 8 columns (the halo items of a strip whose second tile row holds no run top are shared out row by row: k_mc_luma)
+__device__ inline void h_row_luma(const u32x4 (&r)[2], const uint32_t* __restrict__ tap, int (&sum)[8]) {
+  const u32x4 t0 = *reinterpret_cast<const u32x4*>(tap), t1 = *reinterpret_cast<const u32x4*>(tap + 4);
+  const u32x2 t2 = *reinterpret_cast<const u32x2*>(tap + 8);
+  const uint32_t te[5] = {t0.x, t0.y, t0.z, t0.w, t1.x}, to[5] = {t1.y, t1.z, t1.w, t2.x, t2.y};
+  const uint32_t d[8] = {r[0].x, r[0].y, r[0].z, r[0].w, r[1].x, r[1].y, r[1].z, r[1].w};
+#pragma unroll
+  for (int x = 0; x < 8; x++) {
+    int v = dot2_first(d[x >> 1], (x & 1) ? to[0] : te[0]);
+#pragma unroll
+    for (int j = 1; j < 5; j++) v = dot2(d[(x >> 1) + j], (x & 1) ? to[j] : te[j], v);
+    sum[x] = v;
+  }
+}
+// the value lane + 32 holds, in the lanes of the lower half (v_permlane32_swap)
+__device__ inline int from_upper_half(int v) { return __builtin_amdgcn_permlane32_swap(v, v, false, false)[1]; }
+__device__ inline uint32_t low_half(uint32_t v, int lane) { return (uint32_t)__shfl((int)v, lane & 31); }
+__device__ inline const char* low_half(const char* p, int lane) {
+  const uint64_t v = (uint64_t)(uintptr_t)p;
+  return (const char*)(uintptr_t)(((uint64_t)low_half((uint32_t)(v >> 32), lane) << 32) | low_half((uint32_t)v, lane));
+}
+
 // One wave = one strip of the square: tile rows 2w, 2w+1.  Lane -> tile (tx = lane & 7, strip row r = lane >> 5), row pair
 // q = (lane >> 3) & 3: the lane's H items are window rows 8+2q, 9+2q ("body") and, if its tile starts a run, rows 2q, 2q+1
 // ("halo") of THAT tile; its V item is output rows 2q, 2q+1 of the same tile.  The first tile row of a strip always starts a run
@@ -443,6 +465,34 @@ __global__ void __launch_bounds__(256, (WP || BI) ? 1 : MC_LB_LUMA) k_mc_luma(co
       if (bon) h_item_luma(rb, tap, sh1, body_t + q * 16);
       if constexpr (HALO) { if (hon) h_item_luma(rh, tap, sh1, halo_t + q * 16); }
     };
+#ifndef MC_NO_SPLIT
+    // Run tops in the strip's first tile row only (any PU 16 rows tall or more): their halo items would keep half of the lanes busy with
+    // two rows each.  Shared out instead: the lane below (lane + 32: same tile column, same row pair) takes the item's second row --
+    // half the arithmetic and two window loads instead of four per lane -- and hands its eight sums up (v_permlane32_swap).
+    auto h_phase_split = [&]() {
+      u32x4 rb[4], rh[2];
+      {
+        const wref p0 = bon ? pw + pitch * 16 : nowhere;
+        rb[0] = win.load(p0); rb[1] = win.load(bon && two ? p0 + 16 : nowhere);
+        rb[2] = win.load(b2on ? p0 + pitch * 2 : nowhere); rb[3] = win.load(b2on && two ? p0 + pitch * 2 + 16 : nowhere);
+      }
+      const bool hon0 = (hon_m >> (lane & 31)) & 1, two0 = (__ballot(two) >> (lane & 31)) & 1;
+      const wref pw0 = low_half(pw, lane) + (r ? pitch * 2 : 0);
+      const uint32_t* const tap0 = S.taps + low_half((uint32_t)(tap - S.taps), lane);
+      rh[0] = win.load(hon0 ? pw0 : nowhere); rh[1] = win.load(hon0 && two0 ? pw0 + 16 : nowhere);
+      if (bon) h_item_luma(rb, tap, sh1, body_t + q * 16);
+      int sum[8], up[8];
+      h_row_luma(rh, tap0, sum);
+#pragma unroll
+      for (int x = 0; x < 8; x++) up[x] = from_upper_half(sum[x]);
+      if (hon) {                                             // (lanes of the first tile row: hon is never set below it here)
+#pragma unroll
+        for (int c = 0; c < 4; c++)
+          *reinterpret_cast<u32x2*>(halo_t + q * 16 + c * 64) = u32x2{pack_shr(sum[2 * c], up[2 * c], sh1), pack_shr(sum[2 * c + 1], up[2 * c + 1], sh1)};
+      }
+    };
+    if (hon_m && !(hon_m >> 32)) h_phase_split(); else
+#endif
     if (hon_m) h_phase(std::true_type()); else h_phase(std::false_type());
     wave_lds_sync();
     if (bact) {

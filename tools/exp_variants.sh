@@ -10,7 +10,7 @@ for v in "$@"; do
   if [ $v = base ]; then cp /tmp/libhmgpu_base.so libhm_amd/libhmgpu.so; else cp libhm_amd/variants/$v/libhmgpu.so libhm_amd/libhmgpu.so; fi
   for cfg in "mix" "p64 --mode-probs 1,0,0,0,0" "p32 --mode-probs 0,1,0,0,0" "p16 --mode-probs 0,0,1,0,0" "p8 --mode-probs 0,0,0,1,0" "bi --workload mc_bi"; do
     set -- $cfg; name=$1; shift
-    python3 bench.py --workload mc "$@" --steps 30 --no-cpu-baseline > $out/${v}_$name.json 2> $out/${v}_$name.err
+    python3 bench.py --workload mc "$@" --steps 10 --no-cpu-baseline > $out/${v}_$name.json 2> $out/${v}_$name.err
     python3 - $out/${v}_$name.json ${v}_$name <<'PY'
 import json,sys
 try:
