@@ -92,7 +92,7 @@ def main():
     ap.add_argument("--intra-frac", type=float, default=None, help="experiment: fraction of CUs that are intra (with intra modes: reconstructed on the GPU)")
     ap.add_argument("--cbf-prob", type=float, default=None, help="experiment: probability that a TU is coded")
     ap.add_argument("--mv-range", type=int, default=None, help="experiment: integer MV range in luma samples (default 64)")
-    ap.add_argument("--streams", type=int, default=1, choices=(1, 2), help="2: the batch runs as two half-batches on two HIP streams (kernels of different kinds overlap)")
+    ap.add_argument("--streams", type=int, default=2, choices=(1, 2), help="2: the batch runs as two half-batches on two HIP streams (kernels of different kinds overlap)")
     ap.add_argument("--threads", type=int, default=8, help="decode workload: parser threads of libhmdec (1 = all on the calling thread)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-inclusive", action="store_true", help="skip the host-inclusive (staging included) measurement of the default workload")
@@ -175,7 +175,18 @@ def main():
     elapsed = hdist.timed_region(dist, lambda: ctx.replay(pics, ALL, args.steps), ctx.sync,
                                  device=("cuda:%d" % local_rank) if dist is not None else None)
 
-    # ---- per-kernel device times: hipEvents on the context's own stream, around every launch of extra steps
+    # the same steps on ONE stream (kernel after kernel: what the per-kernel times below add up to)
+    ms_one_stream = None
+    if args.streams == 2 and world == 1:
+        ctx.set_streams(1)
+        ctx.replay(pics, ALL, 1)
+        ctx.sync()
+        t1 = time.perf_counter()
+        ctx.replay(pics, ALL, args.steps)
+        ctx.sync()
+        ms_one_stream = (time.perf_counter() - t1) / args.steps * 1e3
+        ctx.set_streams(args.streams)
+    # ---- per-kernel device times: hipEvents on the context's own stream, around every launch of extra steps (one stream while profiling)
     ctx.set_profiling(True)
     ctx.stats(reset=True)
     ctx.replay(pics, ALL, args.profile_steps)
@@ -215,7 +226,7 @@ def main():
         # taken from the kernel sources this run is built from (sha256 over libhm_amd/csrc), else null
         traffic, traffic_source = None, None
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if wl == "full" and nb == 16 and args.streams == 1 and not args.bi and (w, h) == (3840, 2160) and os.path.exists(tpath):
+        if wl == "full" and nb == 16 and not args.bi and (w, h) == (3840, 2160) and os.path.exists(tpath):
             tj = json.load(open(tpath))
             sys.path.insert(0, os.path.join(ROOT, "tools"))
             import pmc_summary_digest
@@ -247,6 +258,8 @@ def main():
                                                     / (elapsed / args.steps) / 1e9, 1),
             "staging_s_for_batch_incl_first_run": round(t_stage, 3),
         }
+        if ms_one_stream is not None:
+            out["ms_per_step_one_stream"] = round(ms_one_stream, 4)
         if copy_gbps is not None:
             out["hbm_copy_GBps_measured"] = copy_gbps
         if hi is not None:
@@ -438,12 +451,12 @@ def decode_main(args, hdist, dist, rank, world, local_rank):
         # the warm-up passes leave pictures in the decoder that the first timed pass puts out: count what actually came out
         return t, state["pixels"], state["pictures"]
     elapsed_off, pixels_off, pictures_off = timed(False)
-    elapsed, pixels_timed, pictures_timed = timed(True)
-    batches_timed = timed.batches
-    # the same with the MD5 chains on the device (hmgpu_picture_hash_begin: no download for the check, no hash threads); the chains of the
-    # last pictures finish after the last picture is out -- a GPU lane runs an MD5 chain ~8x slower than a host core -- reported separately
-    elapsed_dev, _, pictures_dev = timed(True, device_md5=True)
-    tail_dev = timed.tail_s
+    # check on: the MD5 chains run on the device (hmgpu_picture_hash_begin: no download for the check, no hash threads; libhmdec's default).
+    # The chains of the last pictures finish after the last picture is out -- a GPU lane runs an MD5 chain ~8x slower than a host core --
+    # that tail is reported separately.  Beside it: the check on the decoder's hash threads (round 2's form).
+    elapsed, pixels_timed, pictures_timed = timed(True, device_md5=True)
+    batches_timed, tail_dev = timed.batches, timed.tail_s
+    elapsed_host, _, pictures_host = timed(True, device_md5=False)
     # host parsing alone (no device work): what bounds the decoder today
     t0 = time.perf_counter()
     with hmdec.Decoder(parse_only=True, threads=args.threads) as d:
@@ -460,9 +473,9 @@ def decode_main(args, hdist, dist, rank, world, local_rank):
                                    "picture download, %d NAL units" % (w, h, args.threads, "" if args.threads == 1 else "s, frame-parallel", len(nals)),
                        "sub_benchmark": "decode", "parser_threads": args.threads, "pictures_per_step": npic, "parallelism": "replicas, 1 process per GPU"},
             "fps": round(world * pictures_timed / elapsed, 2),
-            "hash_sei_check": "on in the timed passes (MD5 of every picture on the decoder's hash threads)",
+            "hash_sei_check": "on in the timed passes (MD5 of every picture, chains on the device: one lane per plane, batches of up to 32 pictures)",
             "fps_hash_check_off": round(world * pictures_off / elapsed_off, 2),
-            "fps_hash_check_on_device": round(world * pictures_dev / elapsed_dev, 2),
+            "fps_hash_check_on_host_threads": round(world * pictures_host / elapsed_host, 2),
             "device_md5_tail_s": round(tail_dev, 3),
             "device_batches_per_step": round(batches_timed / max(1, args.steps + max(1, args.warmup)), 2),
             "host_parse_only_Mpixels_s": round(pixels / t_parse / 1e6, 1),

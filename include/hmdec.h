@@ -71,8 +71,8 @@ void hmdec_set_threads(libHMDec_context* ctx, int n);
 void hmdec_set_parse_only(libHMDec_context* ctx, int on);                     /* no device work: parser output only (planes unavailable) */
 int hmdec_hash_mismatches(libHMDec_context* ctx);                             /* pictures whose reconstruction disagreed with the hash SEI */
 int hmdec_pictures_decoded(libHMDec_context* ctx);
-void hmdec_set_device_md5(libHMDec_context* ctx, int on);                     /* MD5 hash SEIs checked on the device (hmgpu_picture_hash_begin) instead of
-                                                                                  on the decoder's hash threads; default off (HMDEC_DEVICE_MD5=1 turns it on) */
+void hmdec_set_device_md5(libHMDec_context* ctx, int on);                     /* MD5 hash SEIs checked on the device (hmgpu_picture_hash_begin) (the default;
+                                                                                  HMDEC_DEVICE_MD5=0 or 0 here: on the decoder's hash threads) */
 int hmdec_device_batches(libHMDec_context* ctx);                              /* calls of hmgpu_decompress_pictures so far (pictures retired together share one) */
 const char* hmdec_last_error(libHMDec_context* ctx);
 libHMDec_picture* hmdec_last_decoded_picture(libHMDec_context* ctx);          /* the picture finished most recently, decoding order */

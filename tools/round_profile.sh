@@ -13,7 +13,7 @@ done
 python3 bench.py --workload intra --batch 1 --steps 5 --warmup 1 --profile-steps 2 --no-cpu-baseline > $out/bench_intra_1pic.json 2> $out/bench_intra_1pic.err
 python3 bench.py --workload intra --steps 5 --warmup 1 --profile-steps 2 --no-cpu-baseline > $out/bench_intra.json 2> $out/bench_intra.err
 python3 bench.py --workload gop --steps 10 > $out/bench_gop.json 2> $out/bench_gop.err
-python3 bench.py --streams 2 --no-cpu-baseline > $out/bench_full_2lanes.json 2> $out/bench_full_2lanes.err
+python3 bench.py --streams 1 --no-cpu-baseline > $out/bench_full_1lane.json 2> $out/bench_full_1lane.err
 python3 bench.py --batch 8 --no-cpu-baseline > $out/bench_full_batch8.json 2> $out/bench_full_batch8.err
 python3 bench.py --workload decode --stream tests/golden/bench_ldp_main10_3840x2160.bin --steps 3 --warmup 1 > $out/bench_decode_2160p.json 2> $out/bench_decode_2160p.err
 python3 bench.py --workload decode --stream tests/golden/bench_ra_main10_1920x1080.bin --steps 5 --warmup 2 > $out/bench_decode_1080p.json 2> $out/bench_decode_1080p.err
