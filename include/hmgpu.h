@@ -254,8 +254,9 @@ hmgpu_status hmgpu_decompress_picture(hmgpu_ctx* ctx, hmgpu_pic cur, int32_t num
  * pictures which do not reference each other -- the B pictures of one temporal level, the pictures of independent streams -- hands
  * them over together: the inputs of all of them are staged on a copy stream of their own (so they travel while the kernels of the
  * previous call still run) and every kernel is launched ONCE for the whole set (n <= 16).  Equivalent to hmgpu_decompress_picture /
- * hmgpu_filter_picture per picture.  The input arrays must stay untouched until hmgpu_sync() or until a later call that names the
- * same picture returns (that call waits for the earlier copy). */
+ * hmgpu_filter_picture per picture.  The copies are asynchronous: the input arrays must stay untouched until hmgpu_staging_wait()
+ * (arrays of a staging block) or hmgpu_sync() (any arrays) has returned -- a later call that names the same picture only orders the
+ * DEVICE side behind the earlier copy, it does not wait for it on the host. */
 typedef struct hmgpu_picture_job {
   hmgpu_pic pic;
   int32_t num_slices;
@@ -279,6 +280,9 @@ hmgpu_status hmgpu_filter_pictures(hmgpu_ctx* ctx, int32_t n, const hmgpu_filter
 typedef struct hmgpu_staging hmgpu_staging;
 hmgpu_status hmgpu_staging_alloc(hmgpu_ctx* ctx, hmgpu_staging** out, hmgpu_ctu_meta* meta, hmgpu_coeffs* coeffs);
 void         hmgpu_staging_free(hmgpu_ctx* ctx, hmgpu_staging* staging);
+/* blocks until the copies of the last hmgpu_decompress_pictures call that read the block have been made: from then on a parser may
+ * write the next picture into it (the kernels read the device copies).  A block no call has read yet returns at once. */
+hmgpu_status hmgpu_staging_wait(hmgpu_ctx* ctx, hmgpu_staging* staging);
 /* (the block also holds the three ctu_level_start arrays: coeffs->ctu_level_start[] of hmgpu_staging_alloc points at them; a caller
  * that fills the block with HM's dense layout sets the three pointers to NULL in the struct it passes to the calls) */
 

@@ -59,6 +59,7 @@ struct hmgpu_staging {
   char* host = nullptr;
   size_t meta_bytes = 0, coef_bytes = 0, start_bytes = 0;   // metadata block | dense-capacity levels | [3][num_ctus + 1] CTU starts
   size_t grp[5] = {0, 0, 0, 0, 0};                         // carve_meta: where the optional groups of the metadata block start
+  uint64_t copy_seq = 0;                                   // the staging pass (hmgpu_decompress_pictures) that last read the block
   hmgpu_ctu_meta m;
   hmgpu_coeffs co;
 };
@@ -1325,6 +1326,16 @@ hmgpu_status hmgpu_staging_alloc(hmgpu_ctx* c, hmgpu_staging** out, hmgpu_ctu_me
   return HMGPU_OK;
 }
 
+// the block may be rewritten once the copies of the call that last read it have been made (events of the copy stream are recorded in
+// order: one that has since been re-recorded stands for a later point of the same stream)
+hmgpu_status hmgpu_staging_wait(hmgpu_ctx* c, hmgpu_staging* st) {
+  if (!c || !st) return HMGPU_EINVAL;
+  if (st->copy_seq == 0) return HMGPU_OK;
+  hipSetDevice(c->device);
+  if (hipEventSynchronize(c->copy_ev[st->copy_seq % 8]) != hipSuccess) return HMGPU_EDEVICE;
+  return HMGPU_OK;
+}
+
 void hmgpu_staging_free(hmgpu_ctx* c, hmgpu_staging* st) {
   if (!c || !st) return;
   hipSetDevice(c->device);
@@ -1384,6 +1395,8 @@ hmgpu_status hmgpu_decompress_pictures(hmgpu_ctx* c, int32_t n, const hmgpu_pict
     }
     if (st != HMGPU_OK) return st;
     c->copy_seq++;
+    for (int i = 0; i < n; i++)
+      if (const hmgpu_staging* sb = staging_of(c, jobs[i].meta, jobs[i].coeffs)) const_cast<hmgpu_staging*>(sb)->copy_seq = c->copy_seq;
     HIP_TRY(c, hipEventRecord(c->copy_ev[c->copy_seq % 8], c->copy_stream));
     HIP_TRY(c, hipStreamWaitEvent(c->stream, c->copy_ev[c->copy_seq % 8], 0));
   }

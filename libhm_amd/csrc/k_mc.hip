@@ -373,7 +373,16 @@ __global__ void __launch_bounds__(256, (WP || BI) ? 1 : MC_LB_LUMA) k_mc_luma(co
   const uint32_t flags = tm.z >> 24, rmask = (tm.w >> 8) & 0xff;
   const bool active = (flags & TM_ACTIVE) != 0;
   if (!__ballot(active)) return;
+#if defined(MC_EXP) && (MC_EXP & 64)        // experiment (wrong samples): what sharing rows ACROSS strips would save -- a first-row tile whose
+  // upper neighbour in the strip above has the same record does not start a run (its upper rows are read from wherever)
+  bool top = tile_is_top(tm, r, lane ^ 32);
+  if (wave > 0) {
+    const u32x4 up = load_tile_rec(a, slot, g, x0, y0 - 8);
+    if (r == 0 && up.x == tm.x && up.y == tm.y && up.z == tm.z) top = false;
+  }
+#else
   const bool top = tile_is_top(tm, r, lane ^ 32);
+#endif
 #ifdef MC_DEDUP
   const bool same_right = tx < 7 && !tile_is_top(tm, 1, lane + 1);          // the tile to the right: same lists, pictures, vectors
 #else

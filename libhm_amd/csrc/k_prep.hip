@@ -140,7 +140,11 @@ __global__ void __launch_bounds__(256) k_prep(const PicDev* __restrict__ pics, B
       for (int r = lane_c; r < 2 * pw; r += qpc) {
         const bool left = r >= pw;
         const int i = left ? r - pw : r;
+#if defined(PREP_EXP) && (PREP_EXP & 1)     // experiment: no cells from other workgroups' CTUs
+        if (false) {
+#else
         if (left ? need_left : need_above) {
+#endif
           const u32x4 v = __builtin_bit_cast(u32x4, cell_from_arrays(P, left ? q.ctu - 1 : q.ctu - P.ctus_w, left ? z_of(pw - 1, i) : z_of(i, pw - 1)));
           if (left) lds_left[i] = v; else lds_above[cl * pw + i] = v;
         }
@@ -378,17 +382,23 @@ __global__ void __launch_bounds__(256) k_prep(const PicDev* __restrict__ pics, B
       }
     }
   }
+#if !(defined(PREP_EXP) && (PREP_EXP & 4)) // experiment: no cell exchange
   if (active) {
 #pragma unroll
     for (int j = 0; j < 4; j++) lds_cell[threadIdx.x * 4 + j] = cells[j];
   }
+#endif
   __syncthreads();
   // ---- the area's four edge units (xGetBoundaryStrengthSingle, TComLoopFilter.cpp:411-537): the Q side is one of its own cells, the P side
   // the cell to the left / above -- another thread's, through LDS where that thread belongs to this workgroup (the areas of a CTU are 64,
   // 16 or 4 consecutive threads in z-order, consecutive CTUs follow each other)
   if (active) {
     EdgeRec er; er.v[0] = er.v[1] = er.h[0] = er.h[1] = 0;
+#if defined(PREP_EXP) && (PREP_EXP & 2)     // experiment: no edge units
+    if (false) {
+#else
     if (q.valid) {
+#endif
       const int x4 = zscan_x(q.z0), y4 = zscan_y(q.z0), qpc = parts >> 2;
       const int t0 = (int)threadIdx.x - (q.z0 >> 2);             // the thread of the CTU's first area
 #pragma unroll

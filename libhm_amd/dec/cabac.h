@@ -148,7 +148,7 @@ class Cabac {
       next_byte_ += 4;
       avail_ += 32;
     } else {
-      while (avail_ <= 56) {
+      while (avail_ <= 48) {                           // (at most 56 bits in hand: a shift by avail_ is always defined, get(0) included)
         res_ = (res_ << 8) | (next_byte_ < nbytes_ ? p_[next_byte_] : 0u);
         next_byte_++;
         avail_ += 8;

@@ -268,10 +268,15 @@ PicData* Decoder::acquire_buffer() {
   for (auto& p : pool_)
     if (reusable(p.get(), false)) {
       flush_batch();                                      // (nothing that names the buffer may still be waiting to be submitted)
-      if (gpu_ && p->submit_seq > synced_seq_) {          // the device may still be reading the arrays of the picture that lived here
-        const hmgpu_status st = hmgpu_sync(gpu_);
-        synced_seq_ = submitted_seq_;
-        if (st != HMGPU_OK) throw std::runtime_error(std::string("hmgpu_sync: ") + hmgpu_status_string(st));   // e.g. an intra wavefront that gave up
+      if (gpu_ && p->submit_seq > synced_seq_) {          // the copies out of the arrays of the picture that lived here may still be under way
+        if (p->stg && !p->has_pcm) {                         // (PCM samples travel from arrays of their own)
+          const hmgpu_status st = hmgpu_staging_wait(gpu_, p->stg);   // the copies only: the kernels read the device's arrays
+          if (st != HMGPU_OK) throw std::runtime_error(std::string("hmgpu_staging_wait: ") + hmgpu_status_string(st));
+        } else {
+          const hmgpu_status st = hmgpu_sync(gpu_);
+          synced_seq_ = submitted_seq_;
+          if (st != HMGPU_OK) throw std::runtime_error(std::string("hmgpu_sync: ") + hmgpu_status_string(st));   // e.g. an intra wavefront that gave up
+        }
       }
       return p.get();
     }
