@@ -1073,7 +1073,13 @@ static hmgpu_status stage_inputs(hmgpu_ctx* c, hmgpu_pic cur, int32_t slice_idx,
   if (!compact && (co->ctu_level_start[0] || co->ctu_level_start[1] || co->ctu_level_start[2])) return HMGPU_EINVAL;
   if (compact) {
     if (first_ctu != 0 || num_ctus != c->num_ctus) return HMGPU_EINVAL;      // whole pictures only
-    for (int k = 0; k < 3; k++) if (co->ctu_level_start[k][c->num_ctus] > c->coef_elems[k]) return HMGPU_EINVAL;
+    for (int k = 0; k < 3; k++) {
+      // the CTUs' pieces follow each other and none is longer than a CTU (k_intra stages a CTU's piece into LDS by these numbers)
+      const uint32_t per = (uint32_t)(c->ctu * c->ctu) >> (k ? 2 : 0);
+      const uint32_t* st = co->ctu_level_start[k];
+      if (st[c->num_ctus] > c->coef_elems[k]) return HMGPU_EINVAL;
+      for (int i = 0; i < c->num_ctus; i++) if (st[i + 1] < st[i] || st[i + 1] - st[i] > per) return HMGPU_EINVAL;
+    }
     // the CTU starts (from a staging block: its three arrays in one copy)
     const bool one = stg_starts_contiguous(co, c->num_ctus);
     for (int k = 0; k < (one ? 1 : 3); k++)

@@ -679,7 +679,8 @@ __global__ void __launch_bounds__(64 * WAVES) k_intra(const PicDev* __restrict__
   {
   if (P.coef_start[0] != nullptr) {
     // compact levels: the CTU's coded TUs are one contiguous piece of the stream; where each 8x8 area's TUs start in it (k_prep)
-    const uint32_t s0 = ldg(P.coef_start[comp] + ctu), s1 = ldg(P.coef_start[comp] + ctu + 1);
+    const uint32_t s0 = ldg(P.coef_start[comp] + ctu), s1r = ldg(P.coef_start[comp] + ctu + 1);
+    const uint32_t s1 = s1r < s0 ? s0 : min(s1r, s0 + ((1u << (2 * P.log2ctu)) >> (comp ? 2 : 0)));     // (the host checks both; the LDS copy is sized for a CTU)
     const int16_t* src = P.coef[comp] + s0;
     for (uint32_t i = threadIdx.x * 8u; i < s1 - s0; i += blockDim.x * 8u) *reinterpret_cast<u32x4*>(&L.lev[i]) = ldg4(src + i);
     const int qpc = P.parts >> 2;

@@ -790,6 +790,7 @@ void Decoder::flush_batch() {
   std::vector<hmgpu_picture_job> jobs(n);
   std::vector<hmgpu_pic_params> pps(n);
   std::vector<hmgpu_filter_job> fjobs(n);
+  bool resync = false;
   for (size_t i = 0; i < n; i++) {
     PicData* p = batch_[i];
     hmgpu_ctu_meta& m = metas[i];
@@ -808,10 +809,21 @@ void Decoder::flush_batch() {
     for (int c = 0; c < 3; c++) { co.level[c] = p->coeff[c].data(); co.pcm_sample[c] = p->has_pcm ? p->pcm[c].data() : nullptr; }
     if (p->compact) {
       // CTUs nobody parsed hold no TUs: their start is the next CTU's; the last entry is the length of the stream
+      bool in_order = true;
       for (int c = 0; c < 3; c++) {
         p->level_start[c][p->num_ctbs] = p->level_cursor[c];
         for (int rs = p->num_ctbs - 1; rs >= 0; rs--) if (p->slice_addr[rs] < 0) p->level_start[c][rs] = p->level_start[c][rs + 1];
+        const uint32_t per = (uint32_t)(1u << (2 * p->log2_ctb)) >> (c ? 2 : 0);
+        for (int rs = 0; rs < p->num_ctbs; rs++)
+          in_order &= p->level_start[c][rs + 1] >= p->level_start[c][rs] && p->level_start[c][rs + 1] - p->level_start[c][rs] <= per;
         co.ctu_level_start[c] = p->level_start[c].data();
+      }
+      if (!in_order) {
+        // a damaged stream delivered CTUs twice or out of order: their pieces do not follow each other.  HM's dense layout, rebuilt from
+        // the per-TU offsets, for this one picture (ordinary arrays: copied before the call below returns to the parser)
+        p->expand_dense();
+        for (int c = 0; c < 3; c++) { co.level[c] = p->dense_levels[c].data(); co.ctu_level_start[c] = nullptr; }
+        resync = true;
       }
     }
     for (auto& s : p->slices) slices[i].push_back(&s->params);
@@ -826,6 +838,7 @@ void Decoder::flush_batch() {
   pics.swap(batch_);
   hmgpu_status st = hmgpu_decompress_pictures(gpu_, (int32_t)n, jobs.data());
   if (st != HMGPU_OK) throw std::runtime_error(std::string("hmgpu_decompress_pictures: ") + hmgpu_status_string(st));
+  if (resync) (void)hmgpu_sync(gpu_);                      // (the dense stand-in of a damaged picture is not page-locked staging: let its copies finish)
   st = hmgpu_filter_pictures(gpu_, (int32_t)n, fjobs.data());
   if (st != HMGPU_OK) throw std::runtime_error(std::string("hmgpu_filter_pictures: ") + hmgpu_status_string(st));
   ++submitted_seq_;

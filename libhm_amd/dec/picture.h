@@ -228,11 +228,36 @@ struct PicData {
   int16_t* level_dst(int c, size_t ctb, size_t z, int size) {
     if (!compact) return c == 0 ? &coeff[0][(ctb << (2 * log2_ctb)) + 16 * z] : &coeff[c][(ctb << (2 * log2_ctb - 2)) + 4 * z];
     const uint32_t off = level_cursor[c];
+    // (a damaged stream can deliver the same CTUs twice: what they wrote first is dead space, and the space is finite)
+    if ((size_t)off + (size_t)size * size > coeff[c].size()) throw ParseError("more coded transform blocks than the picture has room for");
     level_cursor[c] += (uint32_t)(size * size);
     tu_off[c][ctb * parts + z] = off;
     int16_t* d = &coeff[c][off];
     memset(d, 0, (size_t)size * size * sizeof(int16_t));
     return d;
+  }
+  // compact -> HM's dense layout, into dense_levels[] (pictures of damaged streams whose CTUs did not arrive once and in order).  A TU's
+  // size follows from its partition's depth and transform depth; only TUs of decoded CTUs that the arrays still call coded are taken
+  HostVec<int16_t> dense_levels[3];
+  void expand_dense() {
+    const size_t luma = (size_t)num_ctbs << (2 * log2_ctb);
+    dense_levels[0].assign(luma, 0); dense_levels[1].assign(luma / 4, 0); dense_levels[2].assign(luma / 4, 0);
+    for (int c = 0; c < 3; c++)
+      for (size_t ctb = 0; ctb < (size_t)num_ctbs; ctb++) {
+        if (slice_addr[ctb] < 0) continue;
+        for (size_t z = 0; z < (size_t)parts; z++) {
+          const size_t part = ctb * parts + z;
+          const uint32_t off = tu_off[c][part];
+          if (off == 0xffffffffu) continue;
+          const int log2tu = log2_ctb - depth[part] - tr_idx[part];
+          int size = 1 << (c ? (log2tu > 2 ? log2tu - 1 : 2) : log2tu);
+          if (size > 32) size = 32;
+          const size_t dst = c == 0 ? (ctb << (2 * log2_ctb)) + 16 * z : (ctb << (2 * log2_ctb - 2)) + 4 * z;
+          const size_t n = (size_t)size * size;
+          if (!((cbf[c][part] >> tr_idx[part]) & 1) || off + n > coeff[c].size() || dst + n > dense_levels[c].size()) continue;
+          memcpy(&dense_levels[c][dst], &coeff[c][off], n * sizeof(int16_t));
+        }
+      }
   }
   // the levels of the TU that starts at partition z of CTB ctb, or null (compact: no coded TU starts there)
   const int16_t* level_src(int c, size_t ctb, size_t z) const {
