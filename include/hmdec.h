@@ -87,6 +87,8 @@ int hmdec_picture_slice_params(libHMDec_picture* pic, int slice, void* out /* hm
  * luma, PCM bit depth chroma, pcm_loop_filter_disabled (and PCM enabled), strong_intra_smoothing, SAO enabled, loop filter across
  * tiles, number of CTBs -- what hmgpu_seq_params / hmgpu_pic_params are filled from */
 int hmdec_picture_geometry(libHMDec_picture* pic, int32_t out[12]);
+/* HMGPU_REXT_* of the picture's SPS (hmgpu_seq_params.range_ext_flags) */
+int hmdec_picture_range_ext_flags(libHMDec_picture* pic);
 /* conformance window of the picture's SPS in luma samples: left, right, top, bottom (libHM hands out the uncropped picture) */
 int hmdec_picture_conformance_window(libHMDec_picture* pic, int32_t window[4]);
 /* libHMDEC_get_internal_info for C callers: pointer to the first element and the count (same storage, same lifetime) */

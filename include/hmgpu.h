@@ -70,8 +70,20 @@ typedef struct hmgpu_seq_params {
   int32_t pcm_loop_filter_disable;/* SPS pcm_loop_filter_disabled_flag && pcm_enabled_flag */
   int32_t strong_intra_smoothing; /* SPS strong_intra_smoothing_enabled_flag (TComPattern.cpp:201-216) */
   int32_t pcm_bit_depth_luma, pcm_bit_depth_chroma;   /* SPS pcm_sample_bit_depth_*: PCM samples are shifted up to the coding bit depth (TDecCu.cpp:770-789) */
-  int32_t reserved[5];
+  int32_t range_ext_flags;        /* HMGPU_REXT_*: the sps_range_extension() tools that change reconstruction (0 for version-1 streams) */
+  int32_t reserved[4];
 } hmgpu_seq_params;
+
+/* hmgpu_seq_params.range_ext_flags: what TComSPS keeps of sps_range_extension() for the residual path */
+enum {
+  HMGPU_REXT_ROTATION = 1,        /* getUseResidualRotation(): 4x4 intra transform-skip / bypass blocks are read back to front
+                                     (TComTU::isNonTransformedResidualRotated, TComTU.cpp:227-233) */
+  HMGPU_REXT_IMPLICIT_RDPCM = 2,  /* getUseResidualDPCM(RDPCM_SIGNAL_IMPLICIT): intra transform-skip / bypass blocks predicted
+                                     horizontally (10) or vertically (26) accumulate their residual along that direction
+                                     (invRdpcmNxN, TComTrQuant.cpp:1737-1792); bypass CUs also lose the intra edge filters
+                                     (TComPrediction.cpp:476) */
+  HMGPU_REXT_EXPLICIT_RDPCM = 4   /* getUseResidualDPCM(RDPCM_SIGNAL_EXPLICIT): inter blocks carry their mode in transform_skip[] */
+};
 
 /* Scaling lists as TDecTop activates them for a slice (TDecTop.cpp:651-668: PPS lists, else SPS lists, else the defaults):
  * TComScalingList's own storage.  De-quantisation with them: TComTrQuant.cpp:1238-1275, tables :2992-3012, 3092-3106. */
@@ -116,7 +128,8 @@ typedef struct hmgpu_ctu_meta {
   const int8_t*  qp;                 /* m_phQP */
   const uint8_t* tr_idx;             /* m_puhTrIdx */
   const uint8_t* cbf[3];             /* m_puhCbf[Y,Cb,Cr]: bit d = cbf at transform depth d (TComDataCU.h:310) */
-  const uint8_t* transform_skip[3];  /* m_puhTransformSkip[Y,Cb,Cr]                         (optional) */
+  const uint8_t* transform_skip[3];  /* bit 0: m_puhTransformSkip[Y,Cb,Cr]; bits 1-2: m_explicitRdpcmMode[Y,Cb,Cr] of inter
+                                        transform-skip / bypass blocks (RDPCM_OFF 0, RDPCM_HOR 1, RDPCM_VER 2: TypeDef.h)   (optional) */
   const int16_t* mv[2];              /* m_acCUMvField[list].m_pcMv as {hor,ver} pairs: [num_ctus][parts][2] */
   const int8_t*  ref_idx[2];         /* m_acCUMvField[list].m_piRefIdx (-1 = list unused) */
   const uint8_t* intra_dir[2];       /* m_puhIntraDir[luma,chroma]                          (optional; intra path) */

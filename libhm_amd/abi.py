@@ -24,7 +24,7 @@ class SeqParams(C.Structure):
     _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("bit_depth_luma", C.c_int32), ("bit_depth_chroma", C.c_int32),
                 ("chroma_format", C.c_int32), ("log2_ctu_size", C.c_int32), ("max_pictures", C.c_int32),
                 ("pcm_loop_filter_disable", C.c_int32), ("strong_intra_smoothing", C.c_int32), ("pcm_bit_depth_luma", C.c_int32), ("pcm_bit_depth_chroma", C.c_int32),
-                ("reserved", C.c_int32 * 5)]
+                ("range_ext_flags", C.c_int32), ("reserved", C.c_int32 * 4)]
 
 
 class ScalingLists(C.Structure):
@@ -80,7 +80,7 @@ def _ptr(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p).value
 
 
-def make_seq(width, height, bd_luma, bd_chroma=None, log2_ctu=6, max_pictures=8, strong_intra_smoothing=1):
+def make_seq(width, height, bd_luma, bd_chroma=None, log2_ctu=6, max_pictures=8, strong_intra_smoothing=1, range_ext_flags=0):
     s = SeqParams()
     s.width, s.height = width, height
     s.bit_depth_luma = bd_luma
@@ -89,6 +89,7 @@ def make_seq(width, height, bd_luma, bd_chroma=None, log2_ctu=6, max_pictures=8,
     s.log2_ctu_size = log2_ctu
     s.max_pictures = max_pictures
     s.strong_intra_smoothing = strong_intra_smoothing
+    s.range_ext_flags = range_ext_flags
     return s
 
 

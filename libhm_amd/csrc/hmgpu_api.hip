@@ -280,6 +280,7 @@ hmgpu_status alloc_picture(hmgpu_ctx* c, Picture& p) {
   d.grid_w = c->grid_w; d.grid_h = c->grid_h;
   d.lf_across_tiles = 1; d.sao_applied = 0;
   d.has_intra_dir = 0; d.strong_intra_smoothing = s.strong_intra_smoothing ? 1 : 0;
+  d.range_ext = s.range_ext_flags;
   d.sl_m = nullptr;
   for (int k = 0; k < 3; k++) { d.pcm[k] = nullptr; d.pcm_shift[k] = 0; d.coef_start[k] = nullptr; }
   d.pcm_lf_disable = s.pcm_loop_filter_disable ? 1 : 0; d.any_nofilt = 0;
@@ -523,6 +524,7 @@ hmgpu_status hmgpu_create(const hmgpu_seq_params* seq, int device_ordinal, hmgpu
   if (seq->log2_ctu_size < 4 || seq->log2_ctu_size > 6) return HMGPU_EINVAL;
   if (seq->max_pictures < 1 || seq->max_pictures > kMaxPics) return HMGPU_EINVAL;
   if (seq->chroma_format != 1) return HMGPU_EUNSUPPORTED;
+  if (seq->range_ext_flags & ~(HMGPU_REXT_ROTATION | HMGPU_REXT_IMPLICIT_RDPCM | HMGPU_REXT_EXPLICIT_RDPCM)) return HMGPU_EUNSUPPORTED;
   if (seq->bit_depth_luma < 8 || seq->bit_depth_luma > 10 || seq->bit_depth_chroma < 8 || seq->bit_depth_chroma > 10) return HMGPU_EUNSUPPORTED;
   hmgpu_ctx* c = new (std::nothrow) hmgpu_ctx();
   if (!c) return HMGPU_ENOMEM;

@@ -262,5 +262,38 @@ __device__ inline void itx_tu_pk(const uint32_t (&lv)[(1 << LOG2N) / 2], int n, 
   }
 }
 
+// sps_range_extension(): what follows a block that skipped the transform (transform-skip or cu_transquant_bypass).  res: row n of
+// the N x N residual; the N lanes of the TU call together.  rotate: the 4x4 block read back to front (TComTrQuant.cpp:1475-1487,
+// :1943; TComTU::isNonTransformedResidualRotated).  rdpcm: invRdpcmNxN (:1737-1792), 1 = running sums along the row, 2 = down the
+// columns; the sums wrap at 16 bits like HM's Pel buffer.
+template <int LOG2N>
+__device__ inline void resid_rotate_rdpcm(uint32_t (&res)[(1 << LOG2N) / 2], int n, bool rotate, int rdpcm) {
+  constexpr int N = 1 << LOG2N;
+  typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+  if constexpr (N == 4) {
+    if (rotate) {
+      const uint32_t a = (uint32_t)__shfl_xor((int)res[1], 3), b = (uint32_t)__shfl_xor((int)res[0], 3);     // row 3 - n, then mirrored
+      res[0] = (a >> 16) | (a << 16); res[1] = (b >> 16) | (b << 16);
+    }
+  }
+  if (rdpcm == 1) {
+    uint32_t carry = 0;
+#pragma unroll
+    for (int i = 0; i < N / 2; i++) {
+      const uint32_t lo = (res[i] + carry) & 0xffffu, hi = ((res[i] >> 16) + lo) & 0xffffu;
+      res[i] = lo | (hi << 16); carry = hi;
+    }
+  } else if (rdpcm == 2) {
+#pragma unroll
+    for (int d = 1; d < N; d <<= 1) {
+#pragma unroll
+      for (int i = 0; i < N / 2; i++) {
+        const uint32_t up = (uint32_t)__shfl_up((int)res[i], d, N);           // row n - d of the same TU
+        const u16x2 s = __builtin_bit_cast(u16x2, res[i]) + __builtin_bit_cast(u16x2, up);
+        if (n >= d) res[i] = __builtin_bit_cast(uint32_t, s);
+      }
+    }
+  }
+}
 
 }  // namespace hmgpu

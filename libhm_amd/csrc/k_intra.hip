@@ -198,6 +198,8 @@ __device__ __attribute__((always_inline)) inline void intra_tu(const PicDev& P, 
   // ---- C. prediction of row n by lane n
   const int* f = filt ? W.filt : W.line;
   const bool edge = comp == 0 && N <= 16;                   // MAXIMUM_INTRA_FILTERED_WIDTH (TypeDef.h:117)
+  // implicit RDPCM in a lossless CU: horizontal / vertical prediction without its edge filter (TComPrediction.cpp:476)
+  const bool edge_ang = edge && !(t.bypass && (P.range_ext & HMGPU_REXT_IMPLICIT_RDPCM));
   int p[N];
   if (t.mode == 0) {
     const int left = f[corner - 1 - n], bl = f[corner - 1 - N], tr = f[corner + 1 + N];
@@ -235,7 +237,7 @@ __device__ __attribute__((always_inline)) inline void intra_tu(const PicDev& P, 
         const int pos = __mul24(a_ + 1, ang), di = pos >> 5, df = pos & 31;
         const int i0 = corner + sgn * (b_ + di + 1);
         int v = df ? (__mul24(32 - df, f[i0]) + __mul24(df, f[i0 + sgn]) + 16) >> 5 : f[i0];
-        if (ang == 0 && edge && b_ == 0) v = clip3(0, maxv, v + ((f[corner - sgn * (a_ + 1)] - f[corner]) >> 1));
+        if (ang == 0 && edge_ang && b_ == 0) v = clip3(0, maxv, v + ((f[corner - sgn * (a_ + 1)] - f[corner]) >> 1));
         p[x] = v;
       }
     } else {
@@ -266,6 +268,9 @@ __device__ __attribute__((always_inline)) inline void intra_tu(const PicDev& P, 
     qp_param_tu(t.qp_cu, comp, bd, t.cqo, per, rem);
     const uint8_t* mrow = (P.sl_m != nullptr && (!t.skip || N == 4)) ? P.sl_m + (((LOG2N - 2) * 6 + comp) << 10) + n * N : nullptr;   // intra lists: 0 + component
     itx_tu_pk<LOG2N>(lv, n, per, rem, t.skip != 0, bd, W.tile, res, comp == 0 && LOG2N == 2, mrow, t.bypass != 0);   // DST: 4x4 intra luma (TComTU::useDST)
+    if (P.range_ext && (t.skip || t.bypass))                 // rotation (4x4) and implicit RDPCM along the final prediction mode
+      resid_rotate_rdpcm<LOG2N>(res, n, (P.range_ext & HMGPU_REXT_ROTATION) != 0,
+                                (P.range_ext & HMGPU_REXT_IMPLICIT_RDPCM) ? (t.mode == 10 ? 1 : t.mode == 26 ? 2 : 0) : 0);
   }
 
   // ---- E. reconstruction of row n: into the LDS copy (what later TUs of this CTU predict from) and, two samples per
@@ -607,7 +612,7 @@ __device__ __attribute__((always_inline)) inline void intra_ctu(const PicDev& P,
       if (comp && mode == 36) mode = L.m_dirl[z];        // DM_CHROMA_IDX (TDecCu.cpp:523-524): the luma mode of the CU's first partition (z: the CU's origin)
       t.mode = mode;
       t.cbf = (L.m_cbf[zc] >> tr) & 1;
-      t.skip = L.m_ts[zc];
+      t.skip = L.m_ts[zc] & 1;
       t.bypass = L.m_byp[zc];
       if (compact) {
         // (HM descends to a TU only through coded ancestors: the cbf chain, as in k_prep's count); 4x4 luma TUs: the coded ones of the

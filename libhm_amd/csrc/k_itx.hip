@@ -84,6 +84,7 @@ __device__ inline void itx_class(const ItxPic& P, int bx, int nbx, char* __restr
       // scaling lists (inter TUs: list 3 + component; not for transform-skip blocks other than 4x4, TComTrQuant.h:180)
       const uint8_t* mrow = (P.sl_m != nullptr && (!(flags & 2) || N == 4)) ? P.sl_m + (((LOG2N - 2) * 6 + 3 + comp) << 10) + n * N : nullptr;
       itx_tu_pk<LOG2N>(lv_c, n, per, rem, (flags & 2) != 0, bd, buf, res, false, mrow, (flags & 4) != 0);
+      if (flags & 0x18) resid_rotate_rdpcm<LOG2N>(res, n, false, (flags >> 3) & 3);        // explicit RDPCM (inter: never rotated)
       if (t < count) {
         // row n of the residual into the tiles it crosses: the eight lanes that hold the rows of one tile write its 128 bytes
         const int cs = comp ? 1 : 0;

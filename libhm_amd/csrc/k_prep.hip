@@ -449,7 +449,9 @@ __global__ void __launch_bounds__(256) k_prep(const PicDev* __restrict__ pics, B
     const int comp = k < 4 ? 0 : k - 3;
     const int j = k < 4 ? k : 0;                          // partition the TU starts at
     const int ts = (q.ts[comp] >> (8 * j)) & 0xff;
-    const int flags = ((comp == 0 && q.log2tu == 2 && q.intra) ? 1 : 0) | (ts ? 2 : 0) | ((q.bypass & 0xff) ? 4 : 0);      // bit 2: cu_transquant_bypass
+    // bit 1: transform skip, bit 2: cu_transquant_bypass, bits 3-4: explicit RDPCM mode of a block that skipped the transform
+    int flags = ((comp == 0 && q.log2tu == 2 && q.intra) ? 1 : 0) | ((ts & 1) ? 2 : 0) | ((q.bypass & 0xff) ? 4 : 0);
+    if ((flags & 6) && (P.range_ext & HMGPU_REXT_EXPLICIT_RDPCM)) flags |= ((ts >> 1) & 3) << 3;
     uint32_t off = comp == 0 ? (uint32_t)q.ctu * ctu_luma + 16u * (q.z0 + j) : (uint32_t)q.ctu * (ctu_luma >> 2) + 4u * q.z0;
     if (P.coef_start[0] != nullptr) off = coff[comp] + (comp == 0 ? 16u * __popc(lmask & ((1u << j) - 1u)) : 0u);
     const TuRec r = make_tu(P, q, sl, q.gx0 + (j & 1), q.gy0 + (j >> 1), comp, flags, off);

@@ -37,10 +37,12 @@ enum Ctx {
   CTX_LAST_X = CTX_TS_FLAG + 2,             // 18
   CTX_LAST_Y = CTX_LAST_X + 18,             // 18
   CTX_CSBF = CTX_LAST_Y + 18,               // 4
-  CTX_SIG = CTX_CSBF + 4,                   // 42
-  CTX_GT1 = CTX_SIG + 42,                   // 24
+  CTX_SIG = CTX_CSBF + 4,                   // 42 + the two transform_skip_context_enabled contexts (luma 42, chroma 43)
+  CTX_GT1 = CTX_SIG + 44,                   // 24
   CTX_GT2 = CTX_GT1 + 24,                   // 6
-  CTX_COUNT = CTX_GT2 + 6
+  CTX_RDPCM_FLAG = CTX_GT2 + 6,             // 2 (luma, chroma): explicit_rdpcm_flag
+  CTX_RDPCM_DIR = CTX_RDPCM_FLAG + 2,       // 2: explicit_rdpcm_dir_flag
+  CTX_COUNT = CTX_RDPCM_DIR + 2
 };
 
 // (a context variable is 7 bits; it is kept in 16 so that stores to it cannot alias the engine's registers -- unsigned char may
@@ -48,6 +50,8 @@ enum Ctx {
 typedef uint16_t ctx_t;
 struct ContextSet {
   ctx_t s[CTX_COUNT];                       // (pStateIdx << 1) | valMps
+  uint8_t stat_coeff[4] = {0, 0, 0, 0};     // persistent_rice_adaptation: StatCoeff[2 * chroma + (skip | bypass)], synchronised and
+                                            // reset with the context variables (9.3.2.4; HM: TDecSbac.cpp:169, 1858)
   void init(int init_type, int slice_qp);   // 9.3.2.2
 };
 

@@ -186,6 +186,7 @@ bool Decoder::opens_new_sequence(const SliceHeader& sh) const {
          sps_->bit_depth_luma != sps->bit_depth_luma || sps_->bit_depth_chroma != sps->bit_depth_chroma || sps_->pcm != sps->pcm ||
          sps_->pcm_bit_depth_luma != sps->pcm_bit_depth_luma || sps_->pcm_bit_depth_chroma != sps->pcm_bit_depth_chroma ||
          sps_->pcm_loop_filter_disabled != sps->pcm_loop_filter_disabled || sps_->strong_intra_smoothing != sps->strong_intra_smoothing ||
+         sps_->range_ext_flags() != sps->range_ext_flags() ||
          sps_->max_dec_pic_buffering[sps_->max_sub_layers - 1] != sps->max_dec_pic_buffering[sps->max_sub_layers - 1];
 }
 
@@ -234,6 +235,7 @@ void Decoder::activate(const SliceHeader& sh) {
   seq_.max_pictures = std::min(40, sps_->max_dec_pic_buffering[sps_->max_sub_layers - 1] + 3 + (threaded() ? threads_ + 1 : 0));
   seq_.pcm_loop_filter_disable = sps_->pcm && sps_->pcm_loop_filter_disabled;
   seq_.strong_intra_smoothing = sps_->strong_intra_smoothing;
+  seq_.range_ext_flags = sps_->range_ext_flags();
   seq_.pcm_bit_depth_luma = sps_->pcm_bit_depth_luma;
   seq_.pcm_bit_depth_chroma = sps_->pcm_bit_depth_chroma;
   if (!parse_only_) {
@@ -444,6 +446,7 @@ void Decoder::start_picture(const SliceHeader& sh) {
   cur_->pcm_bit_depth[0] = sps_->pcm_bit_depth_luma; cur_->pcm_bit_depth[1] = sps_->pcm_bit_depth_chroma;
   cur_->pcm_lf_disable = sps_->pcm && sps_->pcm_loop_filter_disabled;
   cur_->strong_intra = sps_->strong_intra_smoothing;
+  cur_->range_ext_flags = sps_->range_ext_flags();
   cur_->lf_across_tiles = pps_->lf_across_tiles;
   cur_->conf_window[0] = sps_->conf_left; cur_->conf_window[1] = sps_->conf_right; cur_->conf_window[2] = sps_->conf_top; cur_->conf_window[3] = sps_->conf_bottom;
   cur_->is_reference = true;                 // "used for short-term reference" until a later RPS says otherwise (8.3.1 end)

@@ -341,6 +341,8 @@ int hmdec_picture_geometry(libHMDec_picture* pic, int32_t out[12]) {
   return 0;
 }
 
+int hmdec_picture_range_ext_flags(libHMDec_picture* pic) { return pic ? as_pic(pic)->range_ext_flags : 0; }
+
 int hmdec_picture_conformance_window(libHMDec_picture* pic, int32_t window[4]) {
   if (!pic || !window) return 1;
   for (int i = 0; i < 4; i++) window[i] = as_pic(pic)->conf_window[i];

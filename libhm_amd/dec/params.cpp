@@ -310,8 +310,16 @@ std::shared_ptr<Sps> parse_sps(BitReader& br) {
     const bool range_ext = br.flag();
     br.u(7);
     if (range_ext) {
-      const unsigned flags = br.u(9);
-      if (flags) throw Unsupported("range-extension coding tools (RExt) are outside the device path");
+      s.rext_rotation = br.flag();
+      s.rext_ts_context = br.flag();
+      s.rext_implicit_rdpcm = br.flag();
+      s.rext_explicit_rdpcm = br.flag();
+      if (br.flag()) throw Unsupported("extended_precision_processing (RExt)");
+      if (br.flag()) throw Unsupported("intra_smoothing_disabled (RExt)");
+      // high_precision_offsets: offsets in units of the bit depth instead of 8 bits -- the same thing at 8 bits
+      if (br.flag() && (s.bit_depth_luma != 8 || s.bit_depth_chroma != 8)) throw Unsupported("high-precision weighted-prediction offsets above 8 bits (RExt)");
+      s.rext_persistent_rice = br.flag();
+      if (br.flag()) throw Unsupported("cabac_bypass_alignment (RExt)");
     }
   }
   return sp;

@@ -50,6 +50,10 @@ struct Sps {
   int num_long_term_ref_pics_sps = 0, lt_ref_pic_poc_lsb_sps[32] = {0};
   bool used_by_curr_pic_lt_sps[32] = {false};
   bool temporal_mvp = false, strong_intra_smoothing = false;
+  // sps_range_extension() (HM 16.0: TDecCAVLC.cpp:778-786); tools the device path lacks are refused while parsing
+  bool rext_rotation = false, rext_ts_context = false, rext_implicit_rdpcm = false, rext_explicit_rdpcm = false;
+  bool rext_persistent_rice = false;
+  int range_ext_flags() const { return (rext_rotation ? 1 : 0) | (rext_implicit_rdpcm ? 2 : 0) | (rext_explicit_rdpcm ? 4 : 0); }   // HMGPU_REXT_*
   // derived
   int ctb_size() const { return 1 << log2_ctb; }
   int pic_w_ctbs() const { return (width + ctb_size() - 1) >> log2_ctb; }

@@ -875,9 +875,16 @@ void SliceDecoder::residual_coding(int x0, int y0, int log2, int c) {
   const int size = 1 << log2;
   const size_t part = pic_.part_at(x0, y0), ctb = pic_.ctb_at(x0, y0), z = part - ctb * pic_.parts;
   int16_t* dst = pic_.level_dst(c, ctb, z, size);
-  if (pps_.transform_skip_enabled && !cu_bypass_ && log2 == 2 && eng.decision(ctx_.s[CTX_TS_FLAG + (c ? 1 : 0)])) {
-    const int span = c ? 2 : 1;                          // a 4x4 chroma block lies over 2x2 luma partitions
-    for (int y = 0; y < span; y++) for (int x = 0; x < span; x++) pic_.ts[c][pic_.part_at(x0 + 4 * x, y0 + 4 * y)] = 1;
+  const bool ts = pps_.transform_skip_enabled && !cu_bypass_ && log2 == 2 && eng.decision(ctx_.s[CTX_TS_FLAG + (c ? 1 : 0)]);
+  const bool untransformed = ts || cu_bypass_;
+  // explicit_rdpcm_flag / explicit_rdpcm_dir_flag: inter blocks that skip the transform (HM 16.0: TDecSbac.cpp:1322-1350, 1884-1917)
+  int rdpcm = 0;
+  if (untransformed && sps_.rext_explicit_rdpcm && cu_pred_mode_ != MODE_INTRA && eng.decision(ctx_.s[CTX_RDPCM_FLAG + (c ? 1 : 0)]))
+    rdpcm = eng.decision(ctx_.s[CTX_RDPCM_DIR + (c ? 1 : 0)]) ? 2 : 1;
+  if (ts || rdpcm) {
+    const int span = (size << (c ? 1 : 0)) >> 2;         // in 4x4 luma partitions (a 4x4 chroma block lies over 2x2 of them)
+    const uint8_t v = (uint8_t)((ts ? 1 : 0) | (rdpcm << 1));
+    for (int y = 0; y < span; y++) for (int x = 0; x < span; x++) pic_.ts[c][pic_.part_at(x0 + 4 * x, y0 + 4 * y)] = v;
   }
   // last significant coefficient position (9.3.4.2.3)
   int ctx_off, ctx_shift;
@@ -906,7 +913,16 @@ void SliceDecoder::residual_coding(int x0, int y0, int log2, int c) {
   int csbf[9][9] = {{0}};
   int prev_c1 = 1;
   bool first_sb = true;
-  const bool sdh = pps_.sign_data_hiding && !cu_bypass_;
+  // sign data hiding is off wherever RDPCM runs: explicit modes, and intra transform-skip blocks predicted along 10 / 26
+  // (TDecSbac.cpp:1345-1368); a lossless CU never hides signs
+  bool sdh = pps_.sign_data_hiding && !cu_bypass_ && !rdpcm;
+  if (sdh && ts && sps_.rext_implicit_rdpcm && cu_pred_mode_ == MODE_INTRA) {
+    const int mode = c == 0 ? pic_.intra_dir[0][part] : intra_chroma_;
+    if (mode == 10 || mode == 26) sdh = false;
+  }
+  const bool single_sig = sps_.rext_ts_context && untransformed;      // transform_skip_context_enabled_flag (TComChromaFormat.cpp:116-120)
+  uint8_t& stat = ctx_.stat_coeff[(c ? 2 : 0) + (untransformed ? 1 : 0)];   // TComTU::getGolombRiceStatisticsIndex (TComTU.cpp:236-254)
+  const bool persistent_rice = sps_.rext_persistent_rice;
   for (int i = last_sb; i >= 0; i--) {
     const int xs = sb_order[i] % sbw, ys = sb_order[i] / sbw;
     const int right = csbf[ys][xs + 1], below = csbf[ys + 1][xs];
@@ -934,7 +950,7 @@ void SliceDecoder::residual_coding(int x0, int y0, int log2, int c) {
     for (; n >= 0; n--) {
       bool sig;
       if (n > 0 || !infer_dc) {
-        const int sc = (n == 0 && i == 0 && log2 > 2) ? (c ? 27 : 0) : sig_base + sig_tab[in_order[n]];
+        const int sc = single_sig ? 42 + (c ? 1 : 0) : (n == 0 && i == 0 && log2 > 2) ? (c ? 27 : 0) : sig_base + sig_tab[in_order[n]];
         sig = eng.decision(ctx_.s[CTX_SIG + sc]);
         infer_dc = infer_dc && !sig;
       } else {
@@ -962,19 +978,29 @@ void SliceDecoder::residual_coding(int x0, int y0, int log2, int c) {
     const bool hidden = sdh && pos[0] - pos[nsig - 1] > 3;
     const int nsign = nsig - (hidden ? 1 : 0);
     const unsigned signs = eng.bypass_bits(nsign) << (16 - nsign);
-    int rice = 0, sum = 0;
+    int rice = persistent_rice ? stat >> 2 : 0, sum = 0;
+    bool first_remaining = persistent_rice;
     for (int k = 0; k < nsig; k++) {
       int level = 1 + g1[k] + (k == first_g1 ? g2 : 0);
       const int thresh = k < 8 ? (k == first_g1 ? 3 : 2) : 1;
       if (level == thresh) {
         // coeff_abs_level_remaining (9.3.3.11): unary prefix, then rice / escape suffix, all bypass bins: read as one group of 16 bins
         // (enough for prefixes up to 7 at any rice parameter), the engine keeps what the element used
-        unsigned wide;
-        const unsigned q = eng.bypass_peek16(wide);
+        unsigned wide = 0;
+        const unsigned q = rice > 4 ? 0u : eng.bypass_peek16(wide);
         const unsigned zeros = ~q & 0xffffu;
         int prefix = zeros ? __builtin_clz(zeros) - 16 : 16;
         int rem;
-        if (prefix <= 3) {
+        if (rice > 4) {                                      // (only with persistent Rice adaptation) bin by bin
+          prefix = 0;
+          while (prefix < 32 && eng.bypass()) prefix++;
+          if (prefix == 32) throw ParseError("coeff_abs_level_remaining prefix too long");
+          if (prefix <= 3) rem = (prefix << rice) + (int)eng.bypass_bits(rice);
+          else {
+            if (prefix - 3 + rice > 24) throw ParseError("coeff_abs_level_remaining out of range");
+            rem = (((1 << (prefix - 3)) + 3 - 1) << rice) + (int)eng.bypass_bits(prefix - 3 + rice);
+          }
+        } else if (prefix <= 3) {
           const int nb = prefix + 1 + rice;
           rem = (prefix << rice) + (int)((q >> (16 - nb)) & ((1u << rice) - 1u));
           eng.bypass_keep(wide, q, nb);
@@ -990,7 +1016,14 @@ void SliceDecoder::residual_coding(int x0, int y0, int log2, int c) {
           rem = (((1 << (prefix - 3)) + 3 - 1) << rice) + (int)eng.bypass_bits(prefix - 3 + rice);
         }
         level += rem;
-        if (level > 3 * (1 << rice)) rice = std::min(rice + 1, 4);
+        // (HM 16.0 leaves the parameter uncapped under persistent adaptation: TDecSbac.cpp:1576-1579)
+        if (level > 3 * (1 << rice)) rice = persistent_rice ? rice + 1 : std::min(rice + 1, 4);
+        if (first_remaining) {                               // StatCoeff update on the first escape of the sub-block (:1581-1595)
+          const int init = stat >> 2;
+          if (rem >= (3 << init)) stat++;
+          else if (2 * rem < (1 << init) && stat > 0) stat--;
+          first_remaining = false;
+        }
       }
       sum += level;
       bool neg;

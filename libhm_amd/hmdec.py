@@ -43,6 +43,7 @@ def lib():
         L.hmdec_hash_mismatches.argtypes = [C.c_void_p]
         L.hmdec_pictures_decoded.argtypes = [C.c_void_p]
         L.hmdec_device_batches.argtypes = [C.c_void_p]
+        L.hmdec_picture_range_ext_flags.argtypes = [C.c_void_p]
         L.hmdec_set_device_md5.argtypes = [C.c_void_p, C.c_int]
         L.hmdec_last_error.argtypes = [C.c_void_p]
         L.hmdec_last_error.restype = C.c_char_p
@@ -134,7 +135,9 @@ class Picture:
         g = (C.c_int32 * 12)()
         lib().hmdec_picture_geometry(self.h, g)
         keys = ("width", "height", "log2_ctb", "bd_y", "bd_c", "pcm_bd_y", "pcm_bd_c", "pcm_lf_disable", "strong_intra", "sao", "lf_across_tiles", "num_ctbs")
-        return dict(zip(keys, (int(v) for v in g)))
+        out = dict(zip(keys, (int(v) for v in g)))
+        out["range_ext"] = int(lib().hmdec_picture_range_ext_flags(self.h))
+        return out
 
     def conformance_window(self):
         w = (C.c_int32 * 4)()

@@ -237,6 +237,27 @@ void hmo_inverse_transform_tu_sl(const int16_t* level, int16_t* resid, int resid
   for (y = 0; y < n; y++) for (x = 0; x < n; x++) resid[y * resid_stride + x] = (int16_t)block[y * n + x];   /* xIT: :1861-1865 */
 }
 
+/* What sps_range_extension() adds to a block that skipped the transform (transform-skip or cu_transquant_bypass):
+ * rotation = the block read back to front (TComTrQuant.cpp:1475-1487 for bypass, :1943 inside xITransformSkip -- element-wise
+ * scaling commutes with it), then invRdpcmNxN (:1737-1792): running sums along rows (RDPCM_HOR 1) or columns (RDPCM_VER 2),
+ * carried in Pel = 16 bits like HM's residual buffer. */
+void hmo_residual_rotate_rdpcm(int16_t* resid, int stride, int n, int rotate, int rdpcm)
+{
+  int x, y;
+  if (rotate)
+    for (y = 0; y < n / 2; y++)
+      for (x = 0; x < n; x++)
+      {
+        int16_t* a = &resid[y * stride + x];
+        int16_t* b = &resid[(n - 1 - y) * stride + (n - 1 - x)];
+        const int16_t t = *a; *a = *b; *b = t;
+      }
+  if (rdpcm == 2)
+    for (y = 1; y < n; y++) for (x = 0; x < n; x++) resid[y * stride + x] = (int16_t)(resid[y * stride + x] + resid[(y - 1) * stride + x]);
+  else if (rdpcm == 1)
+    for (y = 0; y < n; y++) for (x = 1; x < n; x++) resid[y * stride + x] = (int16_t)(resid[y * stride + x] + resid[y * stride + x - 1]);
+}
+
 /* ------------------------------------------------------------------------------------------------ picture hashes */
 /* compCRC: TComPicYuvMD5.cpp:89-125 */
 void hmo_plane_crc(int bit_depth, const int16_t* plane, int width, int height, int stride, uint8_t out[2])
@@ -442,18 +463,23 @@ static void tu_leaf(cu_ctx* c, int comp, int z_tu, int log2_size, int x_rel, int
   const int16_t* lev = c->co->level[comp] + (size_t)c->ctu_addr * ((g->ctu * g->ctu) >> (comp ? 2 : 0)) + coef_off;
   hmo_qp_param(PM(qp, c->ctu_addr, c->cu_z), comp, g->bd[comp], cqo, &per, &rem);       /* QpParam(cu, compID): getQP(0) */
   if (comp == 0 && PM(pred_mode, c->ctu_addr, z_tu) == HMGPU_MODE_INTRA) flags |= 1;    /* TComTU::useDST, TComTU.cpp:218 */
-  if (g->m->transform_skip[comp] && g->m->transform_skip[comp][(size_t)c->ctu_addr * g->parts + z_tu]) flags |= 2;
+  const int tsb = g->m->transform_skip[comp] ? g->m->transform_skip[comp][(size_t)c->ctu_addr * g->parts + z_tu] : 0;
+  /* inter blocks: the explicit mode parsed with the block (bits 1-2), honoured only while the SPS enables it (isRDPCMEnabled) */
+  const int rdpcm = (g->seq->range_ext_flags & HMGPU_REXT_EXPLICIT_RDPCM) ? (tsb >> 1) & 3 : 0;
+  if (tsb & 1) flags |= 2;
   if (g->m->transquant_bypass && g->m->transquant_bypass[(size_t)c->ctu_addr * g->parts + z_tu])
   {
-    /* cu_transquant_bypass: the residual IS the level block (invTransformNxN, TComTrQuant.cpp:1440-1470; no rotation / RDPCM outside RExt) */
+    /* cu_transquant_bypass: the residual IS the level block (invTransformNxN, TComTrQuant.cpp:1440-1470); rotation is intra only */
     const int n = 1 << log2_size;
     int x, y;
     for (y = 0; y < n; y++) for (x = 0; x < n; x++) c->resi[comp][(y_rel + y) * stride + x_rel + x] = lev[y * n + x];
+    hmo_residual_rotate_rdpcm(&c->resi[comp][y_rel * stride + x_rel], stride, n, 0, rdpcm);
     return;
   }
   /* getScalingListType (TComTrQuant.h): 3 * inter + component */
   hmo_inverse_transform_tu_sl(lev, &c->resi[comp][y_rel * stride + x_rel], stride, log2_size, g->bd[comp], per, rem, flags, sl->scaling_lists,
                               (PM(pred_mode, c->ctu_addr, z_tu) == HMGPU_MODE_INTRA ? 0 : 3) + comp);
+  if (flags & 2) hmo_residual_rotate_rdpcm(&c->resi[comp][y_rel * stride + x_rel], stride, 1 << log2_size, 0, rdpcm);
 }
 
 /* invRecurTransformNxN (TComTrQuant.cpp:1550-1615) with the TComTU child rules for 4:2:0 (TComTU.cpp:89-171) */
@@ -711,7 +737,7 @@ static void intra_smooth(const geom* g, int comp, int mode, int n, int log2n, co
 }
 
 /* predIntraAng: planar, DC (+ edge filter) and the 33 angular modes; pred is n x n, stride n */
-static void intra_predict(int comp, int bd, int mode, int n, int log2n, const int* line, int16_t* pred)
+static void intra_predict(int comp, int bd, int mode, int n, int log2n, const int* line, int16_t* pred, int edge_filters)
 {
   const int corner = 2 * n;
   const int* left = line + corner - 1;          /* left[-r] = row r */
@@ -771,7 +797,7 @@ static void intra_predict(int comp, int bd, int mode, int n, int log2n, const in
       for (x = 0; x < n; x++)
       {
         int v = df ? ((32 - df) * ref[x + di + 1] + df * ref[x + di + 2] + 16) >> 5 : ref[x + di + 1];
-        if (ang == 0 && edge && x == 0) v = CLIP3(0, maxv, v + ((SIDE(y + 1) - SIDE(0)) >> 1));
+        if (ang == 0 && edge && edge_filters && x == 0) v = CLIP3(0, maxv, v + ((SIDE(y + 1) - SIDE(0)) >> 1));
         if (ver) pred[y * n + x] = (int16_t)v; else pred[x * n + y] = (int16_t)v;
       }
     }
@@ -801,19 +827,31 @@ static void intra_tu(cu_ctx* c, int comp, int z_tu, int log2n, int cbf_depth, in
   }
   intra_ref_line(c, comp, z_tu, n, x0, y0, line);
   intra_smooth(g, comp, mode, n, log2n, line, fl);
-  intra_predict(comp, g->bd[comp], mode, n, log2n, fl, pred);
+  {
+    /* implicit RDPCM in a lossless CU switches the edge filters of the horizontal / vertical modes off (TComPrediction.cpp:476) */
+    const int byp = g->m->transquant_bypass && g->m->transquant_bypass[(size_t)a * g->parts + z_tu];
+    intra_predict(comp, g->bd[comp], mode, n, log2n, fl, pred, !(byp && (g->seq->range_ext_flags & HMGPU_REXT_IMPLICIT_RDPCM)));
+  }
   memset(resi, 0, sizeof(int16_t) * n * n);
   if ((g->m->cbf[comp][(size_t)a * g->parts + z_tu] >> cbf_depth) & 1)
   {
     int per, rem, flags = comp == 0 ? 1 : 0;
     const int cqo = comp == 1 ? sl->cb_qp_offset : (comp == 2 ? sl->cr_qp_offset : 0);
     const int16_t* lev = c->co->level[comp] + (size_t)a * ((g->ctu * g->ctu) >> (comp ? 2 : 0)) + coef_off;
-    if (g->m->transquant_bypass && g->m->transquant_bypass[(size_t)a * g->parts + z_tu]) memcpy(resi, lev, sizeof(int16_t) * n * n);
+    const int byp = g->m->transquant_bypass && g->m->transquant_bypass[(size_t)a * g->parts + z_tu];
+    if (byp) memcpy(resi, lev, sizeof(int16_t) * n * n);
     else
     {
     hmo_qp_param(PM(qp, a, c->cu_z), comp, g->bd[comp], cqo, &per, &rem);
-    if (g->m->transform_skip[comp] && g->m->transform_skip[comp][(size_t)a * g->parts + z_tu]) flags |= 2;
+    if (g->m->transform_skip[comp] && (g->m->transform_skip[comp][(size_t)a * g->parts + z_tu] & 1)) flags |= 2;
     hmo_inverse_transform_tu_sl(lev, resi, n, log2n, g->bd[comp], per, rem, flags, sl->scaling_lists, comp);
+    }
+    if (byp || (flags & 2))
+    {
+      /* isNonTransformedResidualRotated (TComTU.cpp:227-233): 4x4 intra; implicit RDPCM follows the final prediction mode (invRdpcmNxN) */
+      const int rx = g->seq->range_ext_flags;
+      hmo_residual_rotate_rdpcm(resi, n, n, (rx & HMGPU_REXT_ROTATION) && n == 4,
+                                (rx & HMGPU_REXT_IMPLICIT_RDPCM) ? (mode == 10 ? 1 : (mode == 26 ? 2 : 0)) : 0);
     }
   }
   for (y = 0; y < n; y++)

@@ -31,6 +31,8 @@ void hmo_inverse_transform_tu(const int16_t* level, int16_t* resid, int resid_st
 /* the same with scaling lists (NULL = flat): list_id = 3 * inter + component (getScalingListType) */
 void hmo_inverse_transform_tu_sl(const int16_t* level, int16_t* resid, int resid_stride, int log2_size, int bit_depth,
                                  int qp_per, int qp_rem, int flags, const hmgpu_scaling_lists* sl, int list_id);
+/* rotation + RDPCM of a block that skipped the transform (TComTrQuant.cpp:1475-1487, 1737-1792): rdpcm 0 off, 1 hor, 2 ver */
+void hmo_residual_rotate_rdpcm(int16_t* resid, int stride, int n, int rotate, int rdpcm);
 /* picture hashes of one plane (TComPicYuvMD5.cpp:89-170): CRC-16 (2 bytes, big endian in out) and checksum (4 bytes) */
 void hmo_plane_crc(int bit_depth, const int16_t* plane, int width, int height, int stride, uint8_t out[2]);
 void hmo_plane_checksum(int bit_depth, const int16_t* plane, int width, int height, int stride, uint8_t out[4]);

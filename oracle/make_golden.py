@@ -231,6 +231,8 @@ def dump_stream(name, bitstream, enc_rec, geom):
 # Streams whose syntax HM 16.0's own decoder does not get through (it asserts in TComBitStream.h:191 on the multi-slice / WPP
 # streams its encoder writes) or that add nothing to the metadata fixtures: the bitstream plus the ENCODER's reconstruction, which
 # is by HM practice what a conforming decoder must output, and whose MD5 the encoder put into the stream as SEI.
+REXT420 = ["--InputChromaFormat=420", "--ChromaFormatIDC=420", "--CrossComponentPrediction=0", "--HighPrecisionPredictionWeighting=0",
+           "--TransformSkipLog2MaxSize=2"]
 LITE = {
     # name: (cfg, w, h, frames, input bit depth, internal bit depth, qp, extra encoder args)
     # (HM 16.0's encoder writes every slice NAL with the data of all following CTUs of the picture appended unless slice SEGMENTS
@@ -283,6 +285,16 @@ LITE = {
     "ldp_bd8_10_208x120": ("encoder_lowdelay_P_main10.cfg", 208, 120, 3, 8, 8, 30, ["--InternalBitDepthC=10", "--CbQpOffset=12", "--CrQpOffset=-12"]),
     "ldp_tilesexp_main10_832x192": ("encoder_lowdelay_P_main10.cfg", 832, 192, 2, 10, 10, 34,
                                     ["--TileUniformSpacing=0", "--NumTileColumnsMinus1=2", "--TileColumnWidthArray=4,5", "--NumTileRowsMinus1=1", "--TileRowHeightArray=1", "--LFCrossTileBoundaryFlag=1"]),
+    # range-extension coding tools that exist in 4:2:0 (rotation, implicit + explicit RDPCM, the single significance context,
+    # persistent Rice adaptation); cross-component prediction needs 4:4:4 and stays off
+    "ldb_rext420_main8_208x120": ("encoder_lowdelay_main_rext.cfg", 208, 120, 3, 8, 8, 27, REXT420),
+    "ldb_rext420_lossless_main8_208x120": ("encoder_lowdelay_main_rext.cfg", 208, 120, 2, 8, 8, 30,
+                                           REXT420 + ["--TransquantBypassEnableFlag=1", "--CUTransquantBypassFlagForce=1"]),
+    "intra_rext420_main8_208x120": ("encoder_intra_main_rext.cfg", 208, 120, 2, 8, 8, 24, REXT420),
+    "intra_rext420_lossless_main8_208x120": ("encoder_intra_main_rext.cfg", 208, 120, 1, 8, 8, 30,
+                                             REXT420 + ["--TransquantBypassEnableFlag=1", "--CUTransquantBypassFlagForce=1"]),
+    "ldb_rext420_mixed_main10_208x120": ("encoder_lowdelay_main_rext.cfg", 208, 120, 3, 10, 10, 32,
+                                         REXT420 + ["--TransquantBypassEnableFlag=1", "--CostMode=mixed_lossless_lossy"]),
 }
 
 

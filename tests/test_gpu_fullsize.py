@@ -142,6 +142,63 @@ def test_full_range_levels_through_production_residual_path(oracle, mode_probs, 
             assert np.array_equal(got[c], want[c]), "compact levels, comp %d" % c
 
 
+@pytest.mark.parametrize("flags", [7, 1, 2, 4])
+def test_range_extension_residual_tools(oracle, flags):
+    """sps_range_extension() in 4:2:0 on the production kernels: rotation of 4x4 intra blocks that skipped the transform, implicit RDPCM
+    (intra, modes 10 / 26, with the edge filters off in lossless CUs), explicit RDPCM (inter, mode per TU in bits 1-2 of the
+    transform-skip byte) on transform-skip and cu_transquant_bypass TUs of every size up to 32x32 (TComTrQuant.cpp:1475-1487,
+    1737-1792; TComPrediction.cpp:476).  flags: all tools, then each alone (the others must then stay inert although the per-block
+    data that would drive them is present)."""
+    import libhm_amd
+    width, height, bd = 832, 480, 8
+    p = synth.make_picture(width, height, bd, seed=0x52457874 + flags, mode_probs=(0.15, 0.25, 0.3, 0.3, 0), cbf_prob=0.9, sao=False,
+                           tr_split_prob=0.4, intra_frac=0.4, ref_handles=([0], [1]))
+    p.seq.range_ext_flags = flags
+    m = dict(p.meta_np)
+    rng = np.random.RandomState(flags)
+    z = np.arange(256)[None, :]
+    cu_first = z & ~((256 >> (2 * m["depth"])) - 1)                             # first partition of the CU a partition belongs to
+    per_cu = lambda r: np.take_along_axis(r, cu_first, axis=1)
+    log2tu = 6 - m["depth"] - m["tr_idx"]
+    m["bypass"] = (per_cu(rng.rand(p.num_ctus, 256)) < 0.3).astype(np.uint8)
+    quad = rng.rand(p.num_ctus, 64) < 0.5
+    skip = [((rng.rand(p.num_ctus, 256) < 0.6) & (log2tu == 2)), np.repeat(quad, 4, axis=1) & (log2tu <= 3), np.repeat(~quad, 4, axis=1) & (log2tu <= 3)]
+    for c, k in enumerate(("ts_y", "ts_u", "ts_v")):
+        ts = (skip[c] & (m["bypass"] == 0)).astype(np.uint8)
+        rd = rng.randint(0, 3, size=ts.shape).astype(np.uint8)                  # read at the TU's first partition by both sides
+        inter_untransformed = (m["pred_mode"] == 0) & ((ts != 0) | (m["bypass"] != 0))
+        m[k] = ts | (np.where(inter_untransformed, rd, 0) << 1).astype(np.uint8)
+    pick = per_cu(rng.rand(p.num_ctus, 256))
+    m["intra_dir_l"] = np.where(pick < 0.3, 10, np.where(pick < 0.6, 26, m["intra_dir_l"])).astype(np.uint8)
+    pick = per_cu(rng.rand(p.num_ctus, 256))
+    m["intra_dir_c"] = np.where(pick < 0.25, 10, np.where(pick < 0.5, 26, m["intra_dir_c"])).astype(np.uint8)
+    p.meta = abi.MetaHolder(m)
+    ref0 = synth.noise_planes(width, height, bd, 11)
+    ref1 = synth.blocky_planes(width, height, bd, 12)
+    cur = synth.blocky_planes(width, height, bd, 13)
+    want = [a.copy() for a in cur]
+    oracle.decompress_ctus(p.seq, [p.slice], p.meta, p.coeffs, want, [ref0, ref1])
+    plain = [a.copy() for a in cur]
+    p.seq.range_ext_flags = 0
+    oracle.decompress_ctus(p.seq, [p.slice], p.meta, p.coeffs, plain, [ref0, ref1])
+    p.seq.range_ext_flags = flags
+    assert any(not np.array_equal(a, b) for a, b in zip(want, plain))          # the tools do something on this picture
+    with libhm_amd.Context(p.seq) as ctx:
+        h0, h1, hc = ctx.acquire(), ctx.acquire(), ctx.acquire()
+        ctx.upload(h0, ref0)
+        ctx.upload(h1, ref1)
+        ctx.upload(hc, cur)
+        ctx.decompress_slice(hc, 0, p.slice, p.meta, p.coeffs)
+        got = ctx.download(hc)
+        for c in range(3):
+            assert np.array_equal(got[c], want[c]), "reconstruction comp %d" % c
+        ctx.upload(hc, cur)
+        ctx.decompress_pictures([(hc, [p.slice], p.meta, ctx.pack_levels(p.meta, p.coeffs))])
+        got = ctx.download(hc)
+        for c in range(3):
+            assert np.array_equal(got[c], want[c]), "compact levels, comp %d" % c
+
+
 @pytest.mark.parametrize("mode_probs,intra", [((0, 0, 0, 1, 0), 0.0), ((1, 0, 0, 0, 0), 0.0), ((0, 1, 0, 0, 0), 0.3),
                                               ((0, 0, 0.5, 0, 0.5), 0.1), ((0.25, 0.25, 0.25, 0.25, 0), 0.0)])
 def test_fused_loop_filter_matches_oracle_on_partition_extremes(oracle, mode_probs, intra):

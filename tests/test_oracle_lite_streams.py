@@ -44,7 +44,7 @@ def test_oracle_reconstructs_the_encoders_pictures(oracle, name):
     for k, p in enumerate(pics):
         g = p["geom"]
         seq = abi.make_seq(g["width"], g["height"], g["bd_y"], g["bd_c"], log2_ctu=g["log2_ctb"], max_pictures=len(pics) + 1,
-                           strong_intra_smoothing=g["strong_intra"])
+                           strong_intra_smoothing=g["strong_intra"], range_ext_flags=g["range_ext"])
         seq.pcm_bit_depth_luma, seq.pcm_bit_depth_chroma, seq.pcm_loop_filter_disable = g["pcm_bd_y"], g["pcm_bd_c"], g["pcm_lf_disable"]
         parts = len(p["arrays"]["depth"]) // g["num_ctbs"]
         m = {kk: (v.reshape(g["num_ctbs"], parts, 2) if kk.startswith("mv") else v.reshape(g["num_ctbs"], -1) if v.size != g["num_ctbs"] else v)
