@@ -82,7 +82,9 @@ enum {
                                      horizontally (10) or vertically (26) accumulate their residual along that direction
                                      (invRdpcmNxN, TComTrQuant.cpp:1737-1792); bypass CUs also lose the intra edge filters
                                      (TComPrediction.cpp:476) */
-  HMGPU_REXT_EXPLICIT_RDPCM = 4   /* getUseResidualDPCM(RDPCM_SIGNAL_EXPLICIT): inter blocks carry their mode in transform_skip[] */
+  HMGPU_REXT_EXPLICIT_RDPCM = 4,  /* getUseResidualDPCM(RDPCM_SIGNAL_EXPLICIT): inter blocks carry their mode in transform_skip[] */
+  HMGPU_REXT_INTRA_SMOOTHING_DISABLED = 8   /* getDisableIntraReferenceSmoothing(): intra reference samples are never filtered
+                                               (TComPrediction::filteringIntraReferenceSamples, called from TDecCu.cpp:532) */
 };
 
 /* Scaling lists as TDecTop activates them for a slice (TDecTop.cpp:651-668: PPS lists, else SPS lists, else the defaults):

@@ -240,9 +240,10 @@ def clone_slice(s):
     return SliceParams.from_buffer_copy(s)
 
 
-def make_pic_params(sao_enabled=1, lf_across_tiles=1):
+def make_pic_params(sao_enabled=1, lf_across_tiles=1, sao_offset_shift=(0, 0)):
     p = PicParams()
     p.sao_enabled, p.lf_across_tiles = sao_enabled, lf_across_tiles
+    p.sao_offset_shift_luma, p.sao_offset_shift_chroma = sao_offset_shift
     return p
 
 

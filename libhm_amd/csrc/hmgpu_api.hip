@@ -524,7 +524,7 @@ hmgpu_status hmgpu_create(const hmgpu_seq_params* seq, int device_ordinal, hmgpu
   if (seq->log2_ctu_size < 4 || seq->log2_ctu_size > 6) return HMGPU_EINVAL;
   if (seq->max_pictures < 1 || seq->max_pictures > kMaxPics) return HMGPU_EINVAL;
   if (seq->chroma_format != 1) return HMGPU_EUNSUPPORTED;
-  if (seq->range_ext_flags & ~(HMGPU_REXT_ROTATION | HMGPU_REXT_IMPLICIT_RDPCM | HMGPU_REXT_EXPLICIT_RDPCM)) return HMGPU_EUNSUPPORTED;
+  if (seq->range_ext_flags & ~(HMGPU_REXT_ROTATION | HMGPU_REXT_IMPLICIT_RDPCM | HMGPU_REXT_EXPLICIT_RDPCM | HMGPU_REXT_INTRA_SMOOTHING_DISABLED)) return HMGPU_EUNSUPPORTED;
   if (seq->bit_depth_luma < 8 || seq->bit_depth_luma > 10 || seq->bit_depth_chroma < 8 || seq->bit_depth_chroma > 10) return HMGPU_EUNSUPPORTED;
   hmgpu_ctx* c = new (std::nothrow) hmgpu_ctx();
   if (!c) return HMGPU_ENOMEM;

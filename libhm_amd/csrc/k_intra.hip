@@ -170,7 +170,7 @@ __device__ __attribute__((always_inline)) inline void intra_tu(const PicDev& P, 
   // ---- B. smoothing (filteringIntraReferenceSamples + initAdiPatternChType); most TUs are not smoothed (chroma, 4x4, DC,
   // the modes near horizontal / vertical) and predict straight from line[]: one LDS round trip less on the serial chain
   const int thr = LOG2N == 2 ? 10 : LOG2N == 3 ? 7 : LOG2N == 4 ? 1 : 0;
-  const bool filt = comp == 0 && t.mode != 1 && min(abs(t.mode - 10), abs(t.mode - 26)) > thr;
+  const bool filt = comp == 0 && t.mode != 1 && min(abs(t.mode - 10), abs(t.mode - 26)) > thr && !(P.range_ext & HMGPU_REXT_INTRA_SMOOTHING_DISABLED);
   if (filt) {
     bool strong = false;
     int bl = 0, tl = 0, tr = 0;

@@ -417,10 +417,11 @@ void Decoder::build_slice_params(const SliceHeader& sh, SliceInfo& si) {
       for (int i = 0; i < sh.num_ref_idx[l]; i++) {
         const PredWeight& w = sh.pw[l][i];
         p.wp_weight[l][i][0] = (int16_t)w.luma_weight;
-        p.wp_offset[l][i][0] = (int16_t)(w.luma_offset * (1 << (sps_->bit_depth_luma - 8)));
+        const bool hp = sps_->rext_high_precision_offsets;      // offsets already at the bit depth (TComWeightPrediction.cpp:257)
+        p.wp_offset[l][i][0] = (int16_t)(w.luma_offset * (hp ? 1 : 1 << (sps_->bit_depth_luma - 8)));
         for (int c = 0; c < 2; c++) {
           p.wp_weight[l][i][1 + c] = (int16_t)w.chroma_weight[c];
-          p.wp_offset[l][i][1 + c] = (int16_t)(w.chroma_offset[c] * (1 << (sps_->bit_depth_chroma - 8)));
+          p.wp_offset[l][i][1 + c] = (int16_t)(w.chroma_offset[c] * (hp ? 1 : 1 << (sps_->bit_depth_chroma - 8)));
         }
       }
   }
@@ -447,6 +448,7 @@ void Decoder::start_picture(const SliceHeader& sh) {
   cur_->pcm_lf_disable = sps_->pcm && sps_->pcm_loop_filter_disabled;
   cur_->strong_intra = sps_->strong_intra_smoothing;
   cur_->range_ext_flags = sps_->range_ext_flags();
+  cur_->sao_offset_shift[0] = pps_->sao_offset_shift[0]; cur_->sao_offset_shift[1] = pps_->sao_offset_shift[1];
   cur_->lf_across_tiles = pps_->lf_across_tiles;
   cur_->conf_window[0] = sps_->conf_left; cur_->conf_window[1] = sps_->conf_right; cur_->conf_window[2] = sps_->conf_top; cur_->conf_window[3] = sps_->conf_bottom;
   cur_->is_reference = true;                 // "used for short-term reference" until a later RPS says otherwise (8.3.1 end)
@@ -835,6 +837,7 @@ void Decoder::flush_batch() {
     memset(&pps[i], 0, sizeof(pps[i]));
     pps[i].lf_across_tiles = p->lf_across_tiles;
     pps[i].sao_enabled = p->sao_enabled;
+    pps[i].sao_offset_shift_luma = p->sao_offset_shift[0]; pps[i].sao_offset_shift_chroma = p->sao_offset_shift[1];
     fjobs[i].pic = p->handle; fjobs[i].pp = &pps[i]; fjobs[i].sao = p->sao_enabled ? p->sao.data() : nullptr;
   }
   std::vector<PicData*> pics;

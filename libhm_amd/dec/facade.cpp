@@ -342,6 +342,7 @@ int hmdec_picture_geometry(libHMDec_picture* pic, int32_t out[12]) {
 }
 
 int hmdec_picture_range_ext_flags(libHMDec_picture* pic) { return pic ? as_pic(pic)->range_ext_flags : 0; }
+int hmdec_picture_sao_offset_shift(libHMDec_picture* pic, int chroma) { return pic ? as_pic(pic)->sao_offset_shift[chroma ? 1 : 0] : 0; }
 
 int hmdec_picture_conformance_window(libHMDec_picture* pic, int32_t window[4]) {
   if (!pic || !window) return 1;

@@ -315,9 +315,8 @@ std::shared_ptr<Sps> parse_sps(BitReader& br) {
       s.rext_implicit_rdpcm = br.flag();
       s.rext_explicit_rdpcm = br.flag();
       if (br.flag()) throw Unsupported("extended_precision_processing (RExt)");
-      if (br.flag()) throw Unsupported("intra_smoothing_disabled (RExt)");
-      // high_precision_offsets: offsets in units of the bit depth instead of 8 bits -- the same thing at 8 bits
-      if (br.flag() && (s.bit_depth_luma != 8 || s.bit_depth_chroma != 8)) throw Unsupported("high-precision weighted-prediction offsets above 8 bits (RExt)");
+      s.rext_intra_smoothing_disabled = br.flag();
+      s.rext_high_precision_offsets = br.flag();
       s.rext_persistent_rice = br.flag();
       if (br.flag()) throw Unsupported("cabac_bypass_alignment (RExt)");
     }
@@ -425,17 +424,25 @@ std::shared_ptr<Pps> parse_pps(BitReader& br) {
     const bool range_ext = br.flag();
     br.u(7);
     if (range_ext) {
-      if (p.transform_skip_enabled && br.ue() != 0) throw Unsupported("transform skip blocks larger than 4x4 (RExt)");
+      if (p.transform_skip_enabled) {
+        p.log2_max_ts_size = 2 + (int)br.ue();
+        if (p.log2_max_ts_size > 5) throw ParseError("log2_max_transform_skip_block_size_minus2 out of range");
+      }
       if (br.flag()) throw Unsupported("cross-component prediction (RExt)");
       if (br.flag()) throw Unsupported("CU-level chroma QP offsets (RExt)");
-      if (br.ue() != 0 || br.ue() != 0) throw Unsupported("SAO offset scaling (RExt)");
+      for (int k = 0; k < 2; k++) {
+        p.sao_offset_shift[k] = (int)br.ue();
+        if (p.sao_offset_shift[k] > 5) throw ParseError("log2_sao_offset_scale out of range");   // at most BitDepth - 10 in a conforming stream
+      }
     }
   }
   return pp;
 }
 
 // 7.3.6.3 pred_weight_table()
-static void parse_pred_weight_table(BitReader& br, SliceHeader& sh) {
+static void parse_pred_weight_table(BitReader& br, const Sps& sps, SliceHeader& sh) {
+  // high_precision_offsets_enabled_flag: offsets in units of the coding bit depth (HM 16.0: TDecCAVLC.cpp:1851-1879)
+  const int lrange = sps.rext_high_precision_offsets ? 1 << (sps.bit_depth_luma - 1) : 128, crange = sps.rext_high_precision_offsets ? 1 << (sps.bit_depth_chroma - 1) : 128;
   sh.luma_log2_weight_denom = br.ue();
   if (sh.luma_log2_weight_denom > 7) throw ParseError("luma_log2_weight_denom out of range");
   sh.chroma_log2_weight_denom = sh.luma_log2_weight_denom + br.se();
@@ -453,7 +460,7 @@ static void parse_pred_weight_table(BitReader& br, SliceHeader& sh) {
         if (d < -128 || d > 127) throw ParseError("delta_luma_weight out of range");
         w.luma_weight += d;
         w.luma_offset = br.se();
-        if (w.luma_offset < -128 || w.luma_offset > 127) throw ParseError("luma_offset out of range");
+        if (w.luma_offset < -lrange || w.luma_offset >= lrange) throw ParseError("luma_offset out of range");
       }
       if (w.chroma_flag)
         for (int j = 0; j < 2; j++) {
@@ -461,9 +468,9 @@ static void parse_pred_weight_table(BitReader& br, SliceHeader& sh) {
           if (d < -128 || d > 127) throw ParseError("delta_chroma_weight out of range");
           w.chroma_weight[j] += d;
           const int o = br.se();
-          if (o < -512 || o > 511) throw ParseError("delta_chroma_offset out of range");
-          const int v = o - ((128 * w.chroma_weight[j]) >> sh.chroma_log2_weight_denom) + 128;      // (7-56)
-          w.chroma_offset[j] = std::min(127, std::max(-128, v));
+          if (o < -4 * crange || o >= 4 * crange) throw ParseError("delta_chroma_offset out of range");
+          const int v = o - ((crange * w.chroma_weight[j]) >> sh.chroma_log2_weight_denom) + crange;      // (7-56)
+          w.chroma_offset[j] = std::min(crange - 1, std::max(-crange, v));
         }
     }
   }
@@ -585,7 +592,7 @@ void parse_slice_header(BitReader& br, int nal_type, int temporal_id, const Para
           if (sh.collocated_ref_idx >= sh.num_ref_idx[sh.collocated_from_l0 ? 0 : 1]) throw ParseError("collocated_ref_idx out of range");
         }
       }
-      if ((pps.weighted_pred && type == SLICE_P) || (pps.weighted_bipred && type == SLICE_B)) parse_pred_weight_table(br, sh);
+      if ((pps.weighted_pred && type == SLICE_P) || (pps.weighted_bipred && type == SLICE_B)) parse_pred_weight_table(br, sps, sh);
       const unsigned five_minus = br.ue();
       if (five_minus > 4) throw ParseError("five_minus_max_num_merge_cand out of range");
       sh.max_num_merge_cand = 5 - five_minus;

@@ -52,8 +52,10 @@ struct Sps {
   bool temporal_mvp = false, strong_intra_smoothing = false;
   // sps_range_extension() (HM 16.0: TDecCAVLC.cpp:778-786); tools the device path lacks are refused while parsing
   bool rext_rotation = false, rext_ts_context = false, rext_implicit_rdpcm = false, rext_explicit_rdpcm = false;
-  bool rext_persistent_rice = false;
-  int range_ext_flags() const { return (rext_rotation ? 1 : 0) | (rext_implicit_rdpcm ? 2 : 0) | (rext_explicit_rdpcm ? 4 : 0); }   // HMGPU_REXT_*
+  bool rext_persistent_rice = false, rext_intra_smoothing_disabled = false, rext_high_precision_offsets = false;
+  int range_ext_flags() const {                // HMGPU_REXT_*
+    return (rext_rotation ? 1 : 0) | (rext_implicit_rdpcm ? 2 : 0) | (rext_explicit_rdpcm ? 4 : 0) | (rext_intra_smoothing_disabled ? 8 : 0);
+  }
   // derived
   int ctb_size() const { return 1 << log2_ctb; }
   int pic_w_ctbs() const { return (width + ctb_size() - 1) >> log2_ctb; }
@@ -77,6 +79,7 @@ struct Pps {
   ScalingListSet scaling_lists;
   bool lists_modification_present = false, slice_header_extension_present = false;
   int log2_par_mrg_level = 2;
+  int log2_max_ts_size = 2, sao_offset_shift[2] = {0, 0};      // pps_range_extension(): log2 MaxTbSkipSize, log2_sao_offset_scale_{luma,chroma}
   // derived once the SPS is known (6.5.1)
   std::vector<int> col_bd, row_bd, ctb_rs_to_ts, ctb_ts_to_rs, tile_id;     // tile_id indexed by TS address
   int derived_w = -1, derived_h = -1;      // picture size in CTBs the tables above were derived for

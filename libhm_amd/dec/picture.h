@@ -122,6 +122,7 @@ struct PicData {
   bool sao_enabled = false, lf_across_tiles = true;   // of the parameter sets the picture was decoded with
   int bit_depth[2] = {8, 8}, pcm_bit_depth[2] = {8, 8};
   bool pcm_lf_disable = false, strong_intra = false;
+  int sao_offset_shift[2] = {0, 0};            // PPS log2_sao_offset_scale_{luma,chroma}
   int range_ext_flags = 0;                     // HMGPU_REXT_* of the active SPS
   hmgpu_pic handle = HMGPU_NO_PIC;
   uint64_t submit_seq = 0;           // device submission that last read these arrays

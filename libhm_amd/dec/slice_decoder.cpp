@@ -875,7 +875,7 @@ void SliceDecoder::residual_coding(int x0, int y0, int log2, int c) {
   const int size = 1 << log2;
   const size_t part = pic_.part_at(x0, y0), ctb = pic_.ctb_at(x0, y0), z = part - ctb * pic_.parts;
   int16_t* dst = pic_.level_dst(c, ctb, z, size);
-  const bool ts = pps_.transform_skip_enabled && !cu_bypass_ && log2 == 2 && eng.decision(ctx_.s[CTX_TS_FLAG + (c ? 1 : 0)]);
+  const bool ts = pps_.transform_skip_enabled && !cu_bypass_ && log2 <= pps_.log2_max_ts_size && eng.decision(ctx_.s[CTX_TS_FLAG + (c ? 1 : 0)]);
   const bool untransformed = ts || cu_bypass_;
   // explicit_rdpcm_flag / explicit_rdpcm_dir_flag: inter blocks that skip the transform (HM 16.0: TDecSbac.cpp:1322-1350, 1884-1917)
   int rdpcm = 0;

@@ -44,6 +44,7 @@ def lib():
         L.hmdec_pictures_decoded.argtypes = [C.c_void_p]
         L.hmdec_device_batches.argtypes = [C.c_void_p]
         L.hmdec_picture_range_ext_flags.argtypes = [C.c_void_p]
+        L.hmdec_picture_sao_offset_shift.argtypes = [C.c_void_p, C.c_int]
         L.hmdec_set_device_md5.argtypes = [C.c_void_p, C.c_int]
         L.hmdec_last_error.argtypes = [C.c_void_p]
         L.hmdec_last_error.restype = C.c_char_p
@@ -137,6 +138,7 @@ class Picture:
         keys = ("width", "height", "log2_ctb", "bd_y", "bd_c", "pcm_bd_y", "pcm_bd_c", "pcm_lf_disable", "strong_intra", "sao", "lf_across_tiles", "num_ctbs")
         out = dict(zip(keys, (int(v) for v in g)))
         out["range_ext"] = int(lib().hmdec_picture_range_ext_flags(self.h))
+        out["sao_shift"] = (int(lib().hmdec_picture_sao_offset_shift(self.h, 0)), int(lib().hmdec_picture_sao_offset_shift(self.h, 1)))
         return out
 
     def conformance_window(self):

@@ -712,7 +712,7 @@ static void intra_smooth(const geom* g, int comp, int mode, int n, int log2n, co
   static const int thr[6] = { 0, 0, 10, 7, 1, 0 };                     /* m_aucIntraFilter by log2 size: TComPrediction.cpp:49-66 */
   const int total = 4 * n + 1, corner = 2 * n;
   int i, filt = 0;
-  if (comp == 0 && mode != 1 /* DC_IDX */)
+  if (comp == 0 && mode != 1 /* DC_IDX */ && !(g->seq->range_ext_flags & HMGPU_REXT_INTRA_SMOOTHING_DISABLED))
   {
     const int d0 = iabs(mode - 10), d1 = iabs(mode - 26);
     filt = imin(d0, d1) > thr[log2n];

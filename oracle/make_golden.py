@@ -293,6 +293,12 @@ LITE = {
     "intra_rext420_main8_208x120": ("encoder_intra_main_rext.cfg", 208, 120, 2, 8, 8, 24, REXT420),
     "intra_rext420_lossless_main8_208x120": ("encoder_intra_main_rext.cfg", 208, 120, 1, 8, 8, 30,
                                              REXT420 + ["--TransquantBypassEnableFlag=1", "--CUTransquantBypassFlagForce=1"]),
+    # transform skip up to 32x32 without intra reference smoothing; weighted prediction with offsets in units of the bit depth
+    # (log2_sao_offset_scale can only be non-zero above 10 bits: outside the device's bit depths)
+    "ldb_rext420_ts32_nosmooth_main8_208x120": ("encoder_lowdelay_main_rext.cfg", 208, 120, 3, 8, 8, 27,
+                                                REXT420[:-1] + ["--TransformSkipLog2MaxSize=5", "--IntraReferenceSmoothing=0"]),
+    "ldb_rext420_wp_hp_main10_208x120": ("encoder_lowdelay_main_rext.cfg", 208, 120, 3, 10, 10, 30,
+                                                  REXT420[:-2] + ["--TransformSkipLog2MaxSize=2", "--WeightedPredP=1", "--WeightedPredB=1", "--HighPrecisionPredictionWeighting=1"]),
     "ldb_rext420_mixed_main10_208x120": ("encoder_lowdelay_main_rext.cfg", 208, 120, 3, 10, 10, 32,
                                          REXT420 + ["--TransquantBypassEnableFlag=1", "--CostMode=mixed_lossless_lossy"]),
 }

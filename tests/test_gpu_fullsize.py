@@ -142,12 +142,12 @@ def test_full_range_levels_through_production_residual_path(oracle, mode_probs, 
             assert np.array_equal(got[c], want[c]), "compact levels, comp %d" % c
 
 
-@pytest.mark.parametrize("flags", [7, 1, 2, 4])
+@pytest.mark.parametrize("flags", [15, 1, 2, 4, 8])
 def test_range_extension_residual_tools(oracle, flags):
     """sps_range_extension() in 4:2:0 on the production kernels: rotation of 4x4 intra blocks that skipped the transform, implicit RDPCM
     (intra, modes 10 / 26, with the edge filters off in lossless CUs), explicit RDPCM (inter, mode per TU in bits 1-2 of the
-    transform-skip byte) on transform-skip and cu_transquant_bypass TUs of every size up to 32x32 (TComTrQuant.cpp:1475-1487,
-    1737-1792; TComPrediction.cpp:476).  flags: all tools, then each alone (the others must then stay inert although the per-block
+    transform-skip byte) on transform-skip (log2_max_transform_skip_block_size = 5) and cu_transquant_bypass TUs of every size up to
+    32x32 (TComTrQuant.cpp:1475-1487, 1737-1792; TComPrediction.cpp:476); intra reference smoothing switched off.  flags: all tools, then each alone (the others must then stay inert although the per-block
     data that would drive them is present)."""
     import libhm_amd
     width, height, bd = 832, 480, 8
@@ -162,10 +162,13 @@ def test_range_extension_residual_tools(oracle, flags):
     log2tu = 6 - m["depth"] - m["tr_idx"]
     m["bypass"] = (per_cu(rng.rand(p.num_ctus, 256)) < 0.3).astype(np.uint8)
     quad = rng.rand(p.num_ctus, 64) < 0.5
-    skip = [((rng.rand(p.num_ctus, 256) < 0.6) & (log2tu == 2)), np.repeat(quad, 4, axis=1) & (log2tu <= 3), np.repeat(~quad, 4, axis=1) & (log2tu <= 3)]
+    tu_first = z & ~(np.maximum(256 >> (2 * (m["depth"] + m["tr_idx"])), 1) - 1)
+    per_tu = lambda r: np.take_along_axis(r, tu_first, axis=1)
+    skip = [per_tu(rng.rand(p.num_ctus, 256)) < 0.6, np.where(log2tu <= 3, np.repeat(quad, 4, axis=1), per_tu(rng.rand(p.num_ctus, 256)) < 0.5),
+            np.where(log2tu <= 3, np.repeat(~quad, 4, axis=1), per_tu(rng.rand(p.num_ctus, 256)) < 0.5)]
     for c, k in enumerate(("ts_y", "ts_u", "ts_v")):
         ts = (skip[c] & (m["bypass"] == 0)).astype(np.uint8)
-        rd = rng.randint(0, 3, size=ts.shape).astype(np.uint8)                  # read at the TU's first partition by both sides
+        rd = per_tu(rng.randint(0, 3, size=ts.shape)).astype(np.uint8)
         inter_untransformed = (m["pred_mode"] == 0) & ((ts != 0) | (m["bypass"] != 0))
         m[k] = ts | (np.where(inter_untransformed, rd, 0) << 1).astype(np.uint8)
     pick = per_cu(rng.rand(p.num_ctus, 256))

@@ -61,7 +61,7 @@ def test_oracle_reconstructs_the_encoders_pictures(oracle, name):
                 sp.scaling_lists = C.pointer(lists)
             slices.append(sp)
         multi_slice |= len(slices) > 1
-        pp = abi.make_pic_params(sao_enabled=g["sao"], lf_across_tiles=g["lf_across_tiles"])
+        pp = abi.make_pic_params(sao_enabled=g["sao"], lf_across_tiles=g["lf_across_tiles"], sao_offset_shift=g["sao_shift"])
         cur = [np.full((g["height"] >> (1 if c else 0), g["width"] >> (1 if c else 0)), -1, dtype=np.int16) for c in range(3)]
         oracle.decompress_ctus(seq, slices, meta, coeffs, cur, finals)
         oracle.loop_filter_pic(seq, slices, meta, pp, cur, 3)
