@@ -113,6 +113,9 @@ __global__ void __launch_bounds__(256) k_prep(const PicDev* __restrict__ pics, B
   if (threadIdx.x < 2) lds_stat[threadIdx.x] = 0;
   __syncthreads();
   const int parts = P.parts;
+#if defined(PREP_STOP) && PREP_STOP == 1   // experiment: stop after phase n (timing of the phases by difference)
+  if (parts > 0) return;
+#endif
   const int gq = blockIdx.x * 256 + threadIdx.x;                 // quad index inside the call's CTU range
   const bool active = gq < b.num_ctus[blockIdx.z] * (parts >> 2);
   Quad q; q.valid = false; q.intra = false; q.log2tu = 3; q.tr = 0; q.ctu = 0; q.z0 = 0; q.gx0 = q.gy0 = 0;
@@ -150,6 +153,9 @@ __global__ void __launch_bounds__(256) k_prep(const PicDev* __restrict__ pics, B
         }
       }
     }
+#if defined(PREP_STOP) && PREP_STOP == 2
+    if (parts > 0) return;
+#endif
     // ---- the quad's share of HM's arrays
     const uint32_t part4 = ldg(reinterpret_cast<const uint32_t*>(P.part_size + idx));
     const uint32_t depth4 = ldg(reinterpret_cast<const uint32_t*>(P.depth + idx));
@@ -182,6 +188,13 @@ __global__ void __launch_bounds__(256) k_prep(const PicDev* __restrict__ pics, B
     const int lf_across_slices = ldg(&sl->lf_across_slices);
     const int slice_type = ldg(&sl->slice_type);
     const bool wp = ldg(&sl->weighted_pred) != 0;
+#if defined(PREP_STOP) && PREP_STOP == 3
+    if (parts > 0) {
+      if ((part4 ^ depth4 ^ pred4 ^ qp4 ^ tr4 ^ byp4 ^ pcm4 ^ r04 ^ r14 ^ mv0.x ^ mv1.w ^ q.cbf[0] ^ q.cbf[1] ^ q.cbf[2] ^ q.ts[0] ^ (uint32_t)q.qp_cu ^ (uint32_t)deblock ^
+           (uint32_t)lf_across_slices ^ (uint32_t)slice_type ^ (uint32_t)wp) == 0x12345677u) stg(P.tu_count, 1u);
+      return;
+    }
+#endif
     const uint32_t mvw0[4] = {mv0.x, mv0.y, mv0.z, mv0.w}, mvw1[4] = {mv1.x, mv1.y, mv1.z, mv1.w};
     // the tile's motion for k_mc.hip: what the four cells must agree on (TileMv)
     uint32_t tm_mv[4][2], tm_key[4];
@@ -336,6 +349,9 @@ __global__ void __launch_bounds__(256) k_prep(const PicDev* __restrict__ pics, B
         if (((q.cbf[2] & 0xff) & chain) == chain) cnt[2] = 16;
       }
     }
+#if defined(PREP_STOP) && PREP_STOP == 4
+    if (parts > 0) return;
+#endif
     if (q.valid) atomicAdd(&lds_stat[q.intra ? 0 : 1], 4u);
     if (q.valid && q.intra) stg(P.ctu_intra + q.ctu, (uint8_t)1);        // same value from every writer
     // ---- which transform units originate in this 8x8 area (the TUs of intra CUs are not listed: k_intra.hip walks them in decoding order)
@@ -382,6 +398,9 @@ __global__ void __launch_bounds__(256) k_prep(const PicDev* __restrict__ pics, B
       }
     }
   }
+#if defined(PREP_STOP) && PREP_STOP == 5
+  if (parts > 0) return;
+#endif
 #if !(defined(PREP_EXP) && (PREP_EXP & 4)) // experiment: no cell exchange
   if (active) {
 #pragma unroll
@@ -433,6 +452,9 @@ __global__ void __launch_bounds__(256) k_prep(const PicDev* __restrict__ pics, B
     }
     stg2(reinterpret_cast<uint32_t*>(P.edges + (size_t)(q.gy0 >> 1) * (P.grid_w >> 1) + (q.gx0 >> 1)), __builtin_bit_cast(u32x2, er));
   }
+#if defined(PREP_STOP) && PREP_STOP == 6
+  if (parts > 0) return;
+#endif
   const int shard = blockIdx.x & (kTuShards - 1);
   if (threadIdx.x < 4) {
     const uint32_t n = lds_cnt[threadIdx.x];
@@ -442,6 +464,9 @@ __global__ void __launch_bounds__(256) k_prep(const PicDev* __restrict__ pics, B
     if (n) atomicAdd(&P.stats[(threadIdx.x - 4) * kTuShards + shard], (unsigned long long)n);
   }
   __syncthreads();
+#if defined(PREP_STOP) && PREP_STOP == 7
+  if (parts > 0) return;
+#endif
   const int ctu_luma = 1 << (2 * P.log2ctu);
 #pragma unroll
   for (int k = 0; k < 6; k++) {
