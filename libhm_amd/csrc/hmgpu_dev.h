@@ -81,9 +81,10 @@ enum : uint8_t { TR_LUMA = 15, TR_CB = 16, TR_CR = 32 };
 // ---- coded transform unit ---------------------------------------------------------------------------------------
 struct TuRec {
   uint16_t x4, y4;        // origin in 4-luma-sample units (picture coordinates)
-  uint8_t  comp_flags;    // bits 0-1 component, bit 2 DST (4x4 intra luma), bit 3 transform skip
+  uint8_t  comp_flags;    // bits 0-1 component, bit 2 DST (4x4 intra luma), bit 3 transform skip, bit 4 cu_transquant_bypass, bits 5-6 RDPCM
+                          // (1 horizontal, 2 vertical: explicit for inter blocks, implied by the prediction mode for intra ones), bit 7 intra CU
   int8_t   per, rem;      // QpParam per / rem
-  uint8_t  pad;
+  uint8_t  xflags;        // bit 0: the 4x4 block is read back to front (transform_skip_rotation, intra)
   uint32_t coef_off;      // element offset into the component's coefficient array
 };
 static_assert(sizeof(TuRec) == 12, "TuRec must be 12 bytes");

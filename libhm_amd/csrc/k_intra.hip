@@ -10,35 +10,22 @@
 // CUs are done (one flag per CTU and component).  CTUs without intra CUs (flags from k_prep) cost nothing: their samples were
 // finished by the MC / residual kernels before this kernel started.  Inside a CTU the wave takes the TUs in z order; for each TU
 // the lanes build the 4N+1 reference samples together (availability per 4x4 unit as one ballot mask, the substitution
-// process of fillReferenceSamples as bit scans over that mask), lane n predicts row n, the residual comes from the same
-// itx_tu() the inter path uses, and the clipped row goes back to the picture.
+// process of fillReferenceSamples as bit scans over that mask), lane n predicts row n, adds the TU's residual and the clipped row goes
+// back to the picture.  The residual itself -- de-quantisation, inverse transform, the RExt rotation / RDPCM -- depends on no
+// neighbour: k_prep lists the coded TUs of intra CUs beside the inter ones and k_itx has computed them before this kernel starts
+// (round 3; the transform inside the TU chain was 14 % of an I picture's time).
 //
 // Samples written here are read by other waves on other XCDs (whose L2s are not coherent with each other): every access to
 // the picture planes in this kernel is an agent-scope atomic dword access (served at the coherent level), ordered against
 // the progress counters by release / acquire.
 #include "hmgpu_dev.h"
-#include "itx_core.h"
+#include "itx_core.h"       // packed 16-bit helpers, wave_lds_sync
 #include <algorithm>
 
 namespace hmgpu {
 
 namespace {
 
-// QpParam (TComTrQuant.cpp:71-100) for 4:2:0
-__device__ inline void qp_param_tu(int qp_y, int comp, int bd, int chroma_off, int& per, int& rem) {
-  constexpr uint8_t chroma_scale_420[58] = {0,  1,  2,  3,  4,  5,  6,  7,  8,  9,  10, 11, 12, 13, 14, 15, 16, 17, 18, 19,
-                                            20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 29, 30, 31, 32, 33, 33, 34, 34, 35, 35,
-                                            36, 36, 37, 37, 38, 39, 40, 41, 42, 43, 44, 45, 46, 47, 48, 49, 50, 51};   // g_aucChromaScale[CHROMA_420], TComRom.cpp:503
-  const int bdo = 6 * (bd - 8);
-  int base;
-  if (comp == 0) base = qp_y + bdo;
-  else {
-    base = clip3(-bdo, 57, qp_y + chroma_off);
-    base = base < 0 ? base + bdo : chroma_scale_420[base] + bdo;
-  }
-  per = base / 6;
-  rem = base % 6;
-}
 
 // coherent accesses to the picture being reconstructed
 __device__ inline uint32_t ld_coh(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -53,7 +40,6 @@ struct IntraScratch {                    // what ONE TU in flight needs: one per
   int line[4 * 32 + 4];                  // reference line: [0,2N) left column bottom-up, [2N] corner, (2N,4N] row above
   int filt[4 * 32 + 4];                  // the same after smoothing
   int proj[3 * 32 + 4];                  // angular modes: main reference incl. the projected side samples, index k + 32
-  __attribute__((aligned(16))) int16_t tile[PkCfg<5>::TU_ELEMS];   // itx_tu_pk scratch: one TU at a time, the largest is 32x32
 };
 struct IntraLds {
   // the CTU's samples of this component (columns -2..63 at index x + 2) and the row above it (columns -2..127): references
@@ -62,17 +48,16 @@ struct IntraLds {
   __attribute__((aligned(4))) int16_t top[132];
   // the CTU's TComDataCU arrays, fetched once with one dword per lane and array (the walk over CUs and TUs is a serial chain:
   // every byte it had to wait for from global memory would cost a round trip)
-  // the CTU's coefficient levels of this component (HM layout), staged while the block still waits for its neighbours: the
-  // serial TU chain would otherwise pay one trip to HBM per coded TU (the levels are read exactly once: never a cache hit)
-  __attribute__((aligned(16))) int16_t lev[64 * 64];
-  uint32_t qoff[64];                     // compact levels: offset in lev[] of the first TU of every 8x8 luma area of the CTU
+  // the CTU's residual of this component -- de-quantisation and inverse transform do not depend on the neighbours: k_itx has done them
+  // for every coded TU before this kernel starts --, as PicDev::resid lays it out (8x8 tiles of 128 bytes, rows in resid_slot order,
+  // tile (tx, ty) of the CTU at index ty * tiles per CTU row + tx), staged while the block still waits for its neighbours
+  __attribute__((aligned(16))) int16_t res[64 * 64];
   __attribute__((aligned(4))) uint8_t m_depth[256], m_part[256], m_pred[256], m_tr[256], m_qp[256], m_cbf[256], m_ts[256], m_dir[256], m_dirl[256], m_byp[256], m_pcm[256];
 };
 
 struct TuCtx {
-  int comp, ctu, z_tu, log2n, mode, cbf, skip, bypass, x0, y0, qp_cu;     // x0, y0: component samples
-  int lev_off;                                                    // of the TU's levels in IntraLds::lev
-  int cip, cqo, slice, tile, nb_same;                             // per-CTU constants: constrained intra pred, chroma QP offset, slice / tile index, neighbours in the same slice and tile
+  int comp, ctu, z_tu, log2n, mode, cbf, bypass, x0, y0;          // x0, y0: component samples
+  int cip, slice, tile, nb_same;                             // per-CTU constants: constrained intra pred, chroma QP offset, slice / tile index, neighbours in the same slice and tile
   int cx0, cy0;                                                   // CTU origin in component samples
 };
 
@@ -118,20 +103,8 @@ __device__ __attribute__((always_inline)) inline void intra_tu(const PicDev& P, 
   const int lx = t.x0 << cs, ly = t.y0 << cs;              // TU origin in luma samples
   const bool cip = t.cip != 0;
 
-  // the levels are not needed before step D: request them now, their latency hides behind the reference samples
   const int n = lane & (N - 1);
   const bool active = lane < N;
-  uint32_t lv[N / 2];
-#pragma unroll
-  for (int i = 0; i < N / 2; i++) lv[i] = 0;
-  if (t.cbf && active) {
-    const int16_t* lev = &L.lev[t.lev_off + n * N];                        // staged by k_intra before the wait for the neighbours
-    if constexpr (N == 4) { const u32x2 a = *reinterpret_cast<const u32x2*>(lev); lv[0] = a.x; lv[1] = a.y; }
-    else {
-#pragma unroll
-      for (int i = 0; i < N / 8; i++) { const u32x4 a = *reinterpret_cast<const u32x4*>(lev + i * 8); lv[4 * i] = a.x; lv[4 * i + 1] = a.y; lv[4 * i + 2] = a.z; lv[4 * i + 3] = a.w; }
-    }
-  }
 
   // ---- A. availability per unit: units [0, 2U) left column bottom-up, 2U the corner, (2U, 4U] the row above
   bool av = false;
@@ -171,7 +144,11 @@ __device__ __attribute__((always_inline)) inline void intra_tu(const PicDev& P, 
   // the modes near horizontal / vertical) and predict straight from line[]: one LDS round trip less on the serial chain
   const int thr = LOG2N == 2 ? 10 : LOG2N == 3 ? 7 : LOG2N == 4 ? 1 : 0;
   const bool filt = comp == 0 && t.mode != 1 && min(abs(t.mode - 10), abs(t.mode - 26)) > thr && !(P.range_ext & HMGPU_REXT_INTRA_SMOOTHING_DISABLED);
+#if defined(INTRA_EXP) && (INTRA_EXP & 2)      // experiment: no smoothing pass
+  if (false) {
+#else
   if (filt) {
+#endif
     bool strong = false;
     int bl = 0, tl = 0, tr = 0;
     if (N == 32 && P.strong_intra_smoothing) {
@@ -196,7 +173,11 @@ __device__ __attribute__((always_inline)) inline void intra_tu(const PicDev& P, 
   }
 
   // ---- C. prediction of row n by lane n
+#if defined(INTRA_EXP) && (INTRA_EXP & 2)
+  const int* f = W.line;
+#else
   const int* f = filt ? W.filt : W.line;
+#endif
   const bool edge = comp == 0 && N <= 16;                   // MAXIMUM_INTRA_FILTERED_WIDTH (TypeDef.h:117)
   // implicit RDPCM in a lossless CU: horizontal / vertical prediction without its edge filter (TComPrediction.cpp:476)
   const bool edge_ang = edge && !(t.bypass && (P.range_ext & HMGPU_REXT_IMPLICIT_RDPCM));
@@ -259,18 +240,23 @@ __device__ __attribute__((always_inline)) inline void intra_tu(const PicDev& P, 
     }
   }
 
-  // ---- D. residual (lanes beyond N have no part in it: the hand-offs inside itx_tu_pk are wave-local orderings, not barriers)
+  // ---- D. residual of row n: from the CTU's staged tiles (k_itx computed it; RExt rotation / RDPCM included)
   uint32_t res[N / 2];
 #pragma unroll
   for (int i = 0; i < N / 2; i++) res[i] = 0;
+#if defined(INTRA_EXP) && (INTRA_EXP & 1)      // experiment: no residual (wrong samples)
+  if (false) {
+#else
   if (t.cbf && active) {
-    int per, rem;
-    qp_param_tu(t.qp_cu, comp, bd, t.cqo, per, rem);
-    const uint8_t* mrow = (P.sl_m != nullptr && (!t.skip || N == 4)) ? P.sl_m + (((LOG2N - 2) * 6 + comp) << 10) + n * N : nullptr;   // intra lists: 0 + component
-    itx_tu_pk<LOG2N>(lv, n, per, rem, t.skip != 0, bd, W.tile, res, comp == 0 && LOG2N == 2, mrow, t.bypass != 0);   // DST: 4x4 intra luma (TComTU::useDST)
-    if (P.range_ext && (t.skip || t.bypass))                 // rotation (4x4) and implicit RDPCM along the final prediction mode
-      resid_rotate_rdpcm<LOG2N>(res, n, (P.range_ext & HMGPU_REXT_ROTATION) != 0,
-                                (P.range_ext & HMGPU_REXT_IMPLICIT_RDPCM) ? (t.mode == 10 ? 1 : t.mode == 26 ? 2 : 0) : 0);
+#endif
+    const int rx = t.x0 - t.cx0, ry = t.y0 - t.cy0 + n;                    // inside the CTU, component samples
+    const int tpr = ((1 << P.log2ctu) >> cs) >> 3;                          // tiles per CTU row
+    const int16_t* r = &L.res[((ry >> 3) * tpr + (rx >> 3)) * 64 + resid_slot(ry) * 8];
+    if constexpr (N == 4) { const u32x2 a = *reinterpret_cast<const u32x2*>(r + (rx & 4)); res[0] = a.x; res[1] = a.y; }
+    else {
+#pragma unroll
+      for (int i = 0; i < N / 8; i++) { const u32x4 a = *reinterpret_cast<const u32x4*>(r + i * 64); res[4 * i] = a.x; res[4 * i + 1] = a.y; res[4 * i + 2] = a.z; res[4 * i + 3] = a.w; }
+    }
   }
 
   // ---- E. reconstruction of row n: into the LDS copy (what later TUs of this CTU predict from) and, two samples per
@@ -426,7 +412,6 @@ __device__ __attribute__((always_inline)) inline void fetch_border(const PicDev&
 // do not depend on each other -- the next ones along an anti-diagonal of the CTU -- run side by side; the CTU's samples, the done masks
 // and the list are shared in LDS, the reference line / transform scratch of a TU in flight is the wave's own (IntraScratch).
 __device__ __attribute__((always_inline)) inline void intra_ctu(const PicDev& P, int comp, int ctu, IntraLds& L, IntraSched& Q, IntraScratch& W, Neighbours& nb) {
-  const bool compact = P.coef_start[0] != nullptr;
   const int parts = P.parts, pw = P.pw;
   const int ctu_x = (ctu % P.ctus_w) << P.log2ctu, ctu_y = (ctu / P.ctus_w) << P.log2ctu;
   const int cs = comp ? 1 : 0;
@@ -444,7 +429,6 @@ __device__ __attribute__((always_inline)) inline void intra_ctu(const PicDev& P,
     for (int k = 0; k < 4; k++)
       if (nbc[k] >= 0 && ldg(P.slice_idx + nbc[k]) == slice && ldg(P.tile_idx + nbc[k]) == tile) nb_same |= 1 << k;
   }
-  const int cqo = comp == 1 ? ldg(&sd.cb_qp_offset) : comp == 2 ? ldg(&sd.cr_qp_offset) : 0;
   const int wv = threadIdx.x >> 6;
   auto mark_done = [&](int x4, int y4, int U) {           // units [x4, x4 + U) x [y4, y4 + U) are final
     if (lane < 16) {
@@ -602,9 +586,8 @@ __device__ __attribute__((always_inline)) inline void intra_ctu(const PicDev& P,
       const int depth = L.m_depth[z];
       const int log2cu = P.log2ctu - depth;
       const int tr = L.m_tr[zc];
-      const int log2tu = log2cu - tr;
       TuCtx t;
-      t.comp = comp; t.ctu = ctu; t.z_tu = zc; t.qp_cu = (int8_t)L.m_qp[z]; t.cip = cip; t.cqo = cqo; t.slice = slice; t.tile = tile; t.nb_same = nb_same;
+      t.comp = comp; t.ctu = ctu; t.z_tu = zc; t.cip = cip; t.slice = slice; t.tile = tile; t.nb_same = nb_same;
       t.cx0 = ctu_x >> cs; t.cy0 = ctu_y >> cs;
       t.x0 = (ctu_x + 4 * x4) >> cs; t.y0 = (ctu_y + 4 * y4) >> cs;
       t.log2n = e.log2n;
@@ -612,19 +595,7 @@ __device__ __attribute__((always_inline)) inline void intra_ctu(const PicDev& P,
       if (comp && mode == 36) mode = L.m_dirl[z];        // DM_CHROMA_IDX (TDecCu.cpp:523-524): the luma mode of the CU's first partition (z: the CU's origin)
       t.mode = mode;
       t.cbf = (L.m_cbf[zc] >> tr) & 1;
-      t.skip = L.m_ts[zc] & 1;
       t.bypass = L.m_byp[zc];
-      if (compact) {
-        // (HM descends to a TU only through coded ancestors: the cbf chain, as in k_prep's count); 4x4 luma TUs: the coded ones of the
-        // same 8x8 area before this one lie in front of it
-        const int chain = (1 << (tr + 1)) - 1;
-        int coded_before = 0;
-        if (comp == 0 && log2tu == 2)
-          for (int sib = zc & ~3; sib < zc; sib++) if ((L.m_cbf[sib] & chain) == chain) coded_before++;
-        t.lev_off = (int)L.qoff[zc >> 2] + 16 * coded_before;
-      } else {
-        t.lev_off = (comp ? 4 : 16) * zc;
-      }
       fetch_border(P, comp, ctu, x4 == 0 ? Q.need_col[i] : 0u, y4 == 0 ? Q.need_row[i] : 0ull, Q, L);
       intra_tu_any(P, t, L, W);
     }
@@ -678,22 +649,19 @@ __global__ void __launch_bounds__(64 * WAVES) k_intra(const PicDev* __restrict__
     left = __builtin_amdgcn_ballot_w64(l) != 0; right = __builtin_amdgcn_ballot_w64(r) != 0;
     top = __builtin_amdgcn_ballot_w64(t) != 0; bottom = __builtin_amdgcn_ballot_w64(bm) != 0;
   };
-  // the levels of this CTU do not depend on anybody: on their way into LDS while the neighbours finish (all threads of the workgroup stage; the
-  // barrier in front of the TU loop orders it)
+  // the residual of this CTU does not depend on anybody: on its way into LDS while the neighbours finish (all threads of the workgroup
+  // stage; the barrier in front of the TU loop orders it).  Tiles of TUs that are not coded hold stale data and are never read.
   const int wv = threadIdx.x >> 6;
   {
-  if (P.coef_start[0] != nullptr) {
-    // compact levels: the CTU's coded TUs are one contiguous piece of the stream; where each 8x8 area's TUs start in it (k_prep)
-    const uint32_t s0 = ldg(P.coef_start[comp] + ctu), s1r = ldg(P.coef_start[comp] + ctu + 1);
-    const uint32_t s1 = s1r < s0 ? s0 : min(s1r, s0 + ((1u << (2 * P.log2ctu)) >> (comp ? 2 : 0)));     // (the host checks both; the LDS copy is sized for a CTU)
-    const int16_t* src = P.coef[comp] + s0;
-    for (uint32_t i = threadIdx.x * 8u; i < s1 - s0; i += blockDim.x * 8u) *reinterpret_cast<u32x4*>(&L.lev[i]) = ldg4(src + i);
-    const int qpc = P.parts >> 2;
-    if ((int)threadIdx.x < qpc) L.qoff[threadIdx.x] = ldg(P.quad_off[comp] + (size_t)ctu * qpc + threadIdx.x) - s0;
-  } else {
-    const int n_lev = (1 << (2 * P.log2ctu)) >> (comp ? 2 : 0);
-    const int16_t* src = P.coef[comp] + (size_t)ctu * n_lev;
-    for (int i = threadIdx.x * 8; i < n_lev; i += blockDim.x * 8) *reinterpret_cast<u32x4*>(&L.lev[i]) = ldg4(src + i);
+  {
+    const int cs = comp ? 1 : 0;
+    const int tpr = ((1 << P.log2ctu) >> cs) >> 3, rtw = (P.grid_w / 2) >> cs;           // tiles per CTU row / per picture row
+    const int tx0 = cx * tpr, ty0 = cy * tpr;
+    const int16_t* src = P.resid[comp];
+    for (int i = threadIdx.x; i < tpr * tpr * 8; i += blockDim.x) {                       // 16-byte vectors, eight per tile
+      const int tile = i >> 3, v = i & 7;
+      *reinterpret_cast<u32x4*>(&L.res[tile * 64 + v * 8]) = ldg4(src + ((size_t)(ty0 + tile / tpr) * rtw + tx0 + tile % tpr) * 64 + v * 8);
+    }
   }
   intra_stage(P, comp, ctu, L);
   }
@@ -730,10 +698,11 @@ __global__ void __launch_bounds__(64 * WAVES) k_intra(const PicDev* __restrict__
 }
 
 void launch_intra(const PicDev* pics, const Batch& b, const int32_t* order, int num_ctus, hipStream_t s) {
-  // measured on 2160p I pictures: one picture 17.9 / 11.6 / 9.7 ms with 1 / 2 / 4 waves per CTU, sixteen at once 19.4 / 13.5 / 17.7
+  // measured on 2160p I pictures: one picture 17.9 / 11.6 / 9.7 ms with 1 / 2 / 4 waves per CTU, sixteen at once 19.4 / 13.5 / 17.7;
+  // with the residual from k_itx (140 instead of 212 VGPRs: three waves per SIMD) 8.7 ms (4 or 6 waves), sixteen 11.4 / 10.8 / 11.7 (2 / 3 / 4)
 #ifndef INTRA_WAVES_ONE
 #define INTRA_WAVES_ONE 4
-#define INTRA_WAVES_MANY 2
+#define INTRA_WAVES_MANY 3
 #endif
   if (b.n >= 4) hipLaunchKernelGGL(k_intra<INTRA_WAVES_MANY>, dim3((unsigned)b.n * 3, (unsigned)num_ctus), dim3(64 * INTRA_WAVES_MANY), 0, s, pics, b, order);
   else hipLaunchKernelGGL(k_intra<INTRA_WAVES_ONE>, dim3((unsigned)b.n * 3, (unsigned)num_ctus), dim3(64 * INTRA_WAVES_ONE), 0, s, pics, b, order);

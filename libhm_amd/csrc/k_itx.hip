@@ -1,4 +1,4 @@
-// k_itx.hip -- de-quantisation + inverse transform of the coded TUs of inter CUs.
+// k_itx.hip -- de-quantisation + inverse transform of the coded TUs (inter CUs and, ahead of k_intra, intra CUs).
 //   TComTrQuant::invTransformNxN -> xDeQuant (flat) -> xIT -> xITrMxN / xITransformSkip   TComTrQuant.cpp:1423,1203,1836,894,1920
 //
 // One N-lane group per N x N TU (N = 4, 8, 16, 32; a wave holds 64/N TUs).  Stage 1: lane n owns coefficient column
@@ -81,10 +81,10 @@ __device__ inline void itx_class(const ItxPic& P, int bx, int nbx, char* __restr
       const int per = (int)(int8_t)((r.w1 >> 8) & 0xff), rem = (int)(int8_t)((r.w1 >> 16) & 0xff);
       const int bd = by_comp(P.bd, comp);
       uint32_t res[N / 2];
-      // scaling lists (inter TUs: list 3 + component; not for transform-skip blocks other than 4x4, TComTrQuant.h:180)
-      const uint8_t* mrow = (P.sl_m != nullptr && (!(flags & 2) || N == 4)) ? P.sl_m + (((LOG2N - 2) * 6 + 3 + comp) << 10) + n * N : nullptr;
-      itx_tu_pk<LOG2N>(lv_c, n, per, rem, (flags & 2) != 0, bd, buf, res, false, mrow, (flags & 4) != 0);
-      if (flags & 0x18) resid_rotate_rdpcm<LOG2N>(res, n, false, (flags >> 3) & 3);        // explicit RDPCM (inter: never rotated)
+      // scaling lists (getScalingListType: list 3 * inter + component; not for transform-skip blocks other than 4x4, TComTrQuant.h:180)
+      const uint8_t* mrow = (P.sl_m != nullptr && (!(flags & 2) || N == 4)) ? P.sl_m + (((LOG2N - 2) * 6 + ((flags & 32) ? 0 : 3) + comp) << 10) + n * N : nullptr;
+      itx_tu_pk<LOG2N>(lv_c, n, per, rem, (flags & 2) != 0, bd, buf, res, (flags & 1) != 0, mrow, (flags & 4) != 0);   // DST: 4x4 intra luma (TComTU::useDST)
+      if ((flags & 0x18) | (r.w1 >> 24)) resid_rotate_rdpcm<LOG2N>(res, n, ((r.w1 >> 24) & 1) != 0, (flags >> 3) & 3);   // RExt: rotation (intra 4x4), RDPCM
       if (t < count) {
         // row n of the residual into the tiles it crosses: the eight lanes that hold the rows of one tile write its 128 bytes
         const int cs = comp ? 1 : 0;

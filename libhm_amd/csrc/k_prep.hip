@@ -47,13 +47,13 @@ struct Quad {
   uint32_t bypass;                 // m_CUTransquantBypass of the four partitions (one CU: 8x8 is the minimum CU size)
 };
 
-__device__ inline TuRec make_tu(const PicDev& P, const Quad& q, const SliceDev* sl, int gx, int gy, int comp, int flags, uint32_t coef_off) {
+__device__ inline TuRec make_tu(const PicDev& P, const Quad& q, const SliceDev* sl, int gx, int gy, int comp, int flags, int xflags, uint32_t coef_off) {
   TuRec r;
   r.x4 = (uint16_t)gx; r.y4 = (uint16_t)gy;
   r.comp_flags = (uint8_t)(comp | (flags << 2));
   const int coff = comp == 1 ? ldg(&sl->cb_qp_offset) : (comp == 2 ? ldg(&sl->cr_qp_offset) : 0);
   qp_param(q.qp_cu, comp, P.bd[comp], coff, r.per, r.rem);
-  r.pad = 0;
+  r.xflags = (uint8_t)xflags;
   r.coef_off = coef_off;
   return r;
 }
@@ -354,10 +354,11 @@ __global__ void __launch_bounds__(256) k_prep(const PicDev* __restrict__ pics, B
 #endif
     if (q.valid) atomicAdd(&lds_stat[q.intra ? 0 : 1], 4u);
     if (q.valid && q.intra) stg(P.ctu_intra + q.ctu, (uint8_t)1);        // same value from every writer
-    // ---- which transform units originate in this 8x8 area (the TUs of intra CUs are not listed: k_intra.hip walks them in decoding order)
+    // ---- which transform units originate in this 8x8 area.  The TUs of intra CUs are listed too (not those of PCM CUs): their residual
+    // does not depend on the neighbours, k_itx computes it ahead of k_intra, which walks the TUs in dependency order and only adds it.
     // cbf bit d of a partition = cbf of its ancestor TU node at transform depth d (TComDataCU.h:310); HM descends only
     // while every node on the way has its bit set (TComTrQuant.cpp:1558-1564)
-    if (q.valid && !q.intra && q.log2tu <= 5) {
+    if (q.valid && q.log2tu <= 5 && (!q.intra || (P.has_intra_dir && !(pcm4 & 0xff)))) {
       const uint32_t chain = (1u << (q.tr + 1)) - 1;
       if (q.log2tu > 2) {
         // at most one luma TU (and its chroma TUs, half the size) starts here: when partition 0 is aligned to the TU
@@ -474,12 +475,27 @@ __global__ void __launch_bounds__(256) k_prep(const PicDev* __restrict__ pics, B
     const int comp = k < 4 ? 0 : k - 3;
     const int j = k < 4 ? k : 0;                          // partition the TU starts at
     const int ts = (q.ts[comp] >> (8 * j)) & 0xff;
-    // bit 1: transform skip, bit 2: cu_transquant_bypass, bits 3-4: explicit RDPCM mode of a block that skipped the transform
-    int flags = ((comp == 0 && q.log2tu == 2 && q.intra) ? 1 : 0) | ((ts & 1) ? 2 : 0) | ((q.bypass & 0xff) ? 4 : 0);
-    if ((flags & 6) && (P.range_ext & HMGPU_REXT_EXPLICIT_RDPCM)) flags |= ((ts >> 1) & 3) << 3;
+    // bit 0: DST, bit 1: transform skip, bit 2: cu_transquant_bypass, bits 3-4: RDPCM of a block that skipped the transform, bit 5: intra
+    int flags = ((comp == 0 && q.log2tu == 2 && q.intra) ? 1 : 0) | ((ts & 1) ? 2 : 0) | ((q.bypass & 0xff) ? 4 : 0) | (q.intra ? 32 : 0);
+    int xflags = 0;
+    if ((flags & 6) && P.range_ext) {
+      if (!q.intra) {
+        if (P.range_ext & HMGPU_REXT_EXPLICIT_RDPCM) flags |= ((ts >> 1) & 3) << 3;          // the mode parsed with the block
+      } else {
+        // rotation of 4x4 blocks (TComTU::isNonTransformedResidualRotated); implicit RDPCM along the final prediction mode (invRdpcmNxN,
+        // TComTrQuant.cpp:1748-1760): DM_CHROMA = the luma mode of the CU's first partition, as k_intra derives it
+        if ((P.range_ext & HMGPU_REXT_ROTATION) && (comp == 0 ? q.log2tu : max(q.log2tu - 1, 2)) == 2) xflags |= 1;
+        if (P.range_ext & HMGPU_REXT_IMPLICIT_RDPCM) {
+          const size_t cb = (size_t)q.ctu * P.parts;
+          int mode = ldg(P.intra_dir[comp ? 1 : 0] + cb + q.z0 + j);
+          if (comp && mode == 36) mode = ldg(P.intra_dir[0] + cb + (q.z0 & ~((1 << (2 * (q.log2cu - 2))) - 1)));
+          flags |= (mode == 10 ? 1 : mode == 26 ? 2 : 0) << 3;
+        }
+      }
+    }
     uint32_t off = comp == 0 ? (uint32_t)q.ctu * ctu_luma + 16u * (q.z0 + j) : (uint32_t)q.ctu * (ctu_luma >> 2) + 4u * q.z0;
     if (P.coef_start[0] != nullptr) off = coff[comp] + (comp == 0 ? 16u * __popc(lmask & ((1u << j) - 1u)) : 0u);
-    const TuRec r = make_tu(P, q, sl, q.gx0 + (j & 1), q.gy0 + (j >> 1), comp, flags, off);
+    const TuRec r = make_tu(P, q, sl, q.gx0 + (j & 1), q.gy0 + (j >> 1), comp, flags, xflags, off);
     const int c = cls[k];
     const uint32_t i = lds_base[c] + loc[k];
     if (i < P.tu_cap[c]) {
