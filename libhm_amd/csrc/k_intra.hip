@@ -334,6 +334,10 @@ struct IntraSched {
   uint32_t got[3];                   // border units of the neighbouring CTUs whose samples are in LDS (L.pix columns 0, 1 / L.top): column | row lo | row hi
   uint32_t pend[8];                  // list entries nobody has taken yet (bit i & 31 of pend[i >> 5]); a wave takes one with an atomic AND
   int32_t n_tus, running;            // list length; waves inside a TU right now
+#ifdef INTRA_TIMING                  // diagnostic build: where the time of a CTU goes (printed by k_intra for one CTU row)
+  unsigned long long t_tu, t_claim, t_post, t_idle, t_first, t_last;
+  uint32_t n_run, n_idle;
+#endif
 };
 
 struct Neighbours {
@@ -518,6 +522,12 @@ __device__ __attribute__((always_inline)) inline void intra_ctu(const PicDev& P,
   __syncthreads();
   const int n_tus = Q.n_tus;
   uint32_t spins = 0;
+#ifdef INTRA_TIMING
+  unsigned long long tm0 = wall_clock64();
+#define TM_ADD(field) { const unsigned long long tm1 = wall_clock64(); if (lane == 0) atomicAdd(&Q.field, tm1 - tm0); tm0 = tm1; }
+#else
+#define TM_ADD(field)
+#endif
   if (wv == (int)(blockDim.x >> 6) - 1) fetch_border(P, comp, ctu, nb.ext_col, nb.ext_row, Q, L);   // what is final next door already
   for (;;) {
     // the scheduler words in LDS (pend, done_c, done_r, got) are updated by the other waves with atomics: read them afresh in every round
@@ -548,11 +558,15 @@ __device__ __attribute__((always_inline)) inline void intra_ctu(const PicDev& P,
       // nothing this wave can run: either another wave is inside a TU whose units will make one ready, or the neighbours have to get further
       __builtin_amdgcn_s_sleep(4);
       ++spins;
+#ifdef INTRA_TIMING
+      if (lane == 0) atomicAdd(&Q.n_idle, 1u);
+#endif
       if (__hip_atomic_load(&Q.running, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0 || (spins & 15) == 0) {
         if (spins > (1u << 22)) { if (lane == 0) atomicOr(P.fault, 1u); nb.broken = true; }
         poll_neighbours(P, nb, pw);
         fetch_border(P, comp, ctu, nb.ext_col, nb.ext_row, Q, L);   // whatever has become final next door
       }
+      TM_ADD(t_idle)
       continue;
     }
     // claim it
@@ -597,7 +611,12 @@ __device__ __attribute__((always_inline)) inline void intra_ctu(const PicDev& P,
       t.cbf = (L.m_cbf[zc] >> tr) & 1;
       t.bypass = L.m_byp[zc];
       fetch_border(P, comp, ctu, x4 == 0 ? Q.need_col[i] : 0u, y4 == 0 ? Q.need_row[i] : 0ull, Q, L);
+#ifdef INTRA_TIMING
+      if (lane == 0) { atomicMin(&Q.t_first, wall_clock64()); atomicAdd(&Q.n_run, 1u); }
+#endif
+      TM_ADD(t_claim)
       intra_tu_any(P, t, L, W);
+      TM_ADD(t_tu)
     }
     wave_lds_sync();                                         // the TU's samples are in the CTU copy before its units count as final
     mark_done(x4, y4, U);
@@ -608,6 +627,10 @@ __device__ __attribute__((always_inline)) inline void intra_ctu(const PicDev& P,
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       if (lane == 0) __hip_atomic_fetch_or(nb.prog + ctu, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+#ifdef INTRA_TIMING
+    if (lane == 0) atomicMax(&Q.t_last, wall_clock64());
+#endif
+    TM_ADD(t_post)
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
@@ -631,6 +654,10 @@ __global__ void __launch_bounds__(64 * WAVES) k_intra(const PicDev* __restrict__
   if (!P.has_intra_dir || ctu < first || ctu > last || !ldg(P.ctu_intra + ctu)) return;
   uint32_t* done = P.intra_done + (size_t)comp * P.num_ctus;
   const int cx = ctu % P.ctus_w, cy = ctu / P.ctus_w;
+#ifdef INTRA_TIMING
+  const unsigned long long tk0 = wall_clock64();
+  if (threadIdx.x == 0) { Q.t_tu = Q.t_claim = Q.t_post = Q.t_idle = 0; Q.t_first = ~0ull; Q.t_last = 0; Q.n_run = Q.n_idle = 0; }
+#endif
   const int nb[4] = {cx > 0 ? ctu - 1 : -1, (cx > 0 && cy > 0) ? ctu - P.ctus_w - 1 : -1, cy > 0 ? ctu - P.ctus_w : -1,
                      (cy > 0 && cx + 1 < P.ctus_w) ? ctu - P.ctus_w + 1 : -1};
   // which borders matter: an intra CU reads neighbouring samples only across a border it touches, and only the samples of the
@@ -691,6 +718,11 @@ __global__ void __launch_bounds__(64 * WAVES) k_intra(const PicDev* __restrict__
   wave_lds_sync();
   intra_ctu(P, comp, ctu, L, Q, W[wv], nbs);
   __syncthreads();                                           // every wave's stores are acknowledged (intra_ctu ends with the wait)
+#ifdef INTRA_TIMING
+  if (threadIdx.x == 0 && comp == 0 && slot == 0 && (cy == 10 || cy == 11) && cx >= 20 && cx < 32)
+    printf("TM cy %d cx %d start %llu first %llu last %llu end %llu ntu %u tu %llu claim %llu post %llu idle %llu nidle %u\n", cy, cx, tk0, Q.t_first, Q.t_last,
+           wall_clock64(), Q.n_run, Q.t_tu, Q.t_claim, Q.t_post, Q.t_idle, Q.n_idle);
+#endif
   if (wv == 0) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     publish_progress(done, ctu, 0xffffffffu);
