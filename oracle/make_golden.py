@@ -299,6 +299,13 @@ LITE = {
                                                 REXT420[:-1] + ["--TransformSkipLog2MaxSize=5", "--IntraReferenceSmoothing=0"]),
     "ldb_rext420_wp_hp_main10_208x120": ("encoder_lowdelay_main_rext.cfg", 208, 120, 3, 10, 10, 30,
                                                   REXT420[:-2] + ["--TransformSkipLog2MaxSize=2", "--WeightedPredP=1", "--WeightedPredB=1", "--HighPrecisionPredictionWeighting=1"]),
+    # the parser state of the range extensions across the places contexts are stored and restored: wavefronts with dependent slice
+    # segments (StatCoeff synchronised with the context variables), slices of tiles (reset per tile)
+    "ldb_rext420_wpp_depslices_main8_416x240": ("encoder_lowdelay_main_rext.cfg", 416, 240, 3, 8, 8, 26,
+                                                REXT420 + ["--WaveFrontSynchro=1", "--SliceMode=1", "--SliceArgument=10", "--SliceSegmentMode=1", "--SliceSegmentArgument=3"]),
+    "ldb_rext420_tileslices_main10_832x128": ("encoder_lowdelay_main_rext.cfg", 832, 128, 3, 10, 10, 28,
+                                              REXT420 + ["--TileUniformSpacing=1", "--NumTileColumnsMinus1=2", "--NumTileRowsMinus1=1", "--SliceMode=3", "--SliceArgument=2",
+                                                         "--SliceSegmentMode=1", "--SliceSegmentArgument=64", "--LFCrossSliceBoundaryFlag=0"]),
     "ldb_rext420_mixed_main10_208x120": ("encoder_lowdelay_main_rext.cfg", 208, 120, 3, 10, 10, 32,
                                          REXT420 + ["--TransquantBypassEnableFlag=1", "--CostMode=mixed_lossless_lossy"]),
 }
