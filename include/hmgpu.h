@@ -64,7 +64,8 @@ typedef struct hmgpu_seq_params {
   int32_t width, height;          /* SPS pic_{width,height}_in_luma_samples (multiple of the 8x8 minimum CU) */
   int32_t bit_depth_luma;         /* g_bitDepth[CHANNEL_TYPE_LUMA]   (8..10) */
   int32_t bit_depth_chroma;       /* g_bitDepth[CHANNEL_TYPE_CHROMA] (8..10) */
-  int32_t chroma_format;          /* chroma_format_idc; only 1 (4:2:0) */
+  int32_t chroma_format;          /* chroma_format_idc: 1 (4:2:0), or 0 (4:0:0, monochrome: the chroma arrays hold no coded blocks, the chroma
+                                     planes are allocated like those of 4:2:0 and left alone; picture hashes: the first digest) */
   int32_t log2_ctu_size;          /* log2 g_uiMaxCUWidth: 4, 5 or 6.  partitions are 4x4 => (1<<(2*log2_ctu_size-4)) per CTU */
   int32_t max_pictures;           /* device pictures to pre-allocate (DPB size + pictures in flight) */
   int32_t pcm_loop_filter_disable;/* SPS pcm_loop_filter_disabled_flag && pcm_enabled_flag */

@@ -281,6 +281,7 @@ hmgpu_status alloc_picture(hmgpu_ctx* c, Picture& p) {
   d.lf_across_tiles = 1; d.sao_applied = 0;
   d.has_intra_dir = 0; d.strong_intra_smoothing = s.strong_intra_smoothing ? 1 : 0;
   d.range_ext = s.range_ext_flags;
+  d.mono = s.chroma_format == 0 ? 1 : 0;
   d.sl_m = nullptr;
   for (int k = 0; k < 3; k++) { d.pcm[k] = nullptr; d.pcm_shift[k] = 0; d.coef_start[k] = nullptr; }
   d.pcm_lf_disable = s.pcm_loop_filter_disable ? 1 : 0; d.any_nofilt = 0;
@@ -389,7 +390,7 @@ hmgpu_status run_recon(hmgpu_ctx* c, const Batch& b, bool any_intra, bool any_wp
     launch_mc_luma(ma, max_ctus, any_wp, any_bi, c->stream);
     if (any_cells) launch_mc_luma_cells(c->d_pics, c->d_finals, b, max_ctus, c->seq.log2_ctu_size, any_wp, c->stream);
   }
-  {
+  if (c->seq.chroma_format != 0) {
     ProfScope ps(c, K_MC_CHROMA);
     ma.pitch = c->pitch[1]; ma.bd = c->seq.bit_depth_chroma;
     ma.origin_off = (uint32_t)((const char*)d0.rec[1] - base0);
@@ -523,7 +524,7 @@ hmgpu_status hmgpu_create(const hmgpu_seq_params* seq, int device_ordinal, hmgpu
   if (seq->width <= 0 || seq->height <= 0 || (seq->width & 7) || (seq->height & 7)) return HMGPU_EINVAL;
   if (seq->log2_ctu_size < 4 || seq->log2_ctu_size > 6) return HMGPU_EINVAL;
   if (seq->max_pictures < 1 || seq->max_pictures > kMaxPics) return HMGPU_EINVAL;
-  if (seq->chroma_format != 1) return HMGPU_EUNSUPPORTED;
+  if (seq->chroma_format != 1 && seq->chroma_format != 0) return HMGPU_EUNSUPPORTED;      // 0: monochrome -- the chroma planes exist and are left alone
   if (seq->range_ext_flags & ~(HMGPU_REXT_ROTATION | HMGPU_REXT_IMPLICIT_RDPCM | HMGPU_REXT_EXPLICIT_RDPCM | HMGPU_REXT_INTRA_SMOOTHING_DISABLED)) return HMGPU_EUNSUPPORTED;
   if (seq->bit_depth_luma < 8 || seq->bit_depth_luma > 10 || seq->bit_depth_chroma < 8 || seq->bit_depth_chroma > 10) return HMGPU_EUNSUPPORTED;
   hmgpu_ctx* c = new (std::nothrow) hmgpu_ctx();

@@ -161,6 +161,7 @@ struct PicDev {
   int32_t has_intra_dir;           // the caller supplied intra prediction modes (else intra CUs are left untouched)
   int32_t strong_intra_smoothing;  // SPS flag
   int32_t range_ext;               // HMGPU_REXT_* (sps_range_extension tools of the residual path)
+  int32_t mono;                    // chroma_format_idc 0: no chroma blocks are coded, the chroma planes are never read back
   uint8_t* ctu_intra;              // [num_ctus] 1 = the CTU holds intra CUs (written by k_prep)
   uint32_t* intra_done;            // [3][num_ctus]: the CTU's intra CUs of that component are reconstructed
   uint32_t* fault;                 // set by a kernel that gave up waiting (k_intra's bounded spin): checked by the host at hmgpu_sync

@@ -651,7 +651,7 @@ __global__ void __launch_bounds__(64 * WAVES) k_intra(const PicDev* __restrict__
   const int slot = blockIdx.x / 3, comp = blockIdx.x % 3, ctu = ldg(order + blockIdx.y);
   const PicDev& P = pics[b.pic[slot]];
   const int first = b.first_ctu[slot], last = first + b.num_ctus[slot] - 1;
-  if (!P.has_intra_dir || ctu < first || ctu > last || !ldg(P.ctu_intra + ctu)) return;
+  if (!P.has_intra_dir || ctu < first || ctu > last || !ldg(P.ctu_intra + ctu) || (comp && P.mono)) return;
   uint32_t* done = P.intra_done + (size_t)comp * P.num_ctus;
   const int cx = ctu % P.ctus_w, cy = ctu / P.ctus_w;
 #ifdef INTRA_TIMING

@@ -159,9 +159,10 @@ void Decoder::parse_sei(const std::vector<uint8_t>& rbsp, bool suffix) {
     if (suffix && type == 132 && size >= 1) {
       const int hash_type = br.u(8);
       const int bytes = hash_type == 0 ? 16 : hash_type == 1 ? 2 : hash_type == 2 ? 4 : 0;
-      if (bytes && size >= 1 + 3 * bytes) {
+      const int ncomp = (sps_ && sps_->chroma_format_idc == 0) ? 1 : 3;      // one digest per colour component of the format (D.2.19)
+      if (bytes && size >= 1 + ncomp * bytes) {
         memset(pending_hash_val_, 0, sizeof(pending_hash_val_));
-        for (int c = 0; c < 3; c++) for (int i = 0; i < bytes; i++) pending_hash_val_[c][i] = (uint8_t)br.u(8);
+        for (int c = 0; c < ncomp; c++) for (int i = 0; i < bytes; i++) pending_hash_val_[c][i] = (uint8_t)br.u(8);
         pending_hash_method_ = hash_type + 1;
         pending_hash_ = true;
         if (cur_) {                        // the SEI follows the slices of the picture it describes
@@ -230,7 +231,7 @@ void Decoder::activate(const SliceHeader& sh) {
   seq_.height = sps_->height;
   seq_.bit_depth_luma = sps_->bit_depth_luma;
   seq_.bit_depth_chroma = sps_->bit_depth_chroma;
-  seq_.chroma_format = 1;
+  seq_.chroma_format = sps_->chroma_format_idc;            // 1, or 0: monochrome (chroma planes exist on the device and are never shown)
   seq_.log2_ctu_size = sps_->log2_ctb;
   seq_.max_pictures = std::min(40, sps_->max_dec_pic_buffering[sps_->max_sub_layers - 1] + 3 + (threaded() ? threads_ + 1 : 0));
   seq_.pcm_loop_filter_disable = sps_->pcm && sps_->pcm_loop_filter_disabled;
@@ -448,6 +449,7 @@ void Decoder::start_picture(const SliceHeader& sh) {
   cur_->pcm_lf_disable = sps_->pcm && sps_->pcm_loop_filter_disabled;
   cur_->strong_intra = sps_->strong_intra_smoothing;
   cur_->range_ext_flags = sps_->range_ext_flags();
+  cur_->num_comps = sps_->chroma_format_idc == 0 ? 1 : 3;
   cur_->sao_offset_shift[0] = pps_->sao_offset_shift[0]; cur_->sao_offset_shift[1] = pps_->sao_offset_shift[1];
   cur_->lf_across_tiles = pps_->lf_across_tiles;
   cur_->conf_window[0] = sps_->conf_left; cur_->conf_window[1] = sps_->conf_right; cur_->conf_window[2] = sps_->conf_top; cur_->conf_window[3] = sps_->conf_bottom;
@@ -930,7 +932,7 @@ void Decoder::poll_device_hashes(bool block) {
     if (hmgpu_hash_wait(gpu_, dev_hashes_.front().ticket, block ? 1 : 0, got, &len, &ready) != HMGPU_OK) { ready = 1; len = 0; }
     if (!ready) return;
     const DevHash& h = dev_hashes_.front();
-    if (len != 16 || memcmp(got, h.want, sizeof(h.want)) != 0) {
+    if (len != 16 || memcmp(got, h.want, 16 * h.ncomp) != 0) {
       hash_mismatches_++;
       fprintf(stderr, "hmdec: ***ERROR*** decoded picture hash mismatch, POC %d\n", h.poc);
     }
@@ -958,6 +960,7 @@ void Decoder::check_hash(PicData* pic) {
     while (dev_hashes_.size() >= 64) poll_device_hashes(true);         // (the device keeps a ring of 96)
     DevHash h;
     h.poc = pic->poc;
+    h.ncomp = pic->num_comps;
     memcpy(h.want, pic->sei_hash, sizeof(h.want));
     if (hmgpu_picture_hash_begin(gpu_, pic->handle, 1, &h.ticket) != HMGPU_OK) return;
     dev_hashes_.push_back(h);
@@ -979,10 +982,10 @@ void Decoder::check_hash(PicData* pic) {
         if (hmgpu_picture_download_begin(gpu_, pic->handle, planes, strides, &t) != HMGPU_OK) return;
         pic->dl_ticket.store(t);
       }
-      pic->users.fetch_add(3);
+      pic->users.fetch_add(pic->num_comps);
       {
         std::lock_guard<std::mutex> lk(hash_mu_);
-        for (int c = 0; c < 3; c++) {
+        for (int c = 0; c < pic->num_comps; c++) {
           HashJob j;
           j.pic = pic; j.comp = c; j.bd = c ? sps_->bit_depth_chroma : sps_->bit_depth_luma;
           memcpy(j.want, pic->sei_hash[c], 16);
@@ -994,7 +997,7 @@ void Decoder::check_hash(PicData* pic) {
     }
     if (!fetch_planes(pic)) return;
     bool ok = true;
-    for (int c = 0; c < 3; c++) ok &= md5_plane_matches(pic, c, c ? sps_->bit_depth_chroma : sps_->bit_depth_luma, pic->sei_hash[c]);
+    for (int c = 0; c < pic->num_comps; c++) ok &= md5_plane_matches(pic, c, c ? sps_->bit_depth_chroma : sps_->bit_depth_luma, pic->sei_hash[c]);
     if (!ok) {
       pic->hash_mismatch = true;
       hash_mismatches_++;
@@ -1007,7 +1010,7 @@ void Decoder::check_hash(PicData* pic) {
     len = n;
   }
   bool ok = true;
-  for (int c = 0; c < 3; c++) if (memcmp(got[c], pic->sei_hash[c], len)) ok = false;
+  for (int c = 0; c < pic->num_comps; c++) if (memcmp(got[c], pic->sei_hash[c], len)) ok = false;
   if (!ok) {
     pic->hash_mismatch = true;
     hash_mismatches_++;

@@ -119,7 +119,7 @@ class Decoder {
   void drain_hash_jobs();
   static bool md5_plane_matches(const PicData* pic, int comp, int bd, const uint8_t want[16]);
   uint64_t submitted_seq_ = 0, synced_seq_ = 0;            // device submissions / the last one known to have completed
-  struct DevHash { uint64_t ticket; int poc; uint8_t want[3][16]; };
+  struct DevHash { uint64_t ticket; int poc; int ncomp; uint8_t want[3][16]; };
   std::deque<DevHash> dev_hashes_;                         // MD5 chains under way on the device (hmgpu_picture_hash_begin)
   bool device_md5_ = !(getenv("HMDEC_DEVICE_MD5") != nullptr && getenv("HMDEC_DEVICE_MD5")[0] == '0');   // default on
   std::vector<PicData*> batch_;                            // pictures retired and not yet submitted: mutually independent

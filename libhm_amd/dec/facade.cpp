@@ -143,10 +143,14 @@ short* libHMDEC_get_image_plane(libHMDec_picture* pic, libHMDec_ColorComponent c
   if (!pic || c < LIBHMDEC_LUMA || c > LIBHMDEC_CHROMA_V) return nullptr;
   PicData* p = as_pic(pic);
   if (!p->planes_valid) return nullptr;
+  if (c != LIBHMDEC_LUMA && p->num_comps == 1) return nullptr;        // monochrome: HM allocates no chroma buffers (TComPicYuv::create)
   return p->plane[c].data();
 }
 
-libHMDec_ChromaFormat libHMDEC_get_chroma_format(libHMDec_picture* pic) { return pic ? LIBHMDEC_CHROMA_420 : LIBHMDEC_CHROMA_UNKNOWN; }
+libHMDec_ChromaFormat libHMDEC_get_chroma_format(libHMDec_picture* pic) {
+  if (!pic) return LIBHMDEC_CHROMA_UNKNOWN;
+  return as_pic(pic)->num_comps == 1 ? LIBHMDEC_CHROMA_400 : LIBHMDEC_CHROMA_420;
+}
 
 int libHMDEC_get_internal_bit_depth(libHMDec_ColorComponent c) {
   if (c == LIBHMDEC_LUMA) return g_bit_depth[0];

@@ -241,11 +241,12 @@ std::shared_ptr<Sps> parse_sps(BitReader& br) {
   if (s.id > 15) throw ParseError("sps_seq_parameter_set_id out of range");
   s.chroma_format_idc = br.ue();
   if (s.chroma_format_idc == 3) br.u(1);
-  if (s.chroma_format_idc != 1) throw Unsupported("only 4:2:0 pictures are reconstructed on the device");
+  if (s.chroma_format_idc > 1) throw Unsupported("4:2:2 and 4:4:4 pictures: the device path reconstructs 4:2:0 and monochrome (4:0:0)");
   s.width = br.ue();
   s.height = br.ue();
-  if (br.flag()) {                       // conformance window, in chroma units of 2 for 4:2:0
-    s.conf_left = 2 * br.ue(); s.conf_right = 2 * br.ue(); s.conf_top = 2 * br.ue(); s.conf_bottom = 2 * br.ue();
+  if (br.flag()) {                       // conformance window, in units of SubWidthC / SubHeightC: 2 for 4:2:0, 1 for 4:0:0
+    const int unit = s.chroma_format_idc == 1 ? 2 : 1;
+    s.conf_left = unit * br.ue(); s.conf_right = unit * br.ue(); s.conf_top = unit * br.ue(); s.conf_bottom = unit * br.ue();
   }
   s.bit_depth_luma = 8 + br.ue();
   s.bit_depth_chroma = 8 + br.ue();
@@ -445,12 +446,13 @@ static void parse_pred_weight_table(BitReader& br, const Sps& sps, SliceHeader& 
   const int lrange = sps.rext_high_precision_offsets ? 1 << (sps.bit_depth_luma - 1) : 128, crange = sps.rext_high_precision_offsets ? 1 << (sps.bit_depth_chroma - 1) : 128;
   sh.luma_log2_weight_denom = br.ue();
   if (sh.luma_log2_weight_denom > 7) throw ParseError("luma_log2_weight_denom out of range");
-  sh.chroma_log2_weight_denom = sh.luma_log2_weight_denom + br.se();
+  const bool chroma = sps.chroma_format_idc != 0;         // monochrome: no chroma syntax (HM 16.0: TDecCAVLC.cpp:1801, 1827, 1861)
+  sh.chroma_log2_weight_denom = sh.luma_log2_weight_denom + (chroma ? br.se() : 0);
   if (sh.chroma_log2_weight_denom < 0 || sh.chroma_log2_weight_denom > 7) throw ParseError("chroma log2 weight denominator out of range");
   for (int l = 0; l < (sh.type == SLICE_B ? 2 : 1); l++) {
     const int n = sh.num_ref_idx[l];
     for (int i = 0; i < n; i++) { sh.pw[l][i] = PredWeight(); sh.pw[l][i].luma_flag = br.flag(); }
-    for (int i = 0; i < n; i++) sh.pw[l][i].chroma_flag = br.flag();
+    if (chroma) for (int i = 0; i < n; i++) sh.pw[l][i].chroma_flag = br.flag();
     for (int i = 0; i < n; i++) {
       PredWeight& w = sh.pw[l][i];
       w.luma_weight = 1 << sh.luma_log2_weight_denom;
@@ -559,7 +561,7 @@ void parse_slice_header(BitReader& br, int nal_type, int temporal_id, const Para
     sh.num_pic_total_curr = 0;
     for (int i = 0; i < sh.rps.num_delta_pocs(); i++) sh.num_pic_total_curr += sh.rps.used[i];
     for (int i = 0; i < sh.num_long_term; i++) sh.num_pic_total_curr += sh.lt_used[i];
-    if (sps.sao) { sh.sao_luma = br.flag(); sh.sao_chroma = br.flag(); }
+    if (sps.sao) { sh.sao_luma = br.flag(); sh.sao_chroma = sps.chroma_format_idc != 0 && br.flag(); }     // (:1170: absent for 4:0:0)
     sh.num_ref_idx[0] = sh.num_ref_idx[1] = 0;
     sh.collocated_from_l0 = true;
     sh.collocated_ref_idx = 0;
@@ -600,7 +602,7 @@ void parse_slice_header(BitReader& br, int nal_type, int temporal_id, const Para
     sh.qp = pps.init_qp + br.se();
     if (sh.qp < -6 * (sps.bit_depth_luma - 8) || sh.qp > 51) throw ParseError("slice QP out of range");
     sh.cb_qp_offset = sh.cr_qp_offset = 0;
-    if (pps.slice_chroma_qp_offsets_present) {
+    if (pps.slice_chroma_qp_offsets_present && sps.chroma_format_idc != 0) {       // (HM 16.0 reads them per valid component: TDecCAVLC.cpp:1349-1368)
       sh.cb_qp_offset = br.se();
       sh.cr_qp_offset = br.se();
       if (sh.cb_qp_offset < -12 || sh.cb_qp_offset > 12 || sh.cr_qp_offset < -12 || sh.cr_qp_offset > 12) throw ParseError("slice chroma QP offset out of range");

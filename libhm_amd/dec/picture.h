@@ -123,6 +123,7 @@ struct PicData {
   int bit_depth[2] = {8, 8}, pcm_bit_depth[2] = {8, 8};
   bool pcm_lf_disable = false, strong_intra = false;
   int sao_offset_shift[2] = {0, 0};            // PPS log2_sao_offset_scale_{luma,chroma}
+  int num_comps = 3;                           // 1: monochrome (chroma_format_idc 0)
   int range_ext_flags = 0;                     // HMGPU_REXT_* of the active SPS
   hmgpu_pic handle = HMGPU_NO_PIC;
   uint64_t submit_seq = 0;           // device submission that last read these arrays

@@ -492,7 +492,7 @@ void SliceDecoder::pcm_sample(int x0, int y0, int log2) {
   const size_t ctb = pic_.ctb_at(x0, y0), z = pic_.part_at(x0, y0) - ctb * pic_.parts;
   int16_t* y = &pic_.pcm[0][(ctb << (2 * sps_.log2_ctb)) + 16 * z];
   for (int i = 0; i < size * size; i++) y[i] = (int16_t)cabac_.plain_bits(sps_.pcm_bit_depth_luma);
-  for (int c = 1; c < 3; c++) {
+  for (int c = 1; c < 3 && sps_.chroma_format_idc != 0; c++) {
     int16_t* d = &pic_.pcm[c][(ctb << (2 * sps_.log2_ctb - 2)) + 4 * z];
     for (int i = 0; i < size * size / 4; i++) d[i] = (int16_t)cabac_.plain_bits(sps_.pcm_bit_depth_chroma);
   }
@@ -538,7 +538,7 @@ void SliceDecoder::intra_modes(int x0, int y0, int log2, bool nxn) {
     for (int yy = y; yy < y + pb; yy += 4) for (int xx = x; xx < x + pb; xx += 4) pic_.intra_dir[0][pic_.part_at(xx, yy)] = (uint8_t)mode;
   }
   int chroma = 4;
-  if (cabac_.decision(ctx_.s[CTX_CHROMA_MODE])) chroma = cabac_.bypass_bits(2);
+  if (sps_.chroma_format_idc != 0 && cabac_.decision(ctx_.s[CTX_CHROMA_MODE])) chroma = cabac_.bypass_bits(2);     // (TDecEntropy.cpp:119)
   int stored = kDmChroma;
   intra_chroma_ = intra_luma_[0];
   if (chroma != 4) {
@@ -835,7 +835,8 @@ void SliceDecoder::transform_tree(int x0, int y0, int xbase, int ybase, int log2
     split = log2 > sps_.log2_max_tb || (intra_split && tr_depth == 0) || inter_split;
   }
   bool cbf_cb = parent_cb, cbf_cr = parent_cr;          // 4x4 luma blocks: the chroma flags of the parent stand
-  if (log2 > 2) {
+  if (sps_.chroma_format_idc == 0) cbf_cb = cbf_cr = false;          // monochrome: no chroma blocks at all (TDecEntropy.cpp:380)
+  else if (log2 > 2) {
     cbf_cb = (tr_depth == 0 || parent_cb) && cabac_.decision(ctx_.s[CTX_CBF_CHROMA + tr_depth]);
     cbf_cr = (tr_depth == 0 || parent_cr) && cabac_.decision(ctx_.s[CTX_CBF_CHROMA + tr_depth]);
   }

@@ -73,10 +73,10 @@ def synth_clip(w, h, frames, bit_depth, seed, novel=False, fade=False, noisy=Fal
     return out
 
 
-def write_yuv(path, clip, bit_depth):
+def write_yuv(path, clip, bit_depth, mono=False):
     with open(path, "wb") as f:
         for planes in clip:
-            for p in planes:
+            for p in (planes[:1] if mono else planes):
                 f.write(p.astype(np.uint8 if bit_depth == 8 else "<u2").tobytes())
 
 
@@ -136,7 +136,8 @@ def encode(name, tmp):
     cfg, w, h, frames, ibd, bd, qp, extra = STREAMS[name]
     yuv = os.path.join(tmp, name + ".yuv")
     clip = synth_clip(w, h, frames, ibd, seed=0x484D + sum(map(ord, name)), novel="cip" in name, fade="wp" in name, noisy="pcm" in name or "lossless" in name)
-    write_yuv(yuv, clip, ibd)
+    mono = "mono" in name                                               # 4:0:0: luma only in, luma only out
+    write_yuv(yuv, clip, ibd, mono)
     bs = os.path.join(tmp, name + ".bin")
     rec = os.path.join(tmp, name + "_rec.yuv")
     if any("@SLFILE@" in e for e in extra):
@@ -160,7 +161,7 @@ def encode(name, tmp):
     with open(bs, "rb") as f:
         data = f.read()
     # (the reconstruction file has 16-bit samples as soon as either component has more than 8 bits)
-    recdata = np.fromfile(rec, dtype="<u2" if os.path.getsize(rec) == w * h * 3 * frames else np.uint8)
+    recdata = np.fromfile(rec, dtype="<u2" if os.path.getsize(rec) == (w * h * 2 if mono else w * h * 3) * frames else np.uint8)
     return data, recdata, (w, h, frames, bd)
 
 
@@ -233,6 +234,7 @@ def dump_stream(name, bitstream, enc_rec, geom):
 # is by HM practice what a conforming decoder must output, and whose MD5 the encoder put into the stream as SEI.
 REXT420 = ["--InputChromaFormat=420", "--ChromaFormatIDC=420", "--CrossComponentPrediction=0", "--HighPrecisionPredictionWeighting=0",
            "--TransformSkipLog2MaxSize=2"]
+MONO = ["--InputChromaFormat=400", "--ChromaFormatIDC=400", "--CrossComponentPrediction=0", "--HighPrecisionPredictionWeighting=0", "--TransformSkipLog2MaxSize=2"]
 LITE = {
     # name: (cfg, w, h, frames, input bit depth, internal bit depth, qp, extra encoder args)
     # (HM 16.0's encoder writes every slice NAL with the data of all following CTUs of the picture appended unless slice SEGMENTS
@@ -306,6 +308,12 @@ LITE = {
     "ldb_rext420_tileslices_main10_832x128": ("encoder_lowdelay_main_rext.cfg", 832, 128, 3, 10, 10, 28,
                                               REXT420 + ["--TileUniformSpacing=1", "--NumTileColumnsMinus1=2", "--NumTileRowsMinus1=1", "--SliceMode=3", "--SliceArgument=2",
                                                          "--SliceSegmentMode=1", "--SliceSegmentArgument=64", "--LFCrossSliceBoundaryFlag=0"]),
+    # monochrome (chroma_format_idc 0): no chroma syntax anywhere, one digest in the hash SEI; with the range-extension tools, with
+    # weighted prediction, SAO and a conformance window in luma units, and all intra
+    "ldb_mono_rext_main8_208x120": ("encoder_lowdelay_main_rext.cfg", 208, 120, 3, 8, 8, 30, MONO),
+    "ldb_mono_wp_crop_main10_204x116": ("encoder_lowdelay_main_rext.cfg", 204, 116, 3, 10, 10, 32,
+                                        MONO + ["--WeightedPredP=1", "--WeightedPredB=1", "--ConformanceWindowMode=1"]),
+    "intra_mono_main8_208x120": ("encoder_intra_main_rext.cfg", 208, 120, 2, 8, 8, 26, MONO),
     "ldb_rext420_mixed_main10_208x120": ("encoder_lowdelay_main_rext.cfg", 208, 120, 3, 10, 10, 32,
                                          REXT420 + ["--TransquantBypassEnableFlag=1", "--CostMode=mixed_lossless_lossy"]),
 }
@@ -319,11 +327,14 @@ def make_lite(names=None):
             print("encoding", name)
             bs, rec, (w, h, frames, bd) = encode(name, tmp)
             out = {"bitstream": np.frombuffer(bs, dtype=np.uint8), "geom": np.array([w, h, frames, bd], dtype=np.int32)}
-            per = w * h * 3 // 2
+            mono = "mono" in name
+            per = w * h if mono else w * h * 3 // 2
             assert rec.size == per * frames
             for poc in range(frames):                                      # the recon file is in output (POC) order, cropped
                 fr = rec[poc * per:(poc + 1) * per].astype(np.int16)
                 out["poc%02d_0" % poc] = fr[:w * h].reshape(h, w)
+                if mono:
+                    continue
                 out["poc%02d_1" % poc] = fr[w * h:w * h * 5 // 4].reshape(h // 2, w // 2)
                 out["poc%02d_2" % poc] = fr[w * h * 5 // 4:].reshape(h // 2, w // 2)
             path = os.path.join(GOLD, "lite_%s.npz" % name)

@@ -20,7 +20,9 @@ LITE = ["ldp_slices_main8_208x120", "ldp_depslices_main10_208x120", "ldp_wpp_mai
         # sps_range_extension() tools in 4:2:0: rotation, implicit / explicit RDPCM, single significance context, persistent Rice
         "ldb_rext420_main8_208x120", "ldb_rext420_lossless_main8_208x120", "intra_rext420_main8_208x120",
         "intra_rext420_lossless_main8_208x120", "ldb_rext420_mixed_main10_208x120", "ldb_rext420_ts32_nosmooth_main8_208x120",
-        "ldb_rext420_wp_hp_main10_208x120", "ldb_rext420_wpp_depslices_main8_416x240", "ldb_rext420_tileslices_main10_832x128"]
+        "ldb_rext420_wp_hp_main10_208x120", "ldb_rext420_wpp_depslices_main8_416x240", "ldb_rext420_tileslices_main10_832x128",
+        # monochrome (4:0:0)
+        "ldb_mono_rext_main8_208x120", "ldb_mono_wp_crop_main10_204x116", "intra_mono_main8_208x120"]
 # HM-encoded streams rewritten at the bit level (oracle/make_surgery.py) for syntax HM's encoder never writes; expected pictures = HM's own
 # DECODER on the rewritten stream: pps_scaling_list_data; long-term reference pictures + ref_pic_list_modification
 SURGERY = ["surgery_ppssl_main8_208x120", "surgery_ltr_rplm_main10_208x120"]

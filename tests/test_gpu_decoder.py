@@ -95,7 +95,7 @@ def test_syntax_variants_decode_to_the_encoders_reconstruction(name, threads):
     with hmdec.Decoder(threads=threads) as d:
         def on_output(p):
             out.append(p.poc)
-            for c in range(3):
+            for c in range(3 if ("poc%02d_1" % p.poc) in z else 1):          # (monochrome: libHM hands out no chroma planes)
                 assert np.array_equal(p.cropped_plane(c), z["poc%02d_%d" % (p.poc, c)]), "%s POC %d component %d" % (name, p.poc, c)
         d.decode_stream(z["bitstream"], on_output=on_output)
         assert d.hash_mismatches == 0

@@ -69,7 +69,7 @@ def test_oracle_reconstructs_the_encoders_pictures(oracle, name):
             prm = oracle.sao_reconstruct_params(seq, pp, meta, p["sao"])
             cur = oracle.sao_process(seq, slices, pp, meta, prm, cur)
         l, r, t, b = p["crop"]
-        for c in range(3):
+        for c in range(3 if ("poc%02d_1" % p["poc"]) in z else 1):        # (monochrome fixtures hold the luma plane only)
             s = 1 if c else 0
             got = cur[c][t >> s:cur[c].shape[0] - (b >> s), l >> s:cur[c].shape[1] - (r >> s)]
             assert np.array_equal(got, z["poc%02d_%d" % (p["poc"], c)]), "%s POC %d component %d" % (name, p["poc"], c)

@@ -155,9 +155,10 @@ def test_parser_gets_through_every_syntax_variant(name, threads):
         return                                                   # the SEI hashes the uncropped picture, the fixture holds the cropped one; rewritten streams carry no SEI
     for poc in range(frames):
         method, digest = hashes[poc]
+        ncomp = 3 if ("poc%02d_1" % poc) in z else 1                         # (monochrome: one digest)
         want = b"".join(hashlib.md5(z["poc%02d_%d" % (poc, c)].astype(np.uint8 if depths["c" if c else "y"] <= 8 else "<u2").tobytes()).digest()
-                        for c in range(3))
-        assert method == 1 and digest == want, "POC %d" % poc
+                        for c in range(ncomp))
+        assert method == 1 and digest[:16 * ncomp] == want, "POC %d" % poc
 
 
 def test_internal_info_tiles_the_picture():
