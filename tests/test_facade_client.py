@@ -55,7 +55,7 @@ def test_corrupted_streams_never_crash(tmp_path):
     names = ["stream_ldp_main8_416x240", "stream_ra_main10_208x120", "lite_ldp_wpp_depslices_main8_416x240", "lite_ldp_tileslices_main10_832x128",
              "stream_ldp_pcm_main8_208x120", "lite_ra_cra_main8_208x120", "stream_ldp_wp_main10_208x120", "stream_ldp_sl_main10_208x120",
              "lite_ldp_wpp_main10_416x240", "lite_ldb_rext420_main8_208x120", "lite_ldb_rext420_lossless_main8_208x120",
-             "lite_ldb_rext420_ts32_nosmooth_main8_208x120", "lite_intra_rext420_main8_208x120"]
+             "lite_ldb_rext420_ts32_nosmooth_main8_208x120", "lite_intra_rext420_main8_208x120", "lite_ldb_mono_rext_main8_208x120"]
     outcomes = {0: 0, 4: 0}
     for it in range(120):
         b = bytearray(bytes(gu.load(rng.choice(names))["bitstream"]))

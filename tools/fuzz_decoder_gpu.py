@@ -14,7 +14,8 @@ names = ["stream_ldp_main8_416x240", "stream_ra_main10_208x120", "lite_ldp_wpp_d
          "stream_ldp_pcm_main8_208x120", "lite_ra_cra_main8_208x120", "stream_ldp_wp_main10_208x120", "stream_ldp_sl_main10_208x120",
          "lite_ldp_slices_main8_208x120", "lite_ldp_dqp_main10_208x120", "lite_ldp_wpp_main10_416x240",
          "lite_ldb_rext420_main8_208x120", "lite_ldb_rext420_lossless_main8_208x120", "lite_ldb_rext420_ts32_nosmooth_main8_208x120",
-         "lite_intra_rext420_lossless_main8_208x120", "lite_ldb_rext420_wp_hp_main10_208x120"]
+         "lite_intra_rext420_lossless_main8_208x120", "lite_ldb_rext420_wp_hp_main10_208x120", "lite_ldb_mono_rext_main8_208x120",
+         "lite_intra_mono_main8_208x120"]
 with tempfile.TemporaryDirectory() as tmp:
     exe = os.path.join(tmp, "client")
     subprocess.check_call(["g++", "-std=c++17", "-O1", "-o", exe, os.path.join(ROOT, "tests", "client", "libhm_client.cpp"), "-I" + os.path.join(ROOT, "include"),
