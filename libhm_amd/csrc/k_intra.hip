@@ -57,7 +57,8 @@ struct IntraLds {
 
 struct TuCtx {
   int comp, ctu, z_tu, log2n, mode, cbf, bypass, x0, y0;          // x0, y0: component samples
-  int cip, slice, tile, nb_same;                             // per-CTU constants: constrained intra pred, chroma QP offset, slice / tile index, neighbours in the same slice and tile
+  int cip, slice, tile, nb_same;
+  unsigned long long am;                                          // availability of the TU's 4U + 1 reference units (IntraSched::avail)                             // per-CTU constants: constrained intra pred, chroma QP offset, slice / tile index, neighbours in the same slice and tile
   int cx0, cy0;                                                   // CTU origin in component samples
 };
 
@@ -83,9 +84,11 @@ __device__ __attribute__((always_inline)) inline bool intra_avail(const PicDev& 
   return true;
 }
 
+// sum over the first N lanes (the others hold 0), in every one of them: log2 N exchanges, not six -- each is a trip through the LDS crossbar
+template <int N>
 __device__ inline int wave_sum(int v) {
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  for (int o = N / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
 }
 
@@ -106,22 +109,16 @@ __device__ __attribute__((always_inline)) inline void intra_tu(const PicDev& P, 
   const int n = lane & (N - 1);
   const bool active = lane < N;
 
-  // ---- A. availability per unit: units [0, 2U) left column bottom-up, 2U the corner, (2U, 4U] the row above
-  bool av = false;
-  if (lane <= 4 * U) {
-    int px, py;
-    if (lane < 2 * U) { px = lx - 4; py = ly + 4 * (2 * U - 1 - lane); }
-    else if (lane == 2 * U) { px = lx - 4; py = ly - 4; }
-    else { px = lx + 4 * (lane - 2 * U - 1); py = ly - 4; }
-    av = intra_avail(P, t.ctu, t.z_tu, px, py, cip, (unsigned)t.nb_same, L.m_pred);
-  }
-  const unsigned long long am = __builtin_amdgcn_ballot_w64(av);
+  // ---- A. the reference line.  Availability per unit -- units [0, 2U) left column bottom-up, 2U the corner, (2U, 4U] the row above -- is a
+  // property of the TU's position: worked out for the whole list when the CTU starts (IntraSched::avail), not on the serial chain
+  const unsigned long long am = t.am;
+  const bool all_av = am == (2ull << (4 * U)) - 1ull;          // the common case away from picture, slice and decoding-order borders: no substitution
   for (int i = lane; i < total; i += 64) {
     int v = 1 << (bd - 1);
     if (am) {
       const int u = i < corner ? i / us : (i == corner ? 2 * U : 2 * U + 1 + (i - corner - 1) / us);
       int src = i;
-      if (!((am >> u) & 1)) {
+      if (!all_av && !((am >> u) & 1)) {
         const unsigned long long lower = am & ((1ull << u) - 1);
         int j, last;
         if (lower) { j = 63 - __builtin_clzll(lower); last = 1; } else { j = __builtin_ctzll(am); last = 0; }
@@ -178,10 +175,17 @@ __device__ __attribute__((always_inline)) inline void intra_tu(const PicDev& P, 
 #else
   const int* f = filt ? W.filt : W.line;
 #endif
+
   const bool edge = comp == 0 && N <= 16;                   // MAXIMUM_INTRA_FILTERED_WIDTH (TypeDef.h:117)
   // implicit RDPCM in a lossless CU: horizontal / vertical prediction without its edge filter (TComPrediction.cpp:476)
   const bool edge_ang = edge && !(t.bypass && (P.range_ext & HMGPU_REXT_IMPLICIT_RDPCM));
   int p[N];
+#if defined(INTRA_EXP) && (INTRA_EXP & 8)      // experiment (wrong samples): the row above copied down -- what the mode-specific prediction code costs
+  if (true) {
+#pragma unroll
+    for (int x = 0; x < N; x++) p[x] = f[corner + 1 + x];
+  } else
+#endif
   if (t.mode == 0) {
     const int left = f[corner - 1 - n], bl = f[corner - 1 - N], tr = f[corner + 1 + N];
 #pragma unroll
@@ -190,7 +194,7 @@ __device__ __attribute__((always_inline)) inline void intra_tu(const PicDev& P, 
       p[x] = ((left << LOG2N) + N + __mul24(x + 1, tr - left) + (ab << LOG2N) + __mul24(n + 1, bl - ab)) >> (LOG2N + 1);
     }
   } else if (t.mode == 1) {
-    const int dc = (wave_sum(active ? f[corner + 1 + n] + f[corner - 1 - n] : 0) + N) >> (LOG2N + 1);
+    const int dc = (wave_sum<N>(active ? f[corner + 1 + n] + f[corner - 1 - n] : 0) + N) >> (LOG2N + 1);
 #pragma unroll
     for (int x = 0; x < N; x++) p[x] = dc;
     if (edge) {
@@ -217,7 +221,9 @@ __device__ __attribute__((always_inline)) inline void intra_tu(const PicDev& P, 
         const int a_ = ver ? n : x, b_ = ver ? x : n;      // a_: index along the prediction direction, b_: across it
         const int pos = __mul24(a_ + 1, ang), di = pos >> 5, df = pos & 31;
         const int i0 = corner + sgn * (b_ + di + 1);
-        int v = df ? (__mul24(32 - df, f[i0]) + __mul24(df, f[i0 + sgn]) + 16) >> 5 : f[i0];
+        // (both samples always: with df = 0 the weights are 32 and 0, and loads that do not hang on a condition go out together --
+        // one trip to LDS for the row instead of one per sample; line[] / filt[] have room for the one entry past 4N)
+        int v = (__mul24(32 - df, f[i0]) + __mul24(df, f[i0 + sgn]) + 16) >> 5;
         if (ang == 0 && edge_ang && b_ == 0) v = clip3(0, maxv, v + ((f[corner - sgn * (a_ + 1)] - f[corner]) >> 1));
         p[x] = v;
       }
@@ -235,7 +241,7 @@ __device__ __attribute__((always_inline)) inline void intra_tu(const PicDev& P, 
       for (int x = 0; x < N; x++) {
         const int a_ = ver ? n : x, b_ = ver ? x : n;
         const int pos = __mul24(a_ + 1, ang), di = pos >> 5, df = pos & 31;
-        p[x] = df ? (__mul24(32 - df, r[b_ + di + 1]) + __mul24(df, r[b_ + di + 2]) + 16) >> 5 : r[b_ + di + 1];
+        p[x] = (__mul24(32 - df, r[b_ + di + 1]) + __mul24(df, r[b_ + di + 2]) + 16) >> 5;
       }
     }
   }
@@ -329,6 +335,7 @@ struct TuRun { uint8_t z, z_cu, log2n, kind; };             // kind 0: transform
 struct IntraSched {
   TuRun tu[256];
   uint32_t need_col[256];        // bit y: unit (x4 - 1, y) of the column left of the TU must be final (the left CTU's last column when x4 = 0)
+  uint64_t avail[256];           // bit u: reference unit u of the TU (intra_tu's numbering) is available (6.4.1 + constrained intra prediction)
   uint64_t need_row[256];        // bit c + 1: unit (c, y4 - 1), c = -1 .. 31, of the row above the TU (the row of the CTUs above when y4 = 0)
   uint32_t done_r[16], done_c[16];   // final units per row (bit x) / per column (bit y); set with LDS atomics by the wave that finished a TU
   uint32_t got[3];                   // border units of the neighbouring CTUs whose samples are in LDS (L.pix columns 0, 1 / L.top): column | row lo | row hi
@@ -508,6 +515,23 @@ __device__ __attribute__((always_inline)) inline void intra_ctu(const PicDev& P,
       else for (int c = x4; c < min(pw, x4 + 2 * U); c++) if (z_of(c, y4 - 1) < e.z) nr |= 1ull << (c + 1);
     }
     Q.need_col[i] = nc; Q.need_row[i] = nr;
+    // availability of the TU's reference units (intra_tu: 2U units of the left column bottom-up, the corner, 2U units of the row above)
+    uint64_t am = 0;
+    if (!e.kind) {
+      const int lx = ctu_x + 4 * x4, ly = ctu_y + 4 * y4;
+      for (int u = 0; u <= 4 * U; u++) {
+        int px, py;
+        if (u < 2 * U) { px = lx - 4; py = ly + 4 * (2 * U - 1 - u); }
+        else if (u == 2 * U) { px = lx - 4; py = ly - 4; }
+        else { px = lx + 4 * (u - 2 * U - 1); py = ly - 4; }
+#if defined(INTRA_EXP) && (INTRA_EXP & 4)      // experiment (wrong samples): every unit counts as available
+        if (px >= 0 && py >= 0) am |= 1ull << u;
+#else
+        if (intra_avail(P, ctu, e.z, px, py, cip != 0, (unsigned)nb_same, L.m_pred)) am |= 1ull << u;
+#endif
+      }
+    }
+    Q.avail[i] = am;
   }
   wave_lds_sync();
     // ---- 3. what is final before anything ran (the neighbours may pass inter areas at once), the pending mask
@@ -577,7 +601,10 @@ __device__ __attribute__((always_inline)) inline void intra_ctu(const PicDev& P,
     }
     old = (uint32_t)__builtin_amdgcn_readfirstlane((int)old);
     if (!((old >> (i & 31)) & 1)) continue;                  // another wave was faster
-    const TuRun e = Q.tu[i];
+    // everything about the TU is the same in all lanes, but it comes out of LDS into vector registers: moved to scalar ones, what is derived
+    // from it (coordinates, the mode's angle, branch conditions) runs on the scalar unit beside the lanes' own work
+    auto uni = [](int v) { return __builtin_amdgcn_readfirstlane(v); };
+    const TuRun e = __builtin_bit_cast(TuRun, (uint32_t)uni((int)__builtin_bit_cast(uint32_t, Q.tu[i])));
     int x4, y4, U;
     footprint(e, x4, y4, U);
     const int z = e.z_cu, zc = e.z;
@@ -597,19 +624,23 @@ __device__ __attribute__((always_inline)) inline void intra_ctu(const PicDev& P,
         }
       }
     } else {
-      const int depth = L.m_depth[z];
+      const int depth = uni(L.m_depth[z]);
       const int log2cu = P.log2ctu - depth;
-      const int tr = L.m_tr[zc];
+      const int tr = uni(L.m_tr[zc]);
       TuCtx t;
       t.comp = comp; t.ctu = ctu; t.z_tu = zc; t.cip = cip; t.slice = slice; t.tile = tile; t.nb_same = nb_same;
       t.cx0 = ctu_x >> cs; t.cy0 = ctu_y >> cs;
       t.x0 = (ctu_x + 4 * x4) >> cs; t.y0 = (ctu_y + 4 * y4) >> cs;
       t.log2n = e.log2n;
-      int mode = L.m_dir[zc];
-      if (comp && mode == 36) mode = L.m_dirl[z];        // DM_CHROMA_IDX (TDecCu.cpp:523-524): the luma mode of the CU's first partition (z: the CU's origin)
+      int mode = uni(L.m_dir[zc]);
+      if (comp && mode == 36) mode = uni(L.m_dirl[z]);   // DM_CHROMA_IDX (TDecCu.cpp:523-524): the luma mode of the CU's first partition (z: the CU's origin)
       t.mode = mode;
-      t.cbf = (L.m_cbf[zc] >> tr) & 1;
-      t.bypass = L.m_byp[zc];
+      {
+        const uint64_t a = Q.avail[i];
+        t.am = (unsigned long long)(uint32_t)uni((int)(uint32_t)a) | ((unsigned long long)(uint32_t)uni((int)(uint32_t)(a >> 32)) << 32);
+      }
+      t.cbf = (uni(L.m_cbf[zc]) >> tr) & 1;
+      t.bypass = uni(L.m_byp[zc]);
       fetch_border(P, comp, ctu, x4 == 0 ? Q.need_col[i] : 0u, y4 == 0 ? Q.need_row[i] : 0ull, Q, L);
 #ifdef INTRA_TIMING
       if (lane == 0) { atomicMin(&Q.t_first, wall_clock64()); atomicAdd(&Q.n_run, 1u); }
