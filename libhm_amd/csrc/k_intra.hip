@@ -641,7 +641,8 @@ __device__ __attribute__((always_inline)) inline void intra_ctu(const PicDev& P,
       }
       t.cbf = (uni(L.m_cbf[zc]) >> tr) & 1;
       t.bypass = uni(L.m_byp[zc]);
-      fetch_border(P, comp, ctu, x4 == 0 ? Q.need_col[i] : 0u, y4 == 0 ? Q.need_row[i] : 0ull, Q, L);
+      if (x4 == 0 || y4 == 0)                                   // (a TU inside the CTU reads nothing from next door)
+        fetch_border(P, comp, ctu, x4 == 0 ? Q.need_col[i] : 0u, y4 == 0 ? Q.need_row[i] : 0ull, Q, L);
 #ifdef INTRA_TIMING
       if (lane == 0) { atomicMin(&Q.t_first, wall_clock64()); atomicAdd(&Q.n_run, 1u); }
 #endif
