@@ -58,6 +58,8 @@ struct IntraLds {
 struct TuCtx {
   int comp, ctu, z_tu, log2n, mode, cbf, bypass, x0, y0;          // x0, y0: component samples
   int cip, slice, tile, nb_same;
+  // picture constants, read from the descriptor ONCE per CTU (through `P` every use is a fresh scalar load: stores may alias the descriptor)
+  int16_t* plane; int pitch, bd, log2ctu, rext, strong;
   unsigned long long am;                                          // availability of the TU's 4U + 1 reference units (IntraSched::avail)                             // per-CTU constants: constrained intra pred, chroma QP offset, slice / tile index, neighbours in the same slice and tile
   int cx0, cy0;                                                   // CTU origin in component samples
 };
@@ -98,9 +100,9 @@ __device__ __attribute__((always_inline)) inline void intra_tu(const PicDev& P, 
   constexpr int N = 1 << LOG2N;
   const int lane = threadIdx.x & 63;
   const int comp = t.comp, cs = comp ? 1 : 0;
-  const int bd = P.bd[comp], maxv = (1 << bd) - 1;
-  const int pitch = P.pitch[comp];
-  int16_t* plane = P.rec[comp];
+  const int bd = t.bd, maxv = (1 << bd) - 1;
+  const int pitch = t.pitch;
+  int16_t* plane = t.plane;
   const int us = 4 >> cs, U = N / us;                      // samples per availability unit, units per TU side
   const int corner = 2 * N, total = 4 * N + 1;
   const int lx = t.x0 << cs, ly = t.y0 << cs;              // TU origin in luma samples
@@ -140,7 +142,7 @@ __device__ __attribute__((always_inline)) inline void intra_tu(const PicDev& P, 
   // ---- B. smoothing (filteringIntraReferenceSamples + initAdiPatternChType); most TUs are not smoothed (chroma, 4x4, DC,
   // the modes near horizontal / vertical) and predict straight from line[]: one LDS round trip less on the serial chain
   const int thr = LOG2N == 2 ? 10 : LOG2N == 3 ? 7 : LOG2N == 4 ? 1 : 0;
-  const bool filt = comp == 0 && t.mode != 1 && min(abs(t.mode - 10), abs(t.mode - 26)) > thr && !(P.range_ext & HMGPU_REXT_INTRA_SMOOTHING_DISABLED);
+  const bool filt = comp == 0 && t.mode != 1 && min(abs(t.mode - 10), abs(t.mode - 26)) > thr && !(t.rext & HMGPU_REXT_INTRA_SMOOTHING_DISABLED);
 #if defined(INTRA_EXP) && (INTRA_EXP & 2)      // experiment: no smoothing pass
   if (false) {
 #else
@@ -148,7 +150,7 @@ __device__ __attribute__((always_inline)) inline void intra_tu(const PicDev& P, 
 #endif
     bool strong = false;
     int bl = 0, tl = 0, tr = 0;
-    if (N == 32 && P.strong_intra_smoothing) {
+    if (N == 32 && t.strong) {
       bl = W.line[0]; tl = W.line[corner]; tr = W.line[total - 1];
       const int th = 1 << (bd - 5);
       strong = abs(bl + tl - 2 * W.line[N]) < th && abs(tl + tr - 2 * W.line[corner + N]) < th;
@@ -178,7 +180,7 @@ __device__ __attribute__((always_inline)) inline void intra_tu(const PicDev& P, 
 
   const bool edge = comp == 0 && N <= 16;                   // MAXIMUM_INTRA_FILTERED_WIDTH (TypeDef.h:117)
   // implicit RDPCM in a lossless CU: horizontal / vertical prediction without its edge filter (TComPrediction.cpp:476)
-  const bool edge_ang = edge && !(t.bypass && (P.range_ext & HMGPU_REXT_IMPLICIT_RDPCM));
+  const bool edge_ang = edge && !(t.bypass && (t.rext & HMGPU_REXT_IMPLICIT_RDPCM));
   int p[N];
 #if defined(INTRA_EXP) && (INTRA_EXP & 8)      // experiment (wrong samples): the row above copied down -- what the mode-specific prediction code costs
   if (true) {
@@ -256,7 +258,7 @@ __device__ __attribute__((always_inline)) inline void intra_tu(const PicDev& P, 
   if (t.cbf && active) {
 #endif
     const int rx = t.x0 - t.cx0, ry = t.y0 - t.cy0 + n;                    // inside the CTU, component samples
-    const int tpr = ((1 << P.log2ctu) >> cs) >> 3;                          // tiles per CTU row
+    const int tpr = ((1 << t.log2ctu) >> cs) >> 3;                          // tiles per CTU row
     const int16_t* r = &L.res[((ry >> 3) * tpr + (rx >> 3)) * 64 + resid_slot(ry) * 8];
     if constexpr (N == 4) { const u32x2 a = *reinterpret_cast<const u32x2*>(r + (rx & 4)); res[0] = a.x; res[1] = a.y; }
     else {
@@ -386,10 +388,9 @@ __device__ __attribute__((always_inline)) inline void poll_neighbours(const PicD
 // samples of the neighbouring CTUs' border units the TU needs (all final: the TU was ready) into LDS, unless there already
 // (the masks of what has been fetched are shared by the waves of the workgroup: a wave with nothing to run fetches what has become final
 // next door, so that the TUs along the CTU's left and top border find their reference samples in LDS)
-__device__ __attribute__((always_inline)) inline void fetch_border(const PicDev& P, int comp, int ctu, uint32_t need_col, uint64_t need_row, IntraSched& Q, IntraLds& L) {
+// org: the CTU's first sample of this component in the picture, pitch: the plane's
+__device__ __attribute__((always_inline)) inline void fetch_border(const int16_t* org, int pitch, int comp, uint32_t need_col, uint64_t need_row, IntraSched& Q, IntraLds& L) {
   const int cs = comp ? 1 : 0, lane = threadIdx.x & 63, us = 4 >> cs;
-  const int ctu_x = (ctu % P.ctus_w) << P.log2ctu, ctu_y = (ctu / P.ctus_w) << P.log2ctu;
-  const int16_t* org = P.rec[comp] + (ptrdiff_t)(ctu_y >> cs) * P.pitch[comp] + (ctu_x >> cs);
   const uint32_t mc = need_col & ~Q.got[0];
   const uint64_t mr = need_row & ~((uint64_t)Q.got[1] | ((uint64_t)Q.got[2] << 32));
   if (!mc && !mr) return;
@@ -398,7 +399,7 @@ __device__ __attribute__((always_inline)) inline void fetch_border(const PicDev&
     const int u = lane >> 2, r = lane & 3;
     if (((mc >> u) & 1) && r < us) {
       const int row = u * us + r;
-      reinterpret_cast<uint32_t*>(&L.pix[row][0])[0] = ld_coh(reinterpret_cast<const uint32_t*>(org + (ptrdiff_t)row * P.pitch[comp] - 2));
+      reinterpret_cast<uint32_t*>(&L.pix[row][0])[0] = ld_coh(reinterpret_cast<const uint32_t*>(org + (ptrdiff_t)row * pitch - 2));
     }
   }
   if (mr) {
@@ -407,7 +408,7 @@ __device__ __attribute__((always_inline)) inline void fetch_border(const PicDev&
     for (int d = lane; d < dwords && d < 66; d += 64) {
       const int col = 2 * d - 2;                            // first column of the dword
       const int c = col < 0 ? -1 : col / us;
-      if ((mr >> (c + 1)) & 1) reinterpret_cast<uint32_t*>(L.top)[d] = ld_coh(reinterpret_cast<const uint32_t*>(org - P.pitch[comp] - 2) + d);
+      if ((mr >> (c + 1)) & 1) reinterpret_cast<uint32_t*>(L.top)[d] = ld_coh(reinterpret_cast<const uint32_t*>(org - pitch - 2) + d);
     }
   }
   wave_lds_sync();
@@ -440,6 +441,10 @@ __device__ __attribute__((always_inline)) inline void intra_ctu(const PicDev& P,
     for (int k = 0; k < 4; k++)
       if (nbc[k] >= 0 && ldg(P.slice_idx + nbc[k]) == slice && ldg(P.tile_idx + nbc[k]) == tile) nb_same |= 1 << k;
   }
+  // the picture constants the TU chain needs, out of the descriptor once
+  const int h_bd = P.bd[comp], h_pitch = P.pitch[comp], h_log2ctu = P.log2ctu, h_rext = P.range_ext, h_strong = P.strong_intra_smoothing;
+  int16_t* const h_plane = P.rec[comp];
+  const int16_t* const org = h_plane + (ptrdiff_t)(ctu_y >> cs) * h_pitch + (ctu_x >> cs);
   const int wv = threadIdx.x >> 6;
   auto mark_done = [&](int x4, int y4, int U) {           // units [x4, x4 + U) x [y4, y4 + U) are final
     if (lane < 16) {
@@ -552,7 +557,7 @@ __device__ __attribute__((always_inline)) inline void intra_ctu(const PicDev& P,
 #else
 #define TM_ADD(field)
 #endif
-  if (wv == (int)(blockDim.x >> 6) - 1) fetch_border(P, comp, ctu, nb.ext_col, nb.ext_row, Q, L);   // what is final next door already
+  if (wv == (int)(blockDim.x >> 6) - 1) fetch_border(org, h_pitch, comp, nb.ext_col, nb.ext_row, Q, L);   // what is final next door already
   for (;;) {
     // the scheduler words in LDS (pend, done_c, done_r, got) are updated by the other waves with atomics: read them afresh in every round
     asm volatile("" ::: "memory");
@@ -588,7 +593,7 @@ __device__ __attribute__((always_inline)) inline void intra_ctu(const PicDev& P,
       if (__hip_atomic_load(&Q.running, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0 || (spins & 15) == 0) {
         if (spins > (1u << 22)) { if (lane == 0) atomicOr(P.fault, 1u); nb.broken = true; }
         poll_neighbours(P, nb, pw);
-        fetch_border(P, comp, ctu, nb.ext_col, nb.ext_row, Q, L);   // whatever has become final next door
+        fetch_border(org, h_pitch, comp, nb.ext_col, nb.ext_row, Q, L);   // whatever has become final next door
       }
       TM_ADD(t_idle)
       continue;
@@ -614,7 +619,7 @@ __device__ __attribute__((always_inline)) inline void intra_ctu(const PicDev& P,
       const int sx = (ctu_x + 4 * x4) >> cs, sy = (ctu_y + 4 * y4) >> cs;
       if (lane < n_cu) {
         const int16_t* src = P.pcm[comp] + (size_t)ctu * ((size_t)(1 << (2 * P.log2ctu)) >> (comp ? 2 : 0)) + (comp ? 4 : 16) * z + lane * n_cu;
-        uint32_t* row = reinterpret_cast<uint32_t*>(P.rec[comp] + (ptrdiff_t)(sy + lane) * P.pitch[comp] + sx);
+        uint32_t* row = reinterpret_cast<uint32_t*>(h_plane + (ptrdiff_t)(sy + lane) * h_pitch + sx);
         uint32_t* lrow = reinterpret_cast<uint32_t*>(&L.pix[sy - (ctu_y >> cs) + lane][sx - (ctu_x >> cs) + 2]);
         for (int x = 0; x < n_cu; x += 2) {
           const uint32_t v = ldg(reinterpret_cast<const uint32_t*>(src + x));
@@ -624,14 +629,13 @@ __device__ __attribute__((always_inline)) inline void intra_ctu(const PicDev& P,
         }
       }
     } else {
-      const int depth = uni(L.m_depth[z]);
-      const int log2cu = P.log2ctu - depth;
       const int tr = uni(L.m_tr[zc]);
       TuCtx t;
       t.comp = comp; t.ctu = ctu; t.z_tu = zc; t.cip = cip; t.slice = slice; t.tile = tile; t.nb_same = nb_same;
       t.cx0 = ctu_x >> cs; t.cy0 = ctu_y >> cs;
       t.x0 = (ctu_x + 4 * x4) >> cs; t.y0 = (ctu_y + 4 * y4) >> cs;
       t.log2n = e.log2n;
+      t.plane = h_plane; t.pitch = h_pitch; t.bd = h_bd; t.log2ctu = h_log2ctu; t.rext = h_rext; t.strong = h_strong;
       int mode = uni(L.m_dir[zc]);
       if (comp && mode == 36) mode = uni(L.m_dirl[z]);   // DM_CHROMA_IDX (TDecCu.cpp:523-524): the luma mode of the CU's first partition (z: the CU's origin)
       t.mode = mode;
@@ -642,7 +646,7 @@ __device__ __attribute__((always_inline)) inline void intra_ctu(const PicDev& P,
       t.cbf = (uni(L.m_cbf[zc]) >> tr) & 1;
       t.bypass = uni(L.m_byp[zc]);
       if (x4 == 0 || y4 == 0)                                   // (a TU inside the CTU reads nothing from next door)
-        fetch_border(P, comp, ctu, x4 == 0 ? Q.need_col[i] : 0u, y4 == 0 ? Q.need_row[i] : 0ull, Q, L);
+        fetch_border(org, h_pitch, comp, x4 == 0 ? Q.need_col[i] : 0u, y4 == 0 ? Q.need_row[i] : 0ull, Q, L);
 #ifdef INTRA_TIMING
       if (lane == 0) { atomicMin(&Q.t_first, wall_clock64()); atomicAdd(&Q.n_run, 1u); }
 #endif
