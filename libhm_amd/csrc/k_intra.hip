@@ -767,9 +767,10 @@ __global__ void __launch_bounds__(64 * WAVES) k_intra(const PicDev* __restrict__
 
 void launch_intra(const PicDev* pics, const Batch& b, const int32_t* order, int num_ctus, hipStream_t s) {
   // measured on 2160p I pictures: one picture 17.9 / 11.6 / 9.7 ms with 1 / 2 / 4 waves per CTU, sixteen at once 19.4 / 13.5 / 17.7;
-  // with the residual from k_itx (140 instead of 212 VGPRs: three waves per SIMD) 8.7 ms (4 or 6 waves), sixteen 11.4 / 10.8 / 11.7 (2 / 3 / 4)
+  // with the residual from k_itx (140 instead of 212 VGPRs: three waves per SIMD) 8.7 ms (4 or 6 waves), sixteen 11.4 / 10.8 / 11.7 (2 / 3 / 4);
+  // after the trims of the TU chain: 7.78 / 7.41 / 7.27 / 7.15 ms with 3 / 4 / 6 / 8 waves, sixteen 9.93 / 9.66 / 10.7 (2 / 3 / 4)
 #ifndef INTRA_WAVES_ONE
-#define INTRA_WAVES_ONE 4
+#define INTRA_WAVES_ONE 8
 #define INTRA_WAVES_MANY 3
 #endif
   if (b.n >= 4) hipLaunchKernelGGL(k_intra<INTRA_WAVES_MANY>, dim3((unsigned)b.n * 3, (unsigned)num_ctus), dim3(64 * INTRA_WAVES_MANY), 0, s, pics, b, order);
