@@ -216,18 +216,41 @@ __device__ __attribute__((always_inline)) inline void intra_tu(const PicDev& P, 
     const int inv = aa == 0 ? 0 : aa == 1 ? 4096 : aa == 2 ? 1638 : aa == 3 ? 910 : aa == 4 ? 630 : aa == 5 ? 482 : aa == 6 ? 390 : aa == 7 ? 315 : 256;
     const int ang = am_ < 0 ? -ang_abs : ang_abs;
     const int sgn = ver ? 1 : -1;                           // MAIN(i) = f[corner + sgn*i], SIDE(i) = f[corner - sgn*i]
-    if (ang >= 0) {
-      // no projected side samples: the main reference is f[] itself (another LDS round trip less)
+    if (ang == 0) {
+      // pure vertical (26) / horizontal (10): a copy of the row above / the left column, with the edge filter on the first column / row of luma
+      // TUs up to 16x16 (xPredIntraAng, TComPrediction.cpp:279-300) -- kept apart from the interpolating modes: a condition inside their loop
+      // would tie every sample's loads to its own basic block, one trip to LDS per sample instead of one per row
+      if (ver) {
 #pragma unroll
-      for (int x = 0; x < N; x++) {
-        const int a_ = ver ? n : x, b_ = ver ? x : n;      // a_: index along the prediction direction, b_: across it
-        const int pos = __mul24(a_ + 1, ang), di = pos >> 5, df = pos & 31;
-        const int i0 = corner + sgn * (b_ + di + 1);
-        // (both samples always: with df = 0 the weights are 32 and 0, and loads that do not hang on a condition go out together --
-        // one trip to LDS for the row instead of one per sample; line[] / filt[] have room for the one entry past 4N)
-        int v = (__mul24(32 - df, f[i0]) + __mul24(df, f[i0 + sgn]) + 16) >> 5;
-        if (ang == 0 && edge_ang && b_ == 0) v = clip3(0, maxv, v + ((f[corner - sgn * (a_ + 1)] - f[corner]) >> 1));
-        p[x] = v;
+        for (int x = 0; x < N; x++) p[x] = f[corner + 1 + x];
+        if (edge_ang) p[0] = clip3(0, maxv, p[0] + ((f[corner - (n + 1)] - f[corner]) >> 1));
+      } else {
+        const int left = f[corner - 1 - n];
+#pragma unroll
+        for (int x = 0; x < N; x++) p[x] = left;
+        if (edge_ang && n == 0) {
+          const int c0 = f[corner];
+#pragma unroll
+          for (int x = 0; x < N; x++) p[x] = clip3(0, maxv, left + ((f[corner + 1 + x] - c0) >> 1));
+        }
+      }
+    } else if (ang > 0) {
+      // no projected side samples: the main reference is f[] itself (another LDS round trip less).  Both samples always: with df = 0 the
+      // weights are 32 and 0, and loads that do not hang on a condition go out together (line[] / filt[] have room for the entry past 4N)
+      if (ver) {
+        const int pos = __mul24(n + 1, ang), di = pos >> 5, df = pos & 31;      // a lane's row: one offset, one weight
+        int r[N + 1];
+#pragma unroll
+        for (int x = 0; x <= N; x++) r[x] = f[corner + 1 + di + x];
+#pragma unroll
+        for (int x = 0; x < N; x++) p[x] = (__mul24(32 - df, r[x]) + __mul24(df, r[x + 1]) + 16) >> 5;
+      } else {
+#pragma unroll
+        for (int x = 0; x < N; x++) {
+          const int pos = (x + 1) * ang, di = pos >> 5, df = pos & 31;           // the same for all lanes
+          const int i0 = corner - (n + di + 1);
+          p[x] = (__mul24(32 - df, f[i0]) + __mul24(df, f[i0 - 1]) + 16) >> 5;
+        }
       }
     } else {
       // main reference with its extension: proj[k + 32], k in [-N, N]; main = row above for vertical modes, left column otherwise
@@ -239,11 +262,19 @@ __device__ __attribute__((always_inline)) inline void intra_tu(const PicDev& P, 
       }
       wave_lds_sync();
       const int* r = W.proj + 32;
+      if (ver) {
+        const int pos = __mul24(n + 1, ang), di = pos >> 5, df = pos & 31;      // a lane's row: one offset, one weight
+        int q[N + 1];
 #pragma unroll
-      for (int x = 0; x < N; x++) {
-        const int a_ = ver ? n : x, b_ = ver ? x : n;
-        const int pos = __mul24(a_ + 1, ang), di = pos >> 5, df = pos & 31;
-        p[x] = (__mul24(32 - df, r[b_ + di + 1]) + __mul24(df, r[b_ + di + 2]) + 16) >> 5;
+        for (int x = 0; x <= N; x++) q[x] = r[x + di + 1];
+#pragma unroll
+        for (int x = 0; x < N; x++) p[x] = (__mul24(32 - df, q[x]) + __mul24(df, q[x + 1]) + 16) >> 5;
+      } else {
+#pragma unroll
+        for (int x = 0; x < N; x++) {
+          const int pos = (x + 1) * ang, di = pos >> 5, df = pos & 31;           // the same for all lanes
+          p[x] = (__mul24(32 - df, r[n + di + 1]) + __mul24(df, r[n + di + 2]) + 16) >> 5;
+        }
       }
     }
   }
