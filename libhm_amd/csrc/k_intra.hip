@@ -60,7 +60,8 @@ struct TuCtx {
   int cip, slice, tile, nb_same;
   // picture constants, read from the descriptor ONCE per CTU (through `P` every use is a fresh scalar load: stores may alias the descriptor)
   int16_t* plane; int pitch, bd, log2ctu, rext, strong;
-  unsigned long long am;                                          // availability of the TU's 4U + 1 reference units (IntraSched::avail)                             // per-CTU constants: constrained intra pred, chroma QP offset, slice / tile index, neighbours in the same slice and tile
+  unsigned long long am;                                          // availability of the TU's 4U + 1 reference units (IntraSched::avail)
+  int sub_lo, sub_hi;                                             // available units form ONE run: substitution = clamping the line index to [sub_lo, sub_hi]; else sub_lo < 0                             // per-CTU constants: constrained intra pred, chroma QP offset, slice / tile index, neighbours in the same slice and tile
   int cx0, cy0;                                                   // CTU origin in component samples
 };
 
@@ -114,13 +115,13 @@ __device__ __attribute__((always_inline)) inline void intra_tu(const PicDev& P, 
   // ---- A. the reference line.  Availability per unit -- units [0, 2U) left column bottom-up, 2U the corner, (2U, 4U] the row above -- is a
   // property of the TU's position: worked out for the whole list when the CTU starts (IntraSched::avail), not on the serial chain
   const unsigned long long am = t.am;
-  const bool all_av = am == (2ull << (4 * U)) - 1ull;          // the common case away from picture, slice and decoding-order borders: no substitution
   for (int i = lane; i < total; i += 64) {
     int v = 1 << (bd - 1);
     if (am) {
       const int u = i < corner ? i / us : (i == corner ? 2 * U : 2 * U + 1 + (i - corner - 1) / us);
       int src = i;
-      if (!all_av && !((am >> u) & 1)) {
+      if (t.sub_lo >= 0) src = min(max(i, t.sub_lo), t.sub_hi);      // one run of available units (all available included): padding is a clamp
+      else if (!((am >> u) & 1)) {
         const unsigned long long lower = am & ((1ull << u) - 1);
         int j, last;
         if (lower) { j = 63 - __builtin_clzll(lower); last = 1; } else { j = __builtin_ctzll(am); last = 0; }
@@ -368,6 +369,7 @@ struct TuRun { uint8_t z, z_cu, log2n, kind; };             // kind 0: transform
 struct IntraSched {
   TuRun tu[256];
   uint32_t need_col[256];        // bit y: unit (x4 - 1, y) of the column left of the TU must be final (the left CTU's last column when x4 = 0)
+  uint32_t clampi[256];          // the run of available units as line indices: first sample | last sample << 16 (0xffffffff: not one run, the general substitution applies)
   uint64_t avail[256];           // bit u: reference unit u of the TU (intra_tu's numbering) is available (6.4.1 + constrained intra prediction)
   uint64_t need_row[256];        // bit c + 1: unit (c, y4 - 1), c = -1 .. 31, of the row above the TU (the row of the CTUs above when y4 = 0)
   uint32_t done_r[16], done_c[16];   // final units per row (bit x) / per column (bit y); set with LDS atomics by the wave that finished a TU
@@ -568,6 +570,19 @@ __device__ __attribute__((always_inline)) inline void intra_ctu(const PicDev& P,
       }
     }
     Q.avail[i] = am;
+    // fillReferenceSamples pads unavailable samples from the nearest available one before them (the first available one for those in front):
+    // when the available units are one run -- missing below-left and / or above-right units, the usual case -- that is a clamp of the index
+    uint32_t cl = 0xffffffffu;
+    if (am != 0) {
+      const int j0 = __builtin_ctzll(am), j1 = 63 - __builtin_clzll(am);
+      if ((am >> j0) == (2ull << (j1 - j0)) - 1ull) {
+        const int us = 4 >> cs, nn = U * us, corner = 2 * nn;      // samples per unit, TU size, index of the corner sample
+        const int lo = j0 < 2 * U ? j0 * us : (j0 == 2 * U ? corner : corner + 1 + (j0 - 2 * U - 1) * us);
+        const int hi = j1 < 2 * U ? j1 * us + us - 1 : (j1 == 2 * U ? corner : corner + 1 + (j1 - 2 * U - 1) * us + us - 1);
+        cl = (uint32_t)lo | ((uint32_t)hi << 16);
+      }
+    }
+    Q.clampi[i] = cl;
   }
   wave_lds_sync();
     // ---- 3. what is final before anything ran (the neighbours may pass inter areas at once), the pending mask
@@ -673,6 +688,8 @@ __device__ __attribute__((always_inline)) inline void intra_ctu(const PicDev& P,
       {
         const uint64_t a = Q.avail[i];
         t.am = (unsigned long long)(uint32_t)uni((int)(uint32_t)a) | ((unsigned long long)(uint32_t)uni((int)(uint32_t)(a >> 32)) << 32);
+        const uint32_t cl = (uint32_t)uni((int)Q.clampi[i]);
+        t.sub_lo = cl == 0xffffffffu ? -1 : (int)(cl & 0xffff); t.sub_hi = (int)(cl >> 16);
       }
       t.cbf = (uni(L.m_cbf[zc]) >> tr) & 1;
       t.bypass = uni(L.m_byp[zc]);
