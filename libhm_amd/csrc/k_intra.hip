@@ -365,7 +365,10 @@ __device__ __attribute__((always_inline)) inline void intra_stage(const PicDev& 
 // CTUs' border units come from one published word per CTU and component:
 //   PicDev::intra_done[comp][ctu] = units of the CTU's LAST COLUMN that are final (bit y) | units of its LAST ROW << 16 (bit 16 + x).
 // A CTU no longer waits for its neighbours as a whole, and not in their z order either.
-struct TuRun { uint8_t z, z_cu, log2n, kind; };             // kind 0: transform unit, 1: PCM coding unit (log2n: its size)
+// kind 0: transform unit, 1: PCM coding unit (log2n: its size), 2: the first of the four 4x4 luma TUs of an 8x8 area -- it stands for all
+// four in the list: one wave runs them one after the other (they are a dependent chain anyway) without going back to the list in between --,
+// 3: the other three (list entries for their availability masks only, never pending)
+struct TuRun { uint8_t z, z_cu, log2n, kind; };
 struct IntraSched {
   TuRun tu[256];
   uint32_t need_col[256];        // bit y: unit (x4 - 1, y) of the column left of the TU must be final (the left CTU's last column when x4 = 0)
@@ -375,6 +378,7 @@ struct IntraSched {
   uint32_t done_r[16], done_c[16];   // final units per row (bit x) / per column (bit y); set with LDS atomics by the wave that finished a TU
   uint32_t got[3];                   // border units of the neighbouring CTUs whose samples are in LDS (L.pix columns 0, 1 / L.top): column | row lo | row hi
   uint32_t pend[8];                  // list entries nobody has taken yet (bit i & 31 of pend[i >> 5]); a wave takes one with an atomic AND
+  uint8_t member[64][4];             // list entries of the four 4x4 luma TUs of every 8x8 area (kinds 2 and 3), by z >> 2 and z & 3
   int32_t n_tus, running;            // list length; waves inside a TU right now
 #ifdef INTRA_TIMING                  // diagnostic build: where the time of a CTU goes (printed by k_intra for one CTU row)
   unsigned long long t_tu, t_claim, t_post, t_idle, t_first, t_last;
@@ -522,7 +526,7 @@ __device__ __attribute__((always_inline)) inline void intra_ctu(const PicDev& P,
         const int tu_parts = 1 << (2 * (log2tu - 2));
         // chroma: four 4x4 luma TUs share one 4x4 chroma TU, with the first of them (TComTU.cpp:141-171)
         origin = (z & (tu_parts - 1)) == 0 && (comp == 0 || log2tu >= 3 || (z & 3) == 0);
-        e = TuRun{(uint8_t)z, (uint8_t)z_cu, (uint8_t)(comp == 0 ? log2tu : max(2, log2tu - 1)), 0};
+        e = TuRun{(uint8_t)z, (uint8_t)z_cu, (uint8_t)(comp == 0 ? log2tu : max(2, log2tu - 1)), (uint8_t)((comp == 0 && log2tu == 2) ? ((z & 3) ? 3 : 2) : 0)};
       }
     }
     // rows / columns of the done masks covered by this group of 64 units
@@ -544,18 +548,20 @@ __device__ __attribute__((always_inline)) inline void intra_ctu(const PicDev& P,
     footprint(e, x4, y4, U);
     uint32_t nc = 0;
     uint64_t nr = 0;
-    if (!e.kind) {
+    if (e.kind >= 2) Q.member[e.z >> 2][e.z & 3] = (uint8_t)i;
+    if (e.kind == 0 || e.kind == 2) {
+      const int Un = e.kind == 2 ? 2 : U;                 // a group of four 4x4 TUs waits for what an 8x8 TU in its place would wait for
       // left column and below-left: units (x4 - 1, y4 .. y4 + 2U - 1); the corner (x4 - 1, y4 - 1) belongs to this column too when y4 > 0
-      for (int y = (y4 > 0 ? y4 - 1 : 0); y < min(pw, y4 + 2 * U); y++)
+      for (int y = (y4 > 0 ? y4 - 1 : 0); y < min(pw, y4 + 2 * Un); y++)
         if (x4 == 0 || z_of(x4 - 1, y) < e.z) nc |= 1u << y;
       // row above and above-right: units (x4 - 1 .. x4 + 2U - 1, y4 - 1); for y4 = 0 the row of the CTUs above, corner included
-      if (y4 == 0) { for (int c = x4 - 1; c < x4 + 2 * U; c++) nr |= 1ull << (c + 1); }
-      else for (int c = x4; c < min(pw, x4 + 2 * U); c++) if (z_of(c, y4 - 1) < e.z) nr |= 1ull << (c + 1);
+      if (y4 == 0) { for (int c = x4 - 1; c < x4 + 2 * Un; c++) nr |= 1ull << (c + 1); }
+      else for (int c = x4; c < min(pw, x4 + 2 * Un); c++) if (z_of(c, y4 - 1) < e.z) nr |= 1ull << (c + 1);
     }
     Q.need_col[i] = nc; Q.need_row[i] = nr;
     // availability of the TU's reference units (intra_tu: 2U units of the left column bottom-up, the corner, 2U units of the row above)
     uint64_t am = 0;
-    if (!e.kind) {
+    if (e.kind != 1) {
       const int lx = ctu_x + 4 * x4, ly = ctu_y + 4 * y4;
       for (int u = 0; u <= 4 * U; u++) {
         int px, py;
@@ -589,6 +595,8 @@ __device__ __attribute__((always_inline)) inline void intra_ctu(const PicDev& P,
     if (lane < 8) Q.pend[lane] = n_tus >= 32 * (lane + 1) ? 0xffffffffu : (n_tus > 32 * lane ? (1u << (n_tus - 32 * lane)) - 1u : 0u);
     if (lane == 0) { Q.n_tus = n_tus; Q.running = 0; }
     if (lane < 3) Q.got[lane] = 0;
+    wave_lds_sync();
+    for (int i = lane; i < n_tus; i += 64) if (Q.tu[i].kind == 3) atomicAnd(&Q.pend[i >> 5], ~(1u << (i & 31)));     // run by their group's first TU
     wave_lds_sync();
     const uint32_t word0 = Q.done_c[pw - 1] | (Q.done_r[pw - 1] << 16);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -659,7 +667,7 @@ __device__ __attribute__((always_inline)) inline void intra_ctu(const PicDev& P,
     int x4, y4, U;
     footprint(e, x4, y4, U);
     const int z = e.z_cu, zc = e.z;
-    if (e.kind) {
+    if (e.kind == 1) {
       // PCM CU (TDecCu::xReconPCM, TDecCu.cpp:770-830): the transmitted samples, shifted up to the coding bit depth; lane n = row n
       const int n_cu = (1 << e.log2n) >> cs;
       const int sx = (ctu_x + 4 * x4) >> cs, sy = (ctu_y + 4 * y4) >> cs;
@@ -675,31 +683,53 @@ __device__ __attribute__((always_inline)) inline void intra_ctu(const PicDev& P,
         }
       }
     } else {
-      const int tr = uni(L.m_tr[zc]);
-      TuCtx t;
-      t.comp = comp; t.ctu = ctu; t.z_tu = zc; t.cip = cip; t.slice = slice; t.tile = tile; t.nb_same = nb_same;
-      t.cx0 = ctu_x >> cs; t.cy0 = ctu_y >> cs;
-      t.x0 = (ctu_x + 4 * x4) >> cs; t.y0 = (ctu_y + 4 * y4) >> cs;
-      t.log2n = e.log2n;
-      t.plane = h_plane; t.pitch = h_pitch; t.bd = h_bd; t.log2ctu = h_log2ctu; t.rext = h_rext; t.strong = h_strong;
-      int mode = uni(L.m_dir[zc]);
-      if (comp && mode == 36) mode = uni(L.m_dirl[z]);   // DM_CHROMA_IDX (TDecCu.cpp:523-524): the luma mode of the CU's first partition (z: the CU's origin)
-      t.mode = mode;
-      {
-        const uint64_t a = Q.avail[i];
-        t.am = (unsigned long long)(uint32_t)uni((int)(uint32_t)a) | ((unsigned long long)(uint32_t)uni((int)(uint32_t)(a >> 32)) << 32);
-        const uint32_t cl = (uint32_t)uni((int)Q.clampi[i]);
-        t.sub_lo = cl == 0xffffffffu ? -1 : (int)(cl & 0xffff); t.sub_hi = (int)(cl >> 16);
-      }
-      t.cbf = (uni(L.m_cbf[zc]) >> tr) & 1;
-      t.bypass = uni(L.m_byp[zc]);
-      if (x4 == 0 || y4 == 0)                                   // (a TU inside the CTU reads nothing from next door)
+      // one TU of the list: entry idx (its availability), first partition zs, origin unit (xs, ys) of the CTU
+      auto run_tu = [&](int idx, int zs, int xs, int ys) {
+        const int tr = uni(L.m_tr[zs]);
+        TuCtx t;
+        t.comp = comp; t.ctu = ctu; t.z_tu = zs; t.cip = cip; t.slice = slice; t.tile = tile; t.nb_same = nb_same;
+        t.cx0 = ctu_x >> cs; t.cy0 = ctu_y >> cs;
+        t.x0 = (ctu_x + 4 * xs) >> cs; t.y0 = (ctu_y + 4 * ys) >> cs;
+        t.log2n = e.log2n;
+        t.plane = h_plane; t.pitch = h_pitch; t.bd = h_bd; t.log2ctu = h_log2ctu; t.rext = h_rext; t.strong = h_strong;
+        int mode = uni(L.m_dir[zs]);
+        if (comp && mode == 36) mode = uni(L.m_dirl[z]);   // DM_CHROMA_IDX (TDecCu.cpp:523-524): the luma mode of the CU's first partition (z: the CU's origin)
+        t.mode = mode;
+        {
+          const uint64_t a = Q.avail[idx];
+          t.am = (unsigned long long)(uint32_t)uni((int)(uint32_t)a) | ((unsigned long long)(uint32_t)uni((int)(uint32_t)(a >> 32)) << 32);
+          const uint32_t cl = (uint32_t)uni((int)Q.clampi[idx]);
+          t.sub_lo = cl == 0xffffffffu ? -1 : (int)(cl & 0xffff); t.sub_hi = (int)(cl >> 16);
+        }
+        t.cbf = (uni(L.m_cbf[zs]) >> tr) & 1;
+        t.bypass = uni(L.m_byp[zs]);
+        intra_tu_any(P, t, L, W);
+      };
+      if (x4 == 0 || y4 == 0)                                   // (a TU inside the CTU reads nothing from next door; a group: what an 8x8 TU would read)
         fetch_border(org, h_pitch, comp, x4 == 0 ? Q.need_col[i] : 0u, y4 == 0 ? Q.need_row[i] : 0ull, Q, L);
 #ifdef INTRA_TIMING
       if (lane == 0) { atomicMin(&Q.t_first, wall_clock64()); atomicAdd(&Q.n_run, 1u); }
 #endif
       TM_ADD(t_claim)
-      intra_tu_any(P, t, L, W);
+      {
+        // one TU -- or the four 4x4 luma TUs of the area, in z order (each predicts from the ones before it); every one's units are published as
+        // it ends.  (One call site: the TU code is the bulk of this kernel's 47 KB.)
+        const int last = e.kind == 2 ? 3 : 0;
+        const uint32_t mem = e.kind == 2 ? (uint32_t)uni((int)*reinterpret_cast<const uint32_t*>(Q.member[zc >> 2])) : (uint32_t)i;
+        for (int j = 0; j <= last; j++) {
+          const int xs = x4 + (j & 1), ys = y4 + (j >> 1);
+          run_tu((int)((mem >> (8 * j)) & 0xff), zc + j, xs, ys);
+          if (j == last) break;                              // (the last one leaves through the common exit below)
+          wave_lds_sync();
+          mark_done(xs, ys, 1);
+          if (xs + 1 == pw || ys + 1 == pw) {
+            const uint32_t bits = (xs + 1 == pw ? 1u << ys : 0u) | (ys + 1 == pw ? (1u << xs) << 16 : 0u);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (lane == 0) __hip_atomic_fetch_or(nb.prog + ctu, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+        }
+        if (last) { x4 += 1; y4 += 1; }                      // the common exit publishes the fourth TU: unit (x4 + 1, y4 + 1), U = 1
+      }
       TM_ADD(t_tu)
     }
     wave_lds_sync();                                         // the TU's samples are in the CTU copy before its units count as final
