@@ -96,6 +96,41 @@ def test_synthetic_picture_matches_oracle(oracle, width, height, bd, bi, intra):
             assert np.array_equal(got[c], want_fin[c]), "fused loop filter comp %d" % c
 
 
+@pytest.mark.parametrize("width,height,bd,mode_probs,tr_split,intra,cip,slices,seed", [
+    (832, 480, 8, (0, 0, 0, 1, 0), 1.0, 1.0, 0, 1, 1),          # every 8x8 CU split into 4x4 TUs: groups of four 4x4 luma TUs everywhere
+    (832, 480, 10, (0, 0, 0.5, 0.5, 0), 0.6, 1.0, 0, 1, 2),     # 16x16 / 8x8 CUs, 8x8 and 4x4 TUs mixed
+    (200, 136, 8, (0, 0, 0, 1, 0), 0.7, 1.0, 0, 1, 3),          # partial CTUs on both borders (picture sizes are multiples of 8 only)
+    (832, 480, 10, (0.1, 0.3, 0.3, 0.2, 0.1), 0.5, 0.5, 1, 1, 4),   # constrained intra prediction beside inter CUs: availability with holes
+    (832, 480, 8, (0, 0.2, 0.4, 0.4, 0), 0.5, 1.0, 0, 5, 5),    # five slices starting mid-row: no references across their borders
+    (1920, 1080, 10, (0, 0, 0.3, 0.7, 0), 0.8, 1.0, 1, 3, 6)])
+def test_intra_scheduler_paths(oracle, width, height, bd, mode_probs, tr_split, intra, cip, slices, seed):
+    """the shapes k_intra's scheduler treats specially -- groups of four 4x4 luma TUs run as one entry, availability masks worked out
+    per TU when the CTU starts, reference padding as an index clamp or, where the available units have holes (constrained intra
+    prediction, slice borders), bit scans, residual from k_itx's tiles -- against the oracle; single call, then batch entry with compact levels"""
+    import libhm_amd
+    p = synth.make_picture(width, height, bd, seed=0x1A7 + seed, mode_probs=mode_probs, tr_split_prob=tr_split, intra_frac=intra, cbf_prob=0.7,
+                           sao=False, ref_handles=([0], [0]), num_slices=slices)
+    for sl in p.slices:
+        sl.constrained_intra_pred = cip
+    ref0 = synth.noise_planes(width, height, bd, 31)
+    cur = synth.blocky_planes(width, height, bd, 33)
+    want = [a.copy() for a in cur]
+    oracle.decompress_ctus(p.seq, p.slices, p.meta, p.coeffs, want, [ref0])
+    with libhm_amd.Context(p.seq) as ctx:
+        h0, hc = ctx.acquire(), ctx.acquire()
+        ctx.upload(h0, ref0)
+        ctx.upload(hc, cur)
+        ctx.decompress_pictures([(hc, p.slices, p.meta, p.coeffs)])
+        got = ctx.download(hc)
+        for c in range(3):
+            assert np.array_equal(got[c], want[c]), "reconstruction comp %d" % c
+        ctx.upload(hc, cur)
+        ctx.decompress_pictures([(hc, p.slices, p.meta, ctx.pack_levels(p.meta, p.coeffs))])
+        got = ctx.download(hc)
+        for c in range(3):
+            assert np.array_equal(got[c], want[c]), "compact levels, comp %d" % c
+
+
 @pytest.mark.parametrize("dist", ["stress", "dense"])
 @pytest.mark.parametrize("mode_probs,tr_split,intra,ts", [
     ((1.0, 0, 0, 0, 0), 0.35, 0.0, False),      # bench.py --workload idct (SURVEY 8d #2): 64x64 CUs = four 32x32 luma + 16x16 chroma TUs each
