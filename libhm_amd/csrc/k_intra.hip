@@ -712,23 +712,13 @@ __device__ __attribute__((always_inline)) inline void intra_ctu(const PicDev& P,
 #endif
       TM_ADD(t_claim)
       {
-        // one TU -- or the four 4x4 luma TUs of the area, in z order (each predicts from the ones before it); every one's units are published as
-        // it ends.  (One call site: the TU code is the bulk of this kernel's 47 KB.)
+        // one TU -- or the four 4x4 luma TUs of the area, in z order (each predicts from the ones before it; intra_tu ends with the hand-off that
+        // puts its samples into the CTU copy).  The area's units are published together: whatever waits for one of them -- the TUs to the right,
+        // below and below-left -- waits for the fourth TU too.  (One call site: the TU code is the bulk of this kernel's 47 KB.)
         const int last = e.kind == 2 ? 3 : 0;
         const uint32_t mem = e.kind == 2 ? (uint32_t)uni((int)*reinterpret_cast<const uint32_t*>(Q.member[zc >> 2])) : (uint32_t)i;
-        for (int j = 0; j <= last; j++) {
-          const int xs = x4 + (j & 1), ys = y4 + (j >> 1);
-          run_tu((int)((mem >> (8 * j)) & 0xff), zc + j, xs, ys);
-          if (j == last) break;                              // (the last one leaves through the common exit below)
-          wave_lds_sync();
-          mark_done(xs, ys, 1);
-          if (xs + 1 == pw || ys + 1 == pw) {
-            const uint32_t bits = (xs + 1 == pw ? 1u << ys : 0u) | (ys + 1 == pw ? (1u << xs) << 16 : 0u);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (lane == 0) __hip_atomic_fetch_or(nb.prog + ctu, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          }
-        }
-        if (last) { x4 += 1; y4 += 1; }                      // the common exit publishes the fourth TU: unit (x4 + 1, y4 + 1), U = 1
+        for (int j = 0; j <= last; j++) run_tu((int)((mem >> (8 * j)) & 0xff), zc + j, x4 + (j & 1), y4 + (j >> 1));
+        if (last) U = 2;                                     // the common exit publishes the 2 x 2 units of the area
       }
       TM_ADD(t_tu)
     }
