@@ -30,6 +30,9 @@ namespace {
 // coherent accesses to the picture being reconstructed
 __device__ inline uint32_t ld_coh(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ inline void st_coh(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ inline void st_coh2(uint32_t* p, uint32_t v0, uint32_t v1) {         // four samples, p 8-byte aligned
+  __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), (unsigned long long)v0 | ((unsigned long long)v1 << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 __device__ inline int ld_sample(const int16_t* p) {
   const uintptr_t a = reinterpret_cast<uintptr_t>(p);
   const uint32_t w = ld_coh(reinterpret_cast<const uint32_t*>(a & ~(uintptr_t)3));
@@ -157,14 +160,17 @@ __device__ __attribute__((always_inline)) inline void intra_tu(const PicDev& P, 
       strong = abs(bl + tl - 2 * W.line[N]) < th && abs(tl + tr - 2 * W.line[corner + N]) < th;
     }
     for (int i = lane; i < total; i += 64) {
-      int v = W.line[i];
+      // (the three samples always, the ends of the line with themselves as neighbours and kept as they are: loads that hang on no
+      // condition leave together)
+      const int lo = W.line[max(i - 1, 0)], mid = W.line[i], hi = W.line[min(i + 1, total - 1)];
+      int v = mid;
       if (i > 0 && i < total - 1) {
         if (strong) {
           // (24-bit multiplies throughout the prediction: samples and weights are small, v_mul_lo_u32 runs at quarter rate)
           if (i < corner) v = (__mul24(2 * N - i, bl) + __mul24(i, tl) + N) >> (LOG2N + 1);
           else if (i > corner) v = (__mul24(2 * N - (i - corner), tl) + __mul24(i - corner, tr) + N) >> (LOG2N + 1);
         } else {
-          v = (W.line[i - 1] + 2 * v + W.line[i + 1] + 2) >> 2;
+          v = (lo + 2 * mid + hi + 2) >> 2;
         }
       }
       W.filt[i] = v;
@@ -305,11 +311,13 @@ __device__ __attribute__((always_inline)) inline void intra_tu(const PicDev& P, 
     uint32_t* row = reinterpret_cast<uint32_t*>(plane + (ptrdiff_t)(t.y0 + n) * pitch + t.x0);
     uint32_t* lrow = reinterpret_cast<uint32_t*>(&L.pix[t.y0 - t.cy0 + n][t.x0 - t.cx0 + 2]);
     const uint32_t maxv2 = (uint32_t)maxv * 0x10001u;
+    // (a TU's rows start at multiples of four samples of planes whose pitch is a multiple of 64: 8-byte stores)
 #pragma unroll
-    for (int x = 0; x < N; x += 2) {
-      const uint32_t v = pk_clip_u(pk_add_sat(cvt_pk_sat(p[x], p[x + 1]), res[x / 2]), maxv2);
-      lrow[x / 2] = v;
-      st_coh(row + x / 2, v);
+    for (int x = 0; x < N; x += 4) {
+      const uint32_t v0 = pk_clip_u(pk_add_sat(cvt_pk_sat(p[x], p[x + 1]), res[x / 2]), maxv2);
+      const uint32_t v1 = pk_clip_u(pk_add_sat(cvt_pk_sat(p[x + 2], p[x + 3]), res[x / 2 + 1]), maxv2);
+      lrow[x / 2] = v0; lrow[x / 2 + 1] = v1;
+      st_coh2(row + x / 2, v0, v1);
     }
   }
   wave_lds_sync();
