@@ -109,8 +109,6 @@ __device__ __attribute__((always_inline)) inline void intra_tu(const PicDev& P, 
   int16_t* plane = t.plane;
   const int us = 4 >> cs, U = N / us;                      // samples per availability unit, units per TU side
   const int corner = 2 * N, total = 4 * N + 1;
-  const int lx = t.x0 << cs, ly = t.y0 << cs;              // TU origin in luma samples
-  const bool cip = t.cip != 0;
 
   const int n = lane & (N - 1);
   const bool active = lane < N;
