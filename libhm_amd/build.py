@@ -7,7 +7,11 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libhmgpu.so")
 SOURCES = ["k_prep.hip", "k_mc.hip", "k_mc_cells.hip", "k_itx.hip", "k_intra.hip", "k_dbk.hip", "k_sao.hip", "k_filter.hip", "k_out.hip", "hmgpu_api.hip"]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function", "-Wno-unused-value"]
+# Code objects for gfx950 with XNACK (retry on page fault) off, the mode these GPUs run in: with the mode known the compiler schedules loads
+# more freely than for "any" (k_mc_luma 0.213 -> 0.208 ms per launch of 16 pictures, measured A/B/A/B on one box).  A device that runs with
+# HSA_XNACK=1 does not load them: HMGPU_XNACK_ANY=1 in the environment of the build gives the mode-agnostic objects back.
+ARCH = ["--offload-arch=gfx950" if os.environ.get("HMGPU_XNACK_ANY") == "1" else "--offload-arch=gfx950:xnack-"]
+FLAGS = ARCH + ["-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function", "-Wno-unused-value"]
 
 
 def _stale(target, deps):
@@ -43,7 +47,7 @@ def build(force=False, verbose=False):
     if failed:
         raise RuntimeError("libhmgpu.so build failed")
     if force or procs or _stale(OUT, objs):
-        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs
+        cmd = [hipcc] + ARCH + ["-shared", "-fPIC", "-o", OUT] + objs
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)

@@ -6,7 +6,8 @@ name=$1; shift
 root=$(cd $(dirname $0)/.. && pwd)
 d=$root/libhm_amd/variants/$name
 mkdir -p $d
-FLAGS="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wno-unused-function -Wno-unused-value"
+ARCH="--offload-arch=gfx950:xnack-"      # as libhm_amd/build.py
+FLAGS="$ARCH -O3 -fPIC -std=c++17 -Wno-unused-function -Wno-unused-value"
 for f in ${VARIANT_SOURCES:-k_mc.hip}; do
   /opt/rocm/bin/hipcc $FLAGS "$@" -c $root/libhm_amd/csrc/$f -o $d/${f%.hip}.o &
 done
@@ -16,5 +17,5 @@ for o in $root/libhm_amd/build/*.o; do
   b=$(basename $o)
   if [ -f $d/$b ]; then objs="$objs $d/$b"; else objs="$objs $o"; fi
 done
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $d/libhmgpu.so $objs
+/opt/rocm/bin/hipcc $ARCH -shared -fPIC -o $d/libhmgpu.so $objs
 echo $d/libhmgpu.so
