@@ -15,9 +15,15 @@ that configuration's kernel):  idct = config #2 (1920x1080, every CTU four 32x32
 mc / mc_bi = config #3 (prep + MC + residual add only), filter = config #4 (25 % intra CUs for Bs = 2 edges; the
 reconstruction stages run as well because they regenerate the pre-filter picture the in-place deblocking consumes).
 
-Output: ONE JSON line (rank 0), see README/DESIGN.md.  `roofline` is for the dominant kernel (largest share of device
-time); `kernels` lists every kernel.  `cpu_baseline` times the oracle (oracle/hm_oracle.c, the C restatement pinned
-against HM) on this box's host cores on a bounded sample of the same workload -- a reported baseline, not a target.
+Output: ONE JSON line (rank 0), see README/DESIGN.md.  `roofline` is PINNED to `mc_luma`, the kernel BASELINE.json's north star
+puts a number on (sub-benchmarks name their own kernel) -- not the kernel with the largest share of device time, which is
+`filter_fused`; `kernels` lists every kernel, `kernels_bi` the two motion-compensation kernels on B pictures.  `cpu_baseline` times
+the oracle (oracle/hm_oracle.c, the C restatement pinned against HM) on this box's host cores on a bounded sample of the same
+workload; `cpu_baseline_reference` is HM's own decoder (oracle/_ref/TAppDecoder, when the build container shipped it) on an
+HM-encoded 2160p Main10 stream, HM's own per-picture decode time -- reported baselines, not targets.
+
+`--gpus N` (N > 1) without a torch.distributed environment starts the N ranks itself (`python -m torch.distributed.run`, as a child
+process, before anything touches the GPU) and relays rank 0's line; under an external launcher WORLD_SIZE must equal N.
 """
 import argparse
 import json
@@ -50,6 +56,7 @@ def algorithmic_bytes(p):
     chain = (1 << (tr + 1)) - 1
     per_cls = {2: 0, 3: 0, 4: 0, 5: 0}
     coded = [0, 0, 0]
+    n_tu = 0                                               # transform units k_prep lists (12-byte records)
     for comp, key in enumerate(("cbf_y", "cbf_u", "cbf_v")):
         has = inter & ((m[key] & chain) == chain)
         for l2 in (2, 3, 4, 5):
@@ -60,6 +67,8 @@ def algorithmic_bytes(p):
                 cls = max(l2 - 1, 2)
                 per_cls[cls] += n_part * 4
             coded[comp] += n_part * (16 if comp == 0 else 4)
+            # partitions per TU node: (2^(l2-2))^2; the one 4x4 chroma TU of four 4x4 luma TUs counts once per 8x8 area
+            n_tu += n_part // ((1 << (2 * (l2 - 2))) if (comp == 0 or l2 > 2) else 4)
     out["itx"] = 4 * sum(per_cls.values())                # all four TU sizes run in one launch
     out["mc_luma"] += 2 * coded[0]
     out["mc_chroma"] += 2 * (coded[1] + coded[2])
@@ -68,7 +77,10 @@ def algorithmic_bytes(p):
     out["deblock_hor"] = 2 * samples
     out["sao"] = 4 * samples
     out["filter_fused"] = 4 * samples                      # deblocking (both directions) + SAO in one pass: picture read once, written once
-    out["prep"] = int(decoded.sum()) * (21 + 16 + 4)       # HM arrays read + BlkInfo written per partition + TileMv written per four
+    # k_prep: 21 B of HM's arrays read per partition (part size, depth, pred mode, QP, transform index, bypass, PCM, two reference
+    # indices, two vectors, three cbf bytes), per 8x8 area (four partitions) one 16-byte TileMv and one 8-byte EdgeRec written, 12 B per
+    # listed transform unit (the 16-byte BlkInfo records are only stored for calls whose kernels read them: not this workload)
+    out["prep"] = int(decoded.sum()) * (21 + 4 + 2) + 12 * n_tu
     # intra CUs: levels read (coded TUs), reconstruction written once, reference samples read (~ 4N+1 per N x N TU: counted as 2 B/sample)
     intra_p = decoded & (m["pred_mode"] == 1)
     out["intra"] = int(intra_p.sum()) * 24 * (2 + 2 + 2)
@@ -98,10 +110,31 @@ def main():
     ap.add_argument("--no-host-inclusive", action="store_true", help="skip the host-inclusive (staging included) measurement of the default workload")
     ap.add_argument("--profile-steps", type=int, default=5)
     args = ap.parse_args()
+    if args.gpus < 1:
+        ap.error("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ:
+        if args.gpus > 1:
+            return launch_ranks(args.gpus)
+    elif int(os.environ["WORLD_SIZE"]) != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%s ranks" % (args.gpus, os.environ["WORLD_SIZE"]))
 
     import torch  # noqa: F401  -- first, so that libhmgpu.so binds to the HIP runtime torch ships (one runtime per process)
     from libhm_amd import dist as hdist
     dist, rank, world, local_rank = hdist.init_from_env()
+    if world > 1:
+        # every rank says where it runs: a scaling run is self-evidencing
+        sys.stderr.write("bench rank %d of %d: backend %s (world size %d), device cuda:%d of %d visible\n" % (
+            rank, world, dist.get_backend(), dist.get_world_size(), local_rank, torch.cuda.device_count()))
+    if os.environ.get("HMGPU_BENCH_RENDEZVOUS_ONLY"):
+        # rehearsal of the launch path (tests/test_distributed_cpu.py, no GPU needed): the ranks meet, agree on the slowest one's clock
+        # through the same barrier + MAX as the timed region, rank 0 prints the line's launch-related fields, nothing is measured
+        el = hdist.timed_region(dist, lambda: None, lambda: None)
+        if rank == 0:
+            print(json.dumps({"n_gpus": world, "rendezvous_only": True, "backend": dist.get_backend() if dist is not None else None,
+                              "elapsed_max_over_ranks_s": el}), flush=True)
+        if dist is not None:
+            dist.destroy_process_group()
+        return
     copy_gbps = measured_copy_bandwidth(local_rank) if world == 1 else None
 
     import libhm_amd
@@ -264,13 +297,88 @@ def main():
             out["hbm_copy_GBps_measured"] = copy_gbps
         if hi is not None:
             out.update(hi)
+        if wl == "full" and world == 1 and not args.bi:
+            # the two motion-compensation kernels on B pictures (config #3's bi-pred variant, 6 B per sample), beside the P mix above
+            ctx.close()
+            ctx = None
+            out["kernels_bi"] = mc_bi_kernels(w, h, bd, nb, rank, local_rank, args)
         if not args.no_cpu_baseline and world == 1 and wl == "full":
             out["cpu_baseline"] = cpu_baseline(metas[0], w, h, bd, 1, 10.0)
             out["cpu_baseline_all_cores"] = cpu_baseline(metas[0], w, h, bd, 0, 10.0)
+            ref = cpu_baseline_reference()
+            if ref is not None:
+                out["cpu_baseline_reference"] = ref
+                out["speedup_vs_HM_1thread"] = round(value / ref["value"], 1)
         print(json.dumps(out), flush=True)
-    ctx.close()
+    if ctx is not None:
+        ctx.close()
     if dist is not None:
         dist.destroy_process_group()
+
+
+def mc_bi_kernels(w, h, bd, nb, rank, local_rank, args):
+    """`--workload mc_bi` in short, for the default line: the same mix as B pictures (70 % of the PUs bi-predicted), prep + MC + residual
+    only, per-kernel hipEvent times of the two motion-compensation kernels against their algorithmic bytes"""
+    import libhm_amd
+    from libhm_amd import abi
+    from tests import synth
+    metas = [synth.make_picture(w, h, bd, seed=0x484D3136 + 7 * rank + i, bi=True, ref_handles=([0], [1])) for i in range(2)]
+    ctx = libhm_amd.Context(abi.make_seq(w, h, bd, bd, log2_ctu=6, max_pictures=3 * nb), device=local_rank)
+    ref_planes = [synth.noise_planes(w, h, bd, 100 + rank), synth.blocky_planes(w, h, bd, 200 + rank)]
+    pics = []
+    for i in range(nb):
+        r0, r1 = ctx.acquire(), ctx.acquire()
+        ctx.upload(r0, ref_planes[0])
+        ctx.upload(r1, ref_planes[1])
+        hc = ctx.acquire()
+        p = metas[i % 2]
+        for l, r in ((0, r0), (1, r1)):
+            if p.slice.num_ref_idx[l] > 0:
+                p.slice.ref_pic[l][0] = r
+        ctx.decompress_slice(hc, 0, p.slice, p.meta, p.coeffs)
+        pics.append(hc)
+    ctx.sync()
+    ctx.set_streams(1)
+    for _ in range(args.warmup):
+        ctx.replay(pics, 8, 1)
+    ctx.set_profiling(True)
+    ctx.stats(reset=True)
+    ctx.replay(pics, 8, max(args.profile_steps, 5))
+    st = ctx.stats(reset=True)
+    ctx.set_profiling(False)
+    ctx.close()
+    bytes_pp = [algorithmic_bytes(m) for m in metas]
+    out = {}
+    for name in ("mc_luma", "mc_chroma"):
+        ms, launches = st["kernels"][name]
+        avg_ms = ms / launches
+        per_launch = sum(bytes_pp[i % 2][name] for i in range(nb))
+        gbs = per_launch / (avg_ms * 1e-3) / 1e9
+        out[name] = {"avg_ms": round(avg_ms, 5), "alg_MB": round(per_launch / 1e6, 2), "GBps": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4)}
+    return out
+
+
+def launch_ranks(n):
+    """`bench.py --gpus N` called directly: start the N ranks as ONE child process tree (torch.distributed.run, one rank per GPU,
+    rendezvous over 127.0.0.1) before this process has touched the GPU, pass their output through (rank 0 prints the JSON line)
+    and exit with the child's status.  Nothing is exec'ed: the parent only waits."""
+    import socket
+    import subprocess
+    port = os.environ.get("MASTER_PORT")
+    if not port:
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = str(sk.getsockname()[1])
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", port, os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC: RCCL between processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "1")
+    sys.stderr.write("bench.py: starting %d ranks: %s\n" % (n, " ".join(cmd)))
+    rc = subprocess.call(cmd, env=env)
+    if rc != 0:
+        sys.stderr.write("bench.py: a rank failed (exit status %d)\n" % rc)
+    sys.exit(rc if rc >= 0 else 1)
 
 
 def host_inclusive(ctx, metas, pics, refs_of, nb, w, h, args):
@@ -516,6 +624,58 @@ def measured_copy_bandwidth(device):
     del a, b
     torch.cuda.empty_cache()
     return gbps
+
+
+def cpu_baseline_reference(stream="bench_ldp_main10_3840x2160.bin"):
+    """HM itself beside the headline: oracle/_ref/TAppDecoder (HM 16.0 compiled from the reference sources in the build container;
+    the binary travels to the GPU box, the sources do not) on an HM-encoded 3840x2160 Main10 lowdelay_P stream, hash check off, no
+    output file.  The figure is HM's own per-picture decode time -- the [DT] column of its log, clock() around decompressSlice +
+    filterPicture (TDecGop.cpp:113,154,162,186-188), CABAC parsing included, as HM does not separate it -- summed over the pictures;
+    the whole process beside it.  None when the binary or the stream is not there."""
+    import re
+    import subprocess
+    exe = os.path.join(ROOT, "oracle", "_ref", "TAppDecoder")
+    path = os.path.join(ROOT, "tests", "golden", stream)
+    if not (os.path.exists(exe) and os.path.exists(path)):
+        return None
+    best = None
+    for _ in range(2):
+        t0 = time.perf_counter()
+        try:
+            r = subprocess.run([exe, "-b", path, "--SEIDecodedPictureHash=0"], check=True, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, timeout=300)
+        except (subprocess.SubprocessError, OSError):
+            return None
+        wall = time.perf_counter() - t0
+        dts = [float(m.group(1)) for m in re.finditer(r"\[DT\s+([0-9.]+)\]", r.stdout)]
+        types = re.findall(r"\(\s*([IPB])-SLICE", r.stdout)
+        if not dts:
+            return None
+        if best is None or sum(dts) < best[0]:
+            best = (sum(dts), dts, types, wall)
+    dt, dts, types, wall = best
+    m = re.search(r"_(\d+)x(\d+)", stream)
+    w, h = (int(m.group(1)), int(m.group(2))) if m else (3840, 2160)
+    px = len(dts) * w * h
+    p_dts = [d for d, t in zip(dts, types) if t == "P"]
+    model = cpu_model()
+    out = {"value": round(px / dt / 1e6, 2), "unit": "Mpixels/s", "cores": 1, "kind": "reference", "cpu": model,
+           "sample": "HM 16.0 TAppDecoder (oracle/_ref, g++ -O3) on tests/golden/%s: %d pictures %dx%d (%s), hash check off, no output file; "
+                     "sum of HM's own [DT] per picture %.3f s (parsing + reconstruction + loop filters), best of 2; whole process %.2f s" %
+                     (stream, len(dts), w, h, "".join(types), dt, wall),
+           "whole_process_Mpixels_s": round(px / wall / 1e6, 2)}
+    if p_dts:
+        out["P_pictures_Mpixels_s"] = round(len(p_dts) * w * h / sum(p_dts) / 1e6, 2)
+    return out
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return ""
 
 
 def cpu_baseline(p, w, h, bd, threads, seconds):

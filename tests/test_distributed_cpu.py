@@ -164,3 +164,34 @@ def test_gop_plan_properties():
         fp.plan_gop({4: [0], 0: []}, 2)
     # one rank: nothing to send
     assert fp.plan_gop(RA_GOP8, 1)[2] == []
+
+
+# ---- bench.py --gpus N called the way the driver's one-process form calls it: the script itself starts the ranks ------------------
+def _run_bench(extra_args, env_extra, timeout=300):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(HMGPU_BENCH_RENDEZVOUS_ONLY="1", HMGPU_DIST_BACKEND="gloo", **env_extra)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + extra_args, env=env, capture_output=True, text=True, timeout=timeout)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    return r, [json.loads(l) for l in lines]
+
+
+def test_bench_gpus_flag_starts_the_ranks_itself():
+    """`python bench.py --gpus 2` without a torch.distributed environment: two ranks come up (torch.distributed.run as a child
+    process), meet over gloo, every rank reports itself on stderr and rank 0 prints ONE line with n_gpus = 2."""
+    r, lines = _run_bench(["--gpus", "2", "--steps", "3"], {})
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert len(lines) == 1 and lines[0]["n_gpus"] == 2 and lines[0]["backend"] == "gloo"
+    for rank in range(2):
+        assert "bench rank %d of 2: backend gloo (world size 2)" % rank in r.stderr
+
+
+def test_bench_gpus_flag_must_match_the_launcher():
+    """under an external launcher WORLD_SIZE must equal --gpus: a scaling run cannot silently report another rank count"""
+    r, lines = _run_bench(["--gpus", "2"], {"WORLD_SIZE": "3", "RANK": "0", "LOCAL_RANK": "0"}, timeout=60)
+    assert r.returncode != 0 and not lines and "WORLD_SIZE=3" in r.stderr
+    r, lines = _run_bench(["--gpus", "1"], {})
+    assert r.returncode == 0 and lines[0]["n_gpus"] == 1
