@@ -191,6 +191,22 @@ __device__ inline void sao_exempt_mask(const PicDev& P, int comp, int x, int row
   }
 }
 
+// Chroma planes hold Cb and Cr alternately (hmgpu_dev.h "chroma planes").  Eight consecutive samples of component comp (1 / 2) from
+// position x (a multiple of 4) of a row -- `row_c` points at the component's sample of position 0 --, as four packed pairs like a luma load:
+__device__ inline u32x4 ldc8(const int16_t* row_c, int x, int comp) {
+  const int16_t* p = row_c - (comp - 1) + kCStep * x;
+  const u32x4 a = ldg4(p), b = ldg4(p + 8);
+  const uint32_t sel = comp == 2 ? 0x07060302u : 0x05040100u;
+  return u32x4{__builtin_amdgcn_perm(a.y, a.x, sel), __builtin_amdgcn_perm(a.w, a.z, sel), __builtin_amdgcn_perm(b.y, b.x, sel), __builtin_amdgcn_perm(b.w, b.z, sel)};
+}
+// ... and back, sample by sample (the other component's halves belong to another thread)
+__device__ inline void stc8(int16_t* row_c, int x, const u32x4 v) {
+  int16_t* p = row_c + kCStep * x;
+  const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+  for (int j = 0; j < 4; j++) { stg(p + kCStep * 2 * j, (int16_t)(w[j] & 0xffffu)); stg(p + kCStep * (2 * j + 1), (int16_t)(w[j] >> 16)); }
+}
+
 // edge-offset arithmetic of one row of 8 samples once the two neighbour rows are at hand (na / nb = the samples at
 // (x+DX, row+DY) / (x-DX, row-DY) as four packed pairs): shared by k_sao (neighbours from global memory) and the fused
 // filter kernel (neighbours from its LDS tile)

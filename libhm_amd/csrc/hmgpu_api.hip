@@ -134,6 +134,12 @@ namespace {
   } while (0)
 
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+// one set of planes of a picture: luma, then the plane that holds Cb and Cr
+size_t plane_set_bytes(const hmgpu_ctx* c) {
+  size_t n = 0;
+  for (int k = 0; k < 2; k++) n += align_up((size_t)c->pitch[k] * c->rows[k] * sizeof(int16_t), 256);
+  return n;
+}
 
 struct Carver {                       // sub-allocates one device block, 256-byte aligned pieces
   char* base; size_t off = 0;
@@ -290,8 +296,12 @@ hmgpu_status alloc_picture(hmgpu_ctx* c, Picture& p) {
     // plane pointers address sample (0,0); the margins lie at negative coordinates
     Carver m(p.planes);
     for (int k = 0; k < 3; k++) { d.mx[k] = c->mx[k]; d.my[k] = c->my[k]; }
-    for (int k = 0; k < 3; k++) d.rec[k] = m.take<int16_t>((size_t)c->pitch[k] * c->rows[k]) + (size_t)c->my[k] * c->pitch[k] + c->mx[k];
-    for (int k = 0; k < 3; k++) d.sao[k] = m.take<int16_t>((size_t)c->pitch[k] * c->rows[k]) + (size_t)c->my[k] * c->pitch[k] + c->mx[k];
+    d.rec[0] = m.take<int16_t>((size_t)c->pitch[0] * c->rows[0]) + (size_t)c->my[0] * c->pitch[0] + c->mx[0];
+    d.rec[1] = m.take<int16_t>((size_t)c->pitch[1] * c->rows[1]) + (size_t)c->my[1] * c->pitch[1] + kCStep * c->mx[1];
+    d.rec[2] = d.rec[1] + 1;
+    d.sao[0] = m.take<int16_t>((size_t)c->pitch[0] * c->rows[0]) + (size_t)c->my[0] * c->pitch[0] + c->mx[0];
+    d.sao[1] = m.take<int16_t>((size_t)c->pitch[1] * c->rows[1]) + (size_t)c->my[1] * c->pitch[1] + kCStep * c->mx[1];
+    d.sao[2] = d.sao[1] + 1;
   }
   p.slices.assign(HMGPU_MAX_SLICES, SliceDev());
   return HMGPU_OK;
@@ -393,8 +403,8 @@ hmgpu_status run_recon(hmgpu_ctx* c, const Batch& b, bool any_intra, bool any_wp
   if (c->seq.chroma_format != 0) {
     ProfScope ps(c, K_MC_CHROMA);
     ma.pitch = c->pitch[1]; ma.bd = c->seq.bit_depth_chroma;
-    ma.origin_off = (uint32_t)((const char*)d0.rec[1] - base0);
-    ma.cr_off = (uint32_t)((const char*)d0.rec[2] - (const char*)d0.rec[1]);
+    ma.origin_off = (uint32_t)((const char*)d0.rec[1] - base0);      // the plane of both components (hmgpu_dev.h "chroma planes")
+    ma.cr_off = 0;
     ma.rtw = c->grid_w / 4;
     for (int i = 0; i < b.n; i++) {
       const PicDev& d = c->pics[b.pic[i]].dev;
@@ -552,7 +562,8 @@ hmgpu_status hmgpu_create(const hmgpu_seq_params* seq, int device_ordinal, hmgpu
   c->mx[0] = 128; c->mx[1] = c->mx[2] = 64;
   c->my[0] = 80; c->my[1] = c->my[2] = 40;
   c->pitch[0] = (int)align_up((size_t)seq->width, 64) + 2 * c->mx[0] + 64;
-  c->pitch[1] = c->pitch[2] = (int)align_up((size_t)seq->width / 2, 64) + 2 * c->mx[1] + 64;
+  // (Cb and Cr alternate in one plane, hmgpu_dev.h "chroma planes": its pitch is that of kCStep rows of one component)
+  c->pitch[1] = c->pitch[2] = kCStep * ((int)align_up((size_t)seq->width / 2, 64) + 2 * c->mx[1] + 64);
   c->rows[0] = c->ctus_h * c->ctu + 2 * c->my[0] + 8; c->rows[1] = c->rows[2] = c->ctus_h * c->ctu / 2 + 2 * c->my[1] + 8;
   c->coef_elems[0] = (size_t)c->num_ctus * c->ctu * c->ctu;
   c->coef_elems[1] = c->coef_elems[2] = c->coef_elems[0] / 4;
@@ -567,7 +578,7 @@ hmgpu_status hmgpu_create(const hmgpu_seq_params* seq, int device_ordinal, hmgpu
   c->pics.resize(seq->max_pictures);
   c->h_finals.resize(seq->max_pictures);
   hmgpu_status st = HMGPU_OK;
-  for (int k = 0; k < 3; k++) c->plane_bytes += align_up((size_t)c->pitch[k] * c->rows[k] * sizeof(int16_t), 256);
+  c->plane_bytes = plane_set_bytes(c);
   if (hipMalloc((void**)&c->plane_slab, c->plane_bytes * 2 * seq->max_pictures) != hipSuccess ||
       hipMemset(c->plane_slab, 0, c->plane_bytes * 2 * seq->max_pictures) != hipSuccess) st = HMGPU_EDEVICE;
   for (int i = 0; i < seq->max_pictures && st == HMGPU_OK; i++) st = alloc_picture(c, c->pics[i]);
@@ -671,26 +682,47 @@ hmgpu_status hmgpu_picture_upload(hmgpu_ctx* c, hmgpu_pic pic, const int16_t* co
     if (st == HMGPU_OK) st = push_picdev(c, pic);
     if (st != HMGPU_OK) return st;
   }
-  for (int k = 0; k < 3; k++) {
-    const int w = c->seq.width >> (k ? 1 : 0), h = c->seq.height >> (k ? 1 : 0);
-    int16_t* dst = p.dev.rec[k];
-    HIP_TRY(c, hipMemcpy2DAsync(dst, (size_t)c->pitch[k] * 2, planes[k], (size_t)strides[k] * 2, (size_t)w * 2, h,
-                                hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipMemcpy2DAsync(p.dev.rec[0], (size_t)c->pitch[0] * 2, planes[0], (size_t)strides[0] * 2, (size_t)c->seq.width * 2, c->seq.height,
+                              hipMemcpyHostToDevice, c->stream));
+  {
+    // the chroma components arrive as HM's two planes and are laid sample by sample into the device's one (hmgpu_dev.h "chroma planes")
+    const int w = c->seq.width >> 1, h = c->seq.height >> 1;
+    int16_t* d = static_cast<int16_t*>(ctx_scratch(c, (size_t)2 * w * h * sizeof(int16_t)));
+    if (!d) return HMGPU_ENOMEM;
+    for (int k = 1; k < 3; k++) {
+      int16_t* dk = d + (size_t)(k - 1) * w * h;
+      HIP_TRY(c, hipMemcpy2DAsync(dk, (size_t)w * 2, planes[k], (size_t)strides[k] * 2, (size_t)w * 2, h, hipMemcpyHostToDevice, c->stream));
+      launch_unpack(dk, w, h, p.dev.rec[k], c->pitch[k], kCStep, c->stream);
+    }
+    HIP_TRY(c, hipGetLastError());
   }
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   p.extended = false;
   return HMGPU_OK;
 }
 
+// the final planes of a picture to HM's three host planes, enqueued on the context's stream: luma straight from its plane, the chroma
+// components taken apart into a dense block of device scratch first (later users of the scratch follow on the same stream)
+static hmgpu_status enqueue_download(hmgpu_ctx* c, Picture& p, int16_t* const planes[3], const int32_t strides[3]) {
+  const int16_t* y = p.sao_applied ? p.dev.sao[0] : p.dev.rec[0];
+  HIP_TRY(c, hipMemcpy2DAsync(planes[0], (size_t)strides[0] * 2, y, (size_t)c->pitch[0] * 2, (size_t)c->seq.width * 2, c->seq.height, hipMemcpyDeviceToHost, c->stream));
+  const int w = c->seq.width >> 1, h = c->seq.height >> 1;
+  int16_t* d = static_cast<int16_t*>(ctx_scratch(c, (size_t)2 * w * h * sizeof(int16_t)));
+  if (!d) return HMGPU_ENOMEM;
+  for (int k = 1; k < 3; k++) {
+    const int16_t* src = p.sao_applied ? p.dev.sao[k] : p.dev.rec[k];
+    int16_t* dk = d + (size_t)(k - 1) * w * h;
+    launch_pack(src, c->pitch[k], kCStep, 0, 0, w, h, 2, reinterpret_cast<uint8_t*>(dk), w * 2, c->stream);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipMemcpy2DAsync(planes[k], (size_t)strides[k] * 2, dk, (size_t)w * 2, (size_t)w * 2, h, hipMemcpyDeviceToHost, c->stream));
+  }
+  return HMGPU_OK;
+}
+
 hmgpu_status hmgpu_picture_download(hmgpu_ctx* c, hmgpu_pic pic, int16_t* const planes[3], const int32_t strides[3]) {
   if (!c || !valid_pic(c, pic) || !planes || !strides) return HMGPU_EINVAL;
   Picture& p = c->pics[pic];
-  for (int k = 0; k < 3; k++) {
-    const int w = c->seq.width >> (k ? 1 : 0), h = c->seq.height >> (k ? 1 : 0);
-    const int16_t* src = p.sao_applied ? p.dev.sao[k] : p.dev.rec[k];
-    HIP_TRY(c, hipMemcpy2DAsync(planes[k], (size_t)strides[k] * 2, src, (size_t)c->pitch[k] * 2, (size_t)w * 2, h,
-                                hipMemcpyDeviceToHost, c->stream));
-  }
+  { const hmgpu_status st = enqueue_download(c, p, planes, strides); if (st != HMGPU_OK) return st; }
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   prof_drain(c);
   return check_faults(c);
@@ -700,11 +732,7 @@ hmgpu_status hmgpu_picture_download_begin(hmgpu_ctx* c, hmgpu_pic pic, int16_t* 
   if (!c || !valid_pic(c, pic) || !planes || !strides || !ticket) return HMGPU_EINVAL;
   hipSetDevice(c->device);
   Picture& p = c->pics[pic];
-  for (int k = 0; k < 3; k++) {
-    const int w = c->seq.width >> (k ? 1 : 0), h = c->seq.height >> (k ? 1 : 0);
-    const int16_t* src = p.sao_applied ? p.dev.sao[k] : p.dev.rec[k];
-    HIP_TRY(c, hipMemcpy2DAsync(planes[k], (size_t)strides[k] * 2, src, (size_t)c->pitch[k] * 2, (size_t)w * 2, h, hipMemcpyDeviceToHost, c->stream));
-  }
+  { const hmgpu_status st = enqueue_download(c, p, planes, strides); if (st != HMGPU_OK) return st; }
   const uint64_t t = c->dl_seq.load() + 1;
   // the picture's fault word (an intra wavefront that gave up waiting) as it stands behind these copies: hmgpu_download_wait reports it
   HIP_TRY(c, hipMemcpyAsync(&c->dl_fault[t % 32], p.dev.fault, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
@@ -742,7 +770,7 @@ hmgpu_status hmgpu_picture_download_packed(hmgpu_ctx* c, hmgpu_pic pic, void* co
   for (int k = 0; k < 3 && st == HMGPU_OK; k++) {
     const int cs = k ? 1 : 0, w = W >> cs, h = H >> cs;
     const int16_t* src = p.sao_applied ? p.dev.sao[k] : p.dev.rec[k];
-    launch_pack(src, c->pitch[k], crop_left >> cs, crop_top >> cs, w, h, bytes_per_sample, d + off[k], w * bytes_per_sample, c->stream);
+    launch_pack(src, c->pitch[k], k ? kCStep : 1, crop_left >> cs, crop_top >> cs, w, h, bytes_per_sample, d + off[k], w * bytes_per_sample, c->stream);
     if (hipGetLastError() != hipSuccess ||
         hipMemcpy2DAsync(planes[k], (size_t)stride_bytes[k], d + off[k], (size_t)w * bytes_per_sample, (size_t)w * bytes_per_sample, h,
                          hipMemcpyDeviceToHost, c->stream) != hipSuccess) st = HMGPU_EDEVICE;
@@ -776,8 +804,8 @@ hmgpu_status hmgpu_picture_hash(hmgpu_ctx* c, hmgpu_pic pic, int32_t method, uin
     const int cs = k ? 1 : 0, w = c->seq.width >> cs, h = c->seq.height >> cs;
     const int bd = k ? c->seq.bit_depth_chroma : c->seq.bit_depth_luma;
     const int16_t* src = p.sao_applied ? p.dev.sao[k] : p.dev.rec[k];
-    if (method == 3) launch_checksum(src, c->pitch[k], w, h, bd, d + k, c->stream);
-    else launch_crc(src, c->pitch[k], w, h, bd, d + 4, d + k, c->stream);
+    if (method == 3) launch_checksum(src, c->pitch[k], k ? kCStep : 1, w, h, bd, d + k, c->stream);
+    else launch_crc(src, c->pitch[k], k ? kCStep : 1, w, h, bd, d + 4, d + k, c->stream);
     if (hipGetLastError() != hipSuccess) st = HMGPU_EDEVICE;
   }
   uint32_t r[3] = {0, 0, 0};
@@ -871,7 +899,7 @@ hmgpu_status hmgpu_picture_hash_begin(hmgpu_ctx* c, hmgpu_pic pic, int32_t metho
     const int cs = k ? 1 : 0, w = c->seq.width >> cs, h = c->seq.height >> cs;
     const int nb = (k ? c->seq.bit_depth_chroma : c->seq.bit_depth_luma) > 8 ? 2 : 1;
     const int16_t* src = p.sao_applied ? p.dev.sao[k] : p.dev.rec[k];
-    launch_pack(src, c->pitch[k], 0, 0, w, h, nb, d + off[k], w * nb, c->stream);
+    launch_pack(src, c->pitch[k], k ? kCStep : 1, 0, 0, w, h, nb, d + off[k], w * nb, c->stream);
   }
   HIP_TRY(c, hipGetLastError());
   // the picture itself is free again behind the packing; the chains run over the copy
@@ -913,8 +941,7 @@ hmgpu_status hmgpu_picture_device_region(hmgpu_ctx* c, hmgpu_pic pic, int32_t wh
   if (!c || !valid_pic(c, pic) || !base || !bytes || (which != HMGPU_REGION_FINISHED && which != HMGPU_REGION_RECEIVE)) return HMGPU_EINVAL;
   hipSetDevice(c->device);
   Picture& p = c->pics[pic];
-  size_t plane_bytes = 0;
-  for (int k = 0; k < 3; k++) plane_bytes += align_up((size_t)c->pitch[k] * c->rows[k] * sizeof(int16_t), 256);
+  const size_t plane_bytes = plane_set_bytes(c);
   if (which == HMGPU_REGION_FINISHED) {
     hmgpu_status st = ensure_extended(c, pic);
     if (st != HMGPU_OK) return st;

@@ -75,12 +75,12 @@ __global__ void __launch_bounds__(256) k_deblock(const PicDev* __restrict__ pics
 #pragma unroll
     for (int comp = 1; comp < 3; comp++) {
       const int tc = chroma_tc(qp, ldg(comp == 1 ? &slp->pps_cb_qp_offset : &slp->pps_cr_qp_offset), tc_off, P.bd[comp]);
-      int16_t* cb = P.rec[comp] + (size_t)(y >> 1) * cp + (x >> 1);
+      int16_t* cb = P.rec[comp] + (size_t)(y >> 1) * cp + kCStep * (x >> 1);      // (a component's samples lie kCStep elements apart)
 #pragma unroll
       for (int i = 0; i < 2; i++) {
         // xPelFilterChroma (:870-891): two lines per unit
-        int16_t* s = DIR == 0 ? cb + (size_t)i * cp : cb + i;
-        const ptrdiff_t o = DIR == 0 ? 1 : cp;
+        int16_t* s = DIR == 0 ? cb + (size_t)i * cp : cb + kCStep * i;
+        const ptrdiff_t o = DIR == 0 ? kCStep : cp;
         const int m2 = (uint16_t)ldg(s - 2 * o), m3 = (uint16_t)ldg(s - o), m4 = (uint16_t)ldg(s), m5 = (uint16_t)ldg(s + o);
         const int delta = clip3(-tc, tc, ((((m4 - m3) << 2) + m2 - m5 + 4) >> 3));
         if (!p_nf) stg(s - o, (int16_t)clip3(0, maxc, m3 + delta));          // xPelFilterChroma :883-890

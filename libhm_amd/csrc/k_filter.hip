@@ -49,19 +49,18 @@ __device__ inline SaoPrm sao_fetch(const PicDev& P, int comp, int x, int row) {
   return r;
 }
 
+// returns the group's eight output samples (the caller stores them: luma as they are, chroma paired with the other component's)
 template <int W, bool NF>
-__device__ inline void sao_group(const PicDev& P, int comp, const int16_t (*t)[W], int ox, int oy, int x, int row, const SaoPrm& prm) {
+__device__ inline u32x4 sao_group(const PicDev& P, int comp, const int16_t (*t)[W], int ox, int oy, int x, int row, const SaoPrm& prm) {
   const int cs = comp ? 1 : 0;
   const int w = P.width >> cs, h = P.height >> cs;
-  const int pitch = P.pitch[comp];
   const int log2ctb = P.log2ctu - cs;
   const int cx = x >> log2ctb, cy = row >> log2ctb;
   const uint32_t w0 = prm.w0;
   const int type = (int)(int8_t)(w0 & 0xff);
   const int16_t* line = &t[row - oy][x - ox];
   const u32x4 cur = *reinterpret_cast<const u32x4*>(line);
-  int16_t* dst = P.sao[comp] + (size_t)row * pitch + x;
-  if (type < 0) { stg4(dst, cur); return; }
+  if (type < 0) return cur;
   const uint32_t off_lo = prm.off_lo, off_hi = prm.off_hi;
   const int bd = P.bd[comp], maxv = (1 << bd) - 1;
   uint32_t out[4];
@@ -109,8 +108,7 @@ __device__ inline void sao_group(const PicDev& P, int comp, const int16_t (*t)[W
 #pragma unroll
     for (int j = 0; j < 4; j++) out[j] = (c[j] & m[j]) | (out[j] & ~m[j]);
   }
-  u32x4 res = {out[0], out[1], out[2], out[3]};
-  stg4(dst, res);
+  return u32x4{out[0], out[1], out[2], out[3]};
 }
 
 // the EdgeRec unit (k_prep: Bs, mean QP, exemptions) of the edge unit of direction DIR whose Q block is at luma (x, y); requested at
@@ -254,7 +252,8 @@ __global__ void __launch_bounds__(256) k_filter_fused(const PicDev* __restrict__
     lx[k] = x0 + (g & 7) * 8; ly[k] = y0 + (g >> 3);
     sl[k] = sao_fetch(P, 0, lx[k], ly[k]);
   }
-  const int ccomp = 1 + (t >> 7), ccx = (x0 >> 1) + (t & 3) * 8, ccy = (y0 >> 1) + ((t & 127) >> 2);
+  // (neighbouring lanes hold Cb and Cr of the same group: the plane wants them pair by pair, hmgpu_dev.h "chroma planes")
+  const int ccomp = 1 + (t & 1), ccx = (x0 >> 1) + ((t >> 1) & 3) * 8, ccy = (y0 >> 1) + (t >> 3);
   const SaoPrm sc = sao_fetch(P, ccomp, ccx, ccy);
   // ---- 1. the tile and its halo, before any filtering (pictures carry margins: every address is inside the allocation):
   // all loads of the thread are issued, the edge units are classified while they fly, then the copy is written
@@ -269,8 +268,9 @@ __global__ void __launch_bounds__(256) k_filter_fused(const PicDev* __restrict__
     }
 #pragma unroll
     for (int k = 0; k < NC; k++) {
-      const int i = t + 256 * k, comp = i / (kCH * VPC), j = i % (kCH * VPC), r = j / VPC, v = j % VPC;
-      if (i < 2 * kCH * VPC) tc[k] = ldg4(P.rec[1 + comp] + (ptrdiff_t)((y0 >> 1) - 2 + r) * P.pitch[1] + ((x0 >> 1) - 8) + 8 * v);
+      // a vector = the (Cb, Cr) pairs of four positions of a row of the copy
+      const int i = t + 256 * k, r = i / (2 * VPC), v = i % (2 * VPC);
+      if (i < 2 * kCH * VPC) tc[k] = ldg4(P.rec[1] + (ptrdiff_t)((y0 >> 1) - 2 + r) * P.pitch[1] + kCStep * (((x0 >> 1) - 8) + 4 * v));
     }
   }
   if (t < 192) {
@@ -284,8 +284,12 @@ __global__ void __launch_bounds__(256) k_filter_fused(const PicDev* __restrict__
   }
 #pragma unroll
   for (int k = 0; k < NC; k++) {
-    const int i = t + 256 * k, comp = i / (kCH * VPC), j = i % (kCH * VPC), r = j / VPC, v = j % VPC;
-    if (i < 2 * kCH * VPC) *reinterpret_cast<u32x4*>(&L.c[comp][r][8 * v]) = tc[k];
+    const int i = t + 256 * k, r = i / (2 * VPC), v = i % (2 * VPC);
+    if (i < 2 * kCH * VPC) {
+      // the copies in LDS are one per component: the filters run on them as they did on separate planes
+      *reinterpret_cast<u32x2*>(&L.c[0][r][4 * v]) = u32x2{__builtin_amdgcn_perm(tc[k].y, tc[k].x, 0x05040100u), __builtin_amdgcn_perm(tc[k].w, tc[k].z, 0x05040100u)};
+      *reinterpret_cast<u32x2*>(&L.c[1][r][4 * v]) = u32x2{__builtin_amdgcn_perm(tc[k].y, tc[k].x, 0x07060302u), __builtin_amdgcn_perm(tc[k].w, tc[k].z, 0x07060302u)};
+    }
   }
   __syncthreads();
   // ---- 2. vertical edges
@@ -297,8 +301,18 @@ __global__ void __launch_bounds__(256) k_filter_fused(const PicDev* __restrict__
   // ---- 4. SAO of the tile from the deblocked copy
 #pragma unroll
   for (int k = 0; k < 2; k++)
-    if (lx[k] < P.width && ly[k] < P.height) sao_group<kYW, NF>(P, 0, L.y, x0 - 8, y0 - 4, lx[k], ly[k], sl[k]);
-  if (ccx < (P.width >> 1) && ccy < (P.height >> 1)) sao_group<kCW, NF>(P, ccomp, L.c[ccomp - 1], (x0 >> 1) - 8, (y0 >> 1) - 2, ccx, ccy, sc);
+    if (lx[k] < P.width && ly[k] < P.height)
+      stg4(P.sao[0] + (size_t)ly[k] * P.pitch[0] + lx[k], sao_group<kYW, NF>(P, 0, L.y, x0 - 8, y0 - 4, lx[k], ly[k], sl[k]));
+  if (ccx < (P.width >> 1) && ccy < (P.height >> 1)) {
+    const u32x4 own = sao_group<kCW, NF>(P, ccomp, L.c[ccomp - 1], (x0 >> 1) - 8, (y0 >> 1) - 2, ccx, ccy, sc);
+    // the even lane (Cb) writes positions 0..3 of the group, the odd lane (Cr) positions 4..7: each hands the other the half it does not write
+    const bool odd = t & 1;
+    const uint32_t r0 = (uint32_t)__shfl_xor((int)(odd ? own.x : own.z), 1, 64), r1 = (uint32_t)__shfl_xor((int)(odd ? own.y : own.w), 1, 64);
+    const uint32_t cb0 = odd ? r0 : own.x, cb1 = odd ? r1 : own.y, cr0 = odd ? own.z : r0, cr1 = odd ? own.w : r1;
+    const u32x4 o = {__builtin_amdgcn_perm(cr0, cb0, 0x05040100u), __builtin_amdgcn_perm(cr0, cb0, 0x07060302u),
+                     __builtin_amdgcn_perm(cr1, cb1, 0x05040100u), __builtin_amdgcn_perm(cr1, cb1, 0x07060302u)};
+    stg4(P.sao[1] + (size_t)ccy * P.pitch[1] + kCStep * (ccx + (odd ? 4 : 0)), o);
+  }
 }
 
 void launch_filter_fused(const PicDev* pics, const Batch& b, int width, int height, bool nofilt, hipStream_t s) {

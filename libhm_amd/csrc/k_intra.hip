@@ -33,6 +33,16 @@ __device__ inline void st_coh(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v
 __device__ inline void st_coh2(uint32_t* p, uint32_t v0, uint32_t v1) {         // four samples, p 8-byte aligned
   __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), (unsigned long long)v0 | ((unsigned long long)v1 << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// chroma (hmgpu_dev.h "chroma planes": Cb and Cr alternate in one plane, another workgroup writes the other component of every dword): the
+// pairs of two positions in one 8-byte access, this component's halves out of them; stores go sample by sample
+__device__ inline uint32_t ld_coh_c2(const int16_t* pair, int half) {              // pair: 8-byte aligned, the (Cb, Cr) of two positions
+  const unsigned long long w = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(pair), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return __builtin_amdgcn_perm((uint32_t)(w >> 32), (uint32_t)w, half ? 0x07060302u : 0x05040100u);
+}
+__device__ inline void st_coh_c2(int16_t* p, uint32_t v) {                         // two samples of one component, kCStep apart
+  __hip_atomic_store(reinterpret_cast<uint16_t*>(p), (uint16_t)(v & 0xffffu), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(reinterpret_cast<uint16_t*>(p + kCStep), (uint16_t)(v >> 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 __device__ inline int ld_sample(const int16_t* p) {
   const uintptr_t a = reinterpret_cast<uintptr_t>(p);
   const uint32_t w = ld_coh(reinterpret_cast<const uint32_t*>(a & ~(uintptr_t)3));
@@ -306,16 +316,19 @@ __device__ __attribute__((always_inline)) inline void intra_tu(const PicDev& P, 
   // ---- E. reconstruction of row n: into the LDS copy (what later TUs of this CTU predict from) and, two samples per
   // coherent dword store, into the picture (what other CTUs and the loop filters read; nobody here waits for it)
   if (active) {
-    uint32_t* row = reinterpret_cast<uint32_t*>(plane + (ptrdiff_t)(t.y0 + n) * pitch + t.x0);
+    int16_t* prow = plane + (ptrdiff_t)(t.y0 + n) * pitch + (comp ? kCStep : 1) * t.x0;
+    uint32_t* row = reinterpret_cast<uint32_t*>(prow);
     uint32_t* lrow = reinterpret_cast<uint32_t*>(&L.pix[t.y0 - t.cy0 + n][t.x0 - t.cx0 + 2]);
     const uint32_t maxv2 = (uint32_t)maxv * 0x10001u;
-    // (a TU's rows start at multiples of four samples of planes whose pitch is a multiple of 64: 8-byte stores)
+    // (a TU's rows start at multiples of four samples of planes whose pitch is a multiple of 64: 8-byte stores; chroma: sample by sample, the
+    // other component's workgroup owns the other half of every dword)
 #pragma unroll
     for (int x = 0; x < N; x += 4) {
       const uint32_t v0 = pk_clip_u(pk_add_sat(cvt_pk_sat(p[x], p[x + 1]), res[x / 2]), maxv2);
       const uint32_t v1 = pk_clip_u(pk_add_sat(cvt_pk_sat(p[x + 2], p[x + 3]), res[x / 2 + 1]), maxv2);
       lrow[x / 2] = v0; lrow[x / 2 + 1] = v1;
-      st_coh2(row + x / 2, v0, v1);
+      if (comp == 0) st_coh2(row + x / 2, v0, v1);
+      else { st_coh_c2(prow + kCStep * x, v0); st_coh_c2(prow + kCStep * (x + 2), v1); }
     }
   }
   wave_lds_sync();
@@ -349,14 +362,27 @@ __device__ __attribute__((always_inline)) inline void intra_stage(const PicDev& 
   }
   {
     const int S = (1 << P.log2ctu) >> cs;                   // CTU size in samples of this component
-    const int16_t* org = P.rec[comp] + (ptrdiff_t)(ctu_y >> cs) * P.pitch[comp] + (ctu_x >> cs);
     // the interior was written by the MC / residual kernels (earlier launches): plain 16-byte loads
-    const int vpr = S / 8;                                  // 16-byte vectors per row
-    for (int i = threadIdx.x; i < S * vpr; i += blockDim.x) {
-      const int r = i / vpr, v = i % vpr;
-      const u32x4 q = ldg4(org + (ptrdiff_t)r * P.pitch[comp] + 8 * v);
-      uint32_t* d = reinterpret_cast<uint32_t*>(&L.pix[r][2 + 8 * v]);
-      d[0] = q.x; d[1] = q.y; d[2] = q.z; d[3] = q.w;
+    if (comp == 0) {
+      const int16_t* org = P.rec[0] + (ptrdiff_t)ctu_y * P.pitch[0] + ctu_x;
+      const int vpr = S / 8;                                  // 16-byte vectors per row
+      for (int i = threadIdx.x; i < S * vpr; i += blockDim.x) {
+        const int r = i / vpr, v = i % vpr;
+        const u32x4 q = ldg4(org + (ptrdiff_t)r * P.pitch[0] + 8 * v);
+        uint32_t* d = reinterpret_cast<uint32_t*>(&L.pix[r][2 + 8 * v]);
+        d[0] = q.x; d[1] = q.y; d[2] = q.z; d[3] = q.w;
+      }
+    } else {
+      // a vector = the (Cb, Cr) of four positions: this component's halves
+      const int16_t* org = P.rec[1] + (ptrdiff_t)(ctu_y >> 1) * P.pitch[1] + kCStep * (ctu_x >> 1);
+      const uint32_t sel = comp == 2 ? 0x07060302u : 0x05040100u;
+      const int vpr = S / 4;
+      for (int i = threadIdx.x; i < S * vpr; i += blockDim.x) {
+        const int r = i / vpr, v = i % vpr;
+        const u32x4 q = ldg4(org + (ptrdiff_t)r * P.pitch[1] + 8 * v);
+        uint32_t* d = reinterpret_cast<uint32_t*>(&L.pix[r][2 + 4 * v]);
+        d[0] = __builtin_amdgcn_perm(q.y, q.x, sel); d[1] = __builtin_amdgcn_perm(q.w, q.z, sel);
+      }
     }
   }
 }
@@ -442,7 +468,9 @@ __device__ __attribute__((always_inline)) inline void fetch_border(const int16_t
     const int u = lane >> 2, r = lane & 3;
     if (((mc >> u) & 1) && r < us) {
       const int row = u * us + r;
-      reinterpret_cast<uint32_t*>(&L.pix[row][0])[0] = ld_coh(reinterpret_cast<const uint32_t*>(org + (ptrdiff_t)row * pitch - 2));
+      // (chroma: org = the CTU's first (Cb, Cr) pair, positions -2, -1 are the eight bytes in front of the row)
+      reinterpret_cast<uint32_t*>(&L.pix[row][0])[0] = comp == 0 ? ld_coh(reinterpret_cast<const uint32_t*>(org + (ptrdiff_t)row * pitch - 2))
+                                                                 : ld_coh_c2(org + (ptrdiff_t)row * pitch - 2 * kCStep, comp - 1);
     }
   }
   if (mr) {
@@ -451,7 +479,8 @@ __device__ __attribute__((always_inline)) inline void fetch_border(const int16_t
     for (int d = lane; d < dwords && d < 66; d += 64) {
       const int col = 2 * d - 2;                            // first column of the dword
       const int c = col < 0 ? -1 : col / us;
-      if ((mr >> (c + 1)) & 1) reinterpret_cast<uint32_t*>(L.top)[d] = ld_coh(reinterpret_cast<const uint32_t*>(org - pitch - 2) + d);
+      if ((mr >> (c + 1)) & 1) reinterpret_cast<uint32_t*>(L.top)[d] = comp == 0 ? ld_coh(reinterpret_cast<const uint32_t*>(org - pitch - 2) + d)
+                                                                                    : ld_coh_c2(org - pitch + 2 * kCStep * (d - 1), comp - 1);
     }
   }
   wave_lds_sync();
@@ -487,7 +516,8 @@ __device__ __attribute__((always_inline)) inline void intra_ctu(const PicDev& P,
   // the picture constants the TU chain needs, out of the descriptor once
   const int h_bd = P.bd[comp], h_pitch = P.pitch[comp], h_log2ctu = P.log2ctu, h_rext = P.range_ext, h_strong = P.strong_intra_smoothing;
   int16_t* const h_plane = P.rec[comp];
-  const int16_t* const org = h_plane + (ptrdiff_t)(ctu_y >> cs) * h_pitch + (ctu_x >> cs);
+  // the CTU's first sample in the plane; chroma: its first (Cb, Cr) pair in the plane of both components (fetch_border reads whole pairs)
+  const int16_t* const org = comp == 0 ? h_plane + (ptrdiff_t)ctu_y * h_pitch + ctu_x : P.rec[1] + (ptrdiff_t)(ctu_y >> 1) * h_pitch + kCStep * (ctu_x >> 1);
   const int wv = threadIdx.x >> 6;
   auto mark_done = [&](int x4, int y4, int U) {           // units [x4, x4 + U) x [y4, y4 + U) are final
     if (lane < 16) {
@@ -679,13 +709,14 @@ __device__ __attribute__((always_inline)) inline void intra_ctu(const PicDev& P,
       const int sx = (ctu_x + 4 * x4) >> cs, sy = (ctu_y + 4 * y4) >> cs;
       if (lane < n_cu) {
         const int16_t* src = P.pcm[comp] + (size_t)ctu * ((size_t)(1 << (2 * P.log2ctu)) >> (comp ? 2 : 0)) + (comp ? 4 : 16) * z + lane * n_cu;
-        uint32_t* row = reinterpret_cast<uint32_t*>(h_plane + (ptrdiff_t)(sy + lane) * h_pitch + sx);
+        int16_t* prow = h_plane + (ptrdiff_t)(sy + lane) * h_pitch + (comp ? kCStep : 1) * sx;
+        uint32_t* row = reinterpret_cast<uint32_t*>(prow);
         uint32_t* lrow = reinterpret_cast<uint32_t*>(&L.pix[sy - (ctu_y >> cs) + lane][sx - (ctu_x >> cs) + 2]);
         for (int x = 0; x < n_cu; x += 2) {
           const uint32_t v = ldg(reinterpret_cast<const uint32_t*>(src + x));
           const uint32_t o = ((v & 0xffffu) << P.pcm_shift[comp]) | ((v >> 16) << (16 + P.pcm_shift[comp]));
           lrow[x / 2] = o;
-          st_coh(row + x / 2, o);
+          if (comp == 0) st_coh(row + x / 2, o); else st_coh_c2(prow + kCStep * x, o);
         }
       }
     } else {

@@ -126,6 +126,7 @@ template <bool CHROMA> struct McLds {
   static constexpr int ROW_DW = CHROMA ? 128 : 256;           // dwords per tile row
   struct { uint32_t body[2 * ROW_DW], halo[2 * ROW_DW]; } w[4];   // halo: the first 8 (4) window rows of run tops, at the top tile's position
   uint32_t taps[144];                           // the tap table (every wave writes the same values, reads its own)
+  uint32_t htap[CHROMA ? 36 : 1];               // chroma H pass: the halved taps of fraction f as (c/2, c/2) pairs at [4 f], f = 8: the identity at tap 0
 #ifdef MC_LDS_PAD
   uint32_t pad[MC_LDS_PAD / 4];                               // experiment: fewer workgroups per CU
 #endif
@@ -164,7 +165,9 @@ __device__ inline WpTile wp_tile(const SliceDev* __restrict__ slices, uint32_t f
 //   pass 0, uni: final samples (filter isLast / weightUnidir) -> dst;  pass 0, bi: HM's 14-bit values (16-bit Pel) wait in park[];
 //   pass 1: addAvg / weightBidir with the parked first list -> dst
 // rsd: the residual of the two rows (zero where the tile carries none): reconstruction = ClipBD(prediction + residual), TComYuv::addClip
-template <int W, bool WP, bool BI>
+// IL (chroma): lanes l and l + 32 hold the same rows of Cb and Cr; dst = where THIS lane's row (row 0 below 32, row 1 above) starts in the
+// plane in which the two components alternate
+template <int W, bool WP, bool BI, bool IL = false>
 __device__ inline void finish_rows(int (&v6)[2][W], uint32_t (&park)[W], int pass, bool bi, int bd, const WpTile& wp,
                                    const uint32_t (&rsd)[2][W / 2], int16_t* __restrict__ dst, int pitch) {
   const int head = bd >= 12 ? 2 : 14 - bd;
@@ -222,6 +225,19 @@ __device__ inline void finish_rows(int (&v6)[2][W], uint32_t (&park)[W], int pas
   for (int r = 0; r < 2; r++)
 #pragma unroll
     for (int x = 0; x < W / 2; x++) res[r][x] = pk_clip_u(pk_add_sat(res[r][x], rsd[r][x]), maxv2);
+  if constexpr (IL) {
+    static_assert(W == 4, "chroma tiles");
+    uint32_t o[4];
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+      // v_permlane32_swap: [0] = Cb, [1] = Cr of this lane's row (below 32: own row 0 | the upper lane's row 0; above: the lower lane's row 1 | own row 1)
+      const auto sw = __builtin_amdgcn_permlane32_swap(res[0][j], res[1][j], false, false);
+      o[2 * j] = __builtin_amdgcn_perm(sw[1], sw[0], 0x05040100u);
+      o[2 * j + 1] = __builtin_amdgcn_perm(sw[1], sw[0], 0x07060302u);
+    }
+    stg4(dst, u32x4{o[0], o[1], o[2], o[3]});
+    return;
+  }
 #pragma unroll
   for (int r = 0; r < 2; r++) {
     int16_t* row = dst + (ptrdiff_t)r * pitch;
@@ -536,29 +552,60 @@ __global__ void __launch_bounds__(256, (WP || BI) ? 1 : MC_LB_LUMA) k_mc_luma(co
 }
 
 // ====================================================================================================== chroma
-// H pass work item: window rows (2i, 2i+1) x 4 columns of BOTH planes.  r[2 * plane + row] = one row (4 dwords = 8 samples).
-// out (LDS): plane p, piece c at out[p * 64 + c * 32]
+// Cb and Cr alternate in ONE plane (hmgpu_dev.h "chroma planes"): a dword of a window row is the pair (Cb, Cr) of one position, so the
+// horizontal pass runs on both components at once in packed 16-bit arithmetic, tap by tap (v_pk_mad_i16 with the tap in both halves) --
+// no pairing of neighbouring samples, no parity of the window start.  16 bits are enough because every chroma tap is even: with
+// S = sum of (c_k / 2) x_k, HM's first-stage value (sum of c_k x_k - (8192 << s)) >> s, s = bit depth - 8 (filter<4, false, true, false>,
+// TComInterpolationFilter.cpp:195-212) is ((S - (4096 << s)) << 1) >> s, and S - (4096 << s) lies in [-21499, 21467] at 10 bits, [-5371,
+// 5339] at 8 (wrapping on the way is harmless, the end value fits).  Bit depths above 10 would need the 32-bit form.
+struct alignas(16) HTapsChroma { uint32_t e[9][4]; };
+constexpr HTapsChroma make_htaps_chroma() {
+  constexpr int c[9][4] = {{0, 64, 0, 0}, {-2, 58, 10, -2}, {-4, 54, 16, -2}, {-6, 46, 28, -4}, {-4, 36, 36, -4}, {-4, 28, 46, -6}, {-2, 16, 54, -4}, {-2, 10, 58, -2},
+                           {64, 0, 0, 0}};
+  HTapsChroma t = {};
+  for (int f = 0; f < 9; f++)
+    for (int k = 0; k < 4; k++) t.e[f][k] = pk16(c[f][k] / 2, c[f][k] / 2);
+  return t;
+}
+__device__ const HTapsChroma g_htaps_chroma = make_htaps_chroma();
+__device__ inline uint32_t pk_mad(uint32_t a, uint32_t b, uint32_t c) {                 // per half: a * b + c (wrapping)
+  uint32_t d;
+  asm("v_pk_mad_i16 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+  return d;
+}
+__device__ inline uint32_t pk_ashr(uint32_t v, uint32_t sh2) {                          // per half: v >> sh (sh2 = sh | sh << 16)
+  uint32_t d;
+  asm("v_pk_ashrrev_i16 %0, %1, %2" : "=v"(d) : "v"(sh2), "v"(v));
+  return d;
+}
+__device__ inline uint32_t pk_shl(uint32_t v, uint32_t sh2) {
+  uint32_t d;
+  asm("v_pk_lshlrev_b16 %0, %1, %2" : "=v"(d) : "v"(sh2), "v"(v));
+  return d;
+}
+// H pass work item: window rows (2i, 2i+1) x 4 columns of BOTH components.  r[2 * row], r[2 * row + 1] = the row's 8 (Cb, Cr) pairs from the
+// window's first position on.  tap: the fraction's four (c/2, c/2) pairs.  out (LDS): component p, piece c at out[p * 64 + c * 32], a dword =
+// (row 2i | row 2i+1 << 16) of one column -- HM's first-stage values WITH their -8192 offset (the V pass seeds its sums with 8192 * 64)
 __device__ inline void h_item_chroma(const u32x4 (&r)[4], const uint32_t* __restrict__ tap, int sh1, uint32_t* __restrict__ out) {
-  const u32x4 t0 = *reinterpret_cast<const u32x4*>(tap);
-  const u32x2 t1 = *reinterpret_cast<const u32x2*>(tap + 4);
-  const uint32_t te[3] = {t0.x, t0.y, t0.z}, to[3] = {t0.w, t1.x, t1.y};
+  const u32x4 t = *reinterpret_cast<const u32x4*>(tap);
+  const uint32_t tc[4] = {t.x, t.y, t.z, t.w};
+  const uint32_t init = (uint32_t)((-(4096 << sh1)) & 0xffff) * 0x10001u;
+  uint32_t h[2][4];
 #pragma unroll
-  for (int pl = 0; pl < 2; pl++) {
-    int sum[2][4];
+  for (int row = 0; row < 2; row++) {
+    const uint32_t d[8] = {r[2 * row].x, r[2 * row].y, r[2 * row].z, r[2 * row].w, r[2 * row + 1].x, r[2 * row + 1].y, r[2 * row + 1].z, r[2 * row + 1].w};
 #pragma unroll
-    for (int row = 0; row < 2; row++) {
-      const uint32_t d[4] = {r[2 * pl + row].x, r[2 * pl + row].y, r[2 * pl + row].z, r[2 * pl + row].w};
+    for (int x = 0; x < 4; x++) {
+      uint32_t v = pk_mad(d[x], tc[0], init);
 #pragma unroll
-      for (int x = 0; x < 4; x++) {
-        int v = dot2_first(d[x >> 1], (x & 1) ? to[0] : te[0]);
-#pragma unroll
-        for (int j = 1; j < 3; j++) v = dot2(d[(x >> 1) + j], (x & 1) ? to[j] : te[j], v);
-        sum[row][x] = v;
-      }
+      for (int k = 1; k < 4; k++) v = pk_mad(d[x + k], tc[k], v);
+      h[row][x] = sh1 == 0 ? pk_shl(v, 0x00010001u) : pk_ashr(v, (uint32_t)(sh1 - 1) * 0x10001u);
     }
+  }
 #pragma unroll
-    for (int c = 0; c < 2; c++)
-      *reinterpret_cast<u32x2*>(out + pl * 64 + c * 32) = u32x2{pack_shr(sum[0][2 * c], sum[1][2 * c], sh1), pack_shr(sum[0][2 * c + 1], sum[1][2 * c + 1], sh1)};
+  for (int c = 0; c < 2; c++) {
+    *reinterpret_cast<u32x2*>(out + c * 32) = u32x2{__builtin_amdgcn_perm(h[1][2 * c], h[0][2 * c], 0x05040100u), __builtin_amdgcn_perm(h[1][2 * c + 1], h[0][2 * c + 1], 0x05040100u)};
+    *reinterpret_cast<u32x2*>(out + 64 + c * 32) = u32x2{__builtin_amdgcn_perm(h[1][2 * c], h[0][2 * c], 0x07060302u), __builtin_amdgcn_perm(h[1][2 * c + 1], h[0][2 * c + 1], 0x07060302u)};
   }
 }
 
@@ -577,6 +624,7 @@ __global__ void __launch_bounds__(256, (WP && BI) ? 6 : MC_LB_CHROMA) k_mc_chrom
   const int x0 = g.sx + tx * 8, y0 = g.sy + wave * 16 + r * 8;                            // luma position of the tile
   const u32x4 tm = load_tile_rec(a, slot, g, x0, y0);
   if (lane < 36) *reinterpret_cast<u32x4*>(&S.taps[4 * lane]) = ldg4(&g_taps_chroma.e[0][0] + 4 * lane);
+  else if (lane < 45) *reinterpret_cast<u32x4*>(&S.htap[4 * (lane - 36)]) = ldg4(&g_htaps_chroma.e[0][0] + 4 * (lane - 36));
   const uint32_t flags = tm.z >> 24, rmask = (tm.w >> 8) & 0xff;
   const bool active = (flags & TM_ACTIVE) != 0;
   if (!__ballot(active)) return;
@@ -630,10 +678,16 @@ __global__ void __launch_bounds__(256, (WP && BI) ? 6 : MC_LB_CHROMA) k_mc_chrom
     const bool row2 = true;
 #endif
     if (hact) {
-      const int xs = (x0 >> 1) + (ix >> 1) - 1, ys = (y0 >> 1) + (iy >> 1) - (yz ? 2 : 1) + (hi ? 0 : 4) + 2 * hq;
       const int xf = ((ix & 1) << 2) | (fr & 3);
-      const wref p0 = win.at(win.plane(a, (int)((tm.z >> (8 + 8 * pass)) & (kMaxPics - 1))), ys, pitch, xs & ~1);
-      const wref p1 = p0 + a.cr_off;
+#ifdef MC_F0
+      const bool xz = xf == 0;          // no horizontal interpolation: the window starts at the block's first column (identity at tap 0), one piece per row
+#else
+      const bool xz = false;
+#endif
+      const int xs = (x0 >> 1) + (ix >> 1) - (xz ? 0 : 1), ys = (y0 >> 1) + (iy >> 1) - (yz ? 2 : 1) + (hi ? 0 : 4) + 2 * hq;
+      // a window row = the (Cb, Cr) pairs xs .. xs + 6 of one plane row: two 16-byte pieces of ONE line (hmgpu_dev.h "chroma planes")
+      const wref p0 = win.at(win.plane(a, (int)((tm.z >> (8 + 8 * pass)) & (kMaxPics - 1))), ys, pitch, kCStep * xs);
+      const int rowb = pitch * 2;
       u32x4 rr[4];
 #if defined(MC_CEXP) && (MC_CEXP & 1)       // experiment: no halo rows
       const bool ld = hi == 0;
@@ -642,9 +696,9 @@ __global__ void __launch_bounds__(256, (WP && BI) ? 6 : MC_LB_CHROMA) k_mc_chrom
 #else
       const bool ld = true;
 #endif
-      rr[0] = win.load(ld ? p0 : win.nowhere()); rr[1] = win.load(ld && row2 ? p0 + pitch * 2 : win.nowhere());
-      rr[2] = win.load(ld ? p1 : win.nowhere()); rr[3] = win.load(ld && row2 ? p1 + pitch * 2 : win.nowhere());
-      h_item_chroma(rr, &S.taps[(xf * 2 + (xs & 1)) * 8], sh1, hout);
+      rr[0] = win.load(ld ? p0 : win.nowhere()); rr[1] = win.load(ld && !xz ? p0 + 16 : win.nowhere());
+      rr[2] = win.load(ld && row2 ? p0 + rowb : win.nowhere()); rr[3] = win.load(ld && row2 && !xz ? p0 + rowb + 16 : win.nowhere());
+      h_item_chroma(rr, &S.htap[(xz ? 8 : xf) * 4], sh1, hout);
     }
     wave_lds_sync();
     if (vact) {
@@ -653,7 +707,8 @@ __global__ void __launch_bounds__(256, (WP && BI) ? 6 : MC_LB_CHROMA) k_mc_chrom
       const u32x4 t0 = *reinterpret_cast<const u32x4*>(vtap);
       const u32x2 t1 = *reinterpret_cast<const u32x2*>(vtap + 4);
       const uint32_t A[2] = {t0.x, t0.y}, B[3] = {t0.w, t1.x, t1.y};
-      const int seed = (!WP && !BI) ? 32 << head : 0;
+      // (the first-stage values in LDS carry HM's -8192: the taps sum to 64, so 8192 * 64 brings the sums to what finish_rows expects)
+      const int seed = (8192 << 6) + ((!WP && !BI) ? 32 << head : 0);
       int v6[2][4];
 #pragma unroll
       for (int j = 0; j < 3; j++) {
@@ -671,7 +726,9 @@ __global__ void __launch_bounds__(256, (WP && BI) ? 6 : MC_LB_CHROMA) k_mc_chrom
         }
       }
       const int xc = x0 >> 1, yc = (y0 >> 1) + 2 * hq;
-      finish_rows<4, WP, BI>(v6, park, pass, (flags & TM_BI) != 0, bd, wp, rsd, (hi ? a.dst2[slot] : a.dst[slot]) + (ptrdiff_t)yc * pitch + xc, pitch);
+      // the lane holds rows 2hq, 2hq+1 x 4 columns of ONE component; the plane wants (Cb, Cr) pairs: the two lanes of a position (32 apart)
+      // swap a row each and store 16 bytes -- lane hi writes row 2hq + hi of both components (finish_rows, IL)
+      finish_rows<4, WP, BI, true>(v6, park, pass, (flags & TM_BI) != 0, bd, wp, rsd, a.dst[slot] + (ptrdiff_t)(yc + hi) * pitch + kCStep * xc, pitch);
     }
     if (BI && pass + 1 < npass) wave_lds_sync();
   }

@@ -7,28 +7,40 @@
 namespace hmgpu {
 
 // ---- packing: one thread per output sample pair (bytes = 1) or per sample pair (bytes = 2) of the cropped plane
-__global__ void __launch_bounds__(256) k_pack(const int16_t* __restrict__ src, int pitch, int x0, int y0, int w, int h, int bytes,
+// step: distance of two samples of the plane in memory (1: luma; 2: a chroma component, whose samples alternate with the other one's:
+// hmgpu_dev.h "chroma planes")
+__global__ void __launch_bounds__(256) k_pack(const int16_t* __restrict__ src, int pitch, int step, int x0, int y0, int w, int h, int bytes,
                                               uint8_t* __restrict__ dst, int dst_stride) {
   const int x = (blockIdx.x * 256 + threadIdx.x) * 2, y = blockIdx.y;
   if (x >= w || y >= h) return;
-  const int16_t* s = src + (ptrdiff_t)(y0 + y) * pitch + x0 + x;
-  const int a = (uint16_t)ldg(s), b = x + 1 < w ? (uint16_t)ldg(s + 1) : 0;
+  const int16_t* s = src + (ptrdiff_t)(y0 + y) * pitch + (x0 + x) * step;
+  const int a = (uint16_t)ldg(s), b = x + 1 < w ? (uint16_t)ldg(s + step) : 0;
   uint8_t* d = dst + (size_t)y * dst_stride + (size_t)x * bytes;
   if (bytes == 1) { d[0] = (uint8_t)a; if (x + 1 < w) d[1] = (uint8_t)b; }
   else { d[0] = (uint8_t)a; d[1] = (uint8_t)(a >> 8); if (x + 1 < w) { d[2] = (uint8_t)b; d[3] = (uint8_t)(b >> 8); } }
 }
 
-void launch_pack(const int16_t* src, int pitch, int x0, int y0, int w, int h, int bytes, uint8_t* dst, int dst_stride, hipStream_t s) {
-  hipLaunchKernelGGL(k_pack, dim3((unsigned)((w / 2 + 256) / 256), (unsigned)h), dim3(256), 0, s, src, pitch, x0, y0, w, h, bytes, dst, dst_stride);
+void launch_pack(const int16_t* src, int pitch, int step, int x0, int y0, int w, int h, int bytes, uint8_t* dst, int dst_stride, hipStream_t s) {
+  hipLaunchKernelGGL(k_pack, dim3((unsigned)((w / 2 + 256) / 256), (unsigned)h), dim3(256), 0, s, src, pitch, step, x0, y0, w, h, bytes, dst, dst_stride);
+}
+
+// ---- the way in (hmgpu_picture_upload): a dense w x h block of samples into a plane whose samples lie `step` apart
+__global__ void __launch_bounds__(256) k_unpack(const int16_t* __restrict__ src, int w, int h, int16_t* __restrict__ dst, int pitch, int step) {
+  const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+  if (x >= w || y >= h) return;
+  stg(dst + (ptrdiff_t)y * pitch + x * step, ldg(src + (size_t)y * w + x));
+}
+void launch_unpack(const int16_t* src, int w, int h, int16_t* dst, int pitch, int step, hipStream_t s) {
+  hipLaunchKernelGGL(k_unpack, dim3((unsigned)((w + 255) / 256), (unsigned)h), dim3(256), 0, s, src, w, h, dst, pitch, step);
 }
 
 // ---- checksum: sum over the plane of (byte ^ mask(x, y)) mod 2^32 -- any order
-__global__ void __launch_bounds__(256) k_checksum(const int16_t* __restrict__ src, int pitch, int w, int h, int bd, uint32_t* __restrict__ out) {
+__global__ void __launch_bounds__(256) k_checksum(const int16_t* __restrict__ src, int pitch, int step, int w, int h, int bd, uint32_t* __restrict__ out) {
   __shared__ uint32_t part[256];
   uint32_t sum = 0;
   for (int y = blockIdx.x; y < h; y += gridDim.x)
     for (int x = threadIdx.x; x < w; x += 256) {
-      const uint32_t mask = ((x & 0xff) ^ (y & 0xff) ^ (x >> 8) ^ (y >> 8)) & 0xff, v = (uint16_t)ldg(src + (ptrdiff_t)y * pitch + x);
+      const uint32_t mask = ((x & 0xff) ^ (y & 0xff) ^ (x >> 8) ^ (y >> 8)) & 0xff, v = (uint16_t)ldg(src + (ptrdiff_t)y * pitch + x * step);
       sum += (v & 0xff) ^ mask;
       if (bd > 8) sum += (v >> 8) ^ mask;
     }
@@ -49,13 +61,13 @@ __device__ inline uint32_t crc_byte(uint32_t crc, uint32_t byte) {
   }
   return crc;
 }
-__global__ void __launch_bounds__(256) k_crc_rows(const int16_t* __restrict__ src, int pitch, int w, int h, int bd, uint32_t* __restrict__ rows) {
+__global__ void __launch_bounds__(256) k_crc_rows(const int16_t* __restrict__ src, int pitch, int step, int w, int h, int bd, uint32_t* __restrict__ rows) {
   const int y = blockIdx.x * 256 + threadIdx.x;
   if (y >= h) return;
   uint32_t crc = 0;
   const int16_t* s = src + (ptrdiff_t)y * pitch;
   for (int x = 0; x < w; x++) {
-    const uint32_t v = (uint16_t)ldg(s + x);
+    const uint32_t v = (uint16_t)ldg(s + x * step);
     crc = crc_byte(crc, v & 0xff);                          // HM feeds the low byte first, then the high byte (:95-115)
     if (bd > 8) crc = crc_byte(crc, v >> 8);
   }
@@ -164,11 +176,11 @@ void launch_md5(const Md5Batch& job, hipStream_t s) {
   hipLaunchKernelGGL(k_md5, dim3((unsigned)((job.n + 63) / 64)), dim3(64), 0, s, job);
 }
 
-void launch_checksum(const int16_t* src, int pitch, int w, int h, int bd, uint32_t* out, hipStream_t s) {
-  hipLaunchKernelGGL(k_checksum, dim3((unsigned)((h + 3) / 4)), dim3(256), 0, s, src, pitch, w, h, bd, out);
+void launch_checksum(const int16_t* src, int pitch, int step, int w, int h, int bd, uint32_t* out, hipStream_t s) {
+  hipLaunchKernelGGL(k_checksum, dim3((unsigned)((h + 3) / 4)), dim3(256), 0, s, src, pitch, step, w, h, bd, out);
 }
-void launch_crc(const int16_t* src, int pitch, int w, int h, int bd, uint32_t* rows, uint32_t* out, hipStream_t s) {
-  hipLaunchKernelGGL(k_crc_rows, dim3((unsigned)((h + 255) / 256)), dim3(256), 0, s, src, pitch, w, h, bd, rows);
+void launch_crc(const int16_t* src, int pitch, int step, int w, int h, int bd, uint32_t* rows, uint32_t* out, hipStream_t s) {
+  hipLaunchKernelGGL(k_crc_rows, dim3((unsigned)((h + 255) / 256)), dim3(256), 0, s, src, pitch, step, w, h, bd, rows);
   hipLaunchKernelGGL(k_crc_fold, dim3(1), dim3(64), 0, s, rows, h, w * (bd > 8 ? 2 : 1), out);
 }
 

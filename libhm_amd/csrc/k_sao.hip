@@ -15,18 +15,20 @@
 namespace hmgpu {
 
 // edge offset of one row of 8 samples, compile-time direction (DX, DY in {-1,0,1}); everything stays packed (2 samples / register)
+// src: the component's sample (0, 0); comp > 0: its samples lie kCStep elements apart (ldc8)
 template <int DX, int DY>
-__device__ inline void sao_eo_row(const int16_t* __restrict__ src, int pitch, int w, int h, int x, int row, const u32x4 cur, uint32_t off_lo,
+__device__ inline void sao_eo_row(const int16_t* __restrict__ src, int comp, int pitch, int w, int h, int x, int row, const u32x4 cur, uint32_t off_lo,
                                   uint32_t off_hi, unsigned av, int x0, int y0, int x1, int y1, int maxv, uint32_t (&out)[4]) {
   const int ya = row + DY, yb = row - DY;
   const int16_t* ra = src + (size_t)clip3(0, h - 1, ya) * pitch;
   const int16_t* rb = src + (size_t)clip3(0, h - 1, yb) * pitch;
+  const int st = comp ? kCStep : 1;
   uint32_t na[4], nb[4];
   {
-    const u32x4 ea = DY == 0 ? cur : ldg4(ra + x), eb = DY == 0 ? cur : ldg4(rb + x);
+    const u32x4 ea = DY == 0 ? cur : (comp ? ldc8(ra, x, comp) : ldg4(ra + x)), eb = DY == 0 ? cur : (comp ? ldc8(rb, x, comp) : ldg4(rb + x));
     uint32_t la = 0, raa = 0, lb = 0, rbb = 0;
-    if constexpr (DX < 0) { la = (uint16_t)ldg(ra + max(x - 1, 0)); rbb = (uint16_t)ldg(rb + min(x + 8, w - 1)); }
-    if constexpr (DX > 0) { raa = (uint16_t)ldg(ra + min(x + 8, w - 1)); lb = (uint16_t)ldg(rb + max(x - 1, 0)); }
+    if constexpr (DX < 0) { la = (uint16_t)ldg(ra + st * max(x - 1, 0)); rbb = (uint16_t)ldg(rb + st * min(x + 8, w - 1)); }
+    if constexpr (DX > 0) { raa = (uint16_t)ldg(ra + st * min(x + 8, w - 1)); lb = (uint16_t)ldg(rb + st * max(x - 1, 0)); }
     shifted<DX>(ea, la, raa, na);
     shifted<-DX>(eb, lb, rbb, nb);
   }
@@ -58,8 +60,8 @@ __global__ void __launch_bounds__(256) k_sao(const PicDev* __restrict__ pics, Ba
   const uint32_t* pw = reinterpret_cast<const uint32_t*>(P.saoprm + ((size_t)cy * P.ctus_w + cx) * 3 + comp);
   const uint32_t w0 = ldg(pw);
   const int type = (int)(int8_t)(w0 & 0xff);
-  const u32x4 cur = ldg4(src + (size_t)row * pitch + x);
-  if (type < 0) { stg4(dst + (size_t)row * pitch + x, cur); return; }
+  const u32x4 cur = comp ? ldc8(src + (size_t)row * pitch, x, comp) : ldg4(src + (size_t)row * pitch + x);
+  if (type < 0) { if (comp) stc8(dst + (size_t)row * pitch, x, cur); else stg4(dst + (size_t)row * pitch + x, cur); return; }
   const uint32_t off_lo = ldg(pw + 1), off_hi = ldg(pw + 2);            // off[0..3], off[4..7]
   const int bd = P.bd[comp];
   const int maxv = (1 << bd) - 1;
@@ -81,10 +83,10 @@ __global__ void __launch_bounds__(256) k_sao(const PicDev* __restrict__ pics, Ba
     const int x1 = min(x0 + ctb, w) - 1, y1 = min(y0 + ctb, h) - 1;     // CTB clipped to the picture (offsetCTU :679-682)
     const unsigned av = w0 >> 16;
     switch (type) {                                                      // a = (x+DX, y+DY), b = (x-DX, y-DY)
-      case HMGPU_SAO_EO_0:   sao_eo_row<-1, 0>(src, pitch, w, h, x, row, cur, off_lo, off_hi, av, x0, y0, x1, y1, maxv, out); break;
-      case HMGPU_SAO_EO_90:  sao_eo_row<0, -1>(src, pitch, w, h, x, row, cur, off_lo, off_hi, av, x0, y0, x1, y1, maxv, out); break;
-      case HMGPU_SAO_EO_135: sao_eo_row<-1, -1>(src, pitch, w, h, x, row, cur, off_lo, off_hi, av, x0, y0, x1, y1, maxv, out); break;
-      default:               sao_eo_row<1, -1>(src, pitch, w, h, x, row, cur, off_lo, off_hi, av, x0, y0, x1, y1, maxv, out); break;
+      case HMGPU_SAO_EO_0:   sao_eo_row<-1, 0>(src, comp, pitch, w, h, x, row, cur, off_lo, off_hi, av, x0, y0, x1, y1, maxv, out); break;
+      case HMGPU_SAO_EO_90:  sao_eo_row<0, -1>(src, comp, pitch, w, h, x, row, cur, off_lo, off_hi, av, x0, y0, x1, y1, maxv, out); break;
+      case HMGPU_SAO_EO_135: sao_eo_row<-1, -1>(src, comp, pitch, w, h, x, row, cur, off_lo, off_hi, av, x0, y0, x1, y1, maxv, out); break;
+      default:               sao_eo_row<1, -1>(src, comp, pitch, w, h, x, row, cur, off_lo, off_hi, av, x0, y0, x1, y1, maxv, out); break;
     }
   }
   if (P.any_nofilt) {
@@ -95,60 +97,70 @@ __global__ void __launch_bounds__(256) k_sao(const PicDev* __restrict__ pics, Ba
     for (int j = 0; j < 4; j++) out[j] = (c[j] & m[j]) | (out[j] & ~m[j]);
   }
   u32x4 res = {out[0], out[1], out[2], out[3]};
-  stg4(dst + (size_t)row * pitch + x, res);
+  if (comp) stc8(dst + (size_t)row * pitch, x, res); else stg4(dst + (size_t)row * pitch + x, res);
 }
 
 // TComPicYuv::extendPicBorder (TComPicYuv.cpp:173-217): replicate the edge samples of the picture's FINAL planes into the
 // margins so that motion compensation of later pictures never has to clamp coordinates.  One thread per 16-byte piece of
 // margin (8 samples): side bands first (every row of the padded plane, left and right), then the bands above and below the
 // picture columns.  Every thread reads only samples of the visible picture, so there is no ordering between margin writes.
-__global__ void __launch_bounds__(256) k_extend(const PicDev* __restrict__ pics, Batch b, int luma_vecs, int chroma_vecs) {
-  const PicDev& P = pics[b.pic[blockIdx.z]];
-  int idx = blockIdx.x * 256 + threadIdx.x;
-  int comp = 0;
-  if (idx >= luma_vecs) { idx -= luma_vecs; comp = 1; if (idx >= chroma_vecs) { idx -= chroma_vecs; comp = 2; if (idx >= chroma_vecs) return; } }
-  const int cs = comp ? 1 : 0;
-  const int w = P.width >> cs, h = P.height >> cs, mx = P.mx[comp], my = P.my[comp], pitch = P.pitch[comp];
-  int16_t* pl = P.sao_applied ? P.sao[comp] : P.rec[comp];
-  const int side_vecs_per_row = 2 * mx / 8;                  // left + right band, 8 samples per vector
+// E = int16 elements per picture element: 1 luma (an element = a sample), kCStep chroma (an element = the (Cb, Cr) pair of a position: the two
+// components share a plane, hmgpu_dev.h "chroma planes")
+template <int E>
+__device__ inline void extend_plane(int16_t* pl, int w, int h, int mx, int my, int pitch, int idx) {
+  constexpr int VE = 8 / E;                                  // elements per 16-byte vector
+  auto edge = [&](int y, int x) -> uint32_t {                // element (x, y) as a dword pattern
+    if constexpr (E == 1) return (uint16_t)ldg(pl + (ptrdiff_t)y * pitch + x) * 0x10001u;
+    else return ldg(reinterpret_cast<const uint32_t*>(pl + (ptrdiff_t)y * pitch + E * x));
+  };
+  const int side_vecs_per_row = 2 * mx / VE;                 // left + right band
   const int rows = h + 2 * my;
   if (idx < side_vecs_per_row * rows) {
     const int y = idx / side_vecs_per_row - my, k = idx % side_vecs_per_row;
-    const bool right = k >= mx / 8;
-    const int x = right ? w + (k - mx / 8) * 8 : -mx + k * 8;
-    const uint32_t v = (uint16_t)ldg(pl + (ptrdiff_t)clip3(0, h - 1, y) * pitch + (right ? w - 1 : 0)) * 0x10001u;
+    const bool right = k >= mx / VE;
+    const int x = right ? w + (k - mx / VE) * VE : -mx + k * VE;
+    const uint32_t v = edge(clip3(0, h - 1, y), right ? w - 1 : 0);
     u32x4 o = {v, v, v, v};
-    if (right) stg4_a8(pl + (ptrdiff_t)y * pitch + x, o);    // a chroma width that is 4 mod 8 starts the band on an 8-byte boundary only
-    else stg4(pl + (ptrdiff_t)y * pitch + x, o);
+    stg4(pl + (ptrdiff_t)y * pitch + E * x, o);              // (widths are multiples of 8 luma samples: both bands start on 16-byte boundaries)
   } else {
     idx -= side_vecs_per_row * rows;
-    const int vecs_per_row = (w + 7) / 8;
+    const int vecs_per_row = (w + VE - 1) / VE;
     const int r = idx / vecs_per_row;                         // 0 .. 2*my-1
     if (r >= 2 * my) return;
     const int y = r < my ? r - my : h + (r - my);
-    const int x = (idx % vecs_per_row) * 8;
-    // (a picture whose width is not a multiple of 8 samples lets the last vector run into the right band: same values)
-    u32x4 o = ldg4(pl + (ptrdiff_t)(r < my ? 0 : h - 1) * pitch + x);
-    if (x + 8 > w) {
-      const uint32_t e = (uint16_t)ldg(pl + (ptrdiff_t)(r < my ? 0 : h - 1) * pitch + w - 1) * 0x10001u;
+    const int x = (idx % vecs_per_row) * VE;
+    const int sy = r < my ? 0 : h - 1;
+    // (a picture whose width is not a multiple of a vector lets the last vector run into the right band: same values)
+    u32x4 o = ldg4(pl + (ptrdiff_t)sy * pitch + E * x);
+    if (x + VE > w) {
+      const uint32_t e = edge(sy, w - 1);
       uint32_t t[4] = {o.x, o.y, o.z, o.w};
 #pragma unroll
       for (int j = 0; j < 4; j++) {
-        if (x + 2 * j >= w) t[j] = e;
-        else if (x + 2 * j + 1 >= w) t[j] = (t[j] & 0xffffu) | (e & 0xffff0000u);
+        if constexpr (E == 1) {
+          if (x + 2 * j >= w) t[j] = e;
+          else if (x + 2 * j + 1 >= w) t[j] = (t[j] & 0xffffu) | (e & 0xffff0000u);
+        } else if (x + j >= w) t[j] = e;
       }
       o = (u32x4){t[0], t[1], t[2], t[3]};
     }
-    stg4(pl + (ptrdiff_t)y * pitch + x, o);
+    stg4(pl + (ptrdiff_t)y * pitch + E * x, o);
   }
+}
+__global__ void __launch_bounds__(256) k_extend(const PicDev* __restrict__ pics, Batch b, int luma_vecs, int chroma_vecs) {
+  const PicDev& P = pics[b.pic[blockIdx.z]];
+  int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx < luma_vecs) { extend_plane<1>(P.sao_applied ? P.sao[0] : P.rec[0], P.width, P.height, P.mx[0], P.my[0], P.pitch[0], idx); return; }
+  idx -= luma_vecs;
+  if (idx < chroma_vecs) extend_plane<kCStep>(P.sao_applied ? P.sao[1] : P.rec[1], P.width >> 1, P.height >> 1, P.mx[1], P.my[1], P.pitch[1], idx);
 }
 
 void launch_extend(const PicDev* pics, const Batch& b, int width, int height, int mx, int my, hipStream_t s) {
-  // luma margins (mx, my); chroma margins are half of them
+  // luma margins (mx, my); chroma margins are half of them, a chroma element is a (Cb, Cr) pair = 4 bytes
   const int luma = (2 * mx / 8) * (height + 2 * my) + ((width + 7) / 8) * 2 * my;
-  const int cw = width / 2, chh = height / 2, cmx = mx / 2, cmy = my / 2;
-  const int chroma = (2 * cmx / 8) * (chh + 2 * cmy) + ((cw + 7) / 8) * 2 * cmy;
-  dim3 grid((unsigned)((luma + 2 * chroma + 255) / 256), 1, (unsigned)b.n);
+  const int cw = width / 2, chh = height / 2, cmx = mx / 2, cmy = my / 2, ve = 8 / kCStep;
+  const int chroma = (2 * cmx / ve) * (chh + 2 * cmy) + ((cw + ve - 1) / ve) * 2 * cmy;
+  dim3 grid((unsigned)((luma + chroma + 255) / 256), 1, (unsigned)b.n);
   hipLaunchKernelGGL(k_extend, grid, dim3(256), 0, s, pics, b, luma, chroma);
 }
 

@@ -32,8 +32,11 @@ __device__ inline void clip_mv(const PicDev& P, int cu_x, int cu_y, int& mvx, in
 // fetched as dwords (two samples each), re-paired for even and odd output columns with one funnel shift per dword,
 // filtered horizontally with TAPS/2 dot2 per output, and every pair of consecutive intermediate rows is folded into the
 // vertical accumulators it contributes to (again TAPS/2 dot2 per output).
-template <int TAPS, int W, int H>
-__device__ inline void predict14(const int16_t* __restrict__ ref, int pitch, int x0, int y0, int mvx, int mvy, int bd, int (&out)[H][W]) {
+// STEP 2 (chroma): `ref` is the plane in which Cb and Cr alternate (hmgpu_dev.h "chroma planes"), a dword of a row = one position's
+// (Cb, Cr), `half` picks the component; the pairs of neighbouring samples the dot products want come out of two dwords with one byte
+// permute, whatever the parity of the window start.
+template <int TAPS, int W, int H, int STEP = 1>
+__device__ inline void predict14(const int16_t* __restrict__ ref, int pitch, int x0, int y0, int mvx, int mvy, int bd, int (&out)[H][W], int half = 0) {
   constexpr int FB = TAPS == 8 ? 2 : 3;
   constexpr int BEFORE = TAPS / 2 - 1;
   constexpr int ROWS = H + TAPS - 1, COLS = W + TAPS - 1;
@@ -54,34 +57,48 @@ __device__ inline void predict14(const int16_t* __restrict__ ref, int pitch, int
   for (int y = 0; y < H; y++)
 #pragma unroll
     for (int x = 0; x < W; x++) out[y][x] = 0;
-  const int sh_odd = (xs & 1) * 16;
-  const int16_t* base = ref + (ptrdiff_t)ys * pitch + (xs & ~1);
+  const int sh_odd = STEP == 1 ? (xs & 1) * 16 : 0;
+  const int16_t* base = ref + (ptrdiff_t)ys * pitch + (STEP == 1 ? (xs & ~1) : STEP * xs);
+  constexpr int NL = STEP == 1 ? ND : COLS;                // dwords loaded per row
+  const uint32_t sel = half ? 0x07060302u : 0x05040100u;
   // every row of the window is requested before any arithmetic starts: one memory latency per tile instead of one per
   // row (left to itself the compiler issues each row's loads ~100 instructions before their use and then waits for them).
   // Loads return in order, so the counted waits let row r be filtered while rows r+1.. are still in flight.
-  uint32_t raw[ROWS][ND];
+  uint32_t raw[ROWS][NL];
 #pragma unroll
   for (int r = 0; r < ROWS; r++) {
     const uint32_t* q = reinterpret_cast<const uint32_t*>(base + (ptrdiff_t)r * pitch);
 #pragma unroll
-    for (int i = 0; i < ND; i++) raw[r][i] = ldg(q + i);
+    for (int i = 0; i < NL; i++) raw[r][i] = ldg(q + i);
   }
   __builtin_amdgcn_sched_barrier(0);
   int prev[W];
 #pragma unroll
   for (int r = 0; r < ROWS; r++) {
-    uint32_t a[ND + 1];
+    uint32_t a[ND + 1], bq[ND];
+    if constexpr (STEP == 1) {
 #pragma unroll
-    for (int i = 0; i < ND; i++) a[i] = raw[r][i];
-    a[ND] = 0;
-    // a[j] = (s[2j], s[2j+1]) relative to xs: drop one sample when the start is odd
+      for (int i = 0; i < ND; i++) a[i] = raw[r][i];
+      a[ND] = 0;
+      // a[j] = (s[2j], s[2j+1]) relative to xs: drop one sample when the start is odd
 #pragma unroll
-    for (int i = 0; i < ND; i++) a[i] = __builtin_amdgcn_alignbit(a[i + 1], a[i], sh_odd);
-    // bq[j] = (s[2j+1], s[2j+2])
-    uint32_t bq[ND];
+      for (int i = 0; i < ND; i++) a[i] = __builtin_amdgcn_alignbit(a[i + 1], a[i], sh_odd);
+      // bq[j] = (s[2j+1], s[2j+2])
 #pragma unroll
-    for (int i = 0; i + 1 < ND; i++) bq[i] = __builtin_amdgcn_alignbit(a[i + 1], a[i], 16);
-    bq[ND - 1] = 0;
+      for (int i = 0; i + 1 < ND; i++) bq[i] = __builtin_amdgcn_alignbit(a[i + 1], a[i], 16);
+      bq[ND - 1] = 0;
+    } else {
+      // raw[i] = (Cb, Cr) of position xs + i
+      uint32_t pr[2 * ND + 1];
+#pragma unroll
+      for (int i = 0; i < 2 * ND + 1; i++) pr[i] = i < NL ? raw[r][i < NL ? i : 0] : 0u;
+#pragma unroll
+      for (int i = 0; i < ND; i++) {
+        a[i] = __builtin_amdgcn_perm(pr[2 * i + 1], pr[2 * i], sel);
+        bq[i] = __builtin_amdgcn_perm(pr[2 * i + 2], pr[2 * i + 1], sel);
+      }
+      a[ND] = 0;
+    }
     int t[W];
 #pragma unroll
     for (int x = 0; x < W; x++) {
@@ -168,7 +185,8 @@ __device__ inline void predict_tile(const PicDev& P, const PlaneSet* __restrict_
     int mvx = l0 ? bi.mv[1][0] : bi.mv[0][0], mvy = l0 ? bi.mv[1][1] : bi.mv[0][1];
     const int ref0 = l0 ? bi.ref[1] : bi.ref[0];
     clip_mv(P, cu_x, cu_y, mvx, mvy);
-    predict14<TAPS, W, H>(ldg(&finals[ref0].p[comp]), pitch, x0, y0, mvx, mvy, bd, a);
+    if (comp == 0) predict14<TAPS, W, H>(ldg(&finals[ref0].p[0]), pitch, x0, y0, mvx, mvy, bd, a);
+    else predict14<TAPS, W, H, kCStep>(ldg(&finals[ref0].p[1]), pitch, x0, y0, mvx, mvy, bd, a, comp - 1);
 #pragma unroll
     for (int y = 0; y < H; y++)
 #pragma unroll
@@ -189,7 +207,8 @@ __device__ inline void predict_tile(const PicDev& P, const PlaneSet* __restrict_
     int b[H][W];
     int mvx = bi.mv[1][0], mvy = bi.mv[1][1];
     clip_mv(P, cu_x, cu_y, mvx, mvy);
-    predict14<TAPS, W, H>(ldg(&finals[bi.ref[1]].p[comp]), pitch, x0, y0, mvx, mvy, bd, b);
+    if (comp == 0) predict14<TAPS, W, H>(ldg(&finals[bi.ref[1]].p[0]), pitch, x0, y0, mvx, mvy, bd, b);
+    else predict14<TAPS, W, H, kCStep>(ldg(&finals[bi.ref[1]].p[1]), pitch, x0, y0, mvx, mvy, bd, b, comp - 1);
 #pragma unroll
     for (int y = 0; y < H; y++)
 #pragma unroll
@@ -215,6 +234,16 @@ __device__ inline void predict_tile(const PicDev& P, const PlaneSet* __restrict_
 #pragma unroll
       for (int x = 0; x < W / 2; x++) res[y][x] = pk_clip_u(pk_add_sat(res[y][x], ldg(rp + x)), maxv2);
     }
+  }
+  if (comp) {
+    // a chroma component: every other element of its plane (dst = PicDev::rec[comp])
+#pragma unroll
+    for (int y = 0; y < H; y++) {
+      int16_t* row = dst + (ptrdiff_t)(y0 + y) * pitch + kCStep * x0;
+#pragma unroll
+      for (int x = 0; x < W / 2; x++) { stg(row + kCStep * 2 * x, (int16_t)(res[y][x] & 0xffffu)); stg(row + kCStep * (2 * x + 1), (int16_t)(res[y][x] >> 16)); }
+    }
+    return;
   }
 #pragma unroll
   for (int y = 0; y < H; y++) {
