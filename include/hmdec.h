@@ -89,6 +89,8 @@ int hmdec_picture_slice_params(libHMDec_picture* pic, int slice, void* out /* hm
 int hmdec_picture_geometry(libHMDec_picture* pic, int32_t out[12]);
 /* HMGPU_REXT_* of the picture's SPS (hmgpu_seq_params.range_ext_flags) */
 int hmdec_picture_range_ext_flags(libHMDec_picture* pic);
+/* chroma_format_idc of the picture's SPS (hmgpu_seq_params.chroma_format): 0 4:0:0, 1 4:2:0, 2 4:2:2, 3 4:4:4 */
+int hmdec_picture_chroma_format(libHMDec_picture* pic);
 /* PPS log2_sao_offset_scale_luma / _chroma of the picture (hmgpu_pic_params.sao_offset_shift_*) */
 int hmdec_picture_sao_offset_shift(libHMDec_picture* pic, int chroma);
 /* conformance window of the picture's SPS in luma samples: left, right, top, bottom (libHM hands out the uncropped picture) */

@@ -64,8 +64,10 @@ typedef struct hmgpu_seq_params {
   int32_t width, height;          /* SPS pic_{width,height}_in_luma_samples (multiple of the 8x8 minimum CU) */
   int32_t bit_depth_luma;         /* g_bitDepth[CHANNEL_TYPE_LUMA]   (8..10) */
   int32_t bit_depth_chroma;       /* g_bitDepth[CHANNEL_TYPE_CHROMA] (8..10) */
-  int32_t chroma_format;          /* chroma_format_idc: 1 (4:2:0), or 0 (4:0:0, monochrome: the chroma arrays hold no coded blocks, the chroma
-                                     planes are allocated like those of 4:2:0 and left alone; picture hashes: the first digest) */
+  int32_t chroma_format;          /* chroma_format_idc: 1 (4:2:0), 2 (4:2:2), 3 (4:4:4), or 0 (4:0:0, monochrome: the chroma arrays hold no coded
+                                     blocks, the chroma planes are allocated like those of 4:2:0 and left alone; picture hashes: the first
+                                     digest).  Chroma planes, level arrays and PCM buffers have (width >> sx) x (height >> sy) samples per
+                                     luma area, sx = 1 unless 4:4:4, sy = 1 only for 4:2:0 (getComponentScaleX/Y, TComChromaFormat.h:59-62) */
   int32_t log2_ctu_size;          /* log2 g_uiMaxCUWidth: 4, 5 or 6.  partitions are 4x4 => (1<<(2*log2_ctu_size-4)) per CTU */
   int32_t max_pictures;           /* device pictures to pre-allocate (DPB size + pictures in flight) */
   int32_t pcm_loop_filter_disable;/* SPS pcm_loop_filter_disabled_flag && pcm_enabled_flag */
@@ -140,11 +142,15 @@ typedef struct hmgpu_ctu_meta {
   const uint8_t* ipcm;               /* m_pbIPCMFlag: PCM CUs (samples from coeffs->pcm_sample)                               (optional) */
   const uint16_t* slice_idx;         /* [num_ctus] index into the picture's slice table     (optional: all 0) */
   const uint16_t* tile_idx;          /* [num_ctus] TComPicSym::getTileIdxMap                (optional: all 0) */
+  const int8_t*  ccp_alpha[2];       /* m_crossComponentPredictionAlpha[Cb, Cr] (4:4:4 with cross_component_prediction_enabled_flag: the chroma
+                                        residual of a transform unit takes (alpha * luma residual) >> 3 on top, TComTrQuant.cpp:3294-3335)  (optional) */
 } hmgpu_ctu_meta;
 
 /* Coefficient levels, HM layout (m_pcTrCoeff: TU blocks contiguous in z-order, raster inside a TU, offset of a TU =
  * 16 * z-index of its first partition for luma, 4 * ... for chroma; TComTU.cpp:64-76,186): whole-picture arrays
- * y: [num_ctus][ctu*ctu], cb/cr: [num_ctus][ctu*ctu/4]. */
+ * y: [num_ctus][ctu*ctu], cb/cr: [num_ctus][ctu*ctu/4] (4:2:2: /2 -- a chroma block of a transform unit is two squares, the upper one
+ * first, TComTU::VERTICAL_SPLIT, TComTrQuant.cpp:1436-1462; 4:4:4: /1).  In 4:2:2 cbf[1..2] carry, one transform depth below the unit's
+ * own bit, the flags of the two squares over the upper / lower half of its partitions (TDecSbac.cpp:1058-1095). */
 typedef struct hmgpu_coeffs {
   const int16_t* level[3];
   const int16_t* pcm_sample[3];   /* TComDataCU::getPCMSample (m_pcIPCMSample*): the transmitted samples of PCM CUs, same layout as

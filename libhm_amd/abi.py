@@ -45,7 +45,8 @@ class CtuMeta(C.Structure):
     _fields_ = [("depth", C.c_void_p), ("part_size", C.c_void_p), ("pred_mode", C.c_void_p), ("qp", C.c_void_p),
                 ("tr_idx", C.c_void_p), ("cbf", C.c_void_p * 3), ("transform_skip", C.c_void_p * 3),
                 ("mv", C.c_void_p * 2), ("ref_idx", C.c_void_p * 2), ("intra_dir", C.c_void_p * 2),
-                ("transquant_bypass", C.c_void_p), ("ipcm", C.c_void_p), ("slice_idx", C.c_void_p), ("tile_idx", C.c_void_p)]
+                ("transquant_bypass", C.c_void_p), ("ipcm", C.c_void_p), ("slice_idx", C.c_void_p), ("tile_idx", C.c_void_p),
+                ("ccp_alpha", C.c_void_p * 2)]
 
 
 class Coeffs(C.Structure):
@@ -106,7 +107,7 @@ META_ARRAYS = [("depth", np.uint8), ("part_size", np.int8), ("pred_mode", np.int
                ("cbf_y", np.uint8), ("cbf_u", np.uint8), ("cbf_v", np.uint8), ("ts_y", np.uint8), ("ts_u", np.uint8),
                ("ts_v", np.uint8), ("mv0", np.int16), ("mv1", np.int16), ("ref_idx0", np.int8), ("ref_idx1", np.int8),
                ("intra_dir_l", np.uint8), ("intra_dir_c", np.uint8), ("bypass", np.uint8), ("ipcm", np.uint8),
-               ("slice_idx", np.uint16), ("tile_idx", np.uint16)]
+               ("slice_idx", np.uint16), ("tile_idx", np.uint16), ("ccp_u", np.int8), ("ccp_v", np.int8)]
 
 
 class MetaHolder:
@@ -131,6 +132,7 @@ class MetaHolder:
         m.intra_dir[0], m.intra_dir[1] = _ptr(g["intra_dir_l"]), _ptr(g["intra_dir_c"])
         m.transquant_bypass, m.ipcm = _ptr(g["bypass"]), _ptr(g["ipcm"])
         m.slice_idx, m.tile_idx = _ptr(g["slice_idx"]), _ptr(g["tile_idx"])
+        m.ccp_alpha[0], m.ccp_alpha[1] = _ptr(g["ccp_u"]), _ptr(g["ccp_v"])
         self.struct = m
 
 
@@ -154,6 +156,8 @@ class StagingHolder:
                 "slice_idx": m.slice_idx, "tile_idx": m.tile_idx}
         self.arrays = {}
         for name, dt in META_ARRAYS:
+            if name not in addr:
+                continue                                    # (arrays a staging block does not hold: cross-component prediction weights)
             n = num_ctus if name in ("slice_idx", "tile_idx") else (2 * np_ if name in ("mv0", "mv1") else np_)
             self.arrays[name] = view(addr[name], dt, n)
         self.levels = [view(coeff_struct.level[k], np.int16, num_ctus * ctu * ctu >> (2 if k else 0)) for k in range(3)]
@@ -168,6 +172,8 @@ class StagingHolder:
 
     def _fill_meta(self, meta):
         for name, _ in META_ARRAYS:
+            if name not in self.arrays:
+                continue
             src = meta.arrays.get(name)
             if src is not None:
                 self.arrays[name][:] = src.reshape(-1)

@@ -29,8 +29,8 @@ enum Ctx {
   CTX_MVP = CTX_REF_IDX + 2,                // 1
   CTX_SPLIT_TU = CTX_MVP + 1,               // 3
   CTX_CBF_LUMA = CTX_SPLIT_TU + 3,          // 2
-  CTX_CBF_CHROMA = CTX_CBF_LUMA + 2,        // 4
-  CTX_MVD_GT0 = CTX_CBF_CHROMA + 4,         // 1
+  CTX_CBF_CHROMA = CTX_CBF_LUMA + 2,        // 5 (by transform depth; depth 4: 4x4 chroma blocks of 4:4:4)
+  CTX_MVD_GT0 = CTX_CBF_CHROMA + 5,         // 1
   CTX_MVD_GT1 = CTX_MVD_GT0 + 1,            // 1
   CTX_QP_DELTA = CTX_MVD_GT1 + 1,           // 2
   CTX_TS_FLAG = CTX_QP_DELTA + 2,           // 2 (luma, chroma)
@@ -42,7 +42,8 @@ enum Ctx {
   CTX_GT2 = CTX_GT1 + 24,                   // 6
   CTX_RDPCM_FLAG = CTX_GT2 + 6,             // 2 (luma, chroma): explicit_rdpcm_flag
   CTX_RDPCM_DIR = CTX_RDPCM_FLAG + 2,       // 2: explicit_rdpcm_dir_flag
-  CTX_COUNT = CTX_RDPCM_DIR + 2
+  CTX_CCP = CTX_RDPCM_DIR + 2,              // 10: per chroma component log2_res_scale_abs_plus1 (4, by bin) + res_scale_sign_flag (HM's packing, ContextTables.h:493)
+  CTX_COUNT = CTX_CCP + 10
 };
 
 // (a context variable is 7 bits; it is kept in 16 so that stores to it cannot alias the engine's registers -- unsigned char may

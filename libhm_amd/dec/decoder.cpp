@@ -288,7 +288,7 @@ PicData* Decoder::acquire_buffer() {
   PicData* p = pool_.back().get();
   host_alloc_use_pinned(gpu_ != nullptr);
   p->allocate(*sps_, &zscan_, gpu_);
-  if (gpu_) for (int c = 0; c < 3; c++) p->plane[c].resize((size_t)(p->width >> (c ? 1 : 0)) * (p->height >> (c ? 1 : 0)));
+  if (gpu_) for (int c = 0; c < 3; c++) p->plane[c].resize((size_t)(p->width >> (c ? p->csx : 0)) * (p->height >> (c ? p->csy : 0)));
   host_alloc_use_pinned(false);
   if (gpu_) {
     const hmgpu_status st = hmgpu_picture_acquire(gpu_, &p->handle);
@@ -439,7 +439,9 @@ void Decoder::start_picture(const SliceHeader& sh) {
   cur_ = acquire_buffer();
   cur_->reset();
   // levels in the compact form when one parser walks the picture from front to back (wavefront rows / tiles may be shared out among threads)
-  cur_->compact = gpu_ && cur_->stg && !pps_->entropy_coding_sync && !pps_->tiles_enabled && !getenv("HMDEC_DENSE_LEVELS");
+  // (4:2:2 / 4:4:4 pictures keep HM's dense layout: the lower square of a 4:2:2 chroma block has its place behind the upper one)
+  cur_->compact = gpu_ && cur_->stg && !pps_->entropy_coding_sync && !pps_->tiles_enabled && sps_->chroma_format_idc <= 1 && !getenv("HMDEC_DENSE_LEVELS");
+  cur_->chroma_format = sps_->chroma_format_idc;
   cur_->poc = sh.poc;
   cur_->nal_type = sh.nal_type;
   cur_->temporal_id = sh.temporal_id;
@@ -865,10 +867,10 @@ bool Decoder::fetch_planes(PicData* pic) {
     return true;
   }
   pic->plane[0].resize((size_t)pic->width * pic->height);
-  pic->plane[1].resize((size_t)pic->width * pic->height / 4);
-  pic->plane[2].resize((size_t)pic->width * pic->height / 4);
+  pic->plane[1].resize(((size_t)pic->width * pic->height) >> pic->cshift);
+  pic->plane[2].resize(((size_t)pic->width * pic->height) >> pic->cshift);
   int16_t* planes[3] = {pic->plane[0].data(), pic->plane[1].data(), pic->plane[2].data()};
-  const int32_t strides[3] = {pic->width, pic->width / 2, pic->width / 2};
+  const int32_t strides[3] = {pic->width, pic->width >> pic->csx, pic->width >> pic->csx};
   const uint64_t seq = submitted_seq_;
   if (hmgpu_picture_download(gpu_, pic->handle, planes, strides) != HMGPU_OK) return false;
   synced_seq_ = seq;                         // a download returns after everything enqueued before it
@@ -974,10 +976,10 @@ void Decoder::check_hash(PicData* pic) {
       // the copy is only enqueued here: the hash threads wait for it, the decoding thread goes on submitting pictures
       if (!pic->planes_valid && !pic->dl_ticket.load()) {
         pic->plane[0].resize((size_t)pic->width * pic->height);
-        pic->plane[1].resize((size_t)pic->width * pic->height / 4);
-        pic->plane[2].resize((size_t)pic->width * pic->height / 4);
+        pic->plane[1].resize(((size_t)pic->width * pic->height) >> pic->cshift);
+        pic->plane[2].resize(((size_t)pic->width * pic->height) >> pic->cshift);
         int16_t* planes[3] = {pic->plane[0].data(), pic->plane[1].data(), pic->plane[2].data()};
-        const int32_t strides[3] = {pic->width, pic->width / 2, pic->width / 2};
+        const int32_t strides[3] = {pic->width, pic->width >> pic->csx, pic->width >> pic->csx};
         uint64_t t = 0;
         if (hmgpu_picture_download_begin(gpu_, pic->handle, planes, strides, &t) != HMGPU_OK) return;
         pic->dl_ticket.store(t);

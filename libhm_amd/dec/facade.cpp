@@ -131,11 +131,11 @@ int libHMDEC_get_POC(libHMDec_picture* pic) { return pic ? as_pic(pic)->poc : -1
 
 int libHMDEC_get_picture_width(libHMDec_picture* pic, libHMDec_ColorComponent c) {
   if (!pic || c < LIBHMDEC_LUMA || c > LIBHMDEC_CHROMA_V) return -1;
-  return as_pic(pic)->width >> (c == LIBHMDEC_LUMA ? 0 : 1);
+  return as_pic(pic)->width >> (c == LIBHMDEC_LUMA ? 0 : as_pic(pic)->csx);
 }
 int libHMDEC_get_picture_height(libHMDec_picture* pic, libHMDec_ColorComponent c) {
   if (!pic || c < LIBHMDEC_LUMA || c > LIBHMDEC_CHROMA_V) return -1;
-  return as_pic(pic)->height >> (c == LIBHMDEC_LUMA ? 0 : 1);
+  return as_pic(pic)->height >> (c == LIBHMDEC_LUMA ? 0 : as_pic(pic)->csy);
 }
 int libHMDEC_get_picture_stride(libHMDec_picture* pic, libHMDec_ColorComponent c) { return libHMDEC_get_picture_width(pic, c); }
 
@@ -149,7 +149,12 @@ short* libHMDEC_get_image_plane(libHMDec_picture* pic, libHMDec_ColorComponent c
 
 libHMDec_ChromaFormat libHMDEC_get_chroma_format(libHMDec_picture* pic) {
   if (!pic) return LIBHMDEC_CHROMA_UNKNOWN;
-  return as_pic(pic)->num_comps == 1 ? LIBHMDEC_CHROMA_400 : LIBHMDEC_CHROMA_420;
+  switch (as_pic(pic)->chroma_format) {
+    case 0: return LIBHMDEC_CHROMA_400;
+    case 2: return LIBHMDEC_CHROMA_422;
+    case 3: return LIBHMDEC_CHROMA_444;
+    default: return LIBHMDEC_CHROMA_420;
+  }
 }
 
 int libHMDEC_get_internal_bit_depth(libHMDec_ColorComponent c) {
@@ -321,6 +326,7 @@ int hmdec_picture_array(libHMDec_picture* pic, const char* name, const void** da
   if (n.compare(0, 9, "intra_dir") == 0 && idx(9) >= 0 && idx(9) < 2) return give(p.intra_dir[idx(9)].data(), p.intra_dir[idx(9)].size());
   if (n.compare(0, 5, "coeff") == 0 && idx(5) >= 0 && idx(5) < 3) return give(p.coeff[idx(5)].data(), p.coeff[idx(5)].size() * 2);
   if (n.compare(0, 3, "pcm") == 0 && idx(3) >= 0 && idx(3) < 3) return give(p.pcm[idx(3)].data(), p.pcm[idx(3)].size() * 2);
+  if (n.compare(0, 3, "ccp") == 0 && idx(3) >= 0 && idx(3) < 2 && !p.ccp[idx(3)].empty()) return give(p.ccp[idx(3)].data(), p.ccp[idx(3)].size());
   if (n.compare(0, 5, "plane") == 0 && idx(5) >= 0 && idx(5) < 3 && p.planes_valid) return give(p.plane[idx(5)].data(), p.plane[idx(5)].size() * 2);
   return 1;
 }
@@ -346,6 +352,7 @@ int hmdec_picture_geometry(libHMDec_picture* pic, int32_t out[12]) {
 }
 
 int hmdec_picture_range_ext_flags(libHMDec_picture* pic) { return pic ? as_pic(pic)->range_ext_flags : 0; }
+int hmdec_picture_chroma_format(libHMDec_picture* pic) { return pic ? as_pic(pic)->chroma_format : -1; }
 int hmdec_picture_sao_offset_shift(libHMDec_picture* pic, int chroma) { return pic ? as_pic(pic)->sao_offset_shift[chroma ? 1 : 0] : 0; }
 
 int hmdec_picture_conformance_window(libHMDec_picture* pic, int32_t window[4]) {

@@ -240,13 +240,13 @@ std::shared_ptr<Sps> parse_sps(BitReader& br) {
   s.id = br.ue();
   if (s.id > 15) throw ParseError("sps_seq_parameter_set_id out of range");
   s.chroma_format_idc = br.ue();
-  if (s.chroma_format_idc == 3) br.u(1);
-  if (s.chroma_format_idc > 1) throw Unsupported("4:2:2 and 4:4:4 pictures: the device path reconstructs 4:2:0 and monochrome (4:0:0)");
+  if (s.chroma_format_idc > 3) throw ParseError("chroma_format_idc out of range");
+  if (s.chroma_format_idc == 3 && br.u(1)) throw Unsupported("separate_colour_plane_flag (three monochrome pictures per access unit)");
   s.width = br.ue();
   s.height = br.ue();
-  if (br.flag()) {                       // conformance window, in units of SubWidthC / SubHeightC: 2 for 4:2:0, 1 for 4:0:0
-    const int unit = s.chroma_format_idc == 1 ? 2 : 1;
-    s.conf_left = unit * br.ue(); s.conf_right = unit * br.ue(); s.conf_top = unit * br.ue(); s.conf_bottom = unit * br.ue();
+  if (br.flag()) {                       // conformance window, in units of SubWidthC / SubHeightC (Table 6-1): 2 / 2 for 4:2:0, 2 / 1 for 4:2:2, else 1 / 1
+    const int ux = (s.chroma_format_idc == 1 || s.chroma_format_idc == 2) ? 2 : 1, uy = s.chroma_format_idc == 1 ? 2 : 1;
+    s.conf_left = ux * br.ue(); s.conf_right = ux * br.ue(); s.conf_top = uy * br.ue(); s.conf_bottom = uy * br.ue();
   }
   s.bit_depth_luma = 8 + br.ue();
   s.bit_depth_chroma = 8 + br.ue();
@@ -429,7 +429,7 @@ std::shared_ptr<Pps> parse_pps(BitReader& br) {
         p.log2_max_ts_size = 2 + (int)br.ue();
         if (p.log2_max_ts_size > 5) throw ParseError("log2_max_transform_skip_block_size_minus2 out of range");
       }
-      if (br.flag()) throw Unsupported("cross-component prediction (RExt)");
+      p.cross_component_prediction = br.flag();           // (only meaningful with ChromaArrayType 3: checked where the PPS is activated)
       if (br.flag()) throw Unsupported("CU-level chroma QP offsets (RExt)");
       for (int k = 0; k < 2; k++) {
         p.sao_offset_shift[k] = (int)br.ue();

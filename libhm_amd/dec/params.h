@@ -37,6 +37,9 @@ struct Vps { int id = 0; };
 struct Sps {
   int id = 0, vps_id = 0, max_sub_layers = 1;
   int chroma_format_idc = 1, width = 0, height = 0;
+  // chroma subsampling (Table 6-1): log2 SubWidthC / SubHeightC; monochrome keeps 4:2:0-shaped dummy planes
+  int csx() const { return chroma_format_idc == 3 ? 0 : 1; }
+  int csy() const { return (chroma_format_idc == 2 || chroma_format_idc == 3) ? 0 : 1; }
   int conf_left = 0, conf_right = 0, conf_top = 0, conf_bottom = 0;       // in luma samples
   int bit_depth_luma = 8, bit_depth_chroma = 8, log2_max_poc_lsb = 4;
   int max_dec_pic_buffering[8] = {0}, num_reorder_pics[8] = {0}, max_latency_increase_plus1[8] = {0};
@@ -71,6 +74,7 @@ struct Pps {
   int diff_cu_qp_delta_depth = 0, cb_qp_offset = 0, cr_qp_offset = 0;
   bool slice_chroma_qp_offsets_present = false, weighted_pred = false, weighted_bipred = false, transquant_bypass_enabled = false;
   bool tiles_enabled = false, entropy_coding_sync = false, uniform_spacing = true, lf_across_tiles = true;
+  bool cross_component_prediction = false;         // pps_range_extension(): cross_component_prediction_enabled_flag (4:4:4)
   int num_tile_cols = 1, num_tile_rows = 1;
   std::vector<int> col_width_minus1, row_height_minus1;      // explicit spacing, all but the last
   bool lf_across_slices = false, deblocking_control_present = false, deblocking_override_enabled = false, deblocking_disabled = false;

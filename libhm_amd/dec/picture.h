@@ -103,6 +103,8 @@ struct PicData {
   uint32_t level_cursor[3] = {0, 0, 0};
   std::vector<uint32_t> tu_off[3];   // compact: offset of the TU that starts at a partition (what the dense layout gives by arithmetic)
   HostVec<int16_t> pcm[3];           // PCM samples in HM's dense layout
+  HostVec<int8_t> ccp[2];            // cross_component_prediction weights of Cb / Cr per partition (4:4:4 with the PPS flag; else empty)
+  int csx = 1, csy = 1, cshift = 2;  // chroma subsampling; a chroma block has (luma samples >> cshift) samples
   // the staging block the arrays above are views of (null: they own their storage)
   hmgpu_ctx* stg_ctx = nullptr;
   hmgpu_staging* stg = nullptr;
@@ -124,6 +126,7 @@ struct PicData {
   bool pcm_lf_disable = false, strong_intra = false;
   int sao_offset_shift[2] = {0, 0};            // PPS log2_sao_offset_scale_{luma,chroma}
   int num_comps = 3;                           // 1: monochrome (chroma_format_idc 0)
+  int chroma_format = 1;                       // chroma_format_idc of the active SPS
   int range_ext_flags = 0;                     // HMGPU_REXT_* of the active SPS
   hmgpu_pic handle = HMGPU_NO_PIC;
   uint64_t submit_seq = 0;           // device submission that last read these arrays
@@ -157,8 +160,10 @@ struct PicData {
     ctbs_w = sps.pic_w_ctbs(); ctbs_h = sps.pic_h_ctbs(); num_ctbs = ctbs_w * ctbs_h;
     parts = 1 << (2 * log2_ctb - 4);
     zs = z;
+    csx = sps.csx(); csy = sps.csy(); cshift = csx + csy;
     const size_t n = (size_t)num_ctbs * parts;
     const size_t luma = (size_t)num_ctbs << (2 * log2_ctb);
+    const size_t chroma = luma >> cshift;
     if (gpu && hmgpu_staging_alloc(gpu, &stg, &stg_meta, &stg_co) == HMGPU_OK) {
       stg_ctx = gpu;
       const hmgpu_ctu_meta& m = stg_meta;
@@ -167,7 +172,7 @@ struct PicData {
       for (int l = 0; l < 2; l++) { mv[l].bind(m.mv[l], 2 * n); ref_idx[l].bind(m.ref_idx[l], n); intra_dir[l].bind(m.intra_dir[l], n); }
       bypass.bind(m.transquant_bypass, n); ipcm.bind(m.ipcm, n);
       slice_idx.bind(m.slice_idx, num_ctbs); tile_idx.bind(m.tile_idx, num_ctbs);
-      for (int c = 0; c < 3; c++) { coeff[c].bind(stg_co.level[c], c ? luma / 4 : luma); level_start[c].bind(stg_co.ctu_level_start[c], num_ctbs + 1); }
+      for (int c = 0; c < 3; c++) { coeff[c].bind(stg_co.level[c], c ? chroma : luma); level_start[c].bind(stg_co.ctu_level_start[c], num_ctbs + 1); }
       for (int c = 0; c < 3; c++) tu_off[c].assign(n, 0xffffffffu);
     } else {
       stg = nullptr;
@@ -178,13 +183,14 @@ struct PicData {
       slice_idx.assign(num_ctbs, 0);
       tile_idx.assign(num_ctbs, 0);
       coeff[0].assign(luma, 0);
-      coeff[1].assign(luma / 4, 0);
-      coeff[2].assign(luma / 4, 0);
+      coeff[1].assign(chroma, 0);
+      coeff[2].assign(chroma, 0);
       for (int c = 0; c < 3; c++) level_start[c].assign(num_ctbs + 1, 0);
     }
     for (auto* v : {&skip, &merge, &merge_idx, &inter_dir}) v->assign(n, 0);
     slice_addr.assign(num_ctbs, -1);
-    if (sps.pcm) { pcm[0].assign(luma, 0); pcm[1].assign(luma / 4, 0); pcm[2].assign(luma / 4, 0); }
+    if (sps.pcm) { pcm[0].assign(luma, 0); pcm[1].assign(chroma, 0); pcm[2].assign(chroma, 0); }
+    if (sps.chroma_format_idc == 3) { ccp[0].assign(n, 0); ccp[1].assign(n, 0); }
     sao.assign((size_t)num_ctbs * 3, hmgpu_sao_param{});
   }
   // a new picture in the same buffers.  Only the per-CTB bookkeeping is cleared here; the arrays of a CTU are brought to the
@@ -210,6 +216,7 @@ struct PicData {
     fill(intra_dir[0], (uint8_t)1);
     fill(intra_dir[1], (uint8_t)0);
     fill(bypass, (uint8_t)0); fill(ipcm, (uint8_t)0); fill(skip, (uint8_t)0); fill(merge, (uint8_t)0); fill(merge_idx, (uint8_t)0); fill(inter_dir, (uint8_t)0);
+    if (!ccp[0].empty()) { fill(ccp[0], (int8_t)0); fill(ccp[1], (int8_t)0); }
     fill(part_size, (int8_t)HMGPU_SIZE_NONE);
     fill(pred_mode, (int8_t)2);          // HM's NUMBER_OF_PREDICTION_MODES: nothing decoded here
     fill(qp, (int8_t)0);
@@ -223,13 +230,14 @@ struct PicData {
       for (int c = 0; c < 3; c++) { level_start[c][rs] = level_cursor[c]; std::fill(tu_off[c].begin() + first, tu_off[c].begin() + first + parts, 0xffffffffu); }
     } else {
       std::fill(coeff[0].begin() + rs * luma, coeff[0].begin() + (rs + 1) * luma, (int16_t)0);
-      for (int c = 1; c < 3; c++) std::fill(coeff[c].begin() + rs * (luma / 4), coeff[c].begin() + (rs + 1) * (luma / 4), (int16_t)0);
+      for (int c = 1; c < 3; c++) std::fill(coeff[c].begin() + rs * (luma >> cshift), coeff[c].begin() + (rs + 1) * (luma >> cshift), (int16_t)0);
     }
     for (int c = 0; c < 3; c++) sao[(size_t)rs * 3 + c] = hmgpu_sao_param{};
   }
   // where the levels of the TU of component c that starts at partition z of CTB ctb go (size x size, zeroed): HM's place, or the next free one
-  int16_t* level_dst(int c, size_t ctb, size_t z, int size) {
-    if (!compact) return c == 0 ? &coeff[0][(ctb << (2 * log2_ctb)) + 16 * z] : &coeff[c][(ctb << (2 * log2_ctb - 2)) + 4 * z];
+  // sub: the lower square of a 4:2:2 chroma block (dense layout only: it follows the upper one, TComTU::VERTICAL_SPLIT)
+  int16_t* level_dst(int c, size_t ctb, size_t z, int size, int sub = 0) {
+    if (!compact) return c == 0 ? &coeff[0][(ctb << (2 * log2_ctb)) + 16 * z] : &coeff[c][(ctb << (2 * log2_ctb - cshift)) + ((16 * z) >> cshift) + (size_t)sub * size * size];
     const uint32_t off = level_cursor[c];
     // (a damaged stream can deliver the same CTUs twice: what they wrote first is dead space, and the space is finite)
     if ((size_t)off + (size_t)size * size > coeff[c].size()) throw ParseError("more coded transform blocks than the picture has room for");
@@ -244,7 +252,7 @@ struct PicData {
   HostVec<int16_t> dense_levels[3];
   void expand_dense() {
     const size_t luma = (size_t)num_ctbs << (2 * log2_ctb);
-    dense_levels[0].assign(luma, 0); dense_levels[1].assign(luma / 4, 0); dense_levels[2].assign(luma / 4, 0);
+    dense_levels[0].assign(luma, 0); dense_levels[1].assign(luma >> cshift, 0); dense_levels[2].assign(luma >> cshift, 0);
     for (int c = 0; c < 3; c++)
       for (size_t ctb = 0; ctb < (size_t)num_ctbs; ctb++) {
         if (slice_addr[ctb] < 0) continue;
@@ -264,7 +272,7 @@ struct PicData {
   }
   // the levels of the TU that starts at partition z of CTB ctb, or null (compact: no coded TU starts there)
   const int16_t* level_src(int c, size_t ctb, size_t z) const {
-    if (!compact) return c == 0 ? &coeff[0][(ctb << (2 * log2_ctb)) + 16 * z] : &coeff[c][(ctb << (2 * log2_ctb - 2)) + 4 * z];
+    if (!compact) return c == 0 ? &coeff[0][(ctb << (2 * log2_ctb)) + 16 * z] : &coeff[c][(ctb << (2 * log2_ctb - cshift)) + ((16 * z) >> cshift)];
     const uint32_t off = tu_off[c][ctb * parts + z];
     return off == 0xffffffffu ? nullptr : &coeff[c][off];
   }

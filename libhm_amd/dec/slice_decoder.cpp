@@ -493,8 +493,8 @@ void SliceDecoder::pcm_sample(int x0, int y0, int log2) {
   int16_t* y = &pic_.pcm[0][(ctb << (2 * sps_.log2_ctb)) + 16 * z];
   for (int i = 0; i < size * size; i++) y[i] = (int16_t)cabac_.plain_bits(sps_.pcm_bit_depth_luma);
   for (int c = 1; c < 3 && sps_.chroma_format_idc != 0; c++) {
-    int16_t* d = &pic_.pcm[c][(ctb << (2 * sps_.log2_ctb - 2)) + 4 * z];
-    for (int i = 0; i < size * size / 4; i++) d[i] = (int16_t)cabac_.plain_bits(sps_.pcm_bit_depth_chroma);
+    int16_t* d = &pic_.pcm[c][(ctb << (2 * sps_.log2_ctb - pic_.cshift)) + ((16 * z) >> pic_.cshift)];
+    for (int i = 0; i < (size * size) >> pic_.cshift; i++) d[i] = (int16_t)cabac_.plain_bits(sps_.pcm_bit_depth_chroma);
   }
 }
 
@@ -537,17 +537,34 @@ void SliceDecoder::intra_modes(int x0, int y0, int log2, bool nxn) {
     intra_luma_[i] = mode;
     for (int yy = y; yy < y + pb; yy += 4) for (int xx = x; xx < x + pb; xx += 4) pic_.intra_dir[0][pic_.part_at(xx, yy)] = (uint8_t)mode;
   }
-  int chroma = 4;
-  if (sps_.chroma_format_idc != 0 && cabac_.decision(ctx_.s[CTX_CHROMA_MODE])) chroma = cabac_.bypass_bits(2);     // (TDecEntropy.cpp:119)
-  int stored = kDmChroma;
-  intra_chroma_ = intra_luma_[0];
-  if (chroma != 4) {
-    static const int kModes[4] = {0, 26, 10, 1};
-    intra_chroma_ = kModes[chroma] == intra_luma_[0] ? 34 : kModes[chroma];
-    stored = intra_chroma_;
-  }
+  // intra_chroma_pred_mode: one per CU, in 4:4:4 one per prediction block (7.3.8.5; HM: enable4ChromaPUsInIntraNxNCU, TComChromaFormat.h:118-121)
+  const int nc = (sps_.chroma_format_idc == 3 && nxn) ? 4 : 1;
   const size_t base = pic_.part_at(x0, y0);
-  fill_z(pic_.intra_dir[1], base, 1 << (2 * (log2 - 2)), (uint8_t)stored);
+  const int cu_parts = 1 << (2 * (log2 - 2));
+  for (int i = 0; i < nc; i++) {
+    int chroma = 4;
+    if (sps_.chroma_format_idc != 0 && cabac_.decision(ctx_.s[CTX_CHROMA_MODE])) chroma = cabac_.bypass_bits(2);     // (TDecEntropy.cpp:119)
+    int stored = kDmChroma;
+    if (chroma != 4) {
+      static const int kModes[4] = {0, 26, 10, 1};
+      stored = kModes[chroma] == intra_luma_[i] ? 34 : kModes[chroma];
+    }
+    if (nc == 1) fill_z(pic_.intra_dir[1], base, cu_parts, (uint8_t)stored);
+    else fill_z(pic_.intra_dir[1], base + (size_t)i * (cu_parts >> 2), cu_parts >> 2, (uint8_t)stored);
+  }
+}
+
+// the prediction mode the chroma block at partition `part` ends up with (8.4.3; HM: TDecCu.cpp:523-525, getChromasCorrespondingPULumaIdx):
+// "same as luma" resolved -- 4:4:4: the luma mode of the same partition; else the one of the CU's first partition --, then the 4:2:2 table
+int SliceDecoder::chroma_pred_mode(size_t part) const {
+  static const uint8_t k422[35] = {0, 1, 2, 2, 2, 2, 3, 5, 7, 8, 10, 12, 13, 15, 17, 18, 19, 20, 21, 22, 23, 23, 24, 24, 25, 25, 26, 27, 27, 28, 28, 29, 29, 30, 31};
+  int mode = pic_.intra_dir[1][part];
+  if (mode == kDmChroma) {
+    const size_t cu_first = pic_.part_at(cu_x_, cu_y_);
+    mode = pic_.intra_dir[0][sps_.chroma_format_idc == 3 ? part : cu_first];
+  }
+  if (sps_.chroma_format_idc == 2 && mode < 35) mode = k422[mode];
+  return mode;
 }
 
 // ------------------------------------------------------------------------------------------------ prediction unit
@@ -821,10 +838,12 @@ void SliceDecoder::prediction_unit(int xcb, int ycb, int ncbs, int x0, int y0, i
 }
 
 // ------------------------------------------------------------------------------------------------ transform tree
-void SliceDecoder::transform_tree(int x0, int y0, int xbase, int ybase, int log2, int tr_depth, int blk, int cu_log2, bool parent_cb, bool parent_cr) {
+// parent_cb / parent_cr: the chroma flags of the node above (4:2:2: bit 0 the upper, bit 1 the lower of its two squares)
+void SliceDecoder::transform_tree(int x0, int y0, int xbase, int ybase, int log2, int tr_depth, int blk, int cu_log2, int parent_cb, int parent_cr) {
   const size_t base = pic_.part_at(x0, y0);
   const int nparts = 1 << (2 * (log2 - 2));
   const int8_t part_mode = pic_.part_size[base];
+  const int fmt = sps_.chroma_format_idc;
   const bool intra_split = cu_pred_mode_ == MODE_INTRA && part_mode == PART_NxN;
   const int max_depth = cu_pred_mode_ == MODE_INTRA ? sps_.max_th_depth_intra + (intra_split ? 1 : 0) : sps_.max_th_depth_inter;
   bool split;
@@ -834,48 +853,86 @@ void SliceDecoder::transform_tree(int x0, int y0, int xbase, int ybase, int log2
     const bool inter_split = sps_.max_th_depth_inter == 0 && cu_pred_mode_ == MODE_INTER && part_mode != PART_2Nx2N && tr_depth == 0;
     split = log2 > sps_.log2_max_tb || (intra_split && tr_depth == 0) || inter_split;
   }
-  bool cbf_cb = parent_cb, cbf_cr = parent_cr;          // 4x4 luma blocks: the chroma flags of the parent stand
-  if (sps_.chroma_format_idc == 0) cbf_cb = cbf_cr = false;          // monochrome: no chroma blocks at all (TDecEntropy.cpp:380)
-  else if (log2 > 2) {
-    cbf_cb = (tr_depth == 0 || parent_cb) && cabac_.decision(ctx_.s[CTX_CBF_CHROMA + tr_depth]);
-    cbf_cr = (tr_depth == 0 || parent_cr) && cabac_.decision(ctx_.s[CTX_CBF_CHROMA + tr_depth]);
+  int cbf_c[2] = {parent_cb, parent_cr};                // blocks that are not divided any further: the chroma flags of the parent stand
+  if (fmt == 0) cbf_c[0] = cbf_c[1] = 0;                // monochrome: no chroma blocks at all (TDecEntropy.cpp:380)
+  else if (log2 > 2 || fmt == 3) {
+    // 7.3.8.8: one flag per component, in 4:2:2 a second one for the lower square where the chroma block is not divided further
+    const bool two = fmt == 2 && (!split || log2 == 3);
+    for (int k = 0; k < 2; k++) {
+      const int parent = cbf_c[k];
+      cbf_c[k] = 0;
+      if (tr_depth == 0 || parent) {
+        cbf_c[k] = cabac_.decision(ctx_.s[CTX_CBF_CHROMA + tr_depth]) ? 1 : 0;
+        if (two) cbf_c[k] |= cabac_.decision(ctx_.s[CTX_CBF_CHROMA + tr_depth]) ? 2 : 0;
+      }
+      // HM's layout (parseQtCbf, TDecSbac.cpp:1027-1126): the node's bit where any square is coded, in 4:2:2 one depth further down the
+      // flag of the upper square over the first half of the partitions, of the lower one over the second
+      if (cbf_c[k]) for (int i = 0; i < nparts; i++) pic_.cbf[1 + k][base + i] |= (uint8_t)(1 << tr_depth);
+      if (two && !split) {                              // (log2 == 3 with four 4x4 luma blocks below: the blocks set the two bits, see there)
+        for (int i = 0; i < nparts; i++)
+          if ((cbf_c[k] >> (i >= nparts / 2 ? 1 : 0)) & 1) pic_.cbf[1 + k][base + i] |= (uint8_t)(1 << (tr_depth + 1));
+      }
+    }
+  } else {
+    // a 4x4 luma block of four: the chroma block of the 8x8 node above is coded with the last of them; the node's flags at this depth
+    // too (lowestTUDepth, :1055), in 4:2:2 the squares' one further down: blocks 0, 1 lie over the upper square, 2, 3 over the lower
+    for (int k = 0; k < 2; k++) {
+      if (cbf_c[k]) pic_.cbf[1 + k][base] |= (uint8_t)(1 << tr_depth);
+      if (fmt == 2 && ((cbf_c[k] >> (blk >> 1)) & 1)) pic_.cbf[1 + k][base] |= (uint8_t)(1 << (tr_depth + 1));
+    }
   }
-  if (cbf_cb) for (int i = 0; i < nparts; i++) pic_.cbf[1][base + i] |= (uint8_t)(1 << tr_depth);
-  if (cbf_cr) for (int i = 0; i < nparts; i++) pic_.cbf[2][base + i] |= (uint8_t)(1 << tr_depth);
   if (split) {
     const int h = 1 << (log2 - 1);
-    transform_tree(x0, y0, x0, y0, log2 - 1, tr_depth + 1, 0, cu_log2, cbf_cb, cbf_cr);
-    transform_tree(x0 + h, y0, x0, y0, log2 - 1, tr_depth + 1, 1, cu_log2, cbf_cb, cbf_cr);
-    transform_tree(x0, y0 + h, x0, y0, log2 - 1, tr_depth + 1, 2, cu_log2, cbf_cb, cbf_cr);
-    transform_tree(x0 + h, y0 + h, x0, y0, log2 - 1, tr_depth + 1, 3, cu_log2, cbf_cb, cbf_cr);
+    transform_tree(x0, y0, x0, y0, log2 - 1, tr_depth + 1, 0, cu_log2, cbf_c[0], cbf_c[1]);
+    transform_tree(x0 + h, y0, x0, y0, log2 - 1, tr_depth + 1, 1, cu_log2, cbf_c[0], cbf_c[1]);
+    transform_tree(x0, y0 + h, x0, y0, log2 - 1, tr_depth + 1, 2, cu_log2, cbf_c[0], cbf_c[1]);
+    transform_tree(x0 + h, y0 + h, x0, y0, log2 - 1, tr_depth + 1, 3, cu_log2, cbf_c[0], cbf_c[1]);
     uint8_t any = 0;
     for (int i = 0; i < nparts; i++) any |= pic_.cbf[0][base + i];
     if ((any >> (tr_depth + 1)) & 1) for (int i = 0; i < nparts; i++) pic_.cbf[0][base + i] |= (uint8_t)(1 << tr_depth);
     return;
   }
   bool cbf_luma = true;
-  if (cu_pred_mode_ == MODE_INTRA || tr_depth != 0 || cbf_cb || cbf_cr) cbf_luma = cabac_.decision(ctx_.s[CTX_CBF_LUMA + (tr_depth == 0 ? 1 : 0)]);
+  if (cu_pred_mode_ == MODE_INTRA || tr_depth != 0 || cbf_c[0] || cbf_c[1]) cbf_luma = cabac_.decision(ctx_.s[CTX_CBF_LUMA + (tr_depth == 0 ? 1 : 0)]);
   fill_z(pic_.tr_idx, base, nparts, (uint8_t)tr_depth);
   if (cbf_luma) for (int i = 0; i < nparts; i++) pic_.cbf[0][base + i] |= (uint8_t)(1 << tr_depth);
-  if (cbf_luma || cbf_cb || cbf_cr) {                   // 7.3.8.10 transform_unit()
+  if (cbf_luma || cbf_c[0] || cbf_c[1]) {                   // 7.3.8.10 transform_unit()
     if (pps_.cu_qp_delta_enabled && !is_cu_qp_delta_coded_) qp_delta();
     if (cbf_luma) residual_coding(x0, y0, log2, 0);
-    if (log2 > 2) {
-      if (cbf_cb) residual_coding(x0, y0, log2 - 1, 1);
-      if (cbf_cr) residual_coding(x0, y0, log2 - 1, 2);
+    if (log2 > 2 || fmt == 3) {
+      const int log2c = fmt == 3 ? log2 : log2 - 1;
+      for (int k = 0; k < 2; k++) {
+        // 7.3.8.12 cross_comp_pred(): the weight of the luma residual in this block's chroma residual (4:4:4)
+        if (pps_.cross_component_prediction && fmt == 3 && cbf_luma && (cu_pred_mode_ == MODE_INTER || pic_.intra_dir[1][base] == kDmChroma)) {
+          const int c0 = CTX_CCP + 5 * k;
+          int alpha = 0;
+          if (cabac_.decision(ctx_.s[c0])) {
+            int v = 0;
+            if (cabac_.decision(ctx_.s[c0 + 1])) { v = 1; if (cabac_.decision(ctx_.s[c0 + 2])) { v = 2; if (cabac_.decision(ctx_.s[c0 + 3])) v = 3; } }
+            alpha = cabac_.decision(ctx_.s[c0 + 4]) ? -(1 << v) : (1 << v);
+          }
+          if (alpha) fill_z(pic_.ccp[k], base, nparts, (int8_t)alpha);
+        }
+        if (cbf_c[k] & 1) residual_coding(x0, y0, log2c, 1 + k);
+        if (cbf_c[k] & 2) residual_coding(x0, y0 + (1 << log2c), log2c, 1 + k, 1);
+      }
     } else if (blk == 3) {
-      if (cbf_cb) residual_coding(xbase, ybase, 2, 1);
-      if (cbf_cr) residual_coding(xbase, ybase, 2, 2);
+      for (int k = 0; k < 2; k++) {
+        if (cbf_c[k] & 1) residual_coding(xbase, ybase, 2, 1 + k);
+        if (cbf_c[k] & 2) residual_coding(xbase, ybase + 4, 2, 1 + k, 1);
+      }
     }
   }
 }
 
 // 7.3.8.11 residual_coding(); (x0, y0) in luma samples, log2 = size of the block in samples of component c
-void SliceDecoder::residual_coding(int x0, int y0, int log2, int c) {
+// sub: the lower square of a 4:2:2 chroma block ((x0, y0) is its own position; its levels follow the upper square's)
+void SliceDecoder::residual_coding(int x0, int y0, int log2, int c, int sub) {
   Cabac eng = cabac_;                    // the engine's registers stay in CPU registers for the whole block (written back at the end)
   const int size = 1 << log2;
-  const size_t part = pic_.part_at(x0, y0), ctb = pic_.ctb_at(x0, y0), z = part - ctb * pic_.parts;
-  int16_t* dst = pic_.level_dst(c, ctb, z, size);
+  const size_t part = pic_.part_at(x0, y0), ctb = pic_.ctb_at(x0, y0);
+  const size_t z = (sub ? pic_.part_at(x0, y0 - size) : part) - ctb * pic_.parts;
+  int16_t* dst = pic_.level_dst(c, ctb, z, size, sub);
   const bool ts = pps_.transform_skip_enabled && !cu_bypass_ && log2 <= pps_.log2_max_ts_size && eng.decision(ctx_.s[CTX_TS_FLAG + (c ? 1 : 0)]);
   const bool untransformed = ts || cu_bypass_;
   // explicit_rdpcm_flag / explicit_rdpcm_dir_flag: inter blocks that skip the transform (HM 16.0: TDecSbac.cpp:1322-1350, 1884-1917)
@@ -883,9 +940,10 @@ void SliceDecoder::residual_coding(int x0, int y0, int log2, int c) {
   if (untransformed && sps_.rext_explicit_rdpcm && cu_pred_mode_ != MODE_INTRA && eng.decision(ctx_.s[CTX_RDPCM_FLAG + (c ? 1 : 0)]))
     rdpcm = eng.decision(ctx_.s[CTX_RDPCM_DIR + (c ? 1 : 0)]) ? 2 : 1;
   if (ts || rdpcm) {
-    const int span = (size << (c ? 1 : 0)) >> 2;         // in 4x4 luma partitions (a 4x4 chroma block lies over 2x2 of them)
+    // in 4x4 luma partitions (a 4x4 chroma block of a 4:2:0 picture lies over 2x2 of them)
+    const int span_x = (size << (c ? pic_.csx : 0)) >> 2, span_y = (size << (c ? pic_.csy : 0)) >> 2;
     const uint8_t v = (uint8_t)((ts ? 1 : 0) | (rdpcm << 1));
-    for (int y = 0; y < span; y++) for (int x = 0; x < span; x++) pic_.ts[c][pic_.part_at(x0 + 4 * x, y0 + 4 * y)] = v;
+    for (int y = 0; y < span_y; y++) for (int x = 0; x < span_x; x++) pic_.ts[c][pic_.part_at(x0 + 4 * x, y0 + 4 * y)] = v;
   }
   // last significant coefficient position (9.3.4.2.3)
   int ctx_off, ctx_shift;
@@ -899,8 +957,10 @@ void SliceDecoder::residual_coding(int x0, int y0, int log2, int c) {
   if (px > 3) { const int nb = (px >> 1) - 1; lx = (1 << nb) * (2 + (px & 1)) + (int)eng.bypass_bits(nb); }
   if (py > 3) { const int nb = (py >> 1) - 1; ly = (1 << nb) * (2 + (py & 1)) + (int)eng.bypass_bits(nb); }
   int scan_idx = 0;
-  if (cu_pred_mode_ == MODE_INTRA && (log2 == 2 || (log2 == 3 && c == 0))) {
-    const int mode = c == 0 ? pic_.intra_dir[0][part] : intra_chroma_;
+  // 7.4.9.11 scanIdx: mode-dependent scans for 4x4 blocks and for 8x8 blocks of components that are not subsampled (HM: getCoefScanIdx,
+  // TComDataCU.cpp:3525-3580)
+  if (cu_pred_mode_ == MODE_INTRA && (log2 == 2 || (log2 == 3 && (c == 0 || sps_.chroma_format_idc == 3)))) {
+    const int mode = c == 0 ? pic_.intra_dir[0][part] : chroma_pred_mode(part);
     if (mode >= 6 && mode <= 14) scan_idx = 2;
     else if (mode >= 22 && mode <= 30) scan_idx = 1;
   }
@@ -918,7 +978,7 @@ void SliceDecoder::residual_coding(int x0, int y0, int log2, int c) {
   // (TDecSbac.cpp:1345-1368); a lossless CU never hides signs
   bool sdh = pps_.sign_data_hiding && !cu_bypass_ && !rdpcm;
   if (sdh && ts && sps_.rext_implicit_rdpcm && cu_pred_mode_ == MODE_INTRA) {
-    const int mode = c == 0 ? pic_.intra_dir[0][part] : intra_chroma_;
+    const int mode = c == 0 ? pic_.intra_dir[0][part] : chroma_pred_mode(part);
     if (mode == 10 || mode == 26) sdh = false;
   }
   const bool single_sig = sps_.rext_ts_context && untransformed;      // transform_skip_context_enabled_flag (TComChromaFormat.cpp:116-120)

@@ -92,8 +92,9 @@ class SliceDecoder {
   void pcm_sample(int x0, int y0, int log2);
   void prediction_unit(int xcb, int ycb, int ncbs, int x0, int y0, int w, int h, int part_idx, int part_mode, int depth, bool skip);
   void intra_modes(int x0, int y0, int log2, bool nxn);
-  void transform_tree(int x0, int y0, int xbase, int ybase, int log2, int tr_depth, int blk, int cu_log2, bool parent_cbf_cb, bool parent_cbf_cr);
-  void residual_coding(int x0, int y0, int log2, int c);
+  void transform_tree(int x0, int y0, int xbase, int ybase, int log2, int tr_depth, int blk, int cu_log2, int parent_cbf_cb, int parent_cbf_cr);
+  void residual_coding(int x0, int y0, int log2, int c, int sub = 0);
+  int chroma_pred_mode(size_t part) const;
   void qp_delta();
   void start_quant_group(int x0, int y0);
   int cu_qp() const;

@@ -44,6 +44,7 @@ def lib():
         L.hmdec_pictures_decoded.argtypes = [C.c_void_p]
         L.hmdec_device_batches.argtypes = [C.c_void_p]
         L.hmdec_picture_range_ext_flags.argtypes = [C.c_void_p]
+        L.hmdec_picture_chroma_format.argtypes = [C.c_void_p]
         L.hmdec_picture_sao_offset_shift.argtypes = [C.c_void_p, C.c_int]
         L.hmdec_set_device_md5.argtypes = [C.c_void_p, C.c_int]
         L.hmdec_last_error.argtypes = [C.c_void_p]
@@ -126,7 +127,7 @@ class Picture:
         dt = _DTYPES.get(name, _DTYPES.get(base, None))
         if dt is None:
             dt = {"cbf": np.uint8, "ts": np.uint8, "mv": np.int16, "ref_idx": np.int8, "intra_dir": np.uint8, "coeff": np.int16,
-                  "pcm": np.int16, "plane": np.int16}[base]
+                  "pcm": np.int16, "plane": np.int16, "ccp": np.int8}[base]
         if n.value == 0:
             return np.zeros(0, dtype=dt)
         buf = (C.c_char * n.value).from_address(ptr.value)
@@ -138,6 +139,8 @@ class Picture:
         keys = ("width", "height", "log2_ctb", "bd_y", "bd_c", "pcm_bd_y", "pcm_bd_c", "pcm_lf_disable", "strong_intra", "sao", "lf_across_tiles", "num_ctbs")
         out = dict(zip(keys, (int(v) for v in g)))
         out["range_ext"] = int(lib().hmdec_picture_range_ext_flags(self.h))
+        out["chroma_format"] = int(lib().hmdec_picture_chroma_format(self.h))
+        out["csx"], out["csy"] = (0 if out["chroma_format"] == 3 else 1), (1 if out["chroma_format"] in (0, 1) else 0)
         out["sao_shift"] = (int(lib().hmdec_picture_sao_offset_shift(self.h, 0)), int(lib().hmdec_picture_sao_offset_shift(self.h, 1)))
         return out
 
@@ -147,7 +150,10 @@ class Picture:
         return tuple(w)
 
     def cropped_plane(self, c):
-        l, r, t, b = (v >> (1 if c else 0) for v in self.conformance_window())
+        g = self.geometry()
+        l, r, t, b = self.conformance_window()
+        if c:
+            l, r, t, b = l >> g["csx"], r >> g["csx"], t >> g["csy"], b >> g["csy"]
         p = self.plane(c)
         return p[t:p.shape[0] - b, l:p.shape[1] - r]
 

@@ -79,8 +79,14 @@ void hmo_dequant(const int16_t* level, int32_t* coef, int n, int log2_size, int 
   }
 }
 
+/* getScaledChromaQP: g_aucChromaScale[chFmt] (TComRom.cpp:499-506, TComChromaFormat.h:178-181): the 4:2:0 table, min(qPi, 51) otherwise */
+static int scaled_chroma_qp(int qp, int chroma_format)
+{
+  qp = CLIP3(0, 57, qp);
+  return chroma_format == 1 ? k_chroma_scale_420[qp] : imin(qp, 51);
+}
 /* QpParam::QpParam: TLibCommon/TComTrQuant.cpp:71-100 */
-void hmo_qp_param(int qp_y, int comp, int bit_depth, int chroma_qp_offset, int* per, int* rem)
+void hmo_qp_param_fmt(int qp_y, int comp, int bit_depth, int chroma_qp_offset, int chroma_format, int* per, int* rem)
 {
   const int qp_bd_offset = 6 * (bit_depth - 8);
   int base;
@@ -89,9 +95,13 @@ void hmo_qp_param(int qp_y, int comp, int bit_depth, int chroma_qp_offset, int* 
   {
     base = CLIP3(-qp_bd_offset, 57, qp_y + chroma_qp_offset);
     if (base < 0) base = base + qp_bd_offset;
-    else base = k_chroma_scale_420[base] + qp_bd_offset;
+    else base = scaled_chroma_qp(base, chroma_format) + qp_bd_offset;
   }
   *per = base / 6; *rem = base % 6;
+}
+void hmo_qp_param(int qp_y, int comp, int bit_depth, int chroma_qp_offset, int* per, int* rem)
+{
+  hmo_qp_param_fmt(qp_y, comp, bit_depth, chroma_qp_offset, 1, per, rem);
 }
 
 /* ------------------------------------------------------------------------------------------------ inverse transform */
@@ -346,15 +356,17 @@ static void fir_copy(int bit_depth, const int16_t* src, int src_stride, int16_t*
 /* TComPrediction::xPredInterBlk: TLibCommon/TComPrediction.cpp:660-698.  HM reads a border-extended picture
  * (TComPicYuv::extendPicBorder, TComPicYuv.cpp:173); replication == coordinate clamp, so a block whose filter window
  * leaves the picture is first gathered into a small clamped window. */
-void hmo_pred_inter_blk(int is_chroma, int bit_depth, const int16_t* ref, int ref_stride, int ref_w, int ref_h,
-                        int bx, int by, int w, int h, int mvx, int mvy, int bi, int16_t* dst, int dst_stride)
+/* csx / csy: the component's subsampling (getComponentScaleX / Y): the vector is in quarter LUMA samples, i.e. in units of
+ * 1 / (4 << cs) component samples, and the chroma filter is indexed in eighths (TComPrediction.cpp:664-674, TComInterpolationFilter.cpp:344-346) */
+void hmo_pred_inter_blk_fmt(int is_chroma, int csx, int csy, int bit_depth, const int16_t* ref, int ref_stride, int ref_w, int ref_h,
+                            int bx, int by, int w, int h, int mvx, int mvy, int bi, int16_t* dst, int dst_stride)
 {
-  const int sh = is_chroma ? 3 : 2;
+  const int shx = 2 + csx, shy = 2 + csy;
   const int ntaps = is_chroma ? 4 : 8;
-  const int xfrac = mvx & ((1 << sh) - 1), yfrac = mvy & ((1 << sh) - 1);
-  const int* cx = is_chroma ? k_chroma_filter[xfrac] : k_luma_filter[xfrac];
-  const int* cy = is_chroma ? k_chroma_filter[yfrac] : k_luma_filter[yfrac];
-  const int ix = bx + (mvx >> sh), iy = by + (mvy >> sh);
+  const int xfrac = mvx & ((1 << shx) - 1), yfrac = mvy & ((1 << shy) - 1);
+  const int* cx = is_chroma ? k_chroma_filter[xfrac << (1 - csx)] : k_luma_filter[xfrac];
+  const int* cy = is_chroma ? k_chroma_filter[yfrac << (1 - csy)] : k_luma_filter[yfrac];
+  const int ix = bx + (mvx >> shx), iy = by + (mvy >> shy);
   const int before = ntaps / 2 - 1, after = ntaps / 2;
   int16_t win[(64 + 7) * (64 + 8)];
   const int16_t* src; int ss;
@@ -384,6 +396,12 @@ void hmo_pred_inter_blk(int is_chroma, int bit_depth, const int16_t* ref, int re
   }
 }
 
+void hmo_pred_inter_blk(int is_chroma, int bit_depth, const int16_t* ref, int ref_stride, int ref_w, int ref_h,
+                        int bx, int by, int w, int h, int mvx, int mvy, int bi, int16_t* dst, int dst_stride)
+{
+  hmo_pred_inter_blk_fmt(is_chroma, is_chroma ? 1 : 0, is_chroma ? 1 : 0, bit_depth, ref, ref_stride, ref_w, ref_h, bx, by, w, h, mvx, mvy, bi, dst, dst_stride);
+}
+
 /* TComYuv::addAvg: TLibCommon/TComYuv.cpp:336-391 */
 void hmo_add_avg(const int16_t* s0, const int16_t* s1, int16_t* dst, int w, int h, int stride, int bit_depth)
 {
@@ -408,6 +426,7 @@ typedef struct
   const hmgpu_pic_params* pp;
   int ctu, pw, parts, ctus_w, ctus_h, num_ctus, max_cu_depth;
   int w[3], h[3], bd[3];
+  int fmt, csx[3], csy[3];          /* chroma_format_idc (0 handled as 4:2:0 geometry); getComponentScaleX / Y (TComChromaFormat.h:59-62) */
 } geom;
 
 static int zx(int z) { int x = 0, b; for (b = 0; b < 8; b++) x |= ((z >> (2 * b)) & 1) << b; return x; }        /* g_auiZscanToRaster column */
@@ -422,9 +441,17 @@ static void geom_init(geom* g, const hmgpu_seq_params* seq, const hmgpu_slice_pa
   g->ctus_w = (seq->width + g->ctu - 1) / g->ctu; g->ctus_h = (seq->height + g->ctu - 1) / g->ctu;
   g->num_ctus = g->ctus_w * g->ctus_h;
   g->max_cu_depth = seq->log2_ctu_size - 3;           /* g_uiMaxCUDepth - g_uiAddCUDepth: CUs down to 8x8 */
-  g->w[0] = seq->width; g->h[0] = seq->height; g->w[1] = g->w[2] = seq->width / 2; g->h[1] = g->h[2] = seq->height / 2;
+  g->fmt = seq->chroma_format == 0 ? 1 : seq->chroma_format;
+  g->csx[0] = g->csy[0] = 0;
+  g->csx[1] = g->csx[2] = g->fmt == 3 ? 0 : 1;
+  g->csy[1] = g->csy[2] = g->fmt == 1 ? 1 : 0;
+  g->w[0] = seq->width; g->h[0] = seq->height;
+  g->w[1] = g->w[2] = seq->width >> g->csx[1]; g->h[1] = g->h[2] = seq->height >> g->csy[1];
   g->bd[0] = seq->bit_depth_luma; g->bd[1] = g->bd[2] = seq->bit_depth_chroma;
 }
+/* elements of a CTU in the level / PCM arrays of component comp, and where the block of partition z starts in them (TComTU.cpp:64-76) */
+static size_t ctu_elems(const geom* g, int comp) { return (size_t)(g->ctu * g->ctu) >> (g->csx[comp] + g->csy[comp]); }
+static int part_elem_off(const geom* g, int comp, int z) { return (16 * z) >> (g->csx[comp] + g->csy[comp]); }
 static const hmgpu_slice_params* slice_of(const geom* g, int ctu) { return &g->slices[g->m->slice_idx ? g->m->slice_idx[ctu] : 0]; }
 static int slice_id(const geom* g, int ctu) { return g->m->slice_idx ? g->m->slice_idx[ctu] : 0; }
 static int tile_id(const geom* g, int ctu) { return g->m->tile_idx ? g->m->tile_idx[ctu] : 0; }
@@ -457,11 +484,11 @@ static void tu_leaf(cu_ctx* c, int comp, int z_tu, int log2_size, int x_rel, int
 {
   const geom* g = c->g;
   const hmgpu_slice_params* sl = slice_of(g, c->ctu_addr);
-  const int stride = c->cu_size >> (comp ? 1 : 0);
+  const int stride = c->cu_size >> g->csx[comp];
   int per, rem, flags = 0;
   const int cqo = comp == 1 ? sl->cb_qp_offset : (comp == 2 ? sl->cr_qp_offset : 0);
-  const int16_t* lev = c->co->level[comp] + (size_t)c->ctu_addr * ((g->ctu * g->ctu) >> (comp ? 2 : 0)) + coef_off;
-  hmo_qp_param(PM(qp, c->ctu_addr, c->cu_z), comp, g->bd[comp], cqo, &per, &rem);       /* QpParam(cu, compID): getQP(0) */
+  const int16_t* lev = c->co->level[comp] + (size_t)c->ctu_addr * ctu_elems(g, comp) + coef_off;
+  hmo_qp_param_fmt(PM(qp, c->ctu_addr, c->cu_z), comp, g->bd[comp], cqo, g->fmt, &per, &rem);       /* QpParam(cu, compID): getQP(0) */
   if (comp == 0 && PM(pred_mode, c->ctu_addr, z_tu) == HMGPU_MODE_INTRA) flags |= 1;    /* TComTU::useDST, TComTU.cpp:218 */
   const int tsb = g->m->transform_skip[comp] ? g->m->transform_skip[comp][(size_t)c->ctu_addr * g->parts + z_tu] : 0;
   /* inter blocks: the explicit mode parsed with the block (bits 1-2), honoured only while the SPS enables it (isRDPCMEnabled) */
@@ -482,25 +509,61 @@ static void tu_leaf(cu_ctx* c, int comp, int z_tu, int log2_size, int x_rel, int
   if (flags & 2) hmo_residual_rotate_rdpcm(&c->resi[comp][y_rel * stride + x_rel], stride, 1 << log2_size, 0, rdpcm);
 }
 
-/* invRecurTransformNxN (TComTrQuant.cpp:1550-1615) with the TComTU child rules for 4:2:0 (TComTU.cpp:89-171) */
+/* the chroma block that belongs to the luma node (z, 2^log2_luma) at (xl, yl) of the CU: one square in 4:2:0 / 4:4:4, in 4:2:2 two squares
+ * one above the other (invTransformNxN's TComTU::VERTICAL_SPLIT, TComTrQuant.cpp:1436-1462: both are transformed -- an uncoded one holds
+ * zero levels --, the lower one with the flags of the lower half of the node's partitions), then cross-component prediction from the luma
+ * residual of the same area (invRecurTransformNxN :1591-1606, crossComponentPrediction :3294-3335) */
+static void tu_chroma(cu_ctx* c, int comp, int z, int log2_luma, int xl, int yl, int coded, int luma_coded)
+{
+  const geom* g = c->g;
+  const int coff = part_elem_off(g, comp, z);
+  if (coded)
+  {
+    if (g->fmt == 2)
+    {
+      const int l2 = log2_luma - 1, n = 1 << l2, zb = z + ((1 << (2 * (log2_luma - 2))) >> 1);
+      tu_leaf(c, comp, z, l2, xl >> 1, yl, coff);
+      tu_leaf(c, comp, zb, l2, xl >> 1, yl + n, coff + n * n);
+    }
+    else tu_leaf(c, comp, z, log2_luma - g->csx[comp], xl >> g->csx[comp], yl >> g->csy[comp], coff);
+  }
+  if (g->m->ccp_alpha[comp - 1] && luma_coded)
+  {
+    const int alpha = g->m->ccp_alpha[comp - 1][(size_t)c->ctu_addr * g->parts + z];
+    if (alpha)
+    {
+      const int n = 1 << log2_luma, st = c->cu_size, diff = g->bd[0] - g->bd[comp];
+      int x, y;
+      for (y = 0; y < n; y++)
+        for (x = 0; x < n; x++)
+        {
+          const int l = c->resi[0][(yl + y) * st + xl + x];
+          int16_t* r = &c->resi[comp][(yl + y) * st + xl + x];
+          *r = (int16_t)(*r + ((alpha * (diff >= 0 ? l >> diff : l << -diff)) >> 3));
+        }
+    }
+  }
+}
+
+/* invRecurTransformNxN (TComTrQuant.cpp:1550-1615) with the TComTU child rules of the chroma format (TComTU.cpp:89-171) */
 static void tu_recurse(cu_ctx* c, int comp, int z, int tr_depth, int log2_luma, int xl, int yl)
 {
   const geom* g = c->g;
   const int a = c->ctu_addr;
   const uint8_t cbf = g->m->cbf[comp][(size_t)a * g->parts + z];
-  if (((cbf >> tr_depth) & 1) == 0) return;                               /* :1558-1564 */
+  const int ccp = comp != 0 && g->m->ccp_alpha[comp - 1] != NULL;         /* getUseCrossComponentPrediction */
+  if (((cbf >> tr_depth) & 1) == 0 && !ccp) return;                      /* :1558-1564 */
   if (tr_depth == PM(tr_idx, a, z))
   {
     if (comp == 0) tu_leaf(c, 0, z, log2_luma, xl, yl, 16 * z);
-    else tu_leaf(c, comp, z, log2_luma - 1, xl >> 1, yl >> 1, 4 * z);
+    else tu_chroma(c, comp, z, log2_luma, xl, yl, (cbf >> tr_depth) & 1, (g->m->cbf[0][(size_t)a * g->parts + z] >> tr_depth) & 1);
     return;
   }
-  if (comp != 0 && log2_luma == 3)
+  if (comp != 0 && log2_luma == 3 && g->csx[comp])
   {
-    /* the four 4x4 luma children share ONE 4x4 chroma block, carried by the first child on the reconstruction path
+    /* the four 4x4 luma children share ONE chroma block (4x4, in 4:2:2 4x8), carried by the first child on the reconstruction path
      * (bProcessLastOfLevel == false: TComTU.cpp:141-151,171; TComTrQuant.cpp:1608); cbf tested at the child depth */
-    if (((cbf >> (tr_depth + 1)) & 1) == 0) return;
-    tu_leaf(c, comp, z, 2, xl >> 1, yl >> 1, 4 * z);
+    tu_chroma(c, comp, z, 3, xl, yl, (cbf >> (tr_depth + 1)) & 1, 0);
     return;
   }
   {
@@ -536,11 +599,11 @@ static void pred_uni(cu_ctx* c, int list, int z_pu, int xr, int yr, int w, int h
   clip_mv(c, &mvx, &mvy);
   for (comp = 0; comp < 3; comp++)
   {
-    const int cs = comp ? 1 : 0;
-    const int stride = c->cu_size >> cs;
-    hmo_pred_inter_blk(comp != 0, g->bd[comp], rp->plane[comp], g->w[comp], g->w[comp], g->h[comp],
-                       (c->cu_x + xr) >> cs, (c->cu_y + yr) >> cs, w >> cs, h >> cs, mvx, mvy, bi,
-                       dst[comp] + (yr >> cs) * stride + (xr >> cs), stride);
+    const int sx = g->csx[comp], sy = g->csy[comp];
+    const int stride = c->cu_size >> sx;
+    hmo_pred_inter_blk_fmt(comp != 0, sx, sy, g->bd[comp], rp->plane[comp], g->w[comp], g->w[comp], g->h[comp],
+                           (c->cu_x + xr) >> sx, (c->cu_y + yr) >> sy, w >> sx, h >> sy, mvx, mvy, bi,
+                           dst[comp] + (yr >> sy) * stride + (xr >> sx), stride);
   }
 }
 
@@ -565,12 +628,12 @@ static void pred_pu(cu_ctx* c, int z_pu, int xr, int yr, int w, int h)
     if (r1 >= 0) pred_uni(c, 1, z_pu, xr, yr, w, h, 1, b);
     for (comp = 0; comp < 3; comp++)
     {
-      const int cs = comp ? 1 : 0, stride = c->cu_size >> cs;
-      const int o = (yr >> cs) * stride + (xr >> cs);
+      const int sx = g->csx[comp], sy = g->csy[comp], stride = c->cu_size >> sx;
+      const int o = (yr >> sy) * stride + (xr >> sx);
       const int bd = g->bd[comp], maxv = (1 << bd) - 1;
       const int shift_num = imax(2, 14 - bd), log2wd = sl->wp_log2_denom[comp ? 1 : 0];
-      for (y = 0; y < (h >> cs); y++)
-        for (x = 0; x < (w >> cs); x++)
+      for (y = 0; y < (h >> sy); y++)
+        for (x = 0; x < (w >> sx); x++)
         {
           const int i = o + y * stride + x;
           int v;
@@ -607,9 +670,9 @@ static void pred_pu(cu_ctx* c, int z_pu, int xr, int yr, int w, int h)
     pred_uni(c, 1, z_pu, xr, yr, w, h, 1, b);
     for (comp = 0; comp < 3; comp++)
     {
-      const int cs = comp ? 1 : 0, stride = c->cu_size >> cs;
-      const int o = (yr >> cs) * stride + (xr >> cs);
-      hmo_add_avg(a[comp] + o, b[comp] + o, out[comp] + o, w >> cs, h >> cs, stride, g->bd[comp]);
+      const int sx = g->csx[comp], sy = g->csy[comp], stride = c->cu_size >> sx;
+      const int o = (yr >> sy) * stride + (xr >> sx);
+      hmo_add_avg(a[comp] + o, b[comp] + o, out[comp] + o, w >> sx, h >> sy, stride, g->bd[comp]);
     }
     return;
   }
@@ -667,25 +730,28 @@ static int intra_avail(const geom* g, int cur_ctu, int cur_z, int px, int py, in
 static void intra_ref_line(const cu_ctx* c, int comp, int z_tu, int n, int x0, int y0, int* line)
 {
   const geom* g = c->g;
-  const int cs = comp ? 1 : 0, unit = 4 >> cs, units = n / unit;       /* units per TU side = 4x4 luma partitions */
+  const int sx = g->csx[comp], sy = g->csy[comp];
+  const int ux = 4 >> sx, uy = 4 >> sy;                                /* samples of the component per 4x4 luma partition, along x / y */
   const int cip = slice_of(g, c->ctu_addr)->constrained_intra_pred;
-  const int lx = x0 << cs, ly = y0 << cs;                              /* TU origin in luma samples */
+  const int lx = x0 << sx, ly = y0 << sy;                              /* TU origin in luma samples */
   const int16_t* pl = c->cur->plane[comp];
   const int stride = g->w[comp];
   const int total = 4 * n + 1, corner = 2 * n;
   uint8_t ok[4 * 32 + 1];
   int i, any = 0;
-  for (i = 0; i < 2 * units; i++)
+  for (i = 0; i < 2 * n / uy; i++)
   {
     const int al = intra_avail(g, c->ctu_addr, z_tu, lx - 4, ly + 4 * i, cip);        /* left column, unit i from the top */
+    int k;
+    for (k = 0; k < uy; k++) ok[corner - 1 - (i * uy + k)] = (uint8_t)al;
+    any |= al;
+  }
+  for (i = 0; i < 2 * n / ux; i++)
+  {
     const int aa = intra_avail(g, c->ctu_addr, z_tu, lx + 4 * i, ly - 4, cip);        /* row above, unit i from the left */
     int k;
-    for (k = 0; k < unit; k++)
-    {
-      ok[corner - 1 - (i * unit + k)] = (uint8_t)al;
-      ok[corner + 1 + i * unit + k] = (uint8_t)aa;
-    }
-    any |= al | aa;
+    for (k = 0; k < ux; k++) ok[corner + 1 + i * ux + k] = (uint8_t)aa;
+    any |= aa;
   }
   ok[corner] = (uint8_t)intra_avail(g, c->ctu_addr, z_tu, lx - 4, ly - 4, cip);
   any |= ok[corner];
@@ -712,14 +778,15 @@ static void intra_smooth(const geom* g, int comp, int mode, int n, int log2n, co
   static const int thr[6] = { 0, 0, 10, 7, 1, 0 };                     /* m_aucIntraFilter by log2 size: TComPrediction.cpp:49-66 */
   const int total = 4 * n + 1, corner = 2 * n;
   int i, filt = 0;
-  if (comp == 0 && mode != 1 /* DC_IDX */ && !(g->seq->range_ext_flags & HMGPU_REXT_INTRA_SMOOTHING_DISABLED))
+  /* filterIntraReferenceSamples (TComChromaFormat.h:150-153): luma, and chroma where it is not subsampled (4:4:4) */
+  if ((comp == 0 || g->fmt == 3) && mode != 1 /* DC_IDX */ && !(g->seq->range_ext_flags & HMGPU_REXT_INTRA_SMOOTHING_DISABLED))
   {
     const int d0 = iabs(mode - 10), d1 = iabs(mode - 26);
     filt = imin(d0, d1) > thr[log2n];
   }
   for (i = 0; i < total; i++) out[i] = in[i];
   if (!filt) return;
-  if (g->seq->strong_intra_smoothing && n == 32)
+  if (comp == 0 && g->seq->strong_intra_smoothing && n == 32)            /* isLuma(chType) && getUseStrongIntraSmoothing: TComPattern.cpp:196 */
   {
     const int t = 1 << (g->bd[0] - 5);
     const int bl = in[0], tl = in[corner], tr = in[total - 1];
@@ -806,25 +873,31 @@ static void intra_predict(int comp, int bd, int mode, int n, int log2n, const in
   }
 }
 
-/* xIntraRecBlk: prediction, residual, reconstruction straight into the picture (later TUs predict from it) */
-static void intra_tu(cu_ctx* c, int comp, int z_tu, int log2n, int cbf_depth, int coef_off)
+static const unsigned char k_chroma422_mode[36] = {                       /* g_chroma422IntraAngleMappingTable: TComRom.cpp:534-536 */
+  0, 1, 2, 2, 2, 2, 3, 5, 7, 8, 10, 12, 13, 15, 17, 18, 19, 20, 21, 22, 23, 23, 24, 24, 25, 25, 26, 27, 27, 28, 28, 29, 29, 30, 31, 36 };
+
+/* xIntraRecBlk: prediction, residual, reconstruction straight into the picture (later TUs predict from it).  The block is the square of
+ * 2^log2n samples of component comp whose first 4x4 luma partition is z_tu (the lower square of a 4:2:2 chroma block: the first partition of
+ * the lower half); z_mode: the partition the block's mode and cross-component weight are stored at (the upper square's) */
+static void intra_tu(cu_ctx* c, int comp, int z_tu, int z_mode, int log2n, int cbf_depth, int coef_off)
 {
   const geom* g = c->g;
-  const int a = c->ctu_addr, cs = comp ? 1 : 0, n = 1 << log2n;
-  const int x0 = ((a % g->ctus_w) * g->ctu + zx(z_tu) * 4) >> cs, y0 = ((a / g->ctus_w) * g->ctu + zy(z_tu) * 4) >> cs;
+  const int a = c->ctu_addr, sx = g->csx[comp], sy = g->csy[comp], n = 1 << log2n;
+  const int x0 = ((a % g->ctus_w) * g->ctu + zx(z_tu) * 4) >> sx, y0 = ((a / g->ctus_w) * g->ctu + zy(z_tu) * 4) >> sy;
   const hmgpu_slice_params* sl = slice_of(g, a);
-  int mode = comp == 0 ? g->m->intra_dir[0][(size_t)a * g->parts + z_tu] : g->m->intra_dir[1][(size_t)a * g->parts + z_tu];
+  int mode = comp == 0 ? g->m->intra_dir[0][(size_t)a * g->parts + z_mode] : g->m->intra_dir[1][(size_t)a * g->parts + z_mode];
   int line[4 * 32 + 1], fl[4 * 32 + 1];
   int16_t pred[32 * 32], resi[32 * 32];
   int16_t* dst = c->cur->plane[comp] + (size_t)y0 * g->w[comp] + x0;
   const int maxv = (1 << g->bd[comp]) - 1;
   int x, y;
-  if (comp != 0 && mode == 36) {   /* DM_CHROMA_IDX: TDecCu.cpp:523-524 with getChromasCorrespondingPULumaIdx (TComChromaFormat.h:129-132):
-                                      the luma mode of the first partition of the minimum-size CU -- intra NxN only exists at that size,
-                                      every other CU carries one mode throughout, so "first partition of the CU" names the same mode */
-    const int cu_parts = g->parts >> (2 * g->m->depth[(size_t)a * g->parts + z_tu]);
-    mode = g->m->intra_dir[0][(size_t)a * g->parts + (z_tu & ~(cu_parts - 1))];
+  if (comp != 0 && mode == 36) {   /* DM_CHROMA_IDX: TDecCu.cpp:523-524 with getChromasCorrespondingPULumaIdx (TComChromaFormat.h:129-132): 4:4:4: the luma
+                                      mode of the same partition; else the luma mode of the first partition of the minimum-size CU -- intra NxN only
+                                      exists at that size, every other CU carries one mode throughout, so "first partition of the CU" names the same mode */
+    const int cu_parts = g->parts >> (2 * g->m->depth[(size_t)a * g->parts + z_mode]);
+    mode = g->m->intra_dir[0][(size_t)a * g->parts + (g->fmt == 3 ? z_mode : (z_mode & ~(cu_parts - 1)))];
   }
+  if (comp != 0 && g->fmt == 2) mode = k_chroma422_mode[mode];            /* uiChFinalMode: TDecCu.cpp:525 */
   intra_ref_line(c, comp, z_tu, n, x0, y0, line);
   intra_smooth(g, comp, mode, n, log2n, line, fl);
   {
@@ -837,12 +910,12 @@ static void intra_tu(cu_ctx* c, int comp, int z_tu, int log2n, int cbf_depth, in
   {
     int per, rem, flags = comp == 0 ? 1 : 0;
     const int cqo = comp == 1 ? sl->cb_qp_offset : (comp == 2 ? sl->cr_qp_offset : 0);
-    const int16_t* lev = c->co->level[comp] + (size_t)a * ((g->ctu * g->ctu) >> (comp ? 2 : 0)) + coef_off;
+    const int16_t* lev = c->co->level[comp] + (size_t)a * ctu_elems(g, comp) + coef_off;
     const int byp = g->m->transquant_bypass && g->m->transquant_bypass[(size_t)a * g->parts + z_tu];
     if (byp) memcpy(resi, lev, sizeof(int16_t) * n * n);
     else
     {
-    hmo_qp_param(PM(qp, a, c->cu_z), comp, g->bd[comp], cqo, &per, &rem);
+    hmo_qp_param_fmt(PM(qp, a, c->cu_z), comp, g->bd[comp], cqo, g->fmt, &per, &rem);
     if (g->m->transform_skip[comp] && (g->m->transform_skip[comp][(size_t)a * g->parts + z_tu] & 1)) flags |= 2;
     hmo_inverse_transform_tu_sl(lev, resi, n, log2n, g->bd[comp], per, rem, flags, sl->scaling_lists, comp);
     }
@@ -854,9 +927,45 @@ static void intra_tu(cu_ctx* c, int comp, int z_tu, int log2n, int cbf_depth, in
                                 (rx & HMGPU_REXT_IMPLICIT_RDPCM) ? (mode == 10 ? 1 : (mode == 26 ? 2 : 0)) : 0);
     }
   }
+  {
+    /* the luma residual of the CU is kept for the cross-component prediction of its chroma (xIntraRecBlk, TDecCu.cpp:583-612: 4:4:4 only) */
+    const int rx = x0 - (c->cu_x >> sx), ry = y0 - (c->cu_y >> sy), st = c->cu_size;
+    if (comp == 0)
+      for (y = 0; y < n; y++) memcpy(&c->resi[0][(ry + y) * st + rx], &resi[y * n], sizeof(int16_t) * n);
+    else if (g->m->ccp_alpha[comp - 1])
+    {
+      const int alpha = g->m->ccp_alpha[comp - 1][(size_t)a * g->parts + z_mode], diff = g->bd[0] - g->bd[comp];
+      if (alpha)
+        for (y = 0; y < n; y++)
+          for (x = 0; x < n; x++)
+          {
+            const int l = c->resi[0][(ry + y) * st + rx + x];
+            resi[y * n + x] = (int16_t)(resi[y * n + x] + ((alpha * (diff >= 0 ? l >> diff : l << -diff)) >> 3));
+          }
+    }
+  }
   for (y = 0; y < n; y++)
     for (x = 0; x < n; x++)
       dst[(size_t)y * g->w[comp] + x] = (int16_t)CLIP3(0, maxv, pred[y * n + x] + resi[y * n + x]);
+}
+
+/* the chroma of the luma node (z, 2^log2_luma): Cb then Cr, in 4:2:2 each as two squares, the upper one first (xIntraRecBlk's
+ * TComTU::VERTICAL_SPLIT, TDecCu.cpp:505-520: the lower square predicts from the upper one's reconstruction) */
+static void intra_chroma(cu_ctx* c, int z, int log2_luma, int cbf_depth)
+{
+  const geom* g = c->g;
+  int comp;
+  for (comp = 1; comp < 3; comp++)
+  {
+    const int coff = part_elem_off(g, comp, z);
+    if (g->fmt == 2)
+    {
+      const int l2 = log2_luma - 1, n = 1 << l2, zb = z + ((1 << (2 * (log2_luma - 2))) >> 1);
+      intra_tu(c, comp, z, z, l2, cbf_depth, coff);
+      intra_tu(c, comp, zb, z, l2, cbf_depth, coff + n * n);
+    }
+    else intra_tu(c, comp, z, z, log2_luma - g->csx[comp], cbf_depth, coff);
+  }
 }
 
 /* xIntraRecQT for one channel type (ch 0 luma, 1 chroma = Cb then Cr per TU) */
@@ -865,15 +974,14 @@ static void intra_recurse(cu_ctx* c, int ch, int z, int tr_depth, int log2_luma)
   const geom* g = c->g;
   if (tr_depth == PM(tr_idx, c->ctu_addr, z))
   {
-    if (ch == 0) intra_tu(c, 0, z, log2_luma, tr_depth, 16 * z);
-    else { intra_tu(c, 1, z, log2_luma - 1, tr_depth, 4 * z); intra_tu(c, 2, z, log2_luma - 1, tr_depth, 4 * z); }
+    if (ch == 0) intra_tu(c, 0, z, z, log2_luma, tr_depth, 16 * z);
+    else intra_chroma(c, z, log2_luma, tr_depth);
     return;
   }
-  if (ch != 0 && log2_luma == 3)
+  if (ch != 0 && log2_luma == 3 && g->csx[1])
   {
-    /* four 4x4 luma TUs, one 4x4 chroma TU per component with the first of them (TComTU.cpp:141-171), cbf at the child depth */
-    intra_tu(c, 1, z, 2, tr_depth + 1, 4 * z);
-    intra_tu(c, 2, z, 2, tr_depth + 1, 4 * z);
+    /* four 4x4 luma TUs, one chroma block per component (4x4; 4:2:2: 4x8) with the first of them (TComTU.cpp:141-171), cbf at the child depth */
+    intra_chroma(c, z, 3, tr_depth + 1);
     return;
   }
   {
@@ -912,11 +1020,11 @@ static void decompress_cu(cu_ctx* c, int z, int depth, int64_t* n_intra)
     *n_intra += num_part;
     for (comp = 0; comp < 3; comp++)
     {
-      const int cs = comp ? 1 : 0, cw = size >> cs;
+      const int cw = size >> g->csx[comp], chh = size >> g->csy[comp];
       const int shift = g->bd[comp] - (comp ? g->seq->pcm_bit_depth_chroma : g->seq->pcm_bit_depth_luma);
-      const int16_t* src = c->co->pcm_sample[comp] + (size_t)a * ((g->ctu * g->ctu) >> (comp ? 2 : 0)) + (comp ? 4 : 16) * z;
-      int16_t* dst = c->cur->plane[comp] + (size_t)(ty >> cs) * g->w[comp] + (lx >> cs);
-      for (y = 0; y < cw; y++) for (x = 0; x < cw; x++) dst[(size_t)y * g->w[comp] + x] = (int16_t)(src[y * cw + x] << shift);
+      const int16_t* src = c->co->pcm_sample[comp] + (size_t)a * ctu_elems(g, comp) + part_elem_off(g, comp, z);
+      int16_t* dst = c->cur->plane[comp] + (size_t)(ty >> g->csy[comp]) * g->w[comp] + (lx >> g->csx[comp]);
+      for (y = 0; y < chh; y++) for (x = 0; x < cw; x++) dst[(size_t)y * g->w[comp] + x] = (int16_t)(src[y * cw + x] << shift);
     }
     return;
   }
@@ -933,16 +1041,17 @@ static void decompress_cu(cu_ctx* c, int z, int depth, int64_t* n_intra)
     int z_off[4], xr[4], yr[4], w[4], h[4], i, comp, x, y;
     const int n = pu_layout(PM(part_size, a, z), size, num_part, z_off, xr, yr, w, h);
     for (i = 0; i < n; i++) pred_pu(c, z + z_off[i], xr[i], yr[i], w[i], h[i]);
+    for (comp = 0; comp < 3; comp++)                                             /* m_ppcYuvResi->clear(): :413 */
+      memset(c->resi[comp], 0, sizeof(int16_t) * (size >> g->csx[comp]) * (size >> g->csy[comp]));
     for (comp = 0; comp < 3; comp++)
     {
-      const int cs = comp ? 1 : 0, cw = size >> cs;
-      memset(c->resi[comp], 0, sizeof(int16_t) * cw * cw);                     /* m_ppcYuvResi->clear(): :413 */
-      tu_recurse(c, comp, z, 0, g->seq->log2_ctu_size - depth, 0, 0);          /* xDecodeInterTexture: :743-757 */
+      const int cw = size >> g->csx[comp], chh = size >> g->csy[comp];
+      tu_recurse(c, comp, z, 0, g->seq->log2_ctu_size - depth, 0, 0);          /* xDecodeInterTexture: :743-757 (luma first: chroma may predict from its residual) */
       {
         /* addClip (TComYuv.cpp:264-299) then xCopyToPic (TDecCu.cpp:734); adding an all-zero residual == the copy branch */
         const int maxv = (1 << g->bd[comp]) - 1;
-        int16_t* dst = c->cur->plane[comp] + (size_t)(ty >> cs) * g->w[comp] + (lx >> cs);
-        for (y = 0; y < cw; y++)
+        int16_t* dst = c->cur->plane[comp] + (size_t)(ty >> g->csy[comp]) * g->w[comp] + (lx >> g->csx[comp]);
+        for (y = 0; y < chh; y++)
           for (x = 0; x < cw; x++)
           {
             const int v = c->pred[comp][y * cw + x] + c->resi[comp][y * cw + x];
@@ -1189,7 +1298,8 @@ static void edge_filter_luma(lf_ctx* l, int ctu, int z_cu, int depth, int dir, i
   }
 }
 
-/* xEdgeFilterChroma: TComLoopFilter.cpp:656-785 (4:2:0) */
+/* xEdgeFilterChroma: TComLoopFilter.cpp:656-785.  `edge` in 4x4 luma partitions from the CU origin; an edge is filtered when it lies on the
+ * 8-sample grid of the CHROMA plane (:684-692): every 16 luma samples across a subsampled direction, every 8 otherwise */
 static void edge_filter_chroma(lf_ctx* l, int ctu, int z_cu, int depth, int dir, int edge)
 {
   const geom* g = l->g;
@@ -1199,9 +1309,10 @@ static void edge_filter_chroma(lf_ctx* l, int ctu, int z_cu, int depth, int dir,
   const hmgpu_slice_params* sl = slice_of(g, ctu);
   const int off = dir == 0 ? 1 : stride, step = dir == 0 ? stride : 1;
   const int maxv = (1 << g->bd[1]) - 1;
+  const int pels_h = 4 >> g->csx[1], pels_v = 4 >> g->csy[1];           /* uiPelsInPartChromaH / V */
+  const int loop = dir == 0 ? pels_v : pels_h;                           /* samples along the edge per partition */
   int idx, comp;
-  /* chroma edges only on the 8-sample chroma grid: :684-692 */
-  if ((dir == 0 && ((x0 + edge) % 4)) || (dir == 1 && ((y0 + edge) % 4))) return;
+  if ((dir == 0 && ((x0 + edge) % (8 / pels_h))) || (dir == 1 && ((y0 + edge) % (8 / pels_v)))) return;
   for (idx = 0; idx < num_parts; idx++)
   {
     const int zq = dir == 0 ? xy2z(x0 + edge, y0 + idx) : xy2z(x0 + idx, y0 + edge);
@@ -1213,18 +1324,18 @@ static void edge_filter_chroma(lf_ctx* l, int ctu, int z_cu, int depth, int dir,
       qp_q = PM(qp, ctu, zq); qp_p = PM(qp, pctu, zp);
       for (comp = 1; comp < 3; comp++)
       {
-        int16_t* base = l->pic->plane[comp] + (size_t)((ctu / g->ctus_w) * (g->ctu / 2) + y0 * 2) * stride + (ctu % g->ctus_w) * (g->ctu / 2) + x0 * 2;
+        int16_t* base = l->pic->plane[comp] + (size_t)((ctu / g->ctus_w) * (g->ctu >> g->csy[1]) + y0 * pels_v) * stride + (ctu % g->ctus_w) * (g->ctu >> g->csx[1]) + x0 * pels_h;
         int qp = ((qp_p + qp_q + 1) >> 1) + (comp == 1 ? sl->pps_cb_qp_offset : sl->pps_cr_qp_offset);
         int index_tc, tc, stp;
-        if (qp >= 58) qp -= 6;
-        else if (qp >= 0) qp = k_chroma_scale_420[qp];
+        if (qp >= 58) { if (g->fmt == 1) qp -= 6; else if (qp > 51) qp = 51; }                        /* :761-765 */
+        else if (qp >= 0) qp = scaled_chroma_qp(qp, g->fmt);
         index_tc = CLIP3(0, 53, qp + 2 * (bs - 1) + (sl->tc_offset_div2 << 1));
         tc = k_tc_table[index_tc] * (1 << (g->bd[1] - 8));
-        base += dir == 0 ? edge * 2 : edge * 2 * stride;
-        for (stp = 0; stp < 2; stp++)
+        base += dir == 0 ? edge * pels_h : edge * pels_v * stride;
+        for (stp = 0; stp < loop; stp++)
         {
           /* xPelFilterChroma: :870-891 */
-          int16_t* s = base + step * (stp + idx * 2);
+          int16_t* s = base + step * (stp + idx * loop);
           const int m4 = s[0], m3 = s[-off], m5 = s[off], m2 = s[-off * 2];
           const int delta = CLIP3(-tc, tc, ((((m4 - m3) << 2) + m2 - m5 + 4) >> 3));
           if (!no_filter(g, pctu, zp)) s[-off] = (int16_t)CLIP3(0, maxv, m3 + delta);      /* xPelFilterChroma :883-890 */
@@ -1298,7 +1409,9 @@ static void deblock_cu(lf_ctx* l, int ctu, int z, int depth, int dir, int filter
       if (filter)
       {
         edge_filter_luma(l, ctu, z, depth, dir, e);
-        if ((e % 4) == 0) edge_filter_chroma(l, ctu, z, depth, dir, e);
+        /* (HM calls it where (uiPelsInPart >= DEBLOCK_SMALLEST_BLOCK) || the edge index is a multiple of two chroma partitions,
+         * TComLoopFilter.cpp:225-229; the function's own test on the edge's position in the CTU decides) */
+        if (g->seq->chroma_format != 0) edge_filter_chroma(l, ctu, z, depth, dir, e);
       }
     }
   }
@@ -1497,12 +1610,12 @@ int hmo_sao_process(const hmgpu_seq_params* seq, const hmgpu_slice_params* slice
     for (comp = 0; comp < 3; comp++)
     {
       const hmgpu_sao_param* p = &rec[(size_t)a * 3 + comp];
-      const int cs = comp ? 1 : 0;
+      const int sx = g.csx[comp], sy = g.csy[comp];
       if (p->mode_idc == HMGPU_SAO_OFF) continue;
       hmo_sao_offset_block(g.bd[comp], p->type_idc, p->offset,
-                           src->plane[comp] + (size_t)(yp >> cs) * g.w[comp] + (xp >> cs),
-                           dst->plane[comp] + (size_t)(yp >> cs) * g.w[comp] + (xp >> cs),
-                           g.w[comp], g.w[comp], ww >> cs, hh >> cs, av);
+                           src->plane[comp] + (size_t)(yp >> sy) * g.w[comp] + (xp >> sx),
+                           dst->plane[comp] + (size_t)(yp >> sy) * g.w[comp] + (xp >> sx),
+                           g.w[comp], g.w[comp], ww >> sx, hh >> sy, av);
     }
   }
   /* PCMLFDisableProcess (TComSampleAdaptiveOffset.cpp:742-835): PCM (filter disabled) and lossless CUs get their
@@ -1516,12 +1629,12 @@ int hmo_sao_process(const hmgpu_seq_params* seq, const hmgpu_slice_params* slice
       if (px >= seq->width || py >= seq->height || !no_filter(&g, a, z)) continue;
       for (comp = 0; comp < 3; comp++)
       {
-        const int cs = comp ? 1 : 0, n = 4 >> cs;
+        const int sx = g.csx[comp], sy = g.csy[comp];
         int x, y;
-        for (y = 0; y < n; y++)
-          for (x = 0; x < n; x++)
+        for (y = 0; y < (4 >> sy); y++)
+          for (x = 0; x < (4 >> sx); x++)
           {
-            const size_t o = (size_t)((py >> cs) + y) * g.w[comp] + (px >> cs) + x;
+            const size_t o = (size_t)((py >> sy) + y) * g.w[comp] + (px >> sx) + x;
             dst->plane[comp][o] = src->plane[comp][o];
           }
       }

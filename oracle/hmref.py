@@ -41,6 +41,8 @@ def lib():
         _lib.ref_dec_pcm_info.argtypes = [C.c_void_p, C.c_void_p]
         _lib.ref_dec_hashes.argtypes = [C.c_void_p, C.c_void_p]
         _lib.ref_dec_coeffs.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        _lib.ref_dec_ccp_alpha.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        _lib.ref_dec_ccp_alpha.restype = None
         _lib.ref_dec_planes.argtypes = [C.c_void_p] + [C.c_void_p] * 3
         _lib.ref_dec_dpb_planes.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 3
         _lib.ref_dec_meta.argtypes = [C.c_void_p] + [C.c_void_p] * 22
@@ -106,6 +108,16 @@ META_FIELDS = [("depth", np.uint8, 1), ("part_size", np.int8, 1), ("pred_mode", 
                ("ipcm", np.uint8, 1), ("skip", np.uint8, 1), ("merge", np.uint8, 1)]
 
 
+def chroma_scale(info):
+    """(sx, sy) of the chroma planes (getComponentScaleX / Y); 4:0:0 streams keep 4:2:0-shaped dummies"""
+    f = info["chroma_format"]
+    return (0 if f == 3 else 1, 1 if f in (0, 1) else 0)
+
+
+def chroma_shift(info):
+    return sum(chroma_scale(info))
+
+
 class RefDecoder:
     """Iterate over the pictures of an Annex-B stream in decode order, exposing HM's state around the filter stage."""
 
@@ -140,7 +152,7 @@ class RefDecoder:
         n, cs = info["num_ctus"], info["ctu_size"]
         res = []
         for c in range(3):
-            a = np.zeros((n, (cs * cs) >> (2 if c else 0)), dtype=np.int16)
+            a = np.zeros((n, (cs * cs) >> (chroma_shift(info) if c else 0)), dtype=np.int16)
             lib().ref_dec_pcm(self._h, c, _p(a))
             res.append(a)
         return pi, res
@@ -173,11 +185,20 @@ class RefDecoder:
         lib().ref_dec_meta(self._h, *ptrs)
         return out
 
+    def ccp_alpha(self, info):
+        """cross-component prediction weights [2][num_ctus, parts] (Cb, Cr)"""
+        res = []
+        for c in (1, 2):
+            a = np.zeros((info["num_ctus"], info["parts"]), dtype=np.int8)
+            lib().ref_dec_ccp_alpha(self._h, c, _p(a))
+            res.append(a)
+        return res
+
     def coeffs(self, info):
         n, cs = info["num_ctus"], info["ctu_size"]
         res = []
         for c in range(3):
-            a = np.zeros((n, (cs * cs) >> (2 if c else 0)), dtype=np.int32)
+            a = np.zeros((n, (cs * cs) >> (chroma_shift(info) if c else 0)), dtype=np.int32)
             lib().ref_dec_coeffs(self._h, c, _p(a))
             res.append(a)
         return res
@@ -189,9 +210,10 @@ class RefDecoder:
 
     def planes(self, info):
         w, h = info["width"], info["height"]
+        sx, sy = chroma_scale(info)
         y = np.zeros((h, w), dtype=np.int16)
-        cb = np.zeros((h // 2, w // 2), dtype=np.int16)
-        cr = np.zeros((h // 2, w // 2), dtype=np.int16)
+        cb = np.zeros((h >> sy, w >> sx), dtype=np.int16)
+        cr = np.zeros((h >> sy, w >> sx), dtype=np.int16)
         lib().ref_dec_planes(self._h, _p(y), _p(cb), _p(cr))
         return y, cb, cr
 

@@ -28,8 +28,8 @@ HM_CFG = "/root/reference/cfg"
 
 
 # ------------------------------------------------------------------------------------------ synthetic clips
-def synth_clip(w, h, frames, bit_depth, seed, novel=False, fade=False, noisy=False):
-    """gradient + checker + moving textured blobs + seeded noise, 4:2:0 planar, returns list of (Y,U,V) uint16"""
+def synth_clip(w, h, frames, bit_depth, seed, novel=False, fade=False, noisy=False, csx=1, csy=1):
+    """gradient + checker + moving textured blobs + seeded noise, planar with chroma subsampled by (csx, csy), returns list of (Y,U,V) uint16"""
     rng = np.random.RandomState(seed)
     maxv = (1 << bit_depth) - 1
     big = 2 * max(w, h) + 128
@@ -66,9 +66,12 @@ def synth_clip(w, h, frames, bit_depth, seed, novel=False, fade=False, noisy=Fal
         if fade:                            # brightness ramps from frame to frame: what explicit weighted prediction is for
             img = img * (1.0 - 0.09 * f) + 0.02 * f
         Y = np.clip(np.round(img * maxv), 0, maxv).astype(np.uint16)
-        U = np.clip(np.round((0.5 + 0.2 * np.sin((xx[:h // 2, :w // 2] + 3 * f) / 11.0)) * maxv), 0, maxv).astype(np.uint16)
-        V = np.clip(np.round((0.5 + 0.2 * np.cos((yy[:h // 2, :w // 2] - 2 * f) / 17.0)
-                              + 0.1 * (Y[::2, ::2].astype(np.float64) / maxv - 0.5)) * maxv), 0, maxv).astype(np.uint16)
+        ch, cw = h >> csy, w >> csx
+        # (chroma follows the luma texture in part: something for cross-component prediction to find in 4:4:4)
+        ysub = Y[::1 << csy, ::1 << csx].astype(np.float64) / maxv - 0.5
+        U = np.clip(np.round((0.5 + 0.2 * np.sin((xx[:ch, :cw] * (2 >> (1 - csx)) / 2.0 + 3 * f) / 11.0) + (0.0 if csx else 0.15 * ysub)) * maxv), 0, maxv).astype(np.uint16)
+        V = np.clip(np.round((0.5 + 0.2 * np.cos((yy[:ch, :cw] * (2 >> (1 - csy)) / 2.0 - 2 * f) / 17.0)
+                              + 0.1 * ysub) * maxv), 0, maxv).astype(np.uint16)
         out.append((Y, U, V))
     return out
 
@@ -109,6 +112,18 @@ STREAMS = {
 }
 
 
+# 4:2:2 and 4:4:4: the range-extension configurations with the chroma format switched; 4:4:4 with and without
+# cross-component prediction, inter and intra, a bit depth of 10 in one of each
+CF444 = ["--InputChromaFormat=444", "--ChromaFormatIDC=444"]
+CF422 = ["--InputChromaFormat=422", "--ChromaFormatIDC=422", "--CrossComponentPrediction=0"]
+STREAMS.update({
+    "ldb_444_ccp_main8_208x120": ("encoder_lowdelay_main_rext.cfg", 208, 120, 3, 8, 8, 27, CF444),
+    "intra_444_ccp_main10_208x120": ("encoder_intra_main_rext.cfg", 208, 120, 1, 10, 10, 24, CF444),
+    "ldb_422_main10_208x120": ("encoder_lowdelay_main_rext.cfg", 208, 120, 3, 10, 10, 28, CF422),
+    "intra_422_main8_208x120": ("encoder_intra_main_rext.cfg", 208, 120, 1, 8, 8, 24, CF422),
+})
+
+
 def write_scaling_list_file(path):
     """a scaling list file in HM's text format (TComScalingList::xParseScalingList, TComSlice.cpp:2052-2138; names TComRom.cpp:580-638)
     with a different seeded matrix for every size and list"""
@@ -132,10 +147,22 @@ def write_scaling_list_file(path):
                 f.write("\n")
 
 
+def chroma_scale_of(name):
+    """(csx, csy) of a stream by its name: _444_ / _422_, else 4:2:0"""
+    return (0, 0) if "_444" in name else (1, 0) if "_422" in name else (1, 1)
+
+
+def split_planes(fr, w, h, csx, csy):
+    cw, ch = w >> csx, h >> csy
+    return fr[:w * h].reshape(h, w), fr[w * h:w * h + cw * ch].reshape(ch, cw), fr[w * h + cw * ch:w * h + 2 * cw * ch].reshape(ch, cw)
+
+
 def encode(name, tmp):
     cfg, w, h, frames, ibd, bd, qp, extra = STREAMS[name]
     yuv = os.path.join(tmp, name + ".yuv")
-    clip = synth_clip(w, h, frames, ibd, seed=0x484D + sum(map(ord, name)), novel="cip" in name, fade="wp" in name, noisy="pcm" in name or "lossless" in name)
+    csx, csy = chroma_scale_of(name)
+    clip = synth_clip(w, h, frames, ibd, seed=0x484D + sum(map(ord, name)), novel="cip" in name, fade="wp" in name, noisy="pcm" in name or "lossless" in name,
+                      csx=csx, csy=csy)
     mono = "mono" in name                                               # 4:0:0: luma only in, luma only out
     write_yuv(yuv, clip, ibd, mono)
     bs = os.path.join(tmp, name + ".bin")
@@ -161,7 +188,8 @@ def encode(name, tmp):
     with open(bs, "rb") as f:
         data = f.read()
     # (the reconstruction file has 16-bit samples as soon as either component has more than 8 bits)
-    recdata = np.fromfile(rec, dtype="<u2" if os.path.getsize(rec) == (w * h * 2 if mono else w * h * 3) * frames else np.uint8)
+    per8 = w * h if mono else w * h + 2 * (w >> csx) * (h >> csy)
+    recdata = np.fromfile(rec, dtype="<u2" if os.path.getsize(rec) == 2 * per8 * frames else np.uint8)
     return data, recdata, (w, h, frames, bd)
 
 
@@ -190,6 +218,9 @@ def dump_stream(name, bitstream, enc_rec, geom):
         if pcm_info[2] and np.any(meta["ipcm"]):                  # PCM samples only where PCM CUs exist (they are large)
             for c in range(3):
                 out[k + "pcm%d" % c] = pcm[c]
+        if info["chroma_format"] == 3:
+            for c, a in enumerate(dec.ccp_alpha(info)):
+                out[k + "meta_ccp_" + "uv"[c]] = a
         co = dec.coeffs(info)
         for c in range(3):
             assert co[c].min() >= -32768 and co[c].max() <= 32767
@@ -215,13 +246,12 @@ def dump_stream(name, bitstream, enc_rec, geom):
     dec.close()
     assert len(pics) == frames
     # encoder reconstruction == decoder output (HM practice): check in POC order
-    per = w * h * 3 // 2
+    csx, csy = chroma_scale_of(name)
+    per = w * h + 2 * (w >> csx) * (h >> csy)
     for poc in sorted(final_by_poc):
         fr = enc_rec[poc * per:(poc + 1) * per].astype(np.int16)
-        y, cb, cr = final_by_poc[poc]
-        assert np.array_equal(fr[:w * h].reshape(h, w), y)
-        assert np.array_equal(fr[w * h:w * h * 5 // 4].reshape(h // 2, w // 2), cb)
-        assert np.array_equal(fr[w * h * 5 // 4:].reshape(h // 2, w // 2), cr)
+        for a, b in zip(split_planes(fr, w, h, csx, csy), final_by_poc[poc]):
+            assert np.array_equal(a, b)
     out["num_pics"] = np.array([len(pics)], dtype=np.int32)
     path = os.path.join(GOLD, "stream_%s.npz" % name)
     np.savez_compressed(path, **out)
@@ -328,15 +358,15 @@ def make_lite(names=None):
             bs, rec, (w, h, frames, bd) = encode(name, tmp)
             out = {"bitstream": np.frombuffer(bs, dtype=np.uint8), "geom": np.array([w, h, frames, bd], dtype=np.int32)}
             mono = "mono" in name
-            per = w * h if mono else w * h * 3 // 2
+            csx, csy = chroma_scale_of(name)
+            per = w * h if mono else w * h + 2 * (w >> csx) * (h >> csy)
             assert rec.size == per * frames
             for poc in range(frames):                                      # the recon file is in output (POC) order, cropped
                 fr = rec[poc * per:(poc + 1) * per].astype(np.int16)
                 out["poc%02d_0" % poc] = fr[:w * h].reshape(h, w)
                 if mono:
                     continue
-                out["poc%02d_1" % poc] = fr[w * h:w * h * 5 // 4].reshape(h // 2, w // 2)
-                out["poc%02d_2" % poc] = fr[w * h * 5 // 4:].reshape(h // 2, w // 2)
+                _, out["poc%02d_1" % poc], out["poc%02d_2" % poc] = split_planes(fr, w, h, csx, csy)
             path = os.path.join(GOLD, "lite_%s.npz" % name)
             np.savez_compressed(path, **out)
             print("wrote %s (%.1f KB, %d bytes of bitstream)" % (path, os.path.getsize(path) / 1024.0, len(bs)))

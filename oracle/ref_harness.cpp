@@ -247,6 +247,7 @@ void ref_dec_info(void* h, int32_t* info)
  * 9 lfAcrossSlices 10 saoLuma 11 saoChroma 12 numRefIdx0 13 numRefIdx1 14 useWP 15 wpBiPred 16 transquantBypassEnable
  * 17 usePCM 18 pcmFilterDisable 19 sliceCurStartCUAddr(in partitions) 20 scalingListEnabled 21 signHiding(unused)
  * 22 useTransformSkip 23 sliceCurEndCUAddr 24 chromaQpAdjTableSize 25 strongIntraSmoothing 26 constrainedIntraPred 27 flagsValid(=1)
+ * 28 range-extension tools as HMGPU_REXT_* bits (rotation 1, implicit RDPCM 2, explicit RDPCM 4, intra smoothing disabled 8) 29 crossComponentPrediction
  * 32..47 refPOC L0, 48..63 refPOC L1                                                                               */
 void ref_dec_slices(void* h, int32_t* out)
 {
@@ -274,6 +275,9 @@ void ref_dec_slices(void* h, int32_t* out)
     o[25] = s->getSPS()->getUseStrongIntraSmoothing() ? 1 : 0;
     o[26] = s->getPPS()->getConstrainedIntraPred() ? 1 : 0;
     o[27] = 1;
+    o[28] = (s->getSPS()->getUseResidualRotation() ? 1 : 0) | (s->getSPS()->getUseResidualDPCM(RDPCM_SIGNAL_IMPLICIT) ? 2 : 0) |
+            (s->getSPS()->getUseResidualDPCM(RDPCM_SIGNAL_EXPLICIT) ? 4 : 0) | (s->getSPS()->getDisableIntraReferenceSmoothing() ? 8 : 0);
+    o[29] = s->getPPS()->getUseCrossComponentPrediction() ? 1 : 0;
     for (int l = 0; l < 2; l++)
       for (int r = 0; r < o[12 + l] && r < 16; r++)
         o[32 + 16 * l + r] = s->getRefPOC(RefPicList(l), r);
@@ -356,9 +360,17 @@ void ref_dec_meta(void* h, uint8_t* depth, int8_t* partSize, int8_t* predMode, i
     if (cbfY)     memcpy(cbfY + o, cu->getCbf(COMPONENT_Y), np);
     if (cbfU)     memcpy(cbfU + o, cu->getCbf(COMPONENT_Cb), np);
     if (cbfV)     memcpy(cbfV + o, cu->getCbf(COMPONENT_Cr), np);
-    if (tsY)      memcpy(tsY + o, cu->getTransformSkip(COMPONENT_Y), np);
-    if (tsU)      memcpy(tsU + o, cu->getTransformSkip(COMPONENT_Cb), np);
-    if (tsV)      memcpy(tsV + o, cu->getTransformSkip(COMPONENT_Cr), np);
+    /* bit 0: m_puhTransformSkip, bits 1-2: m_explicitRdpcmMode (the layout of hmgpu_ctu_meta::transform_skip) */
+    {
+      uint8_t* ts[3] = { tsY, tsU, tsV };
+      for (int c = 0; c < 3; c++)
+        if (ts[c])
+          for (UInt i = 0; i < np; i++)
+          {
+            const int mode = cu->getExplicitRdpcmMode(ComponentID(c), i);         /* (NUMBER_OF_RDPCM_MODES = "none parsed": TComDataCU.cpp:435) */
+            ts[c][o + i] = (uint8_t)((cu->getTransformSkip(i, ComponentID(c)) ? 1 : 0) | ((mode == RDPCM_HOR || mode == RDPCM_VER ? mode : 0) << 1));
+          }
+    }
     if (intraDirL) memcpy(intraDirL + o, cu->getIntraDir(CHANNEL_TYPE_LUMA), np);
     if (intraDirC) memcpy(intraDirC + o, cu->getIntraDir(CHANNEL_TYPE_CHROMA), np);
     for (UInt i = 0; i < np; i++)
@@ -383,11 +395,26 @@ void ref_dec_meta(void* h, uint8_t* depth, int8_t* partSize, int8_t* predMode, i
   }
 }
 
-/* coefficient levels as parsed, HM layout (TComDataCU.cpp:165-173): comp 0: [numCTUs][W*H], comp 1,2: [numCTUs][W*H/4] */
+/* m_crossComponentPredictionAlpha[Cb / Cr] per partition: [numCTUs][parts] */
+void ref_dec_ccp_alpha(void* h, int comp, int8_t* out)
+{
+  RefDec* d = (RefDec*)h; TComPic* p = cur(d);
+  const UInt np = p->getNumPartInCU();
+  for (UInt a = 0; a < p->getNumCUsInFrame(); a++)
+    for (UInt i = 0; i < np; i++) out[(size_t)a * np + i] = (int8_t)p->getCU(a)->getCrossComponentPredictionAlpha(i, ComponentID(comp));
+}
+
+/* samples of a CTU in the level / PCM arrays of a component (TComDataCU.cpp:165-173) */
+static size_t ctu_elems(TComPic* p, int comp)
+{
+  return (size_t)(g_uiMaxCUWidth * g_uiMaxCUHeight) >> (p->getComponentScaleX(ComponentID(comp)) + p->getComponentScaleY(ComponentID(comp)));
+}
+
+/* coefficient levels as parsed, HM layout (TComDataCU.cpp:165-173): comp 0: [numCTUs][W*H], comp 1,2: [numCTUs][W*H >> (sx + sy)] */
 void ref_dec_coeffs(void* h, int comp, int32_t* out)
 {
   RefDec* d = (RefDec*)h; TComPic* p = cur(d);
-  const size_t n = (size_t)(g_uiMaxCUWidth * g_uiMaxCUHeight) >> (comp ? 2 : 0);
+  const size_t n = ctu_elems(p, comp);
   for (UInt a = 0; a < p->getNumCUsInFrame(); a++)
     memcpy(out + a * n, p->getCU(a)->getCoeff(ComponentID(comp)), n * sizeof(TCoeff));
 }
@@ -398,7 +425,7 @@ void ref_dec_coeffs(void* h, int comp, int32_t* out)
 void ref_dec_pcm(void* h, int comp, int16_t* out)
 {
   RefDec* d = (RefDec*)h; TComPic* p = cur(d);
-  const size_t n = (size_t)(g_uiMaxCUWidth * g_uiMaxCUHeight) >> (comp ? 2 : 0);
+  const size_t n = ctu_elems(p, comp);
   for (UInt a = 0; a < p->getNumCUsInFrame(); a++)
   {
     const Pel* s = p->getCU(a)->getPCMSample(ComponentID(comp));

@@ -9,6 +9,8 @@ from libhm_amd import abi
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 STREAMS = ["ldp_main8_416x240", "ra_main10_208x120", "ldp_main10_208x120", "intra_main10_208x120", "ldp_cip_main10_208x120",
            "ldp_wp_main10_208x120", "ra_wp_main8_208x120", "ldp_sl_main10_208x120", "ldp_sldef_main8_208x120", "ldp_tiles_main10_832x128", "ldp_lossless_main10_208x120", "ldp_pcm_main8_208x120"]
+# 4:2:2 / 4:4:4, the latter with cross-component prediction: range-extension configurations, inter and intra
+STREAMS_CF = ["ldb_444_ccp_main8_208x120", "intra_444_ccp_main10_208x120", "ldb_422_main10_208x120", "intra_422_main8_208x120"]
 # bitstream + encoder reconstruction only (oracle/make_golden.py LITE): syntax HM 16.0's own decoder cannot be run on, or variants
 LITE = ["ldp_slices_main8_208x120", "ldp_depslices_main10_208x120", "ldp_wpp_main10_416x240", "ldp_wpp_depslices_main8_416x240",
         "ldp_dqp_main10_208x120", "ra_cra_main8_208x120", "ldp_ctu32_main8_208x120", "ldp_ctu16_main10_208x120", "ldp_crop_main8_204x116",
@@ -46,7 +48,10 @@ class Picture:
         self.index = idx
         s0 = z[k + "slices"][0]
         self.seq = abi.make_seq(self.width, self.height, self.bd_y, self.bd_c, log2_ctu=int(np.log2(self.ctu_size)), max_pictures=12,
-                                strong_intra_smoothing=int(s0[25]) if int(s0[27]) else 1)
+                                strong_intra_smoothing=int(s0[25]) if int(s0[27]) else 1, range_ext_flags=int(s0[28]))
+        self.chroma_format = int(info[13])
+        self.seq.chroma_format = self.chroma_format
+        self.csx, self.csy = (0 if self.chroma_format == 3 else 1), (1 if self.chroma_format in (0, 1) else 0)
         self.slices = []
         self.ref_pocs = set()
         wp_all = z[k + "wp"] if (k + "wp") in z.files else None
@@ -89,6 +94,8 @@ class Picture:
         m = {n: z[k + "meta_" + n] for n in ("depth", "part_size", "pred_mode", "qp", "tr_idx", "cbf_y", "cbf_u", "cbf_v", "ts_y",
                                              "ts_u", "ts_v", "mv0", "mv1", "ref_idx0", "ref_idx1", "intra_dir_l", "intra_dir_c",
                                              "bypass", "ipcm")}
+        if (k + "meta_ccp_u") in z.files and int(s0[29]):                 # cross-component prediction weights (4:4:4 streams that use the tool)
+            m["ccp_u"], m["ccp_v"] = z[k + "meta_ccp_u"], z[k + "meta_ccp_v"]
         m["slice_idx"] = z[k + "meta_slice_idx"].astype(np.uint16)
         if (k + "tile_idx") in z.files:
             m["tile_idx"] = z[k + "tile_idx"].astype(np.uint16)
@@ -112,12 +119,11 @@ class Picture:
 
     def inter_mask(self, comp):
         """boolean mask of the plane: True where the sample belongs to an inter-coded, decoded CU"""
-        cs = 1 if comp else 0
-        mask = np.zeros((self.height >> cs, self.width >> cs), dtype=bool)
+        sx, sy = (self.csx, self.csy) if comp else (0, 0)
+        mask = np.zeros((self.height >> sy, self.width >> sx), dtype=bool)
         pm = self.meta_np["pred_mode"]
         ps = self.meta_np["part_size"]
         pw = self.ctu_size // 4
-        step = 4 >> cs
         for a in range(self.num_ctus):
             cx, cy = (a % self.ctus_w) * self.ctu_size, (a // self.ctus_w) * self.ctu_size
             for zidx in range(self.parts):
@@ -127,7 +133,7 @@ class Picture:
                 if px >= self.width or py >= self.height:
                     continue
                 if pm[a, zidx] == abi.MODE_INTER and ps[a, zidx] != abi.SIZE_NONE:
-                    mask[py >> cs:(py >> cs) + step, px >> cs:(px >> cs) + step] = True
+                    mask[py >> sy:(py >> sy) + (4 >> sy), px >> sx:(px >> sx) + (4 >> sx)] = True
         return mask
 
 

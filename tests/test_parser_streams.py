@@ -25,6 +25,8 @@ def _decode(name, **kw):
             arrays = {n: p.array(n) for n, _ in ARRAYS}
             for n in ("skip", "merge", "coeff0", "coeff1", "coeff2", "sao", "slice_idx", "tile_idx", "pcm0", "pcm1", "pcm2"):
                 arrays[n] = p.array(n)
+            if p.geometry()["chroma_format"] == 3:
+                arrays["ccp0"], arrays["ccp1"] = p.array("ccp0"), p.array("ccp1")
             by_poc[p.poc] = dict(poc=p.poc, arrays=arrays, slices=[p.slice_params(i) for i in range(p.num_slices())], hash=p.hash_sei())
             outputs.append(p.poc)
         d.decode_stream(z["bitstream"], on_output=on_output)
@@ -34,7 +36,7 @@ def _decode(name, **kw):
 
 
 @pytest.mark.parametrize("threads", [1, 4])
-@pytest.mark.parametrize("name", gu.STREAMS)
+@pytest.mark.parametrize("name", gu.STREAMS + gu.STREAMS_CF)
 def test_parser_reproduces_hm_metadata(name, threads):
     z, got, outputs = _decode(name, threads=threads)
     pics = gu.stream_pictures(name)
@@ -56,6 +58,9 @@ def test_parser_reproduces_hm_metadata(name, threads):
         assert np.array_equal(g["arrays"]["slice_idx"], p.meta_np["slice_idx"])
         if "tile_idx" in p.meta_np:
             assert np.array_equal(g["arrays"]["tile_idx"], p.meta_np["tile_idx"])
+        if "ccp_u" in p.meta_np:                                                 # cross-component prediction weights (4:4:4)
+            for c, key in enumerate(("ccp_u", "ccp_v")):
+                assert np.array_equal(g["arrays"]["ccp%d" % c][decoded], p.meta_np[key].reshape(-1)[decoded]), "%s pic %d: %s" % (name, p.index, key)
         if (k + "pcm0") in z.files and p.meta_np["ipcm"].any():
             ipcm = p.meta_np["ipcm"].reshape(p.num_ctus, -1)
             for c in range(3):
@@ -64,7 +69,7 @@ def test_parser_reproduces_hm_metadata(name, threads):
                 assert np.array_equal(g["arrays"]["pcm%d" % c][mask], z[k + "pcm%d" % c].reshape(-1)[mask])
 
 
-@pytest.mark.parametrize("name", gu.STREAMS)
+@pytest.mark.parametrize("name", gu.STREAMS + gu.STREAMS_CF)
 def test_parser_reproduces_hm_sao_and_slice_constants(name):
     z, got, outputs = _decode(name)
     pics = gu.stream_pictures(name)
