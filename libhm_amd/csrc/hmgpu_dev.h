@@ -169,6 +169,9 @@ struct PicDev {
   int32_t strong_intra_smoothing;  // SPS flag
   int32_t range_ext;               // HMGPU_REXT_* (sps_range_extension tools of the residual path)
   int32_t mono;                    // chroma_format_idc 0: no chroma blocks are coded, the chroma planes are never read back
+  int32_t fmt, csx, csy;           // chroma_format_idc (0 kept as 1) and the chroma subsampling it implies (getComponentScaleX / Y, TComChromaFormat.h:59-62);
+                                   // 4:2:2 / 4:4:4 pictures take their chroma through the format-generic kernels of k_cfmt.hip
+  const int8_t* ccp[2];            // cross-component prediction weights per partition (Cb, Cr), or null
   uint8_t* ctu_intra;              // [num_ctus] 1 = the CTU holds intra CUs (written by k_prep)
   uint32_t* intra_done;            // [3][num_ctus]: the CTU's intra CUs of that component are reconstructed
   uint32_t* fault;                 // set by a kernel that gave up waiting (k_intra's bounded spin): checked by the host at hmgpu_sync
@@ -209,6 +212,7 @@ struct ItxArgs {
   int32_t n; uint32_t class_mask;              // pictures of the batch; size classes to run (bit = log2 size - 2)
   int32_t blocks[4];                           // workgroups per shard and size class (launch_itx)
   int32_t rtw[3], bd[3];                       // residual tiles per tile row; bit depths
+  int32_t csx, csy;                            // chroma subsampling (a TU record carries its LUMA position)
   uint32_t tu_cap[4];                          // capacity of one shard's list
   const TuRec* tu[kMaxBatch][4];
   const uint32_t* tu_count[kMaxBatch];         // [4][kTuShards]
@@ -265,7 +269,7 @@ __host__ inline int xcd_grid(int n, int nb) {
 }
 
 // ---- launchers (one per kernel family; defined in the .hip files) ---------------------------------------------------
-void launch_prep(const PicDev* pics, const Batch& b, int max_ctus, int parts, bool intra, bool write_blk, hipStream_t s);
+void launch_prep(const PicDev* pics, const Batch& b, int max_ctus, int parts, bool intra, bool write_blk, int fmt, hipStream_t s);
 // npics = entries of the finals table (device pictures of the context, <= kMaxPics)
 // bi: the batch holds B slices (the variants that run the H and V passes once per list)
 void launch_mc_luma(McArgs& a, int max_ctus, bool wp, bool bi, hipStream_t s);
@@ -284,9 +288,15 @@ struct Md5Batch { int32_t n, pad_; const uint8_t* msg[128]; unsigned long long b
 void launch_md5(const Md5Batch& job, hipStream_t s);
 void launch_crc(const int16_t* src, int pitch, int step, int w, int h, int bd, uint32_t* rows, uint32_t* out, hipStream_t s);
 void launch_intra(const PicDev* pics, const Batch& b, const int32_t* order, int num_ctus, hipStream_t s);
+// chroma of 4:2:2 / 4:4:4 pictures (k_cfmt.hip): cross-component prediction on the residual tiles, motion compensation of every inter
+// cell, chroma deblocking on the format's own grid; fmt = chroma_format_idc
+void launch_ccp(const PicDev* pics, const Batch& b, int max_ctus, hipStream_t s);
+void launch_mc_chroma_fmt(const PicDev* pics, const PlaneSet* finals, const Batch& b, int max_ctus, int log2ctu, int fmt, bool wp, hipStream_t s);
+void launch_deblock_chroma_fmt(const PicDev* pics, const Batch& b, int dir, int width, int height, hipStream_t s);
+void launch_intra_chroma_422(const PicDev* pics, const Batch& b, hipStream_t s);
 void launch_deblock(const PicDev* pics, const Batch& b, int dir, int width, int height, hipStream_t s);
-void launch_sao(const PicDev* pics, const Batch& b, int width, int height, hipStream_t s);
-void launch_extend(const PicDev* pics, const Batch& b, int width, int height, int mx, int my, hipStream_t s);
+void launch_sao(const PicDev* pics, const Batch& b, int width, int height, int csx, int csy, hipStream_t s);
+void launch_extend(const PicDev* pics, const Batch& b, int width, int height, int mx, int my, int csx, int csy, hipStream_t s);
 // kernel-level seams for tests
 void launch_itx_flat(int log2size, int bit_depth, int n, const int16_t* levels, const int8_t* per, const int8_t* rem,
                      const uint8_t* flags, int16_t* resid, hipStream_t s);

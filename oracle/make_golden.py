@@ -349,6 +349,23 @@ LITE = {
 }
 
 
+# 4:2:2 / 4:4:4 variants: bitstream + the encoder's reconstruction
+LITE.update({
+    "ldb_444_main10_208x120": ("encoder_lowdelay_main_rext.cfg", 208, 120, 3, 10, 10, 30, CF444 + ["--CrossComponentPrediction=0"]),
+    "ldb_444_lossless_main8_208x120": ("encoder_lowdelay_main_rext.cfg", 208, 120, 2, 8, 8, 30, CF444 + ["--TransquantBypassEnableFlag=1", "--CUTransquantBypassFlagForce=1"]),
+    "intra_444_ts32_nosmooth_main8_208x120": ("encoder_intra_main_rext.cfg", 208, 120, 1, 8, 8, 27, CF444 + ["--TransformSkipLog2MaxSize=5", "--IntraReferenceSmoothing=0"]),
+    # cross-component prediction between a 10-bit luma and an 8-bit chroma residual (getDifferentialLumaChromaBitDepth)
+    "ldb_444_ccp_bd10_8_208x120": ("encoder_lowdelay_main_rext.cfg", 208, 120, 3, 8, 10, 28, CF444 + ["--InternalBitDepthC=8"]),
+    "ldb_444_ctu16_main8_208x120": ("encoder_lowdelay_main_rext.cfg", 208, 120, 3, 8, 8, 30, CF444 + ["--MaxCUWidth=16", "--MaxCUHeight=16", "--MaxPartitionDepth=2", "--QuadtreeTULog2MaxSize=4"]),
+    "ldb_422_lossless_main8_208x120": ("encoder_lowdelay_main_rext.cfg", 208, 120, 2, 8, 8, 30, CF422 + ["--TransquantBypassEnableFlag=1", "--CUTransquantBypassFlagForce=1"]),
+    "ldb_422_wp_main10_208x120": ("encoder_lowdelay_main_rext.cfg", 208, 120, 3, 10, 10, 30, CF422 + ["--WeightedPredP=1", "--WeightedPredB=1"]),
+    "ldb_422_wpp_depslices_main8_416x240": ("encoder_lowdelay_main_rext.cfg", 416, 240, 3, 8, 8, 28,
+                                            CF422 + ["--WaveFrontSynchro=1", "--SliceMode=1", "--SliceArgument=10", "--SliceSegmentMode=1", "--SliceSegmentArgument=3"]),
+    "intra_422_qp12_main10_208x120": ("encoder_intra_main_rext.cfg", 208, 120, 1, 10, 10, 12, CF422),
+    "ldb_422_ctu32_main8_208x120": ("encoder_lowdelay_main_rext.cfg", 208, 120, 3, 8, 8, 30, CF422 + ["--MaxCUWidth=32", "--MaxCUHeight=32", "--MaxPartitionDepth=3"]),
+})
+
+
 def make_lite(names=None):
     os.makedirs(GOLD, exist_ok=True)
     STREAMS.update(LITE)

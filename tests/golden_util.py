@@ -25,6 +25,11 @@ LITE = ["ldp_slices_main8_208x120", "ldp_depslices_main10_208x120", "ldp_wpp_mai
         "ldb_rext420_wp_hp_main10_208x120", "ldb_rext420_wpp_depslices_main8_416x240", "ldb_rext420_tileslices_main10_832x128",
         # monochrome (4:0:0)
         "ldb_mono_rext_main8_208x120", "ldb_mono_wp_crop_main10_204x116", "intra_mono_main8_208x120"]
+# 4:2:2 / 4:4:4 variants: without cross-component prediction, lossless (rotation + RDPCM on full-size chroma), transform skip up to 32x32
+# chroma blocks, cross-component prediction between different bit depths, 16- and 32-sample CTUs, weighted prediction, wavefronts + slices
+LITE_CF = ["ldb_444_main10_208x120", "ldb_444_lossless_main8_208x120", "intra_444_ts32_nosmooth_main8_208x120", "ldb_444_ccp_bd10_8_208x120",
+           "ldb_444_ctu16_main8_208x120", "ldb_422_lossless_main8_208x120", "ldb_422_wp_main10_208x120", "ldb_422_wpp_depslices_main8_416x240",
+           "intra_422_qp12_main10_208x120", "ldb_422_ctu32_main8_208x120"]
 # HM-encoded streams rewritten at the bit level (oracle/make_surgery.py) for syntax HM's encoder never writes; expected pictures = HM's own
 # DECODER on the rewritten stream: pps_scaling_list_data; long-term reference pictures + ref_pic_list_modification
 SURGERY = ["surgery_ppssl_main8_208x120", "surgery_ltr_rplm_main10_208x120"]
