@@ -149,6 +149,12 @@ class Context:
     def __exit__(self, *a):
         self.close()
 
+    @property
+    def chroma_scale(self):
+        """(log2 SubWidthC, log2 SubHeightC) of the context's chroma planes; monochrome keeps 4:2:0-shaped dummies"""
+        f = self.seq.chroma_format
+        return (0 if f == 3 else 1, 1 if f in (0, 1) else 0)
+
     def sync(self):
         self._chk(lib().hmgpu_sync(self._h), "hmgpu_sync")
 
@@ -169,7 +175,8 @@ class Context:
 
     def download(self, pic):
         w, h = self.seq.width, self.seq.height
-        planes = [np.zeros((h, w), dtype=np.int16), np.zeros((h // 2, w // 2), dtype=np.int16), np.zeros((h // 2, w // 2), dtype=np.int16)]
+        sx, sy = self.chroma_scale
+        planes = [np.zeros((h, w), dtype=np.int16), np.zeros((h >> sy, w >> sx), dtype=np.int16), np.zeros((h >> sy, w >> sx), dtype=np.int16)]
         ptrs = (C.c_void_p * 3)(*[p.ctypes.data for p in planes])
         strides = (C.c_int32 * 3)(*[p.shape[1] for p in planes])
         self._chk(lib().hmgpu_picture_download(self._h, pic, ptrs, strides), "hmgpu_picture_download")
@@ -184,7 +191,8 @@ class Context:
         l, r, t, b = crop
         W, H = self.seq.width - l - r, self.seq.height - t - b
         dt = np.uint8 if bytes_per_sample == 1 else np.uint16
-        planes = [np.zeros((H, W), dtype=dt), np.zeros((H // 2, W // 2), dtype=dt), np.zeros((H // 2, W // 2), dtype=dt)]
+        sx, sy = self.chroma_scale
+        planes = [np.zeros((H, W), dtype=dt), np.zeros((H >> sy, W >> sx), dtype=dt), np.zeros((H >> sy, W >> sx), dtype=dt)]
         ptrs = (C.c_void_p * 3)(*[p.ctypes.data for p in planes])
         strides = (C.c_int32 * 3)(*[p.strides[0] for p in planes])
         self._chk(lib().hmgpu_picture_download_packed(self._h, pic, ptrs, strides, bytes_per_sample, l, r, t, b), "hmgpu_picture_download_packed")

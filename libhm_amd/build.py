@@ -6,7 +6,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libhmgpu.so")
-SOURCES = ["k_prep.hip", "k_mc.hip", "k_mc_cells.hip", "k_itx.hip", "k_intra.hip", "k_dbk.hip", "k_sao.hip", "k_filter.hip", "k_out.hip", "hmgpu_api.hip"]
+SOURCES = ["k_prep.hip", "k_mc.hip", "k_mc_cells.hip", "k_itx.hip", "k_intra.hip", "k_dbk.hip", "k_sao.hip", "k_filter.hip", "k_out.hip", "k_cfmt.hip", "hmgpu_api.hip"]
 # Code objects for gfx950 with XNACK (retry on page fault) off, the mode these GPUs run in: with the mode known the compiler schedules loads
 # more freely than for "any" (k_mc_luma 0.213 -> 0.208 ms per launch of 16 pictures, measured A/B/A/B on one box).  A device that runs with
 # HSA_XNACK=1 does not load them: HMGPU_XNACK_ANY=1 in the environment of the build gives the mode-agnostic objects back.

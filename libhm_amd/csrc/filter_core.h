@@ -146,11 +146,11 @@ __device__ inline void pairs_to_rows(const uint32_t (&a)[8], uint32_t (&r0)[4], 
   }
 }
 
-// chroma tc for one component (xEdgeFilterChroma :759-775, 4:2:0)
-__device__ inline int chroma_tc(int qp_avg, int pps_off, int tc_offset_div2, int bd) {
+// chroma tc for one component (xEdgeFilterChroma :759-775); fmt: chroma_format_idc (the QP table of 4:2:0, min(qPi, 51) otherwise)
+__device__ inline int chroma_tc(int qp_avg, int pps_off, int tc_offset_div2, int bd, int fmt = 1) {
   int qp = qp_avg + pps_off;
-  if (qp >= 58) qp -= 6;
-  else if (qp >= 0) qp = c_chroma_scale_420_dbk[qp];
+  if (qp >= 58) qp = fmt == 1 ? qp - 6 : min(qp, 51);
+  else if (qp >= 0) qp = fmt == 1 ? c_chroma_scale_420_dbk[qp] : min(qp, 51);
   return c_tc_table[clip3(0, 53, qp + 2 + (tc_offset_div2 << 1))] * (1 << (bd - 8));     // Bs == 2: + DEFAULT_INTRA_TC_OFFSET
 }
 
@@ -181,12 +181,12 @@ __device__ inline s16x2 lut_offsets(uint32_t idx_pk, uint32_t tab_lo, uint32_t t
 // comp belong to lossless / PCM-unfiltered CUs and keep the SAO input.  Returns a mask with 0xffff per exempt sample pair half
 // packed like the samples (4 dwords); only called for pictures that hold such CUs (PicDev::any_nofilt).
 __device__ inline void sao_exempt_mask(const PicDev& P, int comp, int x, int row, uint32_t (&m)[4]) {
-  const int cs = comp ? 1 : 0;
-  const BlkInfo* g = P.blk + (size_t)((row << cs) >> 2) * P.grid_w + ((x << cs) >> 2);
-  // luma: samples 0-3 / 4-7 lie in two 4x4 blocks; chroma: every pair of samples in its own block (four blocks)
+  const int sx = comp ? P.csx : 0, sy = comp ? P.csy : 0;
+  const BlkInfo* g = P.blk + (size_t)((row << sy) >> 2) * P.grid_w + ((x << sx) >> 2);
+  // full horizontal resolution: samples 0-3 / 4-7 lie in two 4x4 blocks; subsampled chroma: every pair of samples in its own block (four blocks)
 #pragma unroll
   for (int j = 0; j < 4; j++) {
-    const int blk = cs ? j : (j >> 1);
+    const int blk = sx ? j : (j >> 1);
     m[j] = (ldg(&g[blk].flags) & BF_NOFILT) ? 0xffffffffu : 0u;
   }
 }

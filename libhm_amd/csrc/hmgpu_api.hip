@@ -37,6 +37,7 @@ struct Picture {
   void* meta = nullptr;                 // raw HM arrays
   void* coef = nullptr;
   void* pcm = nullptr;                  // PCM sample buffers, allocated when the first PCM CU shows up
+  void* ccp = nullptr;                  // cross-component prediction weights (4:4:4), allocated with the first picture that carries them
   void* derived = nullptr;              // blk, tu lists, counters, sao params, slices
   uint8_t* sl_table = nullptr;          // device: expanded scaling-list matrices (inside `derived`)
   uint32_t* coef_start = nullptr;       // device: [3][num_ctus + 1] CTU starts of compact levels (inside `derived`)
@@ -100,6 +101,7 @@ struct hmgpu_ctx {
   int32_t last_err = 0;
   // geometry
   int ctu = 64, pw = 16, parts = 256, ctus_w = 0, ctus_h = 0, num_ctus = 0;
+  int fmt = 1, csx = 1, csy = 1;          // chroma_format_idc (0 handled as 1: the chroma planes exist and are left alone) and its subsampling
   int pitch[3] = {0, 0, 0}, rows[3] = {0, 0, 0};
   int mx[3] = {0, 0, 0}, my[3] = {0, 0, 0};
   int grid_w = 0, grid_h = 0;
@@ -288,6 +290,8 @@ hmgpu_status alloc_picture(hmgpu_ctx* c, Picture& p) {
   d.has_intra_dir = 0; d.strong_intra_smoothing = s.strong_intra_smoothing ? 1 : 0;
   d.range_ext = s.range_ext_flags;
   d.mono = s.chroma_format == 0 ? 1 : 0;
+  d.fmt = c->fmt; d.csx = c->csx; d.csy = c->csy;
+  d.ccp[0] = d.ccp[1] = nullptr;
   d.sl_m = nullptr;
   for (int k = 0; k < 3; k++) { d.pcm[k] = nullptr; d.pcm_shift[k] = 0; d.coef_start[k] = nullptr; }
   d.pcm_lf_disable = s.pcm_loop_filter_disable ? 1 : 0; d.any_nofilt = 0;
@@ -309,6 +313,8 @@ hmgpu_status alloc_picture(hmgpu_ctx* c, Picture& p) {
 
 void free_picture(Picture& p) {
   if (p.pcm) hipFree(p.pcm);                       // (the planes belong to the context's slab)
+  if (p.ccp) hipFree(p.ccp);
+  p.ccp = nullptr;
   if (p.meta) hipFree(p.meta);
   if (p.coef) hipFree(p.coef);
   if (p.derived) hipFree(p.derived);
@@ -335,7 +341,7 @@ hmgpu_status ensure_extended(hmgpu_ctx* c, int pic) {
   if (p.extended) return HMGPU_OK;
   Batch b; memset(&b, 0, sizeof(b));
   b.n = 1; b.pic[0] = pic;
-  { ProfScope ps(c, K_EXTEND); launch_extend(c->d_pics, b, c->seq.width, c->seq.height, c->mx[0], c->my[0], c->stream); }
+  { ProfScope ps(c, K_EXTEND); launch_extend(c->d_pics, b, c->seq.width, c->seq.height, c->mx[0], c->my[0], c->csx, c->csy, c->stream); }
   HIP_TRY(c, hipGetLastError());
   p.extended = true;
   return HMGPU_OK;
@@ -356,7 +362,15 @@ hmgpu_status ensure_refs_extended(hmgpu_ctx* c, const Batch& b, size_t call_idx)
 hmgpu_status run_recon(hmgpu_ctx* c, const Batch& b, bool any_intra, bool any_wp, bool any_cells, bool any_bi) {
   int max_ctus = 0;
   for (int i = 0; i < b.n; i++) max_ctus = std::max(max_ctus, b.num_ctus[i]);
-  { ProfScope ps(c, K_PREP); launch_prep(c->d_pics, b, max_ctus, c->parts, any_intra, any_cells, c->stream); }
+  // 4:2:2 / 4:4:4: the chroma of every inter cell comes from the format-generic kernel, which reads the BlkInfo grid
+  { ProfScope ps(c, K_PREP); launch_prep(c->d_pics, b, max_ctus, c->parts, any_intra, any_cells || c->fmt != 1, c->fmt, c->stream); }
+  if (c->fmt != 1) {
+    // ... and adds the residual wherever it predicts: tiles no coded block covers must read as zero (Cb and Cr tiles are neighbours in memory)
+    for (int i = 0; i < b.n; i++) {
+      const PicDev& d = c->pics[b.pic[i]].dev;
+      HIP_TRY(c, hipMemsetAsync(d.resid[1], 0, (size_t)((char*)d.resid[2] - (char*)d.resid[1]) + c->coef_elems[2] * sizeof(int16_t), c->stream));
+    }
+  }
   McArgs ma;
   memset(&ma, 0, sizeof(ma));
   ma.n = b.n; ma.width = c->seq.width; ma.height = c->seq.height; ma.log2ctu = c->seq.log2_ctu_size; ma.ctus_w = c->ctus_w;
@@ -379,7 +393,8 @@ hmgpu_status run_recon(hmgpu_ctx* c, const Batch& b, bool any_intra, bool any_wp
     ItxArgs ia;
     memset(&ia, 0, sizeof(ia));
     ia.n = b.n; ia.class_mask = 0xf;                        // all four size classes
-    for (int k = 0; k < 3; k++) { ia.rtw[k] = (c->grid_w / 2) >> (k ? 1 : 0); ia.bd[k] = d0.bd[k]; }
+    for (int k = 0; k < 3; k++) { ia.rtw[k] = (c->grid_w / 2) >> (k ? c->csx : 0); ia.bd[k] = d0.bd[k]; }
+    ia.csx = c->csx; ia.csy = c->csy;
     for (int k = 0; k < 4; k++) ia.tu_cap[k] = c->tu_cap[k];
     for (int i = 0; i < b.n; i++) {
       const PicDev& d = c->pics[b.pic[i]].dev;
@@ -390,6 +405,9 @@ hmgpu_status run_recon(hmgpu_ctx* c, const Batch& b, bool any_intra, bool any_wp
     }
     ProfScope ps(c, K_ITX);
     launch_itx(ia, bps, c->stream);
+    bool any_ccp = false;
+    for (int i = 0; i < b.n; i++) any_ccp |= c->pics[b.pic[i]].dev.ccp[0] != nullptr;
+    if (any_ccp) launch_ccp(c->d_pics, b, max_ctus, c->stream);
   }
   {
     ProfScope ps(c, K_MC_LUMA);
@@ -400,7 +418,10 @@ hmgpu_status run_recon(hmgpu_ctx* c, const Batch& b, bool any_intra, bool any_wp
     launch_mc_luma(ma, max_ctus, any_wp, any_bi, c->stream);
     if (any_cells) launch_mc_luma_cells(c->d_pics, c->d_finals, b, max_ctus, c->seq.log2_ctu_size, any_wp, c->stream);
   }
-  if (c->seq.chroma_format != 0) {
+  if (c->fmt != 1) {
+    ProfScope ps(c, K_MC_CHROMA);
+    launch_mc_chroma_fmt(c->d_pics, c->d_finals, b, max_ctus, c->seq.log2_ctu_size, c->fmt, any_wp, c->stream);
+  } else if (c->seq.chroma_format != 0) {
     ProfScope ps(c, K_MC_CHROMA);
     ma.pitch = c->pitch[1]; ma.bd = c->seq.bit_depth_chroma;
     ma.origin_off = (uint32_t)((const char*)d0.rec[1] - base0);      // the plane of both components (hmgpu_dev.h "chroma planes")
@@ -417,6 +438,7 @@ hmgpu_status run_recon(hmgpu_ctx* c, const Batch& b, bool any_intra, bool any_wp
   if (any_intra) {
     ProfScope ps(c, K_INTRA);
     launch_intra(c->d_pics, b, c->d_ctu_order, c->num_ctus, c->stream);
+    if (c->fmt == 2) launch_intra_chroma_422(c->d_pics, b, c->stream);        // (k_intra leaves the chroma of 4:2:2 pictures to it)
     for (int i = 0; i < b.n; i++) if (std::find(c->intra_launched.begin(), c->intra_launched.end(), b.pic[i]) == c->intra_launched.end()) c->intra_launched.push_back(b.pic[i]);
   }
   HIP_TRY(c, hipGetLastError());
@@ -425,7 +447,7 @@ hmgpu_status run_recon(hmgpu_ctx* c, const Batch& b, bool any_intra, bool any_wp
 
 hmgpu_status run_filter(hmgpu_ctx* c, const Batch& b, int stages) {
   // all three stages on pictures that all carry SAO: one pass through LDS instead of three through HBM (k_filter.hip)
-  bool all_sao = stages == 7;
+  bool all_sao = stages == 7 && c->fmt == 1;            // (the fused kernel's tiles are those of 4:2:0 pictures)
   for (int i = 0; i < b.n && all_sao; i++) all_sao = c->pics[b.pic[i]].sao_any;
   if (all_sao) {
     bool nofilt = false;
@@ -434,12 +456,15 @@ hmgpu_status run_filter(hmgpu_ctx* c, const Batch& b, int stages) {
     HIP_TRY(c, hipGetLastError());
     return HMGPU_OK;
   }
-  if (stages & 1) { ProfScope ps(c, K_DBK_VER); launch_deblock(c->d_pics, b, 0, c->seq.width, c->seq.height, c->stream); }
-  if (stages & 2) { ProfScope ps(c, K_DBK_HOR); launch_deblock(c->d_pics, b, 1, c->seq.width, c->seq.height, c->stream); }
+  // (4:2:2 / 4:4:4: k_deblock filters luma only, the chroma edges of the format's own grid follow from k_cfmt.hip -- per direction, as in HM)
+  if (stages & 1) { ProfScope ps(c, K_DBK_VER); launch_deblock(c->d_pics, b, 0, c->seq.width, c->seq.height, c->stream);
+                    if (c->fmt != 1) launch_deblock_chroma_fmt(c->d_pics, b, 0, c->seq.width, c->seq.height, c->stream); }
+  if (stages & 2) { ProfScope ps(c, K_DBK_HOR); launch_deblock(c->d_pics, b, 1, c->seq.width, c->seq.height, c->stream);
+                    if (c->fmt != 1) launch_deblock_chroma_fmt(c->d_pics, b, 1, c->seq.width, c->seq.height, c->stream); }
   if (stages & 4) {
     bool any = false;
     for (int i = 0; i < b.n; i++) any |= c->pics[b.pic[i]].sao_any;
-    if (any) { ProfScope ps(c, K_SAO); launch_sao(c->d_pics, b, c->seq.width, c->seq.height, c->stream); }
+    if (any) { ProfScope ps(c, K_SAO); launch_sao(c->d_pics, b, c->seq.width, c->seq.height, c->csx, c->csy, c->stream); }
   }
   HIP_TRY(c, hipGetLastError());
   return HMGPU_OK;
@@ -534,7 +559,7 @@ hmgpu_status hmgpu_create(const hmgpu_seq_params* seq, int device_ordinal, hmgpu
   if (seq->width <= 0 || seq->height <= 0 || (seq->width & 7) || (seq->height & 7)) return HMGPU_EINVAL;
   if (seq->log2_ctu_size < 4 || seq->log2_ctu_size > 6) return HMGPU_EINVAL;
   if (seq->max_pictures < 1 || seq->max_pictures > kMaxPics) return HMGPU_EINVAL;
-  if (seq->chroma_format != 1 && seq->chroma_format != 0) return HMGPU_EUNSUPPORTED;      // 0: monochrome -- the chroma planes exist and are left alone
+  if (seq->chroma_format < 0 || seq->chroma_format > 3) return HMGPU_EINVAL;              // 0: monochrome -- the chroma planes exist and are left alone
   if (seq->range_ext_flags & ~(HMGPU_REXT_ROTATION | HMGPU_REXT_IMPLICIT_RDPCM | HMGPU_REXT_EXPLICIT_RDPCM | HMGPU_REXT_INTRA_SMOOTHING_DISABLED)) return HMGPU_EUNSUPPORTED;
   if (seq->bit_depth_luma < 8 || seq->bit_depth_luma > 10 || seq->bit_depth_chroma < 8 || seq->bit_depth_chroma > 10) return HMGPU_EUNSUPPORTED;
   hmgpu_ctx* c = new (std::nothrow) hmgpu_ctx();
@@ -559,21 +584,24 @@ hmgpu_status hmgpu_create(const hmgpu_seq_params* seq, int device_ordinal, hmgpu
   // replication) with device-friendly numbers: 128-sample (256-byte) horizontal margins keep sample (0,y) cache-line
   // aligned, rows are a multiple of 128 bytes plus one spare line (vector loads may run past the margin; the pitch is
   // never a power of two)
-  c->mx[0] = 128; c->mx[1] = c->mx[2] = 64;
-  c->my[0] = 80; c->my[1] = c->my[2] = 40;
+  c->fmt = seq->chroma_format == 0 ? 1 : seq->chroma_format;
+  c->csx = c->fmt == 3 ? 0 : 1; c->csy = c->fmt == 1 ? 1 : 0;
+  c->mx[0] = 128; c->mx[1] = c->mx[2] = 128 >> c->csx;
+  c->my[0] = 80; c->my[1] = c->my[2] = 80 >> c->csy;
   c->pitch[0] = (int)align_up((size_t)seq->width, 64) + 2 * c->mx[0] + 64;
   // (Cb and Cr alternate in one plane, hmgpu_dev.h "chroma planes": its pitch is that of kCStep rows of one component)
-  c->pitch[1] = c->pitch[2] = kCStep * ((int)align_up((size_t)seq->width / 2, 64) + 2 * c->mx[1] + 64);
-  c->rows[0] = c->ctus_h * c->ctu + 2 * c->my[0] + 8; c->rows[1] = c->rows[2] = c->ctus_h * c->ctu / 2 + 2 * c->my[1] + 8;
+  c->pitch[1] = c->pitch[2] = kCStep * ((int)align_up((size_t)seq->width >> c->csx, 64) + 2 * c->mx[1] + 64);
+  c->rows[0] = c->ctus_h * c->ctu + 2 * c->my[0] + 8; c->rows[1] = c->rows[2] = ((c->ctus_h * c->ctu) >> c->csy) + 2 * c->my[1] + 8;
   c->coef_elems[0] = (size_t)c->num_ctus * c->ctu * c->ctu;
-  c->coef_elems[1] = c->coef_elems[2] = c->coef_elems[0] / 4;
+  c->coef_elems[1] = c->coef_elems[2] = c->coef_elems[0] >> (c->csx + c->csy);
   {
     // TU list capacity of one shard: prep blocks (256 threads x 4 partitions = 1024 partitions) go round-robin to the
     // shards; 256 partitions (one 64x64 luma area) hold at most 256+128 4x4, 64+32 8x8, 16+8 16x16 and 4 32x32 TUs
     const size_t blocks = ((size_t)c->num_ctus * (c->parts / 4) + 255) / 256;
     const size_t per_shard = (blocks + kTuShards - 1) / kTuShards;
     const uint32_t per_block[4] = {4 * 384, 4 * 96, 4 * 24, 4 * 4};
-    for (int k = 0; k < 4; k++) c->tu_cap[k] = (uint32_t)(per_shard * per_block[k]);
+    // (4:2:2 / 4:4:4: up to as many chroma blocks per component as luma blocks, of every size)
+    for (int k = 0; k < 4; k++) c->tu_cap[k] = (uint32_t)(per_shard * (c->fmt == 1 ? per_block[k] : 3u * (1024u >> (2 * k))));
   }
   c->pics.resize(seq->max_pictures);
   c->h_finals.resize(seq->max_pictures);
@@ -686,7 +714,7 @@ hmgpu_status hmgpu_picture_upload(hmgpu_ctx* c, hmgpu_pic pic, const int16_t* co
                               hipMemcpyHostToDevice, c->stream));
   {
     // the chroma components arrive as HM's two planes and are laid sample by sample into the device's one (hmgpu_dev.h "chroma planes")
-    const int w = c->seq.width >> 1, h = c->seq.height >> 1;
+    const int w = c->seq.width >> c->csx, h = c->seq.height >> c->csy;
     int16_t* d = static_cast<int16_t*>(ctx_scratch(c, (size_t)2 * w * h * sizeof(int16_t)));
     if (!d) return HMGPU_ENOMEM;
     for (int k = 1; k < 3; k++) {
@@ -706,7 +734,7 @@ hmgpu_status hmgpu_picture_upload(hmgpu_ctx* c, hmgpu_pic pic, const int16_t* co
 static hmgpu_status enqueue_download(hmgpu_ctx* c, Picture& p, int16_t* const planes[3], const int32_t strides[3]) {
   const int16_t* y = p.sao_applied ? p.dev.sao[0] : p.dev.rec[0];
   HIP_TRY(c, hipMemcpy2DAsync(planes[0], (size_t)strides[0] * 2, y, (size_t)c->pitch[0] * 2, (size_t)c->seq.width * 2, c->seq.height, hipMemcpyDeviceToHost, c->stream));
-  const int w = c->seq.width >> 1, h = c->seq.height >> 1;
+  const int w = c->seq.width >> c->csx, h = c->seq.height >> c->csy;
   int16_t* d = static_cast<int16_t*>(ctx_scratch(c, (size_t)2 * w * h * sizeof(int16_t)));
   if (!d) return HMGPU_ENOMEM;
   for (int k = 1; k < 3; k++) {
@@ -757,20 +785,20 @@ hmgpu_status hmgpu_download_wait(hmgpu_ctx* c, uint64_t ticket) {
 hmgpu_status hmgpu_picture_download_packed(hmgpu_ctx* c, hmgpu_pic pic, void* const planes[3], const int32_t stride_bytes[3],
                                            int32_t bytes_per_sample, int32_t crop_left, int32_t crop_right, int32_t crop_top, int32_t crop_bottom) {
   if (!c || !valid_pic(c, pic) || !planes || !stride_bytes || (bytes_per_sample != 1 && bytes_per_sample != 2)) return HMGPU_EINVAL;
-  if ((crop_left | crop_right | crop_top | crop_bottom) & 1) return HMGPU_EINVAL;          // 4:2:0: the window is even
+  if (((crop_left | crop_right) & ((1 << c->csx) - 1)) || ((crop_top | crop_bottom) & ((1 << c->csy) - 1))) return HMGPU_EINVAL;   // whole chroma samples
   const int W = c->seq.width - crop_left - crop_right, H = c->seq.height - crop_top - crop_bottom;
   if (crop_left < 0 || crop_right < 0 || crop_top < 0 || crop_bottom < 0 || W <= 0 || H <= 0) return HMGPU_EINVAL;
   hipSetDevice(c->device);
   Picture& p = c->pics[pic];
   size_t off[3], total = 0;
-  for (int k = 0; k < 3; k++) { off[k] = total; total += align_up((size_t)(W >> (k ? 1 : 0)) * bytes_per_sample * (H >> (k ? 1 : 0)), 256); }
+  for (int k = 0; k < 3; k++) { off[k] = total; total += align_up((size_t)(W >> (k ? c->csx : 0)) * bytes_per_sample * (H >> (k ? c->csy : 0)), 256); }
   uint8_t* d = static_cast<uint8_t*>(ctx_scratch(c, total));
   if (!d) return HMGPU_ENOMEM;
   hmgpu_status st = HMGPU_OK;
   for (int k = 0; k < 3 && st == HMGPU_OK; k++) {
-    const int cs = k ? 1 : 0, w = W >> cs, h = H >> cs;
+    const int sx = k ? c->csx : 0, sy = k ? c->csy : 0, w = W >> sx, h = H >> sy;
     const int16_t* src = p.sao_applied ? p.dev.sao[k] : p.dev.rec[k];
-    launch_pack(src, c->pitch[k], k ? kCStep : 1, crop_left >> cs, crop_top >> cs, w, h, bytes_per_sample, d + off[k], w * bytes_per_sample, c->stream);
+    launch_pack(src, c->pitch[k], k ? kCStep : 1, crop_left >> sx, crop_top >> sy, w, h, bytes_per_sample, d + off[k], w * bytes_per_sample, c->stream);
     if (hipGetLastError() != hipSuccess ||
         hipMemcpy2DAsync(planes[k], (size_t)stride_bytes[k], d + off[k], (size_t)w * bytes_per_sample, (size_t)w * bytes_per_sample, h,
                          hipMemcpyDeviceToHost, c->stream) != hipSuccess) st = HMGPU_EDEVICE;
@@ -801,7 +829,7 @@ hmgpu_status hmgpu_picture_hash(hmgpu_ctx* c, hmgpu_pic pic, int32_t method, uin
   hmgpu_status st = HMGPU_OK;
   if (hipMemsetAsync(d, 0, words * 4, c->stream) != hipSuccess) st = HMGPU_EDEVICE;
   for (int k = 0; k < 3 && st == HMGPU_OK; k++) {
-    const int cs = k ? 1 : 0, w = c->seq.width >> cs, h = c->seq.height >> cs;
+    const int w = c->seq.width >> (k ? c->csx : 0), h = c->seq.height >> (k ? c->csy : 0);
     const int bd = k ? c->seq.bit_depth_chroma : c->seq.bit_depth_luma;
     const int16_t* src = p.sao_applied ? p.dev.sao[k] : p.dev.rec[k];
     if (method == 3) launch_checksum(src, c->pitch[k], k ? kCStep : 1, w, h, bd, d + k, c->stream);
@@ -828,7 +856,7 @@ static size_t hash_slot_bytes(const hmgpu_ctx* c, size_t off[4]) {
   for (int k = 0; k < 3; k++) {
     const int bd = k ? c->seq.bit_depth_chroma : c->seq.bit_depth_luma;
     off[k] = total;
-    total += align_up((size_t)(c->seq.width >> (k ? 1 : 0)) * (c->seq.height >> (k ? 1 : 0)) * (bd > 8 ? 2 : 1), 256);
+    total += align_up((size_t)(c->seq.width >> (k ? c->csx : 0)) * (c->seq.height >> (k ? c->csy : 0)) * (bd > 8 ? 2 : 1), 256);
   }
   off[3] = total;
   return total;
@@ -848,7 +876,7 @@ static hmgpu_status hash_launch_pending(hmgpu_ctx* c) {
     for (int k = 0; k < 3; k++) {
       const int nb = (k ? c->seq.bit_depth_chroma : c->seq.bit_depth_luma) > 8 ? 2 : 1;
       job.msg[job.n] = c->hash_buf[slot] + off[k];
-      job.bytes[job.n] = (unsigned long long)(c->seq.width >> (k ? 1 : 0)) * (c->seq.height >> (k ? 1 : 0)) * nb;
+      job.bytes[job.n] = (unsigned long long)(c->seq.width >> (k ? c->csx : 0)) * (c->seq.height >> (k ? c->csy : 0)) * nb;
       job.out[job.n] = c->hash_dev + slot * 12 + k * 4;
       job.n++;
     }
@@ -896,7 +924,7 @@ hmgpu_status hmgpu_picture_hash_begin(hmgpu_ctx* c, hmgpu_pic pic, int32_t metho
   Picture& p = c->pics[pic];
   uint8_t* d = c->hash_buf[slot];
   for (int k = 0; k < 3; k++) {
-    const int cs = k ? 1 : 0, w = c->seq.width >> cs, h = c->seq.height >> cs;
+    const int w = c->seq.width >> (k ? c->csx : 0), h = c->seq.height >> (k ? c->csy : 0);
     const int nb = (k ? c->seq.bit_depth_chroma : c->seq.bit_depth_luma) > 8 ? 2 : 1;
     const int16_t* src = p.sao_applied ? p.dev.sao[k] : p.dev.rec[k];
     launch_pack(src, c->pitch[k], k ? kCStep : 1, 0, 0, w, h, nb, d + off[k], w * nb, c->stream);
@@ -1102,6 +1130,7 @@ static hmgpu_status stage_inputs(hmgpu_ctx* c, hmgpu_pic cur, int32_t slice_idx,
   const bool compact = co->ctu_level_start[0] && co->ctu_level_start[1] && co->ctu_level_start[2];
   if (!compact && (co->ctu_level_start[0] || co->ctu_level_start[1] || co->ctu_level_start[2])) return HMGPU_EINVAL;
   if (compact) {
+    if (c->fmt != 1) return HMGPU_EUNSUPPORTED;                              // (4:2:2 / 4:4:4: HM's dense layout only)
     if (first_ctu != 0 || num_ctus != c->num_ctus) return HMGPU_EINVAL;      // whole pictures only
     for (int k = 0; k < 3; k++) {
       // the CTUs' pieces follow each other and none is longer than a CTU (k_intra stages a CTU's piece into LDS by these numbers)
@@ -1169,9 +1198,19 @@ static hmgpu_status stage_inputs(hmgpu_ctx* c, hmgpu_pic cur, int32_t slice_idx,
       HIP_TRY(c, hipMemcpyAsync((void*)(p.dev.tile_idx + first_ctu), p.h_tile_idx.data() + first_ctu, (size_t)num_ctus * 2, hipMemcpyHostToDevice, hs));
     }
     for (int k = 0; k < 3 && !compact; k++) {
-      const size_t per = (size_t)(c->ctu * c->ctu) >> (k ? 2 : 0);
+      const size_t per = (size_t)(c->ctu * c->ctu) >> (k ? c->csx + c->csy : 0);
       HIP_TRY(c, hipMemcpyAsync((void*)(p.dev.coef[k] + first_ctu * per), co->level[k] + first_ctu * per, (size_t)num_ctus * per * 2,
                                 hipMemcpyHostToDevice, hs));
+    }
+  }
+  // cross-component prediction weights (4:4:4; m_crossComponentPredictionAlpha): device copies allocated with the first picture that carries them
+  p.dev.ccp[0] = p.dev.ccp[1] = nullptr;
+  if (c->fmt == 3 && m->ccp_alpha[0] && m->ccp_alpha[1]) {
+    const size_t np = (size_t)c->num_ctus * c->parts;
+    if (!p.ccp) HIP_TRY(c, hipMalloc(&p.ccp, 2 * np));
+    for (int k = 0; k < 2; k++) {
+      HIP_TRY(c, hipMemcpyAsync((char*)p.ccp + k * np + po, m->ccp_alpha[k] + po, pn, hipMemcpyHostToDevice, hs));
+      p.dev.ccp[k] = (const int8_t*)p.ccp + k * np;
     }
   }
   {
@@ -1184,7 +1223,7 @@ static hmgpu_status stage_inputs(hmgpu_ctx* c, hmgpu_pic cur, int32_t slice_idx,
         for (int k = 0; k < 3; k++) p.dev.pcm[k] = cp.take<int16_t>(c->coef_elems[k]);
       }
       for (int k = 0; k < 3; k++) {
-        const size_t per = (size_t)(c->ctu * c->ctu) >> (k ? 2 : 0);
+        const size_t per = (size_t)(c->ctu * c->ctu) >> (k ? c->csx + c->csy : 0);
         HIP_TRY(c, hipMemcpyAsync((void*)(p.dev.pcm[k] + first_ctu * per), co->pcm_sample[k] + first_ctu * per, (size_t)num_ctus * per * 2,
                                   hipMemcpyHostToDevice, hs));
       }
@@ -1294,6 +1333,7 @@ hmgpu_status hmgpu_pack_levels(const hmgpu_seq_params* seq, const hmgpu_ctu_meta
                                int16_t* const out_level[3], uint32_t* const out_start[3]) {
   if (!seq || !m || !dense || !out_level || !out_start || !m->depth || !m->part_size || !m->tr_idx || !m->cbf[0] || !m->cbf[1] || !m->cbf[2]) return HMGPU_EINVAL;
   for (int k = 0; k < 3; k++) if (!dense->level[k] || !out_level[k] || !out_start[k]) return HMGPU_EINVAL;
+  if (seq->chroma_format > 1) return HMGPU_EUNSUPPORTED;       // (the compact form is defined for 4:2:0 / 4:0:0 pictures)
   const int log2ctu = seq->log2_ctu_size, ctu_sz = 1 << log2ctu, pw = ctu_sz / 4, parts = pw * pw;
   const int ctus_w = (seq->width + ctu_sz - 1) / ctu_sz, n_ctus = hmgpu_num_ctus(seq);
   uint32_t pos[3] = {0, 0, 0};
@@ -1477,7 +1517,7 @@ hmgpu_status hmgpu_filter_pictures(hmgpu_ctx* c, int32_t n, const hmgpu_filter_j
     p.extended = true;                   // (the batched border extension below)
   }
   if (st != HMGPU_OK) return st;
-  { ProfScope ps(c, K_EXTEND); launch_extend(c->d_pics, b, c->seq.width, c->seq.height, c->mx[0], c->my[0], c->stream); }
+  { ProfScope ps(c, K_EXTEND); launch_extend(c->d_pics, b, c->seq.width, c->seq.height, c->mx[0], c->my[0], c->csx, c->csy, c->stream); }
   HIP_TRY(c, hipGetLastError());
   mark_use(c, b);
   return HMGPU_OK;
@@ -1565,7 +1605,7 @@ hmgpu_status hmgpu_replay_batch(hmgpu_ctx* c, const hmgpu_pic* pics, int32_t n, 
         for (int i = lo; i < hi; i++) { b.pic[i - lo] = pics[i]; b.first_ctu[i - lo] = 0; b.num_ctus[i - lo] = c->num_ctus; }
         result = run_filter(c, b, stages & 7);
         if (result == HMGPU_OK) {
-          { ProfScope ps(c, K_EXTEND); launch_extend(c->d_pics, b, c->seq.width, c->seq.height, c->mx[0], c->my[0], c->stream); }
+          { ProfScope ps(c, K_EXTEND); launch_extend(c->d_pics, b, c->seq.width, c->seq.height, c->mx[0], c->my[0], c->csx, c->csy, c->stream); }
           if (hipGetLastError() != hipSuccess) result = HMGPU_EDEVICE;
         }
       }

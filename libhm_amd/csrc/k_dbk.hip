@@ -69,7 +69,8 @@ __global__ void __launch_bounds__(256) k_deblock(const PicDev* __restrict__ pics
     }
   }
   // chroma: Bs 2 only, edges on the 8-sample chroma grid = 16-sample luma grid (:225-229, :684-692, :727)
-  if (bs == 2 && ((DIR == 0 ? x : y) & 15) == 0) {
+  // (4:2:2 / 4:4:4 pictures: k_deblock_chroma_fmt, k_cfmt.hip)
+  if (bs == 2 && P.fmt == 1 && ((DIR == 0 ? x : y) & 15) == 0) {
     const int cp = P.pitch[1];
     const int maxc = (1 << P.bd[1]) - 1;
 #pragma unroll

@@ -113,7 +113,7 @@ template <int LOG2N>
 __device__ __attribute__((always_inline)) inline void intra_tu(const PicDev& P, const TuCtx& t, IntraLds& L, IntraScratch& W) {
   constexpr int N = 1 << LOG2N;
   const int lane = threadIdx.x & 63;
-  const int comp = t.comp, cs = comp ? 1 : 0;
+  const int comp = t.comp, cs = comp ? P.csx : 0;           // (4:2:0: chroma at half size; 4:4:4: like luma.  4:2:2 does not come here)
   const int bd = t.bd, maxv = (1 << bd) - 1;
   const int pitch = t.pitch;
   int16_t* plane = t.plane;
@@ -154,7 +154,8 @@ __device__ __attribute__((always_inline)) inline void intra_tu(const PicDev& P, 
   // ---- B. smoothing (filteringIntraReferenceSamples + initAdiPatternChType); most TUs are not smoothed (chroma, 4x4, DC,
   // the modes near horizontal / vertical) and predict straight from line[]: one LDS round trip less on the serial chain
   const int thr = LOG2N == 2 ? 10 : LOG2N == 3 ? 7 : LOG2N == 4 ? 1 : 0;
-  const bool filt = comp == 0 && t.mode != 1 && min(abs(t.mode - 10), abs(t.mode - 26)) > thr && !(t.rext & HMGPU_REXT_INTRA_SMOOTHING_DISABLED);
+  // (filterIntraReferenceSamples, TComChromaFormat.h:150-153: luma, and chroma where it is not subsampled)
+  const bool filt = (comp == 0 || P.fmt == 3) && t.mode != 1 && min(abs(t.mode - 10), abs(t.mode - 26)) > thr && !(t.rext & HMGPU_REXT_INTRA_SMOOTHING_DISABLED);
 #if defined(INTRA_EXP) && (INTRA_EXP & 2)      // experiment: no smoothing pass
   if (false) {
 #else
@@ -162,7 +163,7 @@ __device__ __attribute__((always_inline)) inline void intra_tu(const PicDev& P, 
 #endif
     bool strong = false;
     int bl = 0, tl = 0, tr = 0;
-    if (N == 32 && t.strong) {
+    if (N == 32 && t.strong && comp == 0) {                 // (strong smoothing: luma only, TComPattern.cpp:196)
       bl = W.line[0]; tl = W.line[corner]; tr = W.line[total - 1];
       const int th = 1 << (bd - 5);
       strong = abs(bl + tl - 2 * W.line[N]) < th && abs(tl + tr - 2 * W.line[corner + N]) < th;
@@ -349,7 +350,7 @@ __device__ __attribute__((always_inline)) inline void intra_stage(const PicDev& 
   const int parts = P.parts;
   const size_t base = (size_t)ctu * parts;
   const int ctu_x = (ctu % P.ctus_w) << P.log2ctu, ctu_y = (ctu / P.ctus_w) << P.log2ctu;
-  const int cs = comp ? 1 : 0;
+  const int cs = comp ? P.csx : 0;
   const int lane = threadIdx.x & 63;
   if (threadIdx.x < 64 && 4 * lane < parts) {
     const size_t o = base + 4 * lane;
@@ -374,7 +375,7 @@ __device__ __attribute__((always_inline)) inline void intra_stage(const PicDev& 
       }
     } else {
       // a vector = the (Cb, Cr) of four positions: this component's halves
-      const int16_t* org = P.rec[1] + (ptrdiff_t)(ctu_y >> 1) * P.pitch[1] + kCStep * (ctu_x >> 1);
+      const int16_t* org = P.rec[1] + (ptrdiff_t)(ctu_y >> cs) * P.pitch[1] + kCStep * (ctu_x >> cs);
       const uint32_t sel = comp == 2 ? 0x07060302u : 0x05040100u;
       const int vpr = S / 4;
       for (int i = threadIdx.x; i < S * vpr; i += blockDim.x) {
@@ -458,8 +459,8 @@ __device__ __attribute__((always_inline)) inline void poll_neighbours(const PicD
 // (the masks of what has been fetched are shared by the waves of the workgroup: a wave with nothing to run fetches what has become final
 // next door, so that the TUs along the CTU's left and top border find their reference samples in LDS)
 // org: the CTU's first sample of this component in the picture, pitch: the plane's
-__device__ __attribute__((always_inline)) inline void fetch_border(const int16_t* org, int pitch, int comp, uint32_t need_col, uint64_t need_row, IntraSched& Q, IntraLds& L) {
-  const int cs = comp ? 1 : 0, lane = threadIdx.x & 63, us = 4 >> cs;
+__device__ __attribute__((always_inline)) inline void fetch_border(const int16_t* org, int pitch, int comp, int cs, uint32_t need_col, uint64_t need_row, IntraSched& Q, IntraLds& L) {
+  const int lane = threadIdx.x & 63, us = 4 >> cs;
   const uint32_t mc = need_col & ~Q.got[0];
   const uint64_t mr = need_row & ~((uint64_t)Q.got[1] | ((uint64_t)Q.got[2] << 32));
   if (!mc && !mr) return;
@@ -498,7 +499,7 @@ __device__ __attribute__((always_inline)) inline void fetch_border(const int16_t
 __device__ __attribute__((always_inline)) inline void intra_ctu(const PicDev& P, int comp, int ctu, IntraLds& L, IntraSched& Q, IntraScratch& W, Neighbours& nb) {
   const int parts = P.parts, pw = P.pw;
   const int ctu_x = (ctu % P.ctus_w) << P.log2ctu, ctu_y = (ctu / P.ctus_w) << P.log2ctu;
-  const int cs = comp ? 1 : 0;
+  const int cs = comp ? P.csx : 0;
   const int lane = threadIdx.x & 63;
   const int slice = ldg(P.slice_idx + ctu), tile = ldg(P.tile_idx + ctu);
   const SliceDev& sd = P.slices[slice];
@@ -517,7 +518,7 @@ __device__ __attribute__((always_inline)) inline void intra_ctu(const PicDev& P,
   const int h_bd = P.bd[comp], h_pitch = P.pitch[comp], h_log2ctu = P.log2ctu, h_rext = P.range_ext, h_strong = P.strong_intra_smoothing;
   int16_t* const h_plane = P.rec[comp];
   // the CTU's first sample in the plane; chroma: its first (Cb, Cr) pair in the plane of both components (fetch_border reads whole pairs)
-  const int16_t* const org = comp == 0 ? h_plane + (ptrdiff_t)ctu_y * h_pitch + ctu_x : P.rec[1] + (ptrdiff_t)(ctu_y >> 1) * h_pitch + kCStep * (ctu_x >> 1);
+  const int16_t* const org = comp == 0 ? h_plane + (ptrdiff_t)ctu_y * h_pitch + ctu_x : P.rec[1] + (ptrdiff_t)(ctu_y >> cs) * h_pitch + kCStep * (ctu_x >> cs);
   const int wv = threadIdx.x >> 6;
   auto mark_done = [&](int x4, int y4, int U) {           // units [x4, x4 + U) x [y4, y4 + U) are final
     if (lane < 16) {
@@ -560,9 +561,9 @@ __device__ __attribute__((always_inline)) inline void intra_ctu(const PicDev& P,
       } else {
         const int log2tu = log2cu - L.m_tr[z];
         const int tu_parts = 1 << (2 * (log2tu - 2));
-        // chroma: four 4x4 luma TUs share one 4x4 chroma TU, with the first of them (TComTU.cpp:141-171)
-        origin = (z & (tu_parts - 1)) == 0 && (comp == 0 || log2tu >= 3 || (z & 3) == 0);
-        e = TuRun{(uint8_t)z, (uint8_t)z_cu, (uint8_t)(comp == 0 ? log2tu : max(2, log2tu - 1)), (uint8_t)((comp == 0 && log2tu == 2) ? ((z & 3) ? 3 : 2) : 0)};
+        // subsampled chroma: four 4x4 luma TUs share one 4x4 chroma TU, with the first of them (TComTU.cpp:141-171); 4:4:4 chroma: the luma TUs' twins
+        origin = (z & (tu_parts - 1)) == 0 && (cs == 0 || log2tu >= 3 || (z & 3) == 0);
+        e = TuRun{(uint8_t)z, (uint8_t)z_cu, (uint8_t)(cs == 0 ? log2tu : max(2, log2tu - 1)), (uint8_t)((cs == 0 && log2tu == 2) ? ((z & 3) ? 3 : 2) : 0)};
       }
     }
     // rows / columns of the done masks covered by this group of 64 units
@@ -647,7 +648,7 @@ __device__ __attribute__((always_inline)) inline void intra_ctu(const PicDev& P,
 #else
 #define TM_ADD(field)
 #endif
-  if (wv == (int)(blockDim.x >> 6) - 1) fetch_border(org, h_pitch, comp, nb.ext_col, nb.ext_row, Q, L);   // what is final next door already
+  if (wv == (int)(blockDim.x >> 6) - 1) fetch_border(org, h_pitch, comp, cs, nb.ext_col, nb.ext_row, Q, L);   // what is final next door already
   for (;;) {
     // the scheduler words in LDS (pend, done_c, done_r, got) are updated by the other waves with atomics: read them afresh in every round
     asm volatile("" ::: "memory");
@@ -683,7 +684,7 @@ __device__ __attribute__((always_inline)) inline void intra_ctu(const PicDev& P,
       if (__hip_atomic_load(&Q.running, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0 || (spins & 15) == 0) {
         if (spins > (1u << 22)) { if (lane == 0) atomicOr(P.fault, 1u); nb.broken = true; }
         poll_neighbours(P, nb, pw);
-        fetch_border(org, h_pitch, comp, nb.ext_col, nb.ext_row, Q, L);   // whatever has become final next door
+        fetch_border(org, h_pitch, comp, cs, nb.ext_col, nb.ext_row, Q, L);   // whatever has become final next door
       }
       TM_ADD(t_idle)
       continue;
@@ -708,7 +709,7 @@ __device__ __attribute__((always_inline)) inline void intra_ctu(const PicDev& P,
       const int n_cu = (1 << e.log2n) >> cs;
       const int sx = (ctu_x + 4 * x4) >> cs, sy = (ctu_y + 4 * y4) >> cs;
       if (lane < n_cu) {
-        const int16_t* src = P.pcm[comp] + (size_t)ctu * ((size_t)(1 << (2 * P.log2ctu)) >> (comp ? 2 : 0)) + (comp ? 4 : 16) * z + lane * n_cu;
+        const int16_t* src = P.pcm[comp] + (size_t)ctu * ((size_t)(1 << (2 * P.log2ctu)) >> (2 * cs)) + ((16 * z) >> (2 * cs)) + lane * n_cu;
         int16_t* prow = h_plane + (ptrdiff_t)(sy + lane) * h_pitch + (comp ? kCStep : 1) * sx;
         uint32_t* row = reinterpret_cast<uint32_t*>(prow);
         uint32_t* lrow = reinterpret_cast<uint32_t*>(&L.pix[sy - (ctu_y >> cs) + lane][sx - (ctu_x >> cs) + 2]);
@@ -730,7 +731,9 @@ __device__ __attribute__((always_inline)) inline void intra_ctu(const PicDev& P,
         t.log2n = e.log2n;
         t.plane = h_plane; t.pitch = h_pitch; t.bd = h_bd; t.log2ctu = h_log2ctu; t.rext = h_rext; t.strong = h_strong;
         int mode = uni(L.m_dir[zs]);
-        if (comp && mode == 36) mode = uni(L.m_dirl[z]);   // DM_CHROMA_IDX (TDecCu.cpp:523-524): the luma mode of the CU's first partition (z: the CU's origin)
+        // DM_CHROMA_IDX (TDecCu.cpp:523-524, getChromasCorrespondingPULumaIdx): the luma mode of the CU's first partition (z: the CU's
+        // origin); 4:4:4: of the block's own partition
+        if (comp && mode == 36) mode = uni(L.m_dirl[P.fmt == 3 ? zs : z]);
         t.mode = mode;
         {
           const uint64_t a = Q.avail[idx];
@@ -738,12 +741,13 @@ __device__ __attribute__((always_inline)) inline void intra_ctu(const PicDev& P,
           const uint32_t cl = (uint32_t)uni((int)Q.clampi[idx]);
           t.sub_lo = cl == 0xffffffffu ? -1 : (int)(cl & 0xffff); t.sub_hi = (int)(cl >> 16);
         }
-        t.cbf = (uni(L.m_cbf[zs]) >> tr) & 1;
+        // (4:4:4: the tiles hold zeros where nothing is coded and the cross-component term where only that is: always added)
+        t.cbf = (comp && P.fmt != 1) ? 1 : (uni(L.m_cbf[zs]) >> tr) & 1;
         t.bypass = uni(L.m_byp[zs]);
         intra_tu_any(P, t, L, W);
       };
       if (x4 == 0 || y4 == 0)                                   // (a TU inside the CTU reads nothing from next door; a group: what an 8x8 TU would read)
-        fetch_border(org, h_pitch, comp, x4 == 0 ? Q.need_col[i] : 0u, y4 == 0 ? Q.need_row[i] : 0ull, Q, L);
+        fetch_border(org, h_pitch, comp, cs, x4 == 0 ? Q.need_col[i] : 0u, y4 == 0 ? Q.need_row[i] : 0ull, Q, L);
 #ifdef INTRA_TIMING
       if (lane == 0) { atomicMin(&Q.t_first, wall_clock64()); atomicAdd(&Q.n_run, 1u); }
 #endif
@@ -792,7 +796,7 @@ __global__ void __launch_bounds__(64 * WAVES) k_intra(const PicDev* __restrict__
   const int slot = blockIdx.x / 3, comp = blockIdx.x % 3, ctu = ldg(order + blockIdx.y);
   const PicDev& P = pics[b.pic[slot]];
   const int first = b.first_ctu[slot], last = first + b.num_ctus[slot] - 1;
-  if (!P.has_intra_dir || ctu < first || ctu > last || !ldg(P.ctu_intra + ctu) || (comp && P.mono)) return;
+  if (!P.has_intra_dir || ctu < first || ctu > last || !ldg(P.ctu_intra + ctu) || (comp && (P.mono || P.fmt == 2))) return;      // (4:2:2 chroma: k_intra_chroma_422)
   uint32_t* done = P.intra_done + (size_t)comp * P.num_ctus;
   const int cx = ctu % P.ctus_w, cy = ctu / P.ctus_w;
 #ifdef INTRA_TIMING
@@ -822,7 +826,7 @@ __global__ void __launch_bounds__(64 * WAVES) k_intra(const PicDev* __restrict__
   const int wv = threadIdx.x >> 6;
   {
   {
-    const int cs = comp ? 1 : 0;
+    const int cs = comp ? P.csx : 0;
     const int tpr = ((1 << P.log2ctu) >> cs) >> 3, rtw = (P.grid_w / 2) >> cs;           // tiles per CTU row / per picture row
     const int tx0 = cx * tpr, ty0 = cy * tpr;
     const int16_t* src = P.resid[comp];
@@ -868,6 +872,161 @@ __global__ void __launch_bounds__(64 * WAVES) k_intra(const PicDev* __restrict__
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     publish_progress(done, ctu, 0xffffffffu);
   }
+}
+
+// ---- 4:2:2 chroma.  A chroma block of a transform unit is two SQUARES of half the unit's width, one above the other, the
+// lower one predicted from the upper one's reconstruction (xIntraRecBlk's TComTU::VERTICAL_SPLIT, TDecCu.cpp:505-520); a 4x4 luma unit
+// covers 2 x 4 chroma samples, so the TU scheduler of intra_ctu (square footprints on the unit grid) does not describe it.  Correct first:
+// ONE wave per picture and component walks the CTUs in raster order and their transform units in z order -- decoding order, so every
+// reference sample is final when it is read (luma and the other component are other kernels' / waves' business: chroma never reads them).
+// Samples go through the coherent level like k_intra's (the wave's own earlier stores must be what its later loads see).  No smoothing and
+// no edge filters: both are luma-only at this format (filterIntraReferenceSamples, TComChromaFormat.h:150-153; TComPrediction.cpp:275).
+namespace {
+__constant__ uint8_t c_mode422[36] = {0, 1, 2, 2, 2, 2, 3, 5, 7, 8, 10, 12, 13, 15, 17, 18, 19, 20, 21, 22, 23, 23, 24, 24, 25, 25, 26, 27, 27, 28, 28, 29, 29, 30, 31, 36};
+
+__device__ inline bool avail_glob(const PicDev& P, int ctu, int z_tu, int px, int py, bool cip, int slice, int tile) {
+  if (px < 0 || py < 0 || px >= P.width || py >= P.height) return false;
+  const int m = (1 << P.log2ctu) - 1;
+  const int nctu = (py >> P.log2ctu) * P.ctus_w + (px >> P.log2ctu);
+  const int nz = z_of((px & m) >> 2, (py & m) >> 2);
+  if (nctu == ctu) { if (nz >= z_tu) return false; }
+  else {
+    if (nctu > ctu) return false;
+    if (ldg(P.slice_idx + nctu) != slice || ldg(P.tile_idx + nctu) != tile) return false;
+  }
+  return !cip || ldg(P.pred_mode + (size_t)nctu * P.parts + nz) == HMGPU_MODE_INTRA;
+}
+
+// one square of n x n chroma samples of component comp whose first 4x4 luma partition is zb; z_mode: the partition the mode is stored at
+__device__ void intra_square_422(const PicDev& P, int comp, int ctu, int zb, int z_mode, int log2n, int slice, int tile, bool cip, int* line, int* proj) {
+  const int lane = threadIdx.x & 63, n = 1 << log2n, corner = 2 * n, total = 4 * n + 1;
+  const int ctu_x = (ctu % P.ctus_w) << P.log2ctu, ctu_y = (ctu / P.ctus_w) << P.log2ctu;
+  const int lx = ctu_x + 4 * zscan_x(zb), ly = ctu_y + 4 * zscan_y(zb);           // luma position of the square
+  const int x0 = lx >> 1, y0 = ly;
+  const int pitch = P.pitch[1], bd = P.bd[comp], maxv = (1 << bd) - 1;
+  int16_t* plane = P.rec[comp];
+  int mode = ldg(P.intra_dir[1] + (size_t)ctu * P.parts + z_mode);
+  if (mode == 36) {
+    const int cu_parts = P.parts >> (2 * ldg(P.depth + (size_t)ctu * P.parts + z_mode));
+    mode = ldg(P.intra_dir[0] + (size_t)ctu * P.parts + (z_mode & ~(cu_parts - 1)));
+  }
+  mode = c_mode422[mode];
+  // ---- reference line: [0, 2n) the left column bottom-up, [2n] the corner, (2n, 4n] the row above; a 4x4 luma partition is 4 rows of the
+  // column and 2 samples of the row.  -1 = not available
+  for (int i = lane; i < total; i += 64) {
+    int px, py, sx, sy;
+    if (i < corner) { const int r = corner - 1 - i; px = lx - 4; py = ly + r; sx = x0 - 1; sy = y0 + r; }
+    else if (i == corner) { px = lx - 4; py = ly - 4; sx = x0 - 1; sy = y0 - 1; }
+    else { const int c = i - corner - 1; px = lx + 2 * c; py = ly - 4; sx = x0 + c; sy = y0 - 1; }
+    int v = -1;
+    if (avail_glob(P, ctu, zb, px, py, cip, slice, tile)) {
+      const uint32_t w = ld_coh(reinterpret_cast<const uint32_t*>(P.rec[1] + (ptrdiff_t)sy * pitch + kCStep * sx));      // the (Cb, Cr) pair
+      v = (int)(comp == 1 ? (w & 0xffffu) : (w >> 16));
+    }
+    line[i] = v;
+  }
+  wave_lds_sync();
+  if (lane == 0) {
+    // fillReferenceSamples (TComPattern.cpp:336-478): unavailable samples take the nearest available one before them, the ones in front the first available
+    int first = 0;
+    while (first < total && line[first] < 0) first++;
+    if (first == total) { for (int i = 0; i < total; i++) line[i] = 1 << (bd - 1); }
+    else {
+      for (int i = 0; i < first; i++) line[i] = line[first];
+      for (int i = first + 1; i < total; i++) if (line[i] < 0) line[i] = line[i - 1];
+    }
+  }
+  wave_lds_sync();
+  // ---- prediction of row `lane` (predIntraAng / xPredIntraPlanar, TComPrediction.cpp:245-491, 746-800)
+  const int row = lane;
+  const bool active = lane < n;
+  int p[16];
+  if (mode == 0) {
+    const int left = line[corner - 1 - min(row, n - 1)], bl = line[corner - 1 - n], tr = line[corner + 1 + n];
+    for (int x = 0; x < n; x++) { const int ab = line[corner + 1 + x]; p[x] = ((left << log2n) + n + (x + 1) * (tr - left) + (ab << log2n) + (row + 1) * (bl - ab)) >> (log2n + 1); }
+  } else if (mode == 1) {
+    int sum = n;
+    for (int x = 0; x < n; x++) sum += line[corner + 1 + x] + line[corner - 1 - x];
+    for (int x = 0; x < n; x++) p[x] = sum >> (log2n + 1);
+  } else {
+    const bool ver = mode >= 18;
+    const int am_ = ver ? mode - 26 : -(mode - 10), aa = abs(am_);
+    const int ang_abs = aa == 0 ? 0 : aa == 1 ? 2 : aa == 2 ? 5 : aa == 3 ? 9 : aa == 4 ? 13 : aa == 5 ? 17 : aa == 6 ? 21 : aa == 7 ? 26 : 32;
+    const int inv = aa == 0 ? 0 : aa == 1 ? 4096 : aa == 2 ? 1638 : aa == 3 ? 910 : aa == 4 ? 630 : aa == 5 ? 482 : aa == 6 ? 390 : aa == 7 ? 315 : 256;
+    const int ang = am_ < 0 ? -ang_abs : ang_abs, sgn = ver ? 1 : -1;        // MAIN(i) = line[corner + sgn * i], SIDE(i) = line[corner - sgn * i]
+    // main reference with its extension to negative indices: proj[k + 32], k in [-n, 2n]
+    for (int k = lane - n; k <= 2 * n; k += 64) {
+      int v = 0;
+      if (k >= 0) v = line[corner + sgn * k];
+      else if (ang < 0 && k > ((n * ang) >> 5)) v = line[corner - sgn * ((128 + (-k) * inv) >> 8)];
+      proj[k + 32] = v;
+    }
+    wave_lds_sync();
+    const int* r = proj + 32;
+    for (int x = 0; x < n; x++) {
+      // vertical modes: row y = lane, column x; horizontal ones are the transpose
+      const int yy = ver ? min(row, n - 1) : x, xx = ver ? x : min(row, n - 1);
+      const int pos = (yy + 1) * ang, di = pos >> 5, df = pos & 31;
+      p[x] = df ? ((32 - df) * r[xx + di + 1] + df * r[xx + di + 2] + 16) >> 5 : r[xx + di + 1];
+    }
+  }
+  // ---- residual (k_itx's tiles; zero where nothing is coded) + reconstruction
+  if (active) {
+    const int rtw = (P.grid_w / 2) >> 1, y = y0 + row;
+    const int16_t* rrow = P.resid[comp] + ((size_t)((y >> 3) * rtw + (x0 >> 3)) * 8 + resid_slot(y)) * 8 + (x0 & 7);
+    int16_t* prow = plane + (ptrdiff_t)y * pitch + kCStep * x0;
+    for (int x = 0; x < n; x += 2) {
+      const uint32_t rs = ldg(reinterpret_cast<const uint32_t*>(rrow + (x & 7) + (x >> 3) * 64));
+      const int v0 = clip3(0, maxv, p[x] + (int)(int16_t)(rs & 0xffffu)), v1 = clip3(0, maxv, p[x + 1] + ((int)rs >> 16));
+      st_coh_c2(prow + kCStep * x, (uint32_t)v0 | ((uint32_t)v1 << 16));
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  wave_lds_sync();
+}
+}  // namespace
+
+__global__ void __launch_bounds__(64) k_intra_chroma_422(const PicDev* __restrict__ pics, Batch b) {
+  __shared__ int line[4 * 16 + 4], proj[3 * 16 + 36];
+  const int slot = blockIdx.x >> 1, comp = 1 + (blockIdx.x & 1);
+  const PicDev& P = pics[b.pic[slot]];
+  if (!P.has_intra_dir) return;
+  const int lane = threadIdx.x & 63;
+  for (int ctu = b.first_ctu[slot]; ctu < b.first_ctu[slot] + b.num_ctus[slot]; ctu++) {
+    if (!ldg(P.ctu_intra + ctu)) continue;
+    const int slice = ldg(P.slice_idx + ctu), tile = ldg(P.tile_idx + ctu);
+    const bool cip = ldg(&P.slices[slice].constrained_intra_pred) != 0;
+    const int ctu_x = (ctu % P.ctus_w) << P.log2ctu, ctu_y = (ctu / P.ctus_w) << P.log2ctu;
+    for (int z = 0; z < P.parts;) {
+      const size_t i = (size_t)ctu * P.parts + z;
+      const int px = ctu_x + 4 * zscan_x(z), py = ctu_y + 4 * zscan_y(z);
+      if (px >= P.width || py >= P.height || (int)ldg(P.part_size + i) == HMGPU_SIZE_NONE || ldg(P.pred_mode + i) != HMGPU_MODE_INTRA) { z++; continue; }
+      const int depth = ldg(P.depth + i), log2cu = P.log2ctu - depth, cu_parts = 1 << (2 * (log2cu - 2));
+      if (ldg(P.ipcm + i) && P.pcm[comp] != nullptr) {
+        // PCM CU (xReconPCM, TDecCu.cpp:770-830): (cu / 2) x cu transmitted samples, shifted up to the coding bit depth; lane = row
+        const int cw = (1 << log2cu) >> 1, chh = 1 << log2cu;
+        const int16_t* src = P.pcm[comp] + (size_t)ctu * ((size_t)(1 << (2 * P.log2ctu)) >> 1) + 8 * z;
+        for (int r = lane; r < chh; r += 64)
+          for (int x = 0; x < cw; x += 2) {
+            const uint32_t v = ldg(reinterpret_cast<const uint32_t*>(src + r * cw + x));
+            st_coh_c2(P.rec[comp] + (ptrdiff_t)(py + r) * P.pitch[1] + kCStep * ((px >> 1) + x),
+                      ((v & 0xffffu) << P.pcm_shift[comp]) | ((v >> 16) << (16 + P.pcm_shift[comp])));
+          }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        z += cu_parts;
+        continue;
+      }
+      // the transform unit node that carries a chroma block here: the luma TU, or the 8x8 area of four 4x4 luma TUs
+      const int log2tu = max(log2cu - (int)ldg(P.tr_idx + i), 3), nparts = 1 << (2 * (log2tu - 2));
+      intra_square_422(P, comp, ctu, z, z, log2tu - 1, slice, tile, cip, line, proj);
+      intra_square_422(P, comp, ctu, z + nparts / 2, z, log2tu - 1, slice, tile, cip, line, proj);
+      z += nparts;
+    }
+  }
+}
+
+void launch_intra_chroma_422(const PicDev* pics, const Batch& b, hipStream_t s) {
+  hipLaunchKernelGGL(k_intra_chroma_422, dim3((unsigned)b.n * 2), dim3(64), 0, s, pics, b);
 }
 
 void launch_intra(const PicDev* pics, const Batch& b, const int32_t* order, int num_ctus, hipStream_t s) {

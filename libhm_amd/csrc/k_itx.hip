@@ -27,6 +27,7 @@ constexpr int kItxLdsBytes = std::max(std::max(ItxLds<2>::BYTES, ItxLds<3>::BYTE
 struct ItxPic {
   const TuRec* list; uint32_t count_cap; const uint32_t* count;
   const int16_t* coef[3]; int16_t* resid[3]; int32_t rtw[3], bd[3]; const uint8_t* sl_m;
+  int32_t csx, csy;                       // chroma subsampling: a record carries the LUMA position of its block's first partition
 };
 template <typename T> __device__ inline T by_comp(const T (&v)[3], int comp) { return comp == 0 ? v[0] : comp == 1 ? v[1] : v[2]; }   // registers, not an indexed array
 
@@ -87,8 +88,7 @@ __device__ inline void itx_class(const ItxPic& P, int bx, int nbx, char* __restr
       if ((flags & 0x18) | (r.w1 >> 24)) resid_rotate_rdpcm<LOG2N>(res, n, ((r.w1 >> 24) & 1) != 0, (flags >> 3) & 3);   // RExt: rotation (intra 4x4), RDPCM
       if (t < count) {
         // row n of the residual into the tiles it crosses: the eight lanes that hold the rows of one tile write its 128 bytes
-        const int cs = comp ? 1 : 0;
-        const int x = ((int)(r.w0 & 0xffff) * 4) >> cs, y = ((((int)(r.w0 >> 16) * 4) >> cs)) + n;
+        const int x = ((int)(r.w0 & 0xffff) * 4) >> (comp ? P.csx : 0), y = ((((int)(r.w0 >> 16) * 4) >> (comp ? P.csy : 0))) + n;
         int16_t* row = by_comp(P.resid, comp) + ((size_t)((y >> 3) * by_comp(P.rtw, comp) + (x >> 3)) * 8 + resid_slot(y)) * 8;
         if constexpr (N == 4) stg2(row + (x & 4), u32x2{res[0], res[1]});
         else {
@@ -123,6 +123,7 @@ __global__ void __launch_bounds__(256) k_itx(const ItxArgs a) {
 #pragma unroll
   for (int k = 0; k < 3; k++) { P.coef[k] = a.coef[z][k]; P.resid[k] = a.resid[z][k]; P.rtw[k] = a.rtw[k]; P.bd[k] = a.bd[k]; }
   P.sl_m = a.sl_m[z];
+  P.csx = a.csx; P.csy = a.csy;
   switch (cls) {
     case 0: itx_class<2>(P, bx, nbx, lds); break;
     case 1: itx_class<3>(P, bx, nbx, lds); break;

@@ -48,6 +48,22 @@ __global__ void __launch_bounds__(256) k_mc_chroma_cells(const PicDev* __restric
   if (is_inter(c11)) chroma_cell<WP>(P, finals, c11, x0 + 4, y0 + 4, rmask);
 }
 
+// chroma of 4:2:2 / 4:4:4 pictures: EVERY inter cell of every tile through the register path (correct first: these formats have no
+// LDS-staged picture kernel yet)
+template <bool WP, int CSX, int CSY>
+__global__ void __launch_bounds__(256) k_mc_chroma_fmt(const PicDev* __restrict__ pics, const PlaneSet* __restrict__ finals, Batch b, int nblocks) {
+  int slot, lb, x0, y0;
+  if (!xcd_remap(blockIdx.x, b.n, nblocks, slot, lb)) return;
+  const PicDev& P = pics[b.pic[slot]];
+  if (!tile_origin(P, b, slot, lb, x0, y0)) return;
+  const BlkInfo* g = P.blk + (size_t)(y0 >> 2) * P.grid_w + (x0 >> 2);
+  const BlkInfo c00 = ld_blk(g), c01 = ld_blk(g + 1), c10 = ld_blk(g + P.grid_w), c11 = ld_blk(g + P.grid_w + 1);
+  if (is_inter(c00)) chroma_cell_fmt<WP, CSX, CSY>(P, finals, c00, x0, y0);
+  if (is_inter(c01)) chroma_cell_fmt<WP, CSX, CSY>(P, finals, c01, x0 + 4, y0);
+  if (is_inter(c10)) chroma_cell_fmt<WP, CSX, CSY>(P, finals, c10, x0, y0 + 4);
+  if (is_inter(c11)) chroma_cell_fmt<WP, CSX, CSY>(P, finals, c11, x0 + 4, y0 + 4);
+}
+
 static int mc_blocks(int max_ctus, int log2ctu) {
   const int sq = std::max(1, (1 << log2ctu) / 64);
   return (max_ctus * sq * sq + 3) / 4;
@@ -61,6 +77,18 @@ void launch_mc_chroma_cells(const PicDev* pics, const PlaneSet* finals, const Ba
   const int nb = mc_blocks(max_ctus, log2ctu);
   if (wp) hipLaunchKernelGGL(k_mc_chroma_cells<true>, dim3((unsigned)xcd_grid(b.n, nb)), dim3(256), 0, s, pics, finals, b, nb);
   else hipLaunchKernelGGL(k_mc_chroma_cells<false>, dim3((unsigned)xcd_grid(b.n, nb)), dim3(256), 0, s, pics, finals, b, nb);
+}
+
+void launch_mc_chroma_fmt(const PicDev* pics, const PlaneSet* finals, const Batch& b, int max_ctus, int log2ctu, int fmt, bool wp, hipStream_t s) {
+  const int nb = mc_blocks(max_ctus, log2ctu);
+  const dim3 grid((unsigned)xcd_grid(b.n, nb));
+  if (fmt == 3) {
+    if (wp) hipLaunchKernelGGL((k_mc_chroma_fmt<true, 0, 0>), grid, dim3(256), 0, s, pics, finals, b, nb);
+    else hipLaunchKernelGGL((k_mc_chroma_fmt<false, 0, 0>), grid, dim3(256), 0, s, pics, finals, b, nb);
+  } else {
+    if (wp) hipLaunchKernelGGL((k_mc_chroma_fmt<true, 1, 0>), grid, dim3(256), 0, s, pics, finals, b, nb);
+    else hipLaunchKernelGGL((k_mc_chroma_fmt<false, 1, 0>), grid, dim3(256), 0, s, pics, finals, b, nb);
+  }
 }
 
 // ---- kernel-level seam: xPredInterBlk on a list of blocks of one plane (tests).  The plane carries replicated margins

@@ -19,14 +19,17 @@ __constant__ uint8_t c_chroma_scale_420[58] = {   // HM g_aucChromaScale[CHROMA_
     0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29,
     29, 30, 31, 32, 33, 33, 34, 34, 35, 35, 36, 36, 37, 37, 38, 39, 40, 41, 42, 43, 44, 45, 46, 47, 48, 49, 50, 51};
 
-// QpParam (TComTrQuant.cpp:71-100)
-__device__ inline void qp_param(int qp_y, int comp, int bd, int chroma_off, int8_t& per, int8_t& rem) {
+__constant__ uint8_t c_chroma422_mode[36] = {      // g_chroma422IntraAngleMappingTable, TComRom.cpp:534-536
+    0, 1, 2, 2, 2, 2, 3, 5, 7, 8, 10, 12, 13, 15, 17, 18, 19, 20, 21, 22, 23, 23, 24, 24, 25, 25, 26, 27, 27, 28, 28, 29, 29, 30, 31, 36};
+
+// QpParam (TComTrQuant.cpp:71-100); fmt: chroma_format_idc -- the 4:2:0 table, min(qPi, 51) otherwise (g_aucChromaScale, TComRom.cpp:499-506)
+__device__ inline void qp_param(int qp_y, int comp, int bd, int chroma_off, int fmt, int8_t& per, int8_t& rem) {
   const int bdo = 6 * (bd - 8);
   int base;
   if (comp == 0) base = qp_y + bdo;
   else {
     base = clip3(-bdo, 57, qp_y + chroma_off);
-    base = base < 0 ? base + bdo : c_chroma_scale_420[base] + bdo;
+    base = base < 0 ? base + bdo : (fmt == 1 ? c_chroma_scale_420[base] : min(base, 51)) + bdo;
   }
   per = (int8_t)(base / 6);
   rem = (int8_t)(base % 6);
@@ -52,7 +55,7 @@ __device__ inline TuRec make_tu(const PicDev& P, const Quad& q, const SliceDev* 
   r.x4 = (uint16_t)gx; r.y4 = (uint16_t)gy;
   r.comp_flags = (uint8_t)(comp | (flags << 2));
   const int coff = comp == 1 ? ldg(&sl->cb_qp_offset) : (comp == 2 ? ldg(&sl->cr_qp_offset) : 0);
-  qp_param(q.qp_cu, comp, P.bd[comp], coff, r.per, r.rem);
+  qp_param(q.qp_cu, comp, P.bd[comp], coff, P.fmt, r.per, r.rem);
   r.xflags = (uint8_t)xflags;
   r.coef_off = coef_off;
   return r;
@@ -100,7 +103,12 @@ __device__ inline uint16_t edge_unit(const BlkInfo& p, const BlkInfo& q, bool tr
   return (uint16_t)edge_unit_pack(bs, ((int)p.qp + (int)q.qp + 1) >> 1, (p.flags & BF_NOFILT) != 0, (q.flags & BF_NOFILT) != 0);
 }
 
+// FMT: chroma_format_idc of the context (1 also for monochrome): which chroma blocks a transform unit has.  4:2:0: one per component, half
+// the size, four 4x4 luma blocks sharing one 4x4; 4:4:4: the luma blocks' twins; 4:2:2: two squares of half the width, one above the other
+// (TComTU.cpp:89-171, TComTrQuant.cpp:1436-1462).  Slot k of a thread = block (k & 3) of component k >> 2 (4:2:0: the six slots it always had).
+template <int FMT>
 __global__ void __launch_bounds__(256) k_prep(const PicDev* __restrict__ pics, Batch b, int write_blk) {
+  constexpr int NS = FMT == 1 ? 6 : 12;
   __shared__ uint32_t lds_cnt[4], lds_base[4], lds_stat[2];
   // the cells of the workgroup's areas, for the edge units of their right and lower neighbours (boundary strength needs both sides)
   __shared__ __attribute__((aligned(16))) u32x4 lds_cell[256 * 4];
@@ -120,10 +128,13 @@ __global__ void __launch_bounds__(256) k_prep(const PicDev* __restrict__ pics, B
   const bool active = gq < b.num_ctus[blockIdx.z] * (parts >> 2);
   Quad q; q.valid = false; q.intra = false; q.log2tu = 3; q.tr = 0; q.ctu = 0; q.z0 = 0; q.gx0 = q.gy0 = 0;
   q.log2cu = 3; q.part_size = 0; q.qp_cu = 0; q.sidx = 0; q.bypass = 0;
-  bool has[6] = {false, false, false, false, false, false};      // slots: luma TU of partition 0..3 (or one larger TU in slot 0), Cb, Cr
+  // (a bit mask, not an array of flags: twelve of those as a vector crash this compiler's type legaliser)
+  uint32_t hasm = 0;                                             // 4:2:0 slots: luma TU of partition 0..3 (or one larger TU in slot 0), Cb, Cr
+  auto set_has = [&](int k, bool v) { hasm |= (v ? 1u : 0u) << k; };
+  auto has = [&](int k) { return ((hasm >> k) & 1u) != 0; };
   uint32_t cnt[3] = {0, 0, 0}, lmask = 0;                        // compact levels: coded coefficients that start in this area (intra CUs too), coded 4x4 luma TUs
-  int cls[6] = {0, 0, 0, 0, 0, 0};
-  uint32_t loc[6] = {0, 0, 0, 0, 0, 0};
+  int cls[NS] = {};
+  uint32_t loc[NS] = {};
   const SliceDev* sl = P.slices;
   u32x4 cells[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
   write_blk |= P.any_nofilt;                                     // SAO reads the exemption flags back (sao_exempt_mask)
@@ -364,19 +375,39 @@ __global__ void __launch_bounds__(256) k_prep(const PicDev* __restrict__ pics, B
         // at most one luma TU (and its chroma TUs, half the size) starts here: when partition 0 is aligned to the TU
         const int tu_parts = 1 << (q.log2tu - 2);
         if ((x4 & (tu_parts - 1)) == 0 && (y4 & (tu_parts - 1)) == 0) {
-          has[0] = ((q.cbf[0] & 0xff) & chain) == chain; cls[0] = q.log2tu - 2;
-          has[4] = ((q.cbf[1] & 0xff) & chain) == chain; cls[4] = q.log2tu - 3;
-          has[5] = ((q.cbf[2] & 0xff) & chain) == chain; cls[5] = q.log2tu - 3;
+          set_has(0, ((q.cbf[0] & 0xff) & chain) == chain); cls[0] = q.log2tu - 2;
+          if constexpr (FMT == 1) {
+            set_has(4, ((q.cbf[1] & 0xff) & chain) == chain); cls[4] = q.log2tu - 3;
+            set_has(5, ((q.cbf[2] & 0xff) & chain) == chain); cls[5] = q.log2tu - 3;
+          } else {
+#pragma unroll
+            for (int c = 1; c < 3; c++) {
+              set_has(4 * c, ((q.cbf[c] & 0xff) & chain) == chain); cls[4 * c] = FMT == 3 ? q.log2tu - 2 : q.log2tu - 3;
+              if constexpr (FMT == 2) { set_has(4 * c + 1, has(4 * c)); cls[4 * c + 1] = cls[4 * c]; }      // the lower square: transformed whenever the block is
+            }
+          }
         }
       } else {
         // four 4x4 luma TUs; the one 4x4 chroma TU of the 8x8 node rides with the first of them (TComTU.cpp:141-151)
 #pragma unroll
-        for (int j = 0; j < 4; j++) { has[j] = (((q.cbf[0] >> (8 * j)) & 0xff) & chain) == chain; cls[j] = 0; }
-        has[4] = ((q.cbf[1] & 0xff) & chain) == chain; cls[4] = 0;
-        has[5] = ((q.cbf[2] & 0xff) & chain) == chain; cls[5] = 0;
+        for (int j = 0; j < 4; j++) { set_has(j, (((q.cbf[0] >> (8 * j)) & 0xff) & chain) == chain); cls[j] = 0; }
+        if constexpr (FMT == 1) {
+          set_has(4, ((q.cbf[1] & 0xff) & chain) == chain); cls[4] = 0;
+          set_has(5, ((q.cbf[2] & 0xff) & chain) == chain); cls[5] = 0;
+        } else if constexpr (FMT == 3) {
+          // 4:4:4: every 4x4 luma block has its chroma twins
+#pragma unroll
+          for (int c = 1; c < 3; c++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) { set_has(4 * c + j, (((q.cbf[c] >> (8 * j)) & 0xff) & chain) == chain); cls[4 * c + j] = 0; }
+        } else {
+          // 4:2:2: the 4x8 chroma block of the 8x8 node, two 4x4 squares
+#pragma unroll
+          for (int c = 1; c < 3; c++) { const bool coded = ((q.cbf[c] & 0xff) & chain) == chain; set_has(4 * c, coded); set_has(4 * c + 1, coded); cls[4 * c] = cls[4 * c + 1] = 0; }
+        }
       }
 #pragma unroll
-      for (int k = 0; k < 6; k++) if (has[k]) loc[k] = atomicAdd(&lds_cnt[cls[k]], 1u);
+      for (int k = 0; k < NS; k++) if (has(k)) loc[k] = atomicAdd(&lds_cnt[cls[k]], 1u);
     }
   }
   // compact levels: where this area's TUs start = the CTU's start + the coefficients of the areas before it in the CTU (z-order).
@@ -470,11 +501,27 @@ __global__ void __launch_bounds__(256) k_prep(const PicDev* __restrict__ pics, B
 #endif
   const int ctu_luma = 1 << (2 * P.log2ctu);
 #pragma unroll
-  for (int k = 0; k < 6; k++) {
-    if (!has[k]) continue;
-    const int comp = k < 4 ? 0 : k - 3;
-    const int j = k < 4 ? k : 0;                          // partition the TU starts at
-    const int ts = (q.ts[comp] >> (8 * j)) & 0xff;
+  for (int k = 0; k < NS; k++) {
+    if (!has(k)) continue;
+    const int comp = FMT == 1 ? (k < 4 ? 0 : k - 3) : k >> 2;
+    // the partition the block's flags are stored at (j: of this area), its position relative to the area's first partition, its place among the levels
+    int j = FMT == 1 ? (k < 4 ? k : 0) : (k & 3), dx = j & 1, dy = j >> 1, bsize = comp == 0 ? q.log2tu : max(q.log2tu - 1, 2);
+    int ts = (q.ts[comp] >> (8 * j)) & 0xff;
+    uint32_t off = comp == 0 ? (uint32_t)q.ctu * ctu_luma + 16u * (q.z0 + j) : (uint32_t)q.ctu * (ctu_luma >> 2) + 4u * q.z0;
+    if constexpr (FMT == 3) {
+      bsize = q.log2tu;
+      off = (uint32_t)q.ctu * ctu_luma + 16u * (q.z0 + j);
+    } else if constexpr (FMT == 2) {
+      if (comp) {
+        // square `j` (0 upper, 1 lower) of the chroma block of the node: the lower one lies half the node's height down -- with the flags of
+        // the lower half of the node's partitions -- and follows the upper one among the levels
+        const int l2 = max(q.log2tu, 3) - 1, n = 1 << l2, lower = j;
+        bsize = l2; dx = 0; dy = lower ? n >> 2 : 0;
+        off = (uint32_t)q.ctu * (ctu_luma >> 1) + 8u * q.z0 + (lower ? (uint32_t)(n * n) : 0u);
+        ts = !lower ? (q.ts[comp] & 0xff) : q.log2tu <= 3 ? (q.ts[comp] >> 16) & 0xff : (P.tskip[comp] ? (int)ldg(P.tskip[comp] + (size_t)q.ctu * P.parts + q.z0 + (1 << (2 * (q.log2tu - 2) - 1))) : 0);
+        j = 0;
+      }
+    }
     // bit 0: DST, bit 1: transform skip, bit 2: cu_transquant_bypass, bits 3-4: RDPCM of a block that skipped the transform, bit 5: intra
     int flags = ((comp == 0 && q.log2tu == 2 && q.intra) ? 1 : 0) | ((ts & 1) ? 2 : 0) | ((q.bypass & 0xff) ? 4 : 0) | (q.intra ? 32 : 0);
     int xflags = 0;
@@ -483,19 +530,20 @@ __global__ void __launch_bounds__(256) k_prep(const PicDev* __restrict__ pics, B
         if (P.range_ext & HMGPU_REXT_EXPLICIT_RDPCM) flags |= ((ts >> 1) & 3) << 3;          // the mode parsed with the block
       } else {
         // rotation of 4x4 blocks (TComTU::isNonTransformedResidualRotated); implicit RDPCM along the final prediction mode (invRdpcmNxN,
-        // TComTrQuant.cpp:1748-1760): DM_CHROMA = the luma mode of the CU's first partition, as k_intra derives it
-        if ((P.range_ext & HMGPU_REXT_ROTATION) && (comp == 0 ? q.log2tu : max(q.log2tu - 1, 2)) == 2) xflags |= 1;
+        // TComTrQuant.cpp:1748-1760): DM_CHROMA = the luma mode of the CU's first partition (4:4:4: of the same partition), as k_intra
+        // derives it; 4:2:2: through the mode table
+        if ((P.range_ext & HMGPU_REXT_ROTATION) && bsize == 2) xflags |= 1;
         if (P.range_ext & HMGPU_REXT_IMPLICIT_RDPCM) {
           const size_t cb = (size_t)q.ctu * P.parts;
           int mode = ldg(P.intra_dir[comp ? 1 : 0] + cb + q.z0 + j);
-          if (comp && mode == 36) mode = ldg(P.intra_dir[0] + cb + (q.z0 & ~((1 << (2 * (q.log2cu - 2))) - 1)));
+          if (comp && mode == 36) mode = ldg(P.intra_dir[0] + cb + (FMT == 3 ? q.z0 + j : (q.z0 & ~((1 << (2 * (q.log2cu - 2))) - 1))));
+          if (FMT == 2 && comp) mode = c_chroma422_mode[mode];
           flags |= (mode == 10 ? 1 : mode == 26 ? 2 : 0) << 3;
         }
       }
     }
-    uint32_t off = comp == 0 ? (uint32_t)q.ctu * ctu_luma + 16u * (q.z0 + j) : (uint32_t)q.ctu * (ctu_luma >> 2) + 4u * q.z0;
-    if (P.coef_start[0] != nullptr) off = coff[comp] + (comp == 0 ? 16u * __popc(lmask & ((1u << j) - 1u)) : 0u);
-    const TuRec r = make_tu(P, q, sl, q.gx0 + (j & 1), q.gy0 + (j >> 1), comp, flags, xflags, off);
+    if (FMT == 1 && P.coef_start[0] != nullptr) off = coff[comp] + (comp == 0 ? 16u * __popc(lmask & ((1u << j) - 1u)) : 0u);
+    const TuRec r = make_tu(P, q, sl, q.gx0 + dx, q.gy0 + dy, comp, flags, xflags, off);
     const int c = cls[k];
     const uint32_t i = lds_base[c] + loc[k];
     if (i < P.tu_cap[c]) {
@@ -517,10 +565,12 @@ __global__ void k_zero_counts(const PicDev* __restrict__ pics, Batch b, int intr
 
 // write_blk: the call runs kernels that read the BlkInfo grid (the cells kernels of mixed-motion tiles); pictures with exempt CUs add
 // themselves (SAO's exemption mask).  Everything else reads TileMv and EdgeRec only.
-void launch_prep(const PicDev* pics, const Batch& b, int max_ctus, int parts, bool intra, bool write_blk, hipStream_t s) {
+void launch_prep(const PicDev* pics, const Batch& b, int max_ctus, int parts, bool intra, bool write_blk, int fmt, hipStream_t s) {
   hipLaunchKernelGGL(k_zero_counts, dim3((unsigned)b.n), dim3(256), 0, s, pics, b, intra ? 1 : 0);
   dim3 grid((unsigned)(((size_t)max_ctus * (parts / 4) + 255) / 256), 1, (unsigned)b.n);
-  hipLaunchKernelGGL(k_prep, grid, dim3(256), 0, s, pics, b, write_blk ? 1 : 0);
+  if (fmt == 3) hipLaunchKernelGGL(k_prep<3>, grid, dim3(256), 0, s, pics, b, write_blk ? 1 : 0);
+  else if (fmt == 2) hipLaunchKernelGGL(k_prep<2>, grid, dim3(256), 0, s, pics, b, write_blk ? 1 : 0);
+  else hipLaunchKernelGGL(k_prep<1>, grid, dim3(256), 0, s, pics, b, write_blk ? 1 : 0);
 }
 
 }  // namespace hmgpu

@@ -43,9 +43,9 @@ __global__ void __launch_bounds__(256) k_sao(const PicDev* __restrict__ pics, Ba
   const int lane = threadIdx.x & 63;
   int comp = 0;
   if (wid >= luma_waves) { wid -= luma_waves; comp = 1; if (wid >= chroma_waves) { wid -= chroma_waves; comp = 2; if (wid >= chroma_waves) return; } }
-  const int cs = comp ? 1 : 0;
-  const int w = P.width >> cs, h = P.height >> cs;
-  const int bw = comp ? 32 : 64, bh = comp ? 16 : 8;        // block covered by the wave (samples)
+  const int sx = comp ? P.csx : 0, sy = comp ? P.csy : 0;    // subsampling of the component (4:2:0: 1, 1; 4:2:2: 1, 0; 4:4:4: 0, 0)
+  const int w = P.width >> sx, h = P.height >> sy;
+  const int bw = 64 >> sx, bh = 8 << sx;                    // block covered by the wave (samples): 64 x 8, or 32 x 16 across a subsampled direction
   const int blocks_x = (w + bw - 1) / bw;
   const int bx = wid % blocks_x, by = wid / blocks_x;
   const int lanes_x = bw / 8;
@@ -55,8 +55,8 @@ __global__ void __launch_bounds__(256) k_sao(const PicDev* __restrict__ pics, Ba
   const int pitch = P.pitch[comp];
   const int16_t* __restrict__ src = P.rec[comp];
   int16_t* __restrict__ dst = P.sao[comp];
-  const int log2ctb = P.log2ctu - cs;
-  const int cx = x >> log2ctb, cy = row >> log2ctb;
+  const int log2ctb_x = P.log2ctu - sx, log2ctb_y = P.log2ctu - sy;
+  const int cx = x >> log2ctb_x, cy = row >> log2ctb_y;
   const uint32_t* pw = reinterpret_cast<const uint32_t*>(P.saoprm + ((size_t)cy * P.ctus_w + cx) * 3 + comp);
   const uint32_t w0 = ldg(pw);
   const int type = (int)(int8_t)(w0 & 0xff);
@@ -78,9 +78,8 @@ __global__ void __launch_bounds__(256) k_sao(const PicDev* __restrict__ pics, Ba
       out[j] = as_u32(__builtin_elementwise_min(__builtin_elementwise_max(as_s16x2(c[j]) + off, splat(0)), splat(maxv)));
     }
   } else {
-    const int ctb = 1 << log2ctb;
-    const int x0 = cx << log2ctb, y0 = cy << log2ctb;
-    const int x1 = min(x0 + ctb, w) - 1, y1 = min(y0 + ctb, h) - 1;     // CTB clipped to the picture (offsetCTU :679-682)
+    const int x0 = cx << log2ctb_x, y0 = cy << log2ctb_y;
+    const int x1 = min(x0 + (1 << log2ctb_x), w) - 1, y1 = min(y0 + (1 << log2ctb_y), h) - 1;     // CTB clipped to the picture (offsetCTU :679-682)
     const unsigned av = w0 >> 16;
     switch (type) {                                                      // a = (x+DX, y+DY), b = (x-DX, y-DY)
       case HMGPU_SAO_EO_0:   sao_eo_row<-1, 0>(src, comp, pitch, w, h, x, row, cur, off_lo, off_hi, av, x0, y0, x1, y1, maxv, out); break;
@@ -152,21 +151,22 @@ __global__ void __launch_bounds__(256) k_extend(const PicDev* __restrict__ pics,
   int idx = blockIdx.x * 256 + threadIdx.x;
   if (idx < luma_vecs) { extend_plane<1>(P.sao_applied ? P.sao[0] : P.rec[0], P.width, P.height, P.mx[0], P.my[0], P.pitch[0], idx); return; }
   idx -= luma_vecs;
-  if (idx < chroma_vecs) extend_plane<kCStep>(P.sao_applied ? P.sao[1] : P.rec[1], P.width >> 1, P.height >> 1, P.mx[1], P.my[1], P.pitch[1], idx);
+  if (idx < chroma_vecs) extend_plane<kCStep>(P.sao_applied ? P.sao[1] : P.rec[1], P.width >> P.csx, P.height >> P.csy, P.mx[1], P.my[1], P.pitch[1], idx);
 }
 
-void launch_extend(const PicDev* pics, const Batch& b, int width, int height, int mx, int my, hipStream_t s) {
-  // luma margins (mx, my); chroma margins are half of them, a chroma element is a (Cb, Cr) pair = 4 bytes
+void launch_extend(const PicDev* pics, const Batch& b, int width, int height, int mx, int my, int csx, int csy, hipStream_t s) {
+  // luma margins (mx, my); chroma margins follow the subsampling (hmgpu_create), a chroma element is a (Cb, Cr) pair = 4 bytes
   const int luma = (2 * mx / 8) * (height + 2 * my) + ((width + 7) / 8) * 2 * my;
-  const int cw = width / 2, chh = height / 2, cmx = mx / 2, cmy = my / 2, ve = 8 / kCStep;
+  const int cw = width >> csx, chh = height >> csy, cmx = mx >> csx, cmy = my >> csy, ve = 8 / kCStep;
   const int chroma = (2 * cmx / ve) * (chh + 2 * cmy) + ((cw + ve - 1) / ve) * 2 * cmy;
   dim3 grid((unsigned)((luma + chroma + 255) / 256), 1, (unsigned)b.n);
   hipLaunchKernelGGL(k_extend, grid, dim3(256), 0, s, pics, b, luma, chroma);
 }
 
-void launch_sao(const PicDev* pics, const Batch& b, int width, int height, hipStream_t s) {
+void launch_sao(const PicDev* pics, const Batch& b, int width, int height, int csx, int csy, hipStream_t s) {
   const int luma = ((width + 63) / 64) * ((height + 7) / 8);
-  const int chroma = ((width / 2 + 31) / 32) * ((height / 2 + 15) / 16);
+  const int cbw = 64 >> csx, cbh = 8 << csx;                 // (k_sao: the block of a chroma wave)
+  const int chroma = (((width >> csx) + cbw - 1) / cbw) * (((height >> csy) + cbh - 1) / cbh);
   dim3 grid((unsigned)((luma + 2 * chroma + 3) / 4), 1, (unsigned)b.n);
   hipLaunchKernelGGL(k_sao, grid, dim3(256), 0, s, pics, b, luma, chroma);
 }

@@ -166,9 +166,12 @@ __device__ inline WpLane wp_lane(const PicDev& P, const BlkInfo& bi, int comp, i
 
 // prediction of one W x H tile of component `comp` with the motion of `bi`, written to dst (the picture being decoded) with the
 // residual added when the tile carries one (coded; PicDev::resid, written by k_itx; W x H lies inside one 4x4 block)
+// mvsx / mvsy (chroma of 4:2:2 / 4:4:4 pictures): the vector is in quarter LUMA samples = 1 / (4 << cs) of the component's; the 4-tap
+// filters are indexed in eighths: shifted up by 1 - cs (TComPrediction.cpp:664-674, TComInterpolationFilter.cpp:344-346)
 template <int TAPS, int W, int H, bool WP = false>
 __device__ inline void predict_tile(const PicDev& P, const PlaneSet* __restrict__ finals, int comp, int x0, int y0,
-                                    const BlkInfo& bi, int cu_x, int cu_y, int16_t* __restrict__ dst, int lx = 0, int ly = 0, bool coded = false) {
+                                    const BlkInfo& bi, int cu_x, int cu_y, int16_t* __restrict__ dst, int lx = 0, int ly = 0, bool coded = false,
+                                    int mvsx = 0, int mvsy = 0) {
   WpLane wp = {false, {1, 1}, {0, 0}, 0};
   if constexpr (WP) wp = wp_lane(P, bi, comp, lx, ly);
   const int bd = P.bd[comp];
@@ -185,6 +188,7 @@ __device__ inline void predict_tile(const PicDev& P, const PlaneSet* __restrict_
     int mvx = l0 ? bi.mv[1][0] : bi.mv[0][0], mvy = l0 ? bi.mv[1][1] : bi.mv[0][1];
     const int ref0 = l0 ? bi.ref[1] : bi.ref[0];
     clip_mv(P, cu_x, cu_y, mvx, mvy);
+    mvx <<= mvsx; mvy <<= mvsy;
     if (comp == 0) predict14<TAPS, W, H>(ldg(&finals[ref0].p[0]), pitch, x0, y0, mvx, mvy, bd, a);
     else predict14<TAPS, W, H, kCStep>(ldg(&finals[ref0].p[1]), pitch, x0, y0, mvx, mvy, bd, a, comp - 1);
 #pragma unroll
@@ -207,6 +211,7 @@ __device__ inline void predict_tile(const PicDev& P, const PlaneSet* __restrict_
     int b[H][W];
     int mvx = bi.mv[1][0], mvy = bi.mv[1][1];
     clip_mv(P, cu_x, cu_y, mvx, mvy);
+    mvx <<= mvsx; mvy <<= mvsy;
     if (comp == 0) predict14<TAPS, W, H>(ldg(&finals[bi.ref[1]].p[0]), pitch, x0, y0, mvx, mvy, bd, b);
     else predict14<TAPS, W, H, kCStep>(ldg(&finals[bi.ref[1]].p[1]), pitch, x0, y0, mvx, mvy, bd, b, comp - 1);
 #pragma unroll
@@ -225,7 +230,7 @@ __device__ inline void predict_tile(const PicDev& P, const PlaneSet* __restrict_
       }
   }
   if (coded) {
-    const int rtw = (P.grid_w * 4 >> (comp ? 1 : 0)) >> 3;
+    const int rtw = (P.grid_w * 4 >> (comp ? P.csx : 0)) >> 3;
     const uint32_t maxv2 = (uint32_t)maxv * 0x10001u;
 #pragma unroll
     for (int y = 0; y < H; y++) {
@@ -276,6 +281,15 @@ __device__ __attribute__((noinline)) void chroma_cell(const PicDev& P, const Pla
   const int cs = 1 << c.log2cu;
   predict_tile<4, 2, 2, WP>(P, finals, 1, lx >> 1, ly >> 1, c, lx & ~(cs - 1), ly & ~(cs - 1), P.rec[1], lx, ly, (rmask & TR_CB) != 0);
   predict_tile<4, 2, 2, WP>(P, finals, 2, lx >> 1, ly >> 1, c, lx & ~(cs - 1), ly & ~(cs - 1), P.rec[2], lx, ly, (rmask & TR_CR) != 0);
+}
+
+// the chroma of one 4x4 luma cell of a 4:2:2 / 4:4:4 picture: (4 >> CSX) x (4 >> CSY) samples of both components, the residual added from
+// the tiles (zero where no coded block lies: hmgpu_api.hip clears them for these formats)
+template <bool WP, int CSX, int CSY>
+__device__ __attribute__((noinline)) void chroma_cell_fmt(const PicDev& P, const PlaneSet* __restrict__ finals, const BlkInfo c, int lx, int ly) {
+  const int cs = 1 << c.log2cu;
+  predict_tile<4, (4 >> CSX), (4 >> CSY), WP>(P, finals, 1, lx >> CSX, ly >> CSY, c, lx & ~(cs - 1), ly & ~(cs - 1), P.rec[1], lx, ly, true, 1 - CSX, 1 - CSY);
+  predict_tile<4, (4 >> CSX), (4 >> CSY), WP>(P, finals, 2, lx >> CSX, ly >> CSY, c, lx & ~(cs - 1), ly & ~(cs - 1), P.rec[2], lx, ly, true, 1 - CSX, 1 - CSY);
 }
 
 // lane -> 8x8 luma area: a wave covers 8x8 areas = 64x64 luma samples, a block four such squares in CTU order

@@ -813,6 +813,7 @@ void Decoder::flush_batch() {
     m.ipcm = p->has_pcm ? p->ipcm.data() : nullptr;
     m.slice_idx = p->slice_idx.data();
     m.tile_idx = p->tile_idx.data();
+    for (int k = 0; k < 2; k++) m.ccp_alpha[k] = p->ccp[k].empty() ? nullptr : p->ccp[k].data();      // 4:4:4: cross-component prediction weights
     hmgpu_coeffs& co = coefs[i];
     memset(&co, 0, sizeof(co));
     for (int c = 0; c < 3; c++) { co.level[c] = p->coeff[c].data(); co.pcm_sample[c] = p->has_pcm ? p->pcm[c].data() : nullptr; }

@@ -84,13 +84,26 @@ def test_internals_describe_the_picture():
         assert np.array_equal(pm[pics[-1].meta_np["part_size"].reshape(-1) != 8], pics[-1].meta_np["pred_mode"].reshape(-1)[pics[-1].meta_np["part_size"].reshape(-1) != 8])
 
 
+# 4:2:2 / 4:4:4 variants on the device; the metadata fixtures' streams too (expected: HM's decoder output)
+LITE_444 = gu.LITE_CF + ["stream:" + n for n in gu.STREAMS_CF]
+
+
 @pytest.mark.parametrize("threads", [1, 3])
-@pytest.mark.parametrize("name", gu.LITE + gu.SURGERY)
+@pytest.mark.parametrize("name", gu.LITE + LITE_444 + gu.SURGERY)
 def test_syntax_variants_decode_to_the_encoders_reconstruction(name, threads):
     """slices, dependent slice segments, wavefronts, CU-level QP, CRA + leading pictures, 32/16-sample CTUs, conformance window,
     slices of tiles, low-delay B: output == HM's encoder reconstruction (== what HM's decoder must produce), hash SEI check green"""
-    z = gu.load("lite_" + name)
-    w, h, frames, bd = (int(v) for v in z["geom"])
+    if name.startswith("stream:"):
+        # a metadata fixture used as a stream: its pictures are HM's decoder output
+        pics = {p.poc: p.fin for p in gu.stream_pictures(name[7:])}
+        z = {"bitstream": gu.load("stream_" + name[7:])["bitstream"]}
+        for poc, fin in pics.items():
+            for c in range(3):
+                z["poc%02d_%d" % (poc, c)] = fin[c]
+        frames = len(pics)
+    else:
+        z = gu.load("lite_" + name)
+        w, h, frames, bd = (int(v) for v in z["geom"])
     out = []
     with hmdec.Decoder(threads=threads) as d:
         def on_output(p):

@@ -23,7 +23,11 @@ def _run_stream(name, check):
     return len(pics)
 
 
-@pytest.mark.parametrize("name", gu.STREAMS)
+# 4:4:4 (with cross-component prediction) and 4:2:2 on the device
+STREAMS_444 = gu.STREAMS_CF
+
+
+@pytest.mark.parametrize("name", gu.STREAMS + STREAMS_444)
 def test_full_chain_matches_hm(name):
     """decompress_slice + filter_picture from the parsed data alone: every sample of every picture, inter and intra CUs
     (I pictures included), is produced on the GPU"""
@@ -72,7 +76,7 @@ def test_single_call_filter_picture_matches_hm(name):
     _run_stream(name, check2)
 
 
-@pytest.mark.parametrize("name", gu.STREAMS)
+@pytest.mark.parametrize("name", gu.STREAMS + STREAMS_444)
 def test_device_hash_and_packed_output_match_hm(name):
     """f-4: the decoded-picture-hash check (MD5, CRC, checksum) and the output packing (8/16-bit, conformance window) happen on the
     device; the hashes are the ones HM computed, the packed planes are HM's planes cropped (TVideoIOYuv.cpp:706-790)"""
@@ -89,13 +93,14 @@ def test_device_hash_and_packed_output_match_hm(name):
             l, r, t, b = crop
             got = ctx.download_packed(h, nbytes, crop)
             for c in range(3):
-                s = 1 if c else 0
-                want = p.fin[c][t >> s:p.fin[c].shape[0] - (b >> s), l >> s:p.fin[c].shape[1] - (r >> s)]
+                sx, sy = (p.csx, p.csy) if c else (0, 0)
+                want = p.fin[c][t >> sy:p.fin[c].shape[0] - (b >> sy), l >> sx:p.fin[c].shape[1] - (r >> sx)]
                 assert got[c].dtype == (np.uint8 if nbytes == 1 else np.uint16)
                 assert np.array_equal(got[c].astype(np.int16), want), "%s pic %d comp %d crop %s" % (name, p.index, c, crop)
         if nbytes == 1:                                              # is16bit output of an 8-bit picture (file bit depth > 8)
             wide = ctx.download_packed(h, 2)
             assert all(np.array_equal(wide[c].astype(np.int16), p.fin[c]) for c in range(3))
-        with pytest.raises(libhm_amd.HmgpuError):
-            ctx.download_packed(h, 1, (1, 0, 0, 0))                  # odd window in 4:2:0
+        if p.csx:
+            with pytest.raises(libhm_amd.HmgpuError):
+                ctx.download_packed(h, 1, (1, 0, 0, 0))              # odd window with subsampled chroma
     _run_stream(name, check)
