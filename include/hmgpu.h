@@ -183,6 +183,10 @@ hmgpu_status hmgpu_create(const hmgpu_seq_params* seq, int device_ordinal, hmgpu
 void         hmgpu_destroy(hmgpu_ctx* ctx);
 int32_t      hmgpu_last_device_error(const hmgpu_ctx* ctx);        /* hipError_t of the last HMGPU_EDEVICE; -2: an intra wavefront gave up
                                                                        waiting for a neighbouring CTU (reported by hmgpu_sync / hmgpu_picture_download) */
+/* Test hook for the error path above: from the next hmgpu_decompress_* call on `pic`, the intra wavefront leaves CTU `ctu` out (no samples,
+ * no progress published), so the CTUs that predict from it run into their bounded wait and the call sequence ends in HMGPU_EDEVICE with
+ * hmgpu_last_device_error() == -2 instead of hanging.  ctu = -1 switches it off.  Not for production use. */
+hmgpu_status hmgpu_debug_stall_intra(hmgpu_ctx* ctx, hmgpu_pic pic, int32_t ctu);
 const char*  hmgpu_status_string(hmgpu_status s);
 hmgpu_status hmgpu_sync(hmgpu_ctx* ctx);                           /* wait for everything enqueued so far */
 

@@ -61,6 +61,7 @@ def lib():
         L.hmgpu_destroy.argtypes = [C.c_void_p]
         L.hmgpu_destroy.restype = None
         L.hmgpu_last_device_error.argtypes = [C.c_void_p]
+        L.hmgpu_debug_stall_intra.argtypes = [C.c_void_p, C.c_int32, C.c_int32]
         L.hmgpu_sync.argtypes = [C.c_void_p]
         L.hmgpu_status_string.restype = C.c_char_p
         L.hmgpu_kernel_name.restype = C.c_char_p
@@ -157,6 +158,10 @@ class Context:
 
     def sync(self):
         self._chk(lib().hmgpu_sync(self._h), "hmgpu_sync")
+
+    def debug_stall_intra(self, pic, ctu):
+        """test hook: the intra wavefront leaves CTU `ctu` of the picture out (-1: off)"""
+        self._chk(lib().hmgpu_debug_stall_intra(self._h, pic, ctu), "hmgpu_debug_stall_intra")
 
     # ---- pictures
     def acquire(self):

@@ -292,6 +292,7 @@ hmgpu_status alloc_picture(hmgpu_ctx* c, Picture& p) {
   d.mono = s.chroma_format == 0 ? 1 : 0;
   d.fmt = c->fmt; d.csx = c->csx; d.csy = c->csy;
   d.ccp[0] = d.ccp[1] = nullptr;
+  d.debug_skip_ctu = -1;
   d.sl_m = nullptr;
   for (int k = 0; k < 3; k++) { d.pcm[k] = nullptr; d.pcm_shift[k] = 0; d.coef_start[k] = nullptr; }
   d.pcm_lf_disable = s.pcm_loop_filter_disable ? 1 : 0; d.any_nofilt = 0;
@@ -663,6 +664,12 @@ void hmgpu_destroy(hmgpu_ctx* c) {
 }
 
 int32_t hmgpu_last_device_error(const hmgpu_ctx* c) { return c ? c->last_err : 0; }
+
+hmgpu_status hmgpu_debug_stall_intra(hmgpu_ctx* c, hmgpu_pic pic, int32_t ctu) {
+  if (!c || !valid_pic(c, pic) || ctu < -1 || ctu >= c->num_ctus) return HMGPU_EINVAL;
+  c->pics[pic].dev.debug_skip_ctu = ctu;               // (reaches the device with the picture's next decompress call)
+  return HMGPU_OK;
+}
 
 void* hmgpu_host_alloc(size_t bytes) {
   void* p = nullptr;

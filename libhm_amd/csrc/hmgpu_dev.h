@@ -175,6 +175,7 @@ struct PicDev {
   uint8_t* ctu_intra;              // [num_ctus] 1 = the CTU holds intra CUs (written by k_prep)
   uint32_t* intra_done;            // [3][num_ctus]: the CTU's intra CUs of that component are reconstructed
   uint32_t* fault;                 // set by a kernel that gave up waiting (k_intra's bounded spin): checked by the host at hmgpu_sync
+  int32_t debug_skip_ctu;          // test hook (hmgpu_debug_stall_intra): the intra workgroups of this CTU leave without reconstructing or publishing (-1: none)
 };
 
 // batched launch descriptor, passed by value

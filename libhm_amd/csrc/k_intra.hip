@@ -797,6 +797,7 @@ __global__ void __launch_bounds__(64 * WAVES) k_intra(const PicDev* __restrict__
   const PicDev& P = pics[b.pic[slot]];
   const int first = b.first_ctu[slot], last = first + b.num_ctus[slot] - 1;
   if (!P.has_intra_dir || ctu < first || ctu > last || !ldg(P.ctu_intra + ctu) || (comp && (P.mono || P.fmt == 2))) return;      // (4:2:2 chroma: k_intra_chroma_422)
+  if (ctu == P.debug_skip_ctu) return;                         // (test hook: its neighbours run into the bounded wait)
   uint32_t* done = P.intra_done + (size_t)comp * P.num_ctus;
   const int cx = ctu % P.ctus_w, cy = ctu / P.ctus_w;
 #ifdef INTRA_TIMING

@@ -131,6 +131,33 @@ def test_intra_scheduler_paths(oracle, width, height, bd, mode_probs, tr_split, 
             assert np.array_equal(got[c], want[c]), "compact levels, comp %d" % c
 
 
+def test_intra_wavefront_gives_up_instead_of_hanging(oracle):
+    """the bounded wait of k_intra (a CTU whose neighbour never finishes flags the picture instead of spinning for ever): with the test
+    hook that leaves one CTU of an all-intra picture out, the next synchronisation returns HMGPU_EDEVICE with device error -2 (never a
+    hang, never a silently wrong picture); switched off again, the same picture reconstructs bit-exactly"""
+    import libhm_amd
+    width, height, bd = 416, 240, 10
+    p = synth.make_picture(width, height, bd, seed=0xFA17, intra_frac=1.0, cbf_prob=0.5, sao=False, ref_handles=([0], [0]))
+    cur = synth.blocky_planes(width, height, bd, 5)
+    want = [a.copy() for a in cur]
+    oracle.decompress_ctus(p.seq, p.slices, p.meta, p.coeffs, want, [cur])
+    with libhm_amd.Context(p.seq) as ctx:
+        h0, hc = ctx.acquire(), ctx.acquire()
+        ctx.upload(h0, cur)
+        ctx.upload(hc, cur)
+        ctx.debug_stall_intra(hc, 1)                               # CTU 1: its right and lower neighbours wait for it
+        ctx.decompress_slice(hc, 0, p.slices[0], p.meta, p.coeffs)
+        with pytest.raises(libhm_amd.HmgpuError) as e:
+            ctx.sync()
+        assert e.value.status == 2 and e.value.device_error == -2      # HMGPU_EDEVICE, "an intra wavefront gave up waiting"
+        ctx.debug_stall_intra(hc, -1)
+        ctx.upload(hc, cur)
+        ctx.decompress_slice(hc, 0, p.slices[0], p.meta, p.coeffs)
+        got = ctx.download(hc)                                     # (and the flag was cleared with the report)
+        for c in range(3):
+            assert np.array_equal(got[c], want[c])
+
+
 @pytest.mark.parametrize("dist", ["stress", "dense"])
 @pytest.mark.parametrize("mode_probs,tr_split,intra,ts", [
     ((1.0, 0, 0, 0, 0), 0.35, 0.0, False),      # bench.py --workload idct (SURVEY 8d #2): 64x64 CUs = four 32x32 luma + 16x16 chroma TUs each

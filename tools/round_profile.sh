@@ -12,6 +12,10 @@ for wl in idct mc mc_bi filter; do
 done
 python3 bench.py --workload intra --batch 1 --steps 5 --warmup 1 --profile-steps 2 --no-cpu-baseline > $out/bench_intra_1pic.json 2> $out/bench_intra_1pic.err
 python3 bench.py --workload intra --steps 5 --warmup 1 --profile-steps 2 --no-cpu-baseline > $out/bench_intra.json 2> $out/bench_intra.err
+# P pictures with a realistic share of intra CUs reconstructed on the device (intra modes supplied): what the wavefront costs in mixed pictures
+for f in 0.05 0.1 0.25; do
+  python3 bench.py --intra-frac $f --steps 10 --no-cpu-baseline --no-host-inclusive > $out/bench_full_intra_$f.json 2> $out/bench_full_intra_$f.err
+done
 python3 bench.py --workload gop --steps 10 > $out/bench_gop.json 2> $out/bench_gop.err
 python3 bench.py --streams 1 --no-cpu-baseline > $out/bench_full_1lane.json 2> $out/bench_full_1lane.err
 python3 bench.py --batch 8 --no-cpu-baseline > $out/bench_full_batch8.json 2> $out/bench_full_batch8.err
