@@ -22,7 +22,7 @@ enum { K_PREP = 0, K_MC_LUMA, K_MC_CHROMA, K_ITX, K_DBK_VER, K_DBK_HOR, K_SAO, K
 const char* const kKernelNames[HMGPU_NUM_KERNELS] = {"prep", "mc_luma", "mc_chroma", "itx", "deblock_ver", "deblock_hor", "sao",
                                                      "extend_border", "h2d_stage", "intra", "filter_fused", ""};
 
-struct SliceCall { int first_ctu, num_ctus, slice_idx; bool intra, wp, cells, bi; };   // intra: the range holds intra CUs the device reconstructs;
+struct SliceCall { int first_ctu, num_ctus, slice_idx; bool intra, wp, cells, bi, islice; };   // intra: the range holds intra CUs the device reconstructs; islice: mostly intra CUs;
                                                                                     // cells: it holds PUs that cut an 8x8 luma tile (k_mc_cells.hip); bi: B slices
 
 struct Picture {
@@ -360,7 +360,7 @@ hmgpu_status ensure_refs_extended(hmgpu_ctx* c, const Batch& b, size_t call_idx)
 }
 
 // device work of one batch of slice calls (one call per picture): counters, prep, inverse transforms, MC (+ residual), intra
-hmgpu_status run_recon(hmgpu_ctx* c, const Batch& b, bool any_intra, bool any_wp, bool any_cells, bool any_bi) {
+hmgpu_status run_recon(hmgpu_ctx* c, const Batch& b, bool any_intra, bool any_wp, bool any_cells, bool any_bi, bool any_islice) {
   int max_ctus = 0;
   for (int i = 0; i < b.n; i++) max_ctus = std::max(max_ctus, b.num_ctus[i]);
   // 4:2:2 / 4:4:4: the chroma of every inter cell comes from the format-generic kernel, which reads the BlkInfo grid
@@ -438,7 +438,7 @@ hmgpu_status run_recon(hmgpu_ctx* c, const Batch& b, bool any_intra, bool any_wp
   // intra CUs predict from finished neighbours (inter ones included): after motion compensation and the inter residuals
   if (any_intra) {
     ProfScope ps(c, K_INTRA);
-    launch_intra(c->d_pics, b, c->d_ctu_order, c->num_ctus, c->stream);
+    launch_intra(c->d_pics, b, c->d_ctu_order, c->num_ctus, !any_islice, c->stream);
     if (c->fmt == 2) launch_intra_chroma_422(c->d_pics, b, c->stream);        // (k_intra leaves the chroma of 4:2:2 pictures to it)
     for (int i = 0; i < b.n; i++) if (std::find(c->intra_launched.begin(), c->intra_launched.end(), b.pic[i]) == c->intra_launched.end()) c->intra_launched.push_back(b.pic[i]);
   }
@@ -1258,9 +1258,16 @@ static hmgpu_status stage_inputs(hmgpu_ctx* c, hmgpu_pic cur, int32_t slice_idx,
       cells = ps[i] != HMGPU_SIZE_2Nx2N && ps[i] != HMGPU_SIZE_NONE && pm[i] != HMGPU_MODE_INTRA &&
               (dp[i] >= d8 || (dp[i] == d8 - 1 && ps[i] >= HMGPU_SIZE_2NxnU));
   }
-  bool any_b = false;
-  for (int si : slices) any_b |= p.slices[si].slice_type == HMGPU_B_SLICE;
-  SliceCall call = {first_ctu, num_ctus, slice_idx, has_intra, any_wp, cells, any_b};
+  bool any_b = false, any_i = false;
+  for (int si : slices) { any_b |= p.slices[si].slice_type == HMGPU_B_SLICE; any_i |= p.slices[si].slice_type == HMGPU_I_SLICE; }
+  // which intra kernel (launch_intra): I slices, or a range at least half intra, take the one that stages whole CTUs
+  if (has_intra && !any_i) {
+    const int8_t* pm = m->pred_mode + po;
+    size_t n_intra = 0;
+    for (size_t i = 0; i < pn; i++) n_intra += (size_t)(pm[i] == HMGPU_MODE_INTRA);
+    any_i = 2 * n_intra >= pn;
+  }
+  SliceCall call = {first_ctu, num_ctus, slice_idx, has_intra, any_wp, cells, any_b, any_i};
   p.calls.push_back(call);
   p.extended = false;
   *call_out = call;
@@ -1288,7 +1295,7 @@ static hmgpu_status stage_and_run(hmgpu_ctx* c, hmgpu_pic cur, int32_t slice_idx
   if (st != HMGPU_OK) return st;
   Batch b; memset(&b, 0, sizeof(b));
   b.n = 1; b.pic[0] = cur; b.first_ctu[0] = first_ctu; b.num_ctus[0] = num_ctus;
-  st = run_recon(c, b, call.intra, call.wp, call.cells, call.bi);
+  st = run_recon(c, b, call.intra, call.wp, call.cells, call.bi, call.islice);
   mark_use(c, b);
   return st;
 }
@@ -1453,7 +1460,7 @@ hmgpu_status hmgpu_decompress_pictures(hmgpu_ctx* c, int32_t n, const hmgpu_pict
   hipSetDevice(c->device);
   Batch b; memset(&b, 0, sizeof(b));
   b.n = n;
-  bool any_intra = false, any_wp = false, any_cells = false, any_bi = false;
+  bool any_intra = false, any_wp = false, any_cells = false, any_bi = false, any_islice = false;
   hmgpu_status st = HMGPU_OK;
   std::vector<std::vector<int>> all(n);
   {
@@ -1474,7 +1481,7 @@ hmgpu_status hmgpu_decompress_pictures(hmgpu_ctx* c, int32_t n, const hmgpu_pict
       if (st == HMGPU_OK) st = stage_inputs(c, j.pic, 0, all[i], wp, j.meta, j.coeffs, 0, c->num_ctus, c->copy_stream, &call);
       if (st != HMGPU_OK) break;
       b.pic[i] = j.pic; b.first_ctu[i] = 0; b.num_ctus[i] = c->num_ctus;
-      any_intra |= call.intra; any_wp |= call.wp; any_cells |= call.cells; any_bi |= call.bi;
+      any_intra |= call.intra; any_wp |= call.wp; any_cells |= call.cells; any_bi |= call.bi; any_islice |= call.islice;
     }
     if (st != HMGPU_OK) return st;
     c->copy_seq++;
@@ -1484,7 +1491,7 @@ hmgpu_status hmgpu_decompress_pictures(hmgpu_ctx* c, int32_t n, const hmgpu_pict
     HIP_TRY(c, hipStreamWaitEvent(c->stream, c->copy_ev[c->copy_seq % 8], 0));
   }
   for (int i = 0; i < n && st == HMGPU_OK; i++) st = extend_refs_of(c, jobs[i].pic, all[i]);
-  if (st == HMGPU_OK) st = run_recon(c, b, any_intra, any_wp, any_cells, any_bi);
+  if (st == HMGPU_OK) st = run_recon(c, b, any_intra, any_wp, any_cells, any_bi, any_islice);
   mark_use(c, b);
   return st;
 }
@@ -1596,14 +1603,14 @@ hmgpu_status hmgpu_replay_batch(hmgpu_ctx* c, const hmgpu_pic* pics, int32_t n, 
         for (size_t k = 0; k < ncalls && result == HMGPU_OK; k++) {
           Batch b; memset(&b, 0, sizeof(b));
           b.n = hi - lo;
-          bool any_intra = false, any_wp = false, any_cells = false, any_bi = false;
+          bool any_intra = false, any_wp = false, any_cells = false, any_bi = false, any_islice = false;
           for (int i = lo; i < hi; i++) {
             const SliceCall& sc = c->pics[pics[i]].calls[k];
             b.pic[i - lo] = pics[i]; b.first_ctu[i - lo] = sc.first_ctu; b.num_ctus[i - lo] = sc.num_ctus;
-            any_intra |= sc.intra; any_wp |= sc.wp; any_cells |= sc.cells; any_bi |= sc.bi;
+            any_intra |= sc.intra; any_wp |= sc.wp; any_cells |= sc.cells; any_bi |= sc.bi; any_islice |= sc.islice;
           }
           result = ensure_refs_extended(c, b, k);
-          if (result == HMGPU_OK) result = run_recon(c, b, any_intra, any_wp, any_cells, any_bi);
+          if (result == HMGPU_OK) result = run_recon(c, b, any_intra, any_wp, any_cells, any_bi, any_islice);
         }
       }
       if ((stages & 7) && result == HMGPU_OK) {

@@ -172,7 +172,7 @@ struct PicDev {
   int32_t fmt, csx, csy;           // chroma_format_idc (0 kept as 1) and the chroma subsampling it implies (getComponentScaleX / Y, TComChromaFormat.h:59-62);
                                    // 4:2:2 / 4:4:4 pictures take their chroma through the format-generic kernels of k_cfmt.hip
   const int8_t* ccp[2];            // cross-component prediction weights per partition (Cb, Cr), or null
-  uint8_t* ctu_intra;              // [num_ctus] 1 = the CTU holds intra CUs (written by k_prep)
+  uint8_t* ctu_intra;              // [num_ctus] number of the CTU's 8x8 areas that belong to intra CUs, 0 = none (written by k_prep)
   uint32_t* intra_done;            // [3][num_ctus]: the CTU's intra CUs of that component are reconstructed
   uint32_t* fault;                 // set by a kernel that gave up waiting (k_intra's bounded spin): checked by the host at hmgpu_sync
   int32_t debug_skip_ctu;          // test hook (hmgpu_debug_stall_intra): the intra workgroups of this CTU leave without reconstructing or publishing (-1: none)
@@ -288,7 +288,7 @@ void launch_checksum(const int16_t* src, int pitch, int step, int w, int h, int 
 struct Md5Batch { int32_t n, pad_; const uint8_t* msg[128]; unsigned long long bytes[128]; uint32_t* out[128]; };
 void launch_md5(const Md5Batch& job, hipStream_t s);
 void launch_crc(const int16_t* src, int pitch, int step, int w, int h, int bd, uint32_t* rows, uint32_t* out, hipStream_t s);
-void launch_intra(const PicDev* pics, const Batch& b, const int32_t* order, int num_ctus, hipStream_t s);
+void launch_intra(const PicDev* pics, const Batch& b, const int32_t* order, int num_ctus, bool lean, hipStream_t s);   // lean: no I slices in the call
 // chroma of 4:2:2 / 4:4:4 pictures (k_cfmt.hip): cross-component prediction on the residual tiles, motion compensation of every inter
 // cell, chroma deblocking on the format's own grid; fmt = chroma_format_idc
 void launch_ccp(const PicDev* pics, const Batch& b, int max_ctus, hipStream_t s);

@@ -28,11 +28,20 @@ namespace {
 
 
 // coherent accesses to the picture being reconstructed
+#if defined(INTRA_EXP) && (INTRA_EXP & 64)      // experiment (stale samples possible): plain loads
+__device__ inline uint32_t ld_coh(const uint32_t* p) { return *p; }
+#else
 __device__ inline uint32_t ld_coh(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+#endif
+#if defined(INTRA_EXP) && (INTRA_EXP & 32)      // experiment (other CTUs may read stale samples): plain stores
+__device__ inline void st_coh(uint32_t* p, uint32_t v) { *p = v; }
+__device__ inline void st_coh2(uint32_t* p, uint32_t v0, uint32_t v1) { *(unsigned long long*)p = (unsigned long long)v0 | ((unsigned long long)v1 << 32); }
+#else
 __device__ inline void st_coh(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ inline void st_coh2(uint32_t* p, uint32_t v0, uint32_t v1) {         // four samples, p 8-byte aligned
   __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), (unsigned long long)v0 | ((unsigned long long)v1 << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+#endif
 // chroma (hmgpu_dev.h "chroma planes": Cb and Cr alternate in one plane, another workgroup writes the other component of every dword): the
 // pairs of two positions in one 8-byte access, this component's halves out of them; stores go sample by sample
 __device__ inline uint32_t ld_coh_c2(const int16_t* pair, int half) {              // pair: 8-byte aligned, the (Cb, Cr) of two positions
@@ -40,6 +49,10 @@ __device__ inline uint32_t ld_coh_c2(const int16_t* pair, int half) {           
   return __builtin_amdgcn_perm((uint32_t)(w >> 32), (uint32_t)w, half ? 0x07060302u : 0x05040100u);
 }
 __device__ inline void st_coh_c2(int16_t* p, uint32_t v) {                         // two samples of one component, kCStep apart
+#if defined(INTRA_EXP) && (INTRA_EXP & 32)
+  *(uint16_t*)p = (uint16_t)(v & 0xffffu); *(uint16_t*)(p + kCStep) = (uint16_t)(v >> 16);
+  return;
+#endif
   __hip_atomic_store(reinterpret_cast<uint16_t*>(p), (uint16_t)(v & 0xffffu), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   __hip_atomic_store(reinterpret_cast<uint16_t*>(p + kCStep), (uint16_t)(v >> 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -49,22 +62,32 @@ __device__ inline int ld_sample(const int16_t* p) {
   return (int)(int16_t)((a & 2) ? (w >> 16) : (w & 0xffffu));
 }
 
+#ifndef INTRA_LEAN_OCC
+#define INTRA_LEAN_OCC 4                 // waves per SIMD the LEAN kernel is compiled for (128 VGPRs; it would take 130)
+#endif
+#ifndef INTRA_SPARSE_MAX
+#define INTRA_SPARSE_MAX 16              // in 64ths of a CTU's 8x8 areas: at most this share intra -> the CTU is not staged (k_intra)
+#endif
+
 struct IntraScratch {                    // what ONE TU in flight needs: one per wave
   int line[4 * 32 + 4];                  // reference line: [0,2N) left column bottom-up, [2N] corner, (2N,4N] row above
   int filt[4 * 32 + 4];                  // the same after smoothing
   int proj[3 * 32 + 4];                  // angular modes: main reference incl. the projected side samples, index k + 32
 };
-struct IntraLds {
+// LEAN: the kernel for calls whose CTUs are ALL taken as sparse (k_intra): no copy of the samples and of the residual at all
+template <bool LEAN>
+struct IntraLdsT {
+  static constexpr bool lean = LEAN;
   // the CTU's samples of this component (columns -2..63 at index x + 2) and the row above it (columns -2..127): references
   // inside the CTU never leave the chip, and a TU does not wait for its stores before the next one starts
-  __attribute__((aligned(4))) int16_t pix[64][66];
-  __attribute__((aligned(4))) int16_t top[132];
+  __attribute__((aligned(4))) int16_t pix[LEAN ? 1 : 64][66];
+  __attribute__((aligned(4))) int16_t top[LEAN ? 2 : 132];
   // the CTU's TComDataCU arrays, fetched once with one dword per lane and array (the walk over CUs and TUs is a serial chain:
   // every byte it had to wait for from global memory would cost a round trip)
   // the CTU's residual of this component -- de-quantisation and inverse transform do not depend on the neighbours: k_itx has done them
   // for every coded TU before this kernel starts --, as PicDev::resid lays it out (8x8 tiles of 128 bytes, rows in resid_slot order,
   // tile (tx, ty) of the CTU at index ty * tiles per CTU row + tx), staged while the block still waits for its neighbours
-  __attribute__((aligned(16))) int16_t res[64 * 64];
+  __attribute__((aligned(16))) int16_t res[LEAN ? 8 : 64 * 64];
   __attribute__((aligned(4))) uint8_t m_depth[256], m_part[256], m_pred[256], m_tr[256], m_qp[256], m_cbf[256], m_ts[256], m_dir[256], m_dirl[256], m_byp[256], m_pcm[256];
 };
 
@@ -73,6 +96,9 @@ struct TuCtx {
   int cip, slice, tile, nb_same;
   // picture constants, read from the descriptor ONCE per CTU (through `P` every use is a fresh scalar load: stores may alias the descriptor)
   int16_t* plane; int pitch, bd, log2ctu, rext, strong;
+  int cs, fmt;                                                    // chroma at half size (4:2:0 chroma); chroma_format_idc
+  int sparse;                                                     // the CTU has no LDS copy of its samples and residual (k_intra): both straight from the picture
+  const int16_t* resid; int rtw;                                  // this component's residual tiles, tiles per picture row
   unsigned long long am;                                          // availability of the TU's 4U + 1 reference units (IntraSched::avail)
   int sub_lo, sub_hi;                                             // available units form ONE run: substitution = clamping the line index to [sub_lo, sub_hi]; else sub_lo < 0                             // per-CTU constants: constrained intra pred, chroma QP offset, slice / tile index, neighbours in the same slice and tile
   int cx0, cy0;                                                   // CTU origin in component samples
@@ -109,41 +135,76 @@ __device__ inline int wave_sum(int v) {
 }
 
 // one TU: everything between "the neighbours are reconstructed" and "this TU is reconstructed"
-template <int LOG2N>
+template <int LOG2N, class IntraLds>
 __device__ __attribute__((always_inline)) inline void intra_tu(const PicDev& P, const TuCtx& t, IntraLds& L, IntraScratch& W) {
+  const bool sparse = IntraLds::lean || t.sparse;
   constexpr int N = 1 << LOG2N;
   const int lane = threadIdx.x & 63;
-  const int comp = t.comp, cs = comp ? P.csx : 0;           // (4:2:0: chroma at half size; 4:4:4: like luma.  4:2:2 does not come here)
+  const int comp = t.comp, cs = t.cs;                       // (4:2:0: chroma at half size; 4:4:4: like luma.  4:2:2 does not come here)
   const int bd = t.bd, maxv = (1 << bd) - 1;
   const int pitch = t.pitch;
   int16_t* plane = t.plane;
-  const int us = 4 >> cs, U = N / us;                      // samples per availability unit, units per TU side
+  const int us = 4 >> cs, lus = 2 - cs, U = N >> lus;      // samples per availability unit (and its log2), units per TU side
   const int corner = 2 * N, total = 4 * N + 1;
 
   const int n = lane & (N - 1);
   const bool active = lane < N;
 
+  // the residual of row n: from the CTU's staged tiles (D.); a sparse CTU has none: from the picture's tiles, on its way while the
+  // reference line is built (k_itx computed it in an earlier launch; RExt rotation / RDPCM included)
+  uint32_t res[N / 2];
+#pragma unroll
+  for (int i = 0; i < N / 2; i++) res[i] = 0;
+  if (sparse && t.cbf && active) {
+    const int ry = t.y0 + n;
+    const int16_t* r = t.resid + ((size_t)(ry >> 3) * t.rtw + (t.x0 >> 3)) * 64 + resid_slot(ry) * 8;
+    if constexpr (N == 4) { const u32x2 a = ldg2(r + (t.x0 & 4)); res[0] = a.x; res[1] = a.y; }
+    else {
+#pragma unroll
+      for (int i = 0; i < N / 8; i++) { const u32x4 a = ldg4(r + i * 64); res[4 * i] = a.x; res[4 * i + 1] = a.y; res[4 * i + 2] = a.z; res[4 * i + 3] = a.w; }
+    }
+  }
+
   // ---- A. the reference line.  Availability per unit -- units [0, 2U) left column bottom-up, 2U the corner, (2U, 4U] the row above -- is a
   // property of the TU's position: worked out for the whole list when the CTU starts (IntraSched::avail), not on the serial chain
   const unsigned long long am = t.am;
+  // the sample line[i] takes: its position in the plane (component samples); false: nothing is available (the default value)
+  auto ref_src = [&](int i, int& sx, int& sy) {
+    if (!am) return false;
+    const int u = i < corner ? i >> lus : (i == corner ? 2 * U : 2 * U + 1 + ((i - corner - 1) >> lus));
+    int src = i;
+    if (t.sub_lo >= 0) src = min(max(i, t.sub_lo), t.sub_hi);      // one run of available units (all available included): padding is a clamp
+    else if (!((am >> u) & 1)) {
+      const unsigned long long lower = am & ((1ull << u) - 1);
+      int j, last;
+      if (lower) { j = 63 - __builtin_clzll(lower); last = 1; } else { j = __builtin_ctzll(am); last = 0; }
+      const int first_of = j < 2 * U ? j << lus : (j == 2 * U ? corner : corner + 1 + ((j - 2 * U - 1) << lus));
+      src = first_of + ((last && j != 2 * U) ? us - 1 : 0);
+    }
+    if (src < corner) { sx = t.x0 - 1; sy = t.y0 + (corner - 1 - src); }
+    else if (src == corner) { sx = t.x0 - 1; sy = t.y0 - 1; }
+    else { sx = t.x0 + (src - corner - 1); sy = t.y0 - 1; }
+    return true;
+  };
+  if (sparse) {
+    // no copy of the CTU in LDS: every sample with a coherent load from the picture, all of a lane's loads in flight together
+    constexpr int K = (4 * N + 1 + 63) / 64;
+    int v[K];
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+      const int i = lane + 64 * k;
+      int sx, sy;
+      v[k] = 1 << (bd - 1);
+      if (i < total && ref_src(i, sx, sy)) v[k] = ld_sample(plane + (ptrdiff_t)sy * pitch + (comp ? kCStep : 1) * sx);
+    }
+#pragma unroll
+    for (int k = 0; k < K; k++) if (lane + 64 * k < total) W.line[lane + 64 * k] = v[k];
+  } else
   for (int i = lane; i < total; i += 64) {
     int v = 1 << (bd - 1);
-    if (am) {
-      const int u = i < corner ? i / us : (i == corner ? 2 * U : 2 * U + 1 + (i - corner - 1) / us);
-      int src = i;
-      if (t.sub_lo >= 0) src = min(max(i, t.sub_lo), t.sub_hi);      // one run of available units (all available included): padding is a clamp
-      else if (!((am >> u) & 1)) {
-        const unsigned long long lower = am & ((1ull << u) - 1);
-        int j, last;
-        if (lower) { j = 63 - __builtin_clzll(lower); last = 1; } else { j = __builtin_ctzll(am); last = 0; }
-        const int first_of = j < 2 * U ? j * us : (j == 2 * U ? corner : corner + 1 + (j - 2 * U - 1) * us);
-        src = first_of + ((last && j != 2 * U) ? us - 1 : 0);
-      }
+    int sx, sy;
+    if (ref_src(i, sx, sy)) {
       // position of the source sample relative to the CTU: row -1 lives in top[], everything else in pix[]
-      int sx, sy;
-      if (src < corner) { sx = t.x0 - 1; sy = t.y0 + (corner - 1 - src); }
-      else if (src == corner) { sx = t.x0 - 1; sy = t.y0 - 1; }
-      else { sx = t.x0 + (src - corner - 1); sy = t.y0 - 1; }
       sx -= t.cx0; sy -= t.cy0;
       v = sy < 0 ? L.top[sx + 2] : L.pix[sy][sx + 2];
     }
@@ -155,7 +216,7 @@ __device__ __attribute__((always_inline)) inline void intra_tu(const PicDev& P, 
   // the modes near horizontal / vertical) and predict straight from line[]: one LDS round trip less on the serial chain
   const int thr = LOG2N == 2 ? 10 : LOG2N == 3 ? 7 : LOG2N == 4 ? 1 : 0;
   // (filterIntraReferenceSamples, TComChromaFormat.h:150-153: luma, and chroma where it is not subsampled)
-  const bool filt = (comp == 0 || P.fmt == 3) && t.mode != 1 && min(abs(t.mode - 10), abs(t.mode - 26)) > thr && !(t.rext & HMGPU_REXT_INTRA_SMOOTHING_DISABLED);
+  const bool filt = (comp == 0 || t.fmt == 3) && t.mode != 1 && min(abs(t.mode - 10), abs(t.mode - 26)) > thr && !(t.rext & HMGPU_REXT_INTRA_SMOOTHING_DISABLED);
 #if defined(INTRA_EXP) && (INTRA_EXP & 2)      // experiment: no smoothing pass
   if (false) {
 #else
@@ -295,14 +356,11 @@ __device__ __attribute__((always_inline)) inline void intra_tu(const PicDev& P, 
     }
   }
 
-  // ---- D. residual of row n: from the CTU's staged tiles (k_itx computed it; RExt rotation / RDPCM included)
-  uint32_t res[N / 2];
-#pragma unroll
-  for (int i = 0; i < N / 2; i++) res[i] = 0;
+  // ---- D. residual of row n: from the CTU's staged tiles
 #if defined(INTRA_EXP) && (INTRA_EXP & 1)      // experiment: no residual (wrong samples)
   if (false) {
 #else
-  if (t.cbf && active) {
+  if (!sparse && t.cbf && active) {
 #endif
     const int rx = t.x0 - t.cx0, ry = t.y0 - t.cy0 + n;                    // inside the CTU, component samples
     const int tpr = ((1 << t.log2ctu) >> cs) >> 3;                          // tiles per CTU row
@@ -327,14 +385,17 @@ __device__ __attribute__((always_inline)) inline void intra_tu(const PicDev& P, 
     for (int x = 0; x < N; x += 4) {
       const uint32_t v0 = pk_clip_u(pk_add_sat(cvt_pk_sat(p[x], p[x + 1]), res[x / 2]), maxv2);
       const uint32_t v1 = pk_clip_u(pk_add_sat(cvt_pk_sat(p[x + 2], p[x + 3]), res[x / 2 + 1]), maxv2);
-      lrow[x / 2] = v0; lrow[x / 2 + 1] = v1;
+      if (!sparse) { lrow[x / 2] = v0; lrow[x / 2 + 1] = v1; }
       if (comp == 0) st_coh2(row + x / 2, v0, v1);
       else { st_coh_c2(prow + kCStep * x, v0); st_coh_c2(prow + kCStep * (x + 2), v1); }
     }
   }
+  // (sparse CTU: whoever predicts from this TU next -- this wave or another -- loads its samples from the picture: acknowledged first)
+  if (sparse) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   wave_lds_sync();
 }
 
+template <class IntraLds>
 __device__ __attribute__((always_inline)) inline void intra_tu_any(const PicDev& P, const TuCtx& t, IntraLds& L, IntraScratch& W) {
   switch (t.log2n) {
     case 2: intra_tu<2>(P, t, L, W); break;
@@ -346,11 +407,12 @@ __device__ __attribute__((always_inline)) inline void intra_tu_any(const PicDev&
 
 // what a CTU can fetch before its neighbours are finished: its TComDataCU arrays and its own samples (inter CUs are final --
 // written by earlier launches --, intra ones get overwritten below)
-__device__ __attribute__((always_inline)) inline void intra_stage(const PicDev& P, int comp, int ctu, IntraLds& L) {
+template <class IntraLds>
+__device__ __attribute__((always_inline)) inline void intra_stage(const PicDev& P, int comp, int ctu, IntraLds& L, bool pix) {
   const int parts = P.parts;
   const size_t base = (size_t)ctu * parts;
   const int ctu_x = (ctu % P.ctus_w) << P.log2ctu, ctu_y = (ctu / P.ctus_w) << P.log2ctu;
-  const int cs = comp ? P.csx : 0;
+  const int cs = (comp && P.csx) ? 1 : 0;
   const int lane = threadIdx.x & 63;
   if (threadIdx.x < 64 && 4 * lane < parts) {
     const size_t o = base + 4 * lane;
@@ -361,7 +423,7 @@ __device__ __attribute__((always_inline)) inline void intra_stage(const PicDev& 
     put(L.m_depth, a0); put(L.m_part, a1); put(L.m_pred, a2); put(L.m_tr, a3); put(L.m_qp, a4); put(L.m_cbf, a5); put(L.m_ts, a6);
     put(L.m_dir, a7); put(L.m_dirl, a8); put(L.m_byp, a9); put(L.m_pcm, a10);
   }
-  {
+  if (pix) {
     const int S = (1 << P.log2ctu) >> cs;                   // CTU size in samples of this component
     // the interior was written by the MC / residual kernels (earlier launches): plain 16-byte loads
     if (comp == 0) {
@@ -414,7 +476,7 @@ struct IntraSched {
   uint8_t member[64][4];             // list entries of the four 4x4 luma TUs of every 8x8 area (kinds 2 and 3), by z >> 2 and z & 3
   int32_t n_tus, running;            // list length; waves inside a TU right now
 #ifdef INTRA_TIMING                  // diagnostic build: where the time of a CTU goes (printed by k_intra for one CTU row)
-  unsigned long long t_tu, t_claim, t_post, t_idle, t_first, t_last;
+  unsigned long long t_tu, t_claim, t_post, t_idle, t_first, t_last, t_a, t_b, t_c;
   uint32_t n_run, n_idle;
 #endif
 };
@@ -459,6 +521,7 @@ __device__ __attribute__((always_inline)) inline void poll_neighbours(const PicD
 // (the masks of what has been fetched are shared by the waves of the workgroup: a wave with nothing to run fetches what has become final
 // next door, so that the TUs along the CTU's left and top border find their reference samples in LDS)
 // org: the CTU's first sample of this component in the picture, pitch: the plane's
+template <class IntraLds>
 __device__ __attribute__((always_inline)) inline void fetch_border(const int16_t* org, int pitch, int comp, int cs, uint32_t need_col, uint64_t need_row, IntraSched& Q, IntraLds& L) {
   const int lane = threadIdx.x & 63, us = 4 >> cs;
   const uint32_t mc = need_col & ~Q.got[0];
@@ -479,7 +542,7 @@ __device__ __attribute__((always_inline)) inline void fetch_border(const int16_t
     const int dwords = 1 + (33 * us) / 2;
     for (int d = lane; d < dwords && d < 66; d += 64) {
       const int col = 2 * d - 2;                            // first column of the dword
-      const int c = col < 0 ? -1 : col / us;
+      const int c = col < 0 ? -1 : col >> (2 - cs);
       if ((mr >> (c + 1)) & 1) reinterpret_cast<uint32_t*>(L.top)[d] = comp == 0 ? ld_coh(reinterpret_cast<const uint32_t*>(org - pitch - 2) + d)
                                                                                     : ld_coh_c2(org - pitch + 2 * kCStep * (d - 1), comp - 1);
     }
@@ -496,10 +559,12 @@ __device__ __attribute__((always_inline)) inline void fetch_border(const int16_t
 // that is ready and that nobody has taken (an atomic AND on the pending mask), runs it and marks its units final (atomic ORs).  TUs that
 // do not depend on each other -- the next ones along an anti-diagonal of the CTU -- run side by side; the CTU's samples, the done masks
 // and the list are shared in LDS, the reference line / transform scratch of a TU in flight is the wave's own (IntraScratch).
-__device__ __attribute__((always_inline)) inline void intra_ctu(const PicDev& P, int comp, int ctu, IntraLds& L, IntraSched& Q, IntraScratch& W, Neighbours& nb) {
+template <class IntraLds>
+__device__ __attribute__((always_inline)) inline void intra_ctu(const PicDev& P, int comp, int ctu, bool sparse_ctu, IntraLds& L, IntraSched& Q, IntraScratch& W, Neighbours& nb) {
+  const bool sparse = IntraLds::lean || sparse_ctu;
   const int parts = P.parts, pw = P.pw;
   const int ctu_x = (ctu % P.ctus_w) << P.log2ctu, ctu_y = (ctu / P.ctus_w) << P.log2ctu;
-  const int cs = comp ? P.csx : 0;
+  const int cs = (comp && P.csx) ? 1 : 0;
   const int lane = threadIdx.x & 63;
   const int slice = ldg(P.slice_idx + ctu), tile = ldg(P.tile_idx + ctu);
   const SliceDev& sd = P.slices[slice];
@@ -515,8 +580,10 @@ __device__ __attribute__((always_inline)) inline void intra_ctu(const PicDev& P,
       if (nbc[k] >= 0 && ldg(P.slice_idx + nbc[k]) == slice && ldg(P.tile_idx + nbc[k]) == tile) nb_same |= 1 << k;
   }
   // the picture constants the TU chain needs, out of the descriptor once
-  const int h_bd = P.bd[comp], h_pitch = P.pitch[comp], h_log2ctu = P.log2ctu, h_rext = P.range_ext, h_strong = P.strong_intra_smoothing;
+  const int h_bd = P.bd[comp], h_pitch = P.pitch[comp], h_log2ctu = P.log2ctu, h_rext = P.range_ext, h_strong = P.strong_intra_smoothing, h_fmt = P.fmt;
   int16_t* const h_plane = P.rec[comp];
+  const int16_t* const h_resid = P.resid[comp];
+  const int h_rtw = (P.grid_w / 2) >> cs;
   // the CTU's first sample in the plane; chroma: its first (Cb, Cr) pair in the plane of both components (fetch_border reads whole pairs)
   const int16_t* const org = comp == 0 ? h_plane + (ptrdiff_t)ctu_y * h_pitch + ctu_x : P.rec[1] + (ptrdiff_t)(ctu_y >> cs) * h_pitch + kCStep * (ctu_x >> cs);
   const int wv = threadIdx.x >> 6;
@@ -532,53 +599,120 @@ __device__ __attribute__((always_inline)) inline void intra_ctu(const PicDev& P,
     x4 = zscan_x(e.z); y4 = zscan_y(e.z);
     U = e.kind ? (1 << (e.log2n - 2)) : max(1, ((1 << e.log2n) << cs) >> 2);
   };
+#if defined(INTRA_STOP) && INTRA_STOP == 6
+  if (IntraLds::lean && pw > 0 && nb_same >= 0 && h_plane != nullptr && h_resid != nullptr) return;
+#endif
   if (wv == 0) {
-  // ---- 1. the list, in raster order of the TU origins (= the priority they run in), lane-parallel over the 4x4 units of the CTU: a unit
-  // starts a TU when its z index is aligned to the TU's size.  Units that are not reconstructed here (inter CUs, outside the picture)
-  // are final from the start.
+  // ---- 1. the list, in raster order of the TU origins (= the priority they run in), one lane per 8x8 AREA of the CTU (a coding unit is at
+  // least that large: prediction mode, transform depth and PCM flag are the same in the area's four partitions).  An area starts a TU of
+  // 8x8 or more when its z index is aligned to the TU's size, or holds the four 4x4 luma TUs of an 8x8 CU (kinds 2, 3, 3, 3 -- with
+  // subsampled chroma their one 4x4 chroma TU).  Areas that are not reconstructed here (inter CUs, outside the picture) are final from the
+  // start.  (Round 4: this walk was lane-parallel over the 256 4x4 units, four rounds of two passes -- 3-4 of a sparse CTU's ~15 us.)
   int n_tus = 0;
-  const int units = pw * pw, log2pw = P.log2ctu - 2;
-  for (int base = 0; base < units; base += 64) {
-    const int u = base + lane;
+  {
+    const int paw = pw >> 1, log2paw = P.log2ctu - 3, areas = paw * paw;       // areas per CTU row (8, 4, 2)
+    const int pic_w = P.width, pic_h = P.height;
+    const bool has_pcm = P.pcm[comp] != nullptr;
     bool preset[2] = {false, false};                          // raster pass (x fastest) and transposed pass (y fastest): final from the start
     TuRun e = {0, 0, 0, 0};
-    bool origin = false;
+    int cnt = 0;                                              // list entries of this area: 0, 1 or 4
 #pragma unroll
     for (int pass = 0; pass < 2; pass++) {
-      const int a0 = u & (pw - 1), a1 = u >> log2pw;
-      const int x4 = pass ? a1 : a0, y4 = pass ? a0 : a1;
-      if (u >= units) continue;
-      const int z = z_of(x4, y4);
-      const int px = ctu_x + 4 * x4, py = ctu_y + 4 * y4;
-      if (px >= P.width || py >= P.height || (int8_t)L.m_part[z] == HMGPU_SIZE_NONE || (int8_t)L.m_pred[z] != HMGPU_MODE_INTRA) { preset[pass] = true; continue; }
+      const int a0 = lane & (paw - 1), a1 = lane >> log2paw;
+      const int ax = pass ? a1 : a0, ay = pass ? a0 : a1;
+      if (lane >= areas) continue;
+      const int z = z_of(2 * ax, 2 * ay);
+      if (ctu_x + 8 * ax >= pic_w || ctu_y + 8 * ay >= pic_h || (int8_t)L.m_part[z] == HMGPU_SIZE_NONE || (int8_t)L.m_pred[z] != HMGPU_MODE_INTRA) { preset[pass] = true; continue; }
       if (pass) continue;
       const int depth = L.m_depth[z];
       const int cu_parts = parts >> (2 * depth), log2cu = P.log2ctu - depth;
       const int z_cu = z & ~(cu_parts - 1);
-      if (L.m_pcm[z_cu] && P.pcm[comp] != nullptr) {
-        origin = z == z_cu;
+      if (L.m_pcm[z_cu] && has_pcm) {
+        cnt = z == z_cu;
         e = TuRun{(uint8_t)z, (uint8_t)z_cu, (uint8_t)log2cu, 1};
       } else {
         const int log2tu = log2cu - L.m_tr[z];
-        const int tu_parts = 1 << (2 * (log2tu - 2));
-        // subsampled chroma: four 4x4 luma TUs share one 4x4 chroma TU, with the first of them (TComTU.cpp:141-171); 4:4:4 chroma: the luma TUs' twins
-        origin = (z & (tu_parts - 1)) == 0 && (cs == 0 || log2tu >= 3 || (z & 3) == 0);
-        e = TuRun{(uint8_t)z, (uint8_t)z_cu, (uint8_t)(cs == 0 ? log2tu : max(2, log2tu - 1)), (uint8_t)((cs == 0 && log2tu == 2) ? ((z & 3) ? 3 : 2) : 0)};
+        if (log2tu >= 3) {
+          cnt = (z & ((1 << (2 * (log2tu - 2))) - 1)) == 0;
+          e = TuRun{(uint8_t)z, (uint8_t)z_cu, (uint8_t)(log2tu - cs), 0};
+        } else if (cs) {
+          // subsampled chroma: the four 4x4 luma TUs share one 4x4 chroma TU, with the first of them (TComTU.cpp:141-171)
+          cnt = 1;
+          e = TuRun{(uint8_t)z, (uint8_t)z_cu, 2, 0};
+        } else {
+          cnt = 4;                                            // (4:4:4 chroma: the luma TUs' twins)
+          e = TuRun{(uint8_t)z, (uint8_t)z_cu, 2, 2};
+        }
       }
     }
-    // rows / columns of the done masks covered by this group of 64 units
+#if defined(INTRA_STOP) && INTRA_STOP == 7
+    if (IntraLds::lean && pw > 0) { if (cnt) Q.tu[lane] = e; return; }
+#endif
+    // the done masks per row / column of UNITS: an area's bit for both of its units
     const unsigned long long m0 = __builtin_amdgcn_ballot_w64(preset[0]), m1 = __builtin_amdgcn_ballot_w64(preset[1]);
-    const int per = 64 >> log2pw;                              // rows (columns) per group
-    if (lane < per && (base >> log2pw) + lane < pw) {
-      Q.done_r[(base >> log2pw) + lane] = (uint32_t)((m0 >> (lane * pw)) & ((1u << pw) - 1u));
-      Q.done_c[(base >> log2pw) + lane] = (uint32_t)((m1 >> (lane * pw)) & ((1u << pw) - 1u));
+    if (lane < pw) {
+      auto twice = [](uint32_t x) { x = (x | (x << 4)) & 0x0f0fu; x = (x | (x << 2)) & 0x3333u; x = (x | (x << 1)) & 0x5555u; return x | (x << 1); };
+      const int sh = (lane >> 1) * paw;
+      Q.done_r[lane] = twice((uint32_t)(m0 >> sh) & ((1u << paw) - 1u));
+      Q.done_c[lane] = twice((uint32_t)(m1 >> sh) & ((1u << paw) - 1u));
     }
-    const unsigned long long mo = __builtin_amdgcn_ballot_w64(origin);
-    if (origin) Q.tu[n_tus + __popcll(mo & ((1ull << lane) - 1ull))] = e;
-    n_tus += __popcll(mo);
+    const unsigned long long c1 = __builtin_amdgcn_ballot_w64(cnt == 1), c4 = __builtin_amdgcn_ballot_w64(cnt == 4);
+    const unsigned long long below = (1ull << lane) - 1ull;
+    const int off = __popcll(c1 & below) + 4 * __popcll(c4 & below);
+    if (cnt) Q.tu[off] = e;
+    if (cnt == 4) {
+#pragma unroll
+      for (int j = 1; j < 4; j++) Q.tu[off + j] = TuRun{(uint8_t)(e.z + j), e.z_cu, 2, 3};
+    }
+    n_tus = __popcll(c1) + 4 * __popcll(c4);
   }
   wave_lds_sync();
-  // ---- 2. what each TU depends on (lane-parallel over the list)
+#if defined(INTRA_STOP) && INTRA_STOP == 4     // (LEAN kernel only: one wave, nobody is left at the barrier)
+  if (IntraLds::lean && pw > 0) return;
+#endif
+  // ---- 2. what each TU depends on.  A short list (scattered intra CUs in a P picture, a CTU of a few large TUs): the TUs one after the other, the
+  // lanes over the units of each -- a 32x32 TU has 33 reference units and as many column / row units to test, which one lane walking them
+  // alone made the longest part of a sparse CTU's life (6-8 of ~18 us, INTRA_TIMING).  A long list: the lanes over the TUs, as before.
+  if (n_tus <= 12) {
+    for (int i = 0; i < n_tus; i++) {
+      const TuRun e = __builtin_bit_cast(TuRun, (uint32_t)__builtin_amdgcn_readfirstlane((int)__builtin_bit_cast(uint32_t, Q.tu[i])));
+      int x4, y4, U;
+      footprint(e, x4, y4, U);
+      if (lane == 0 && e.kind >= 2) Q.member[e.z >> 2][e.z & 3] = (uint8_t)i;
+      bool colbit = false, rowbit = false, ab = false;
+      if (e.kind == 0 || e.kind == 2) {
+        const int Un = e.kind == 2 ? 2 : U;
+        const int y = lane, c = lane - 1;                      // lane y: unit (x4 - 1, y) of the column; lane c + 1: unit (c, y4 - 1) of the row
+        colbit = y < pw && y >= (y4 > 0 ? y4 - 1 : 0) && y < y4 + 2 * Un && (x4 == 0 || z_of(x4 - 1, y) < e.z);
+        rowbit = y4 == 0 ? (c >= x4 - 1 && c < x4 + 2 * Un) : (c >= x4 && c < min(pw, x4 + 2 * Un) && z_of(c, y4 - 1) < e.z);
+      }
+      if (e.kind != 1 && lane <= 4 * U) {
+        const int lx = ctu_x + 4 * x4, ly = ctu_y + 4 * y4, u = lane;
+        int px, py;
+        if (u < 2 * U) { px = lx - 4; py = ly + 4 * (2 * U - 1 - u); }
+        else if (u == 2 * U) { px = lx - 4; py = ly - 4; }
+        else { px = lx + 4 * (u - 2 * U - 1); py = ly - 4; }
+#if defined(INTRA_EXP) && (INTRA_EXP & 4)
+        ab = px >= 0 && py >= 0;
+#else
+        ab = intra_avail(P, ctu, e.z, px, py, cip != 0, (unsigned)nb_same, L.m_pred);
+#endif
+      }
+      const uint32_t nc = (uint32_t)__builtin_amdgcn_ballot_w64(colbit);
+      const uint64_t nr = __builtin_amdgcn_ballot_w64(rowbit), am = __builtin_amdgcn_ballot_w64(ab);
+      uint32_t cl = 0xffffffffu;
+      if (am != 0) {
+        const int j0 = __builtin_ctzll(am), j1 = 63 - __builtin_clzll(am);
+        if ((am >> j0) == (2ull << (j1 - j0)) - 1ull) {
+          const int us = 4 >> cs, nn = U * us, corner = 2 * nn;
+          const int lo = j0 < 2 * U ? j0 * us : (j0 == 2 * U ? corner : corner + 1 + (j0 - 2 * U - 1) * us);
+          const int hi = j1 < 2 * U ? j1 * us + us - 1 : (j1 == 2 * U ? corner : corner + 1 + (j1 - 2 * U - 1) * us + us - 1);
+          cl = (uint32_t)lo | ((uint32_t)hi << 16);
+        }
+      }
+      if (lane == 0) { Q.need_col[i] = nc; Q.need_row[i] = nr; Q.avail[i] = am; Q.clampi[i] = cl; }
+    }
+  } else
   for (int i = lane; i < n_tus; i += 64) {
     const TuRun e = Q.tu[i];
     int x4, y4, U;
@@ -628,6 +762,9 @@ __device__ __attribute__((always_inline)) inline void intra_ctu(const PicDev& P,
     Q.clampi[i] = cl;
   }
   wave_lds_sync();
+#if defined(INTRA_STOP) && INTRA_STOP == 5
+  if (IntraLds::lean && pw > 0) return;
+#endif
     // ---- 3. what is final before anything ran (the neighbours may pass inter areas at once), the pending mask
     if (lane < 8) Q.pend[lane] = n_tus >= 32 * (lane + 1) ? 0xffffffffu : (n_tus > 32 * lane ? (1u << (n_tus - 32 * lane)) - 1u : 0u);
     if (lane == 0) { Q.n_tus = n_tus; Q.running = 0; }
@@ -638,8 +775,14 @@ __device__ __attribute__((always_inline)) inline void intra_ctu(const PicDev& P,
     const uint32_t word0 = Q.done_c[pw - 1] | (Q.done_r[pw - 1] << 16);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (lane == 0 && word0) __hip_atomic_fetch_or(nb.prog + ctu, word0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#ifdef INTRA_TIMING
+    if (lane == 0) Q.t_c = wall_clock64();
+#endif
   }
   __syncthreads();
+#if defined(INTRA_STOP) && INTRA_STOP == 3
+  if (pw > 0) return;
+#endif
   const int n_tus = Q.n_tus;
   uint32_t spins = 0;
 #ifdef INTRA_TIMING
@@ -648,7 +791,7 @@ __device__ __attribute__((always_inline)) inline void intra_ctu(const PicDev& P,
 #else
 #define TM_ADD(field)
 #endif
-  if (wv == (int)(blockDim.x >> 6) - 1) fetch_border(org, h_pitch, comp, cs, nb.ext_col, nb.ext_row, Q, L);   // what is final next door already
+  if (!sparse && wv == (int)(blockDim.x >> 6) - 1) fetch_border(org, h_pitch, comp, cs, nb.ext_col, nb.ext_row, Q, L);   // what is final next door already
   for (;;) {
     // the scheduler words in LDS (pend, done_c, done_r, got) are updated by the other waves with atomics: read them afresh in every round
     asm volatile("" ::: "memory");
@@ -684,7 +827,7 @@ __device__ __attribute__((always_inline)) inline void intra_ctu(const PicDev& P,
       if (__hip_atomic_load(&Q.running, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0 || (spins & 15) == 0) {
         if (spins > (1u << 22)) { if (lane == 0) atomicOr(P.fault, 1u); nb.broken = true; }
         poll_neighbours(P, nb, pw);
-        fetch_border(org, h_pitch, comp, cs, nb.ext_col, nb.ext_row, Q, L);   // whatever has become final next door
+        if (!sparse) fetch_border(org, h_pitch, comp, cs, nb.ext_col, nb.ext_row, Q, L);   // whatever has become final next door
       }
       TM_ADD(t_idle)
       continue;
@@ -729,11 +872,12 @@ __device__ __attribute__((always_inline)) inline void intra_ctu(const PicDev& P,
         t.cx0 = ctu_x >> cs; t.cy0 = ctu_y >> cs;
         t.x0 = (ctu_x + 4 * xs) >> cs; t.y0 = (ctu_y + 4 * ys) >> cs;
         t.log2n = e.log2n;
-        t.plane = h_plane; t.pitch = h_pitch; t.bd = h_bd; t.log2ctu = h_log2ctu; t.rext = h_rext; t.strong = h_strong;
+        t.plane = h_plane; t.pitch = h_pitch; t.bd = h_bd; t.log2ctu = h_log2ctu; t.rext = h_rext; t.strong = h_strong; t.cs = cs; t.fmt = h_fmt;
+        t.sparse = sparse; t.resid = h_resid; t.rtw = h_rtw;
         int mode = uni(L.m_dir[zs]);
         // DM_CHROMA_IDX (TDecCu.cpp:523-524, getChromasCorrespondingPULumaIdx): the luma mode of the CU's first partition (z: the CU's
         // origin); 4:4:4: of the block's own partition
-        if (comp && mode == 36) mode = uni(L.m_dirl[P.fmt == 3 ? zs : z]);
+        if (comp && mode == 36) mode = uni(L.m_dirl[h_fmt == 3 ? zs : z]);
         t.mode = mode;
         {
           const uint64_t a = Q.avail[idx];
@@ -742,11 +886,11 @@ __device__ __attribute__((always_inline)) inline void intra_ctu(const PicDev& P,
           t.sub_lo = cl == 0xffffffffu ? -1 : (int)(cl & 0xffff); t.sub_hi = (int)(cl >> 16);
         }
         // (4:4:4: the tiles hold zeros where nothing is coded and the cross-component term where only that is: always added)
-        t.cbf = (comp && P.fmt != 1) ? 1 : (uni(L.m_cbf[zs]) >> tr) & 1;
+        t.cbf = (comp && h_fmt != 1) ? 1 : (uni(L.m_cbf[zs]) >> tr) & 1;
         t.bypass = uni(L.m_byp[zs]);
         intra_tu_any(P, t, L, W);
       };
-      if (x4 == 0 || y4 == 0)                                   // (a TU inside the CTU reads nothing from next door; a group: what an 8x8 TU would read)
+      if (!sparse && (x4 == 0 || y4 == 0))                      // (a TU inside the CTU reads nothing from next door; a group: what an 8x8 TU would read)
         fetch_border(org, h_pitch, comp, cs, x4 == 0 ? Q.need_col[i] : 0u, y4 == 0 ? Q.need_row[i] : 0ull, Q, L);
 #ifdef INTRA_TIMING
       if (lane == 0) { atomicMin(&Q.t_first, wall_clock64()); atomicAdd(&Q.n_run, 1u); }
@@ -763,6 +907,7 @@ __device__ __attribute__((always_inline)) inline void intra_ctu(const PicDev& P,
       }
       TM_ADD(t_tu)
     }
+    if (sparse) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (sparse CTU: the samples are in the picture, where the CTU's other TUs read them)
     wave_lds_sync();                                         // the TU's samples are in the CTU copy before its units count as final
     mark_done(x4, y4, U);
     if (lane == 0) atomicSub(&Q.running, 1);
@@ -788,9 +933,10 @@ __device__ __attribute__((always_inline)) inline void intra_ctu(const PicDev& P,
 // degenerates into the classic CTU wavefront.  `order` lists the CTUs by anti-diagonal (2*row + column): all four
 // neighbours lie on earlier diagonals, so every block a block can wait for has a smaller linear index and was dispatched
 // before it (no deadlock however few blocks are resident), and the blocks resident at any time are the wavefront itself.
-template <int WAVES>                     // waves per CTU and component: they run the CTU's ready TUs side by side (intra_ctu)
-__global__ void __launch_bounds__(64 * WAVES) k_intra(const PicDev* __restrict__ pics, Batch b, const int32_t* __restrict__ order) {
-  __shared__ IntraLds L;
+// LEAN: every CTU on the unstaged path (below), in a third of the LDS: the variant for calls without I slices
+template <int WAVES, bool LEAN>          // waves per CTU and component: they run the CTU's ready TUs side by side (intra_ctu)
+__global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(LEAN ? INTRA_LEAN_OCC : 1))) k_intra(const PicDev* __restrict__ pics, Batch b, const int32_t* __restrict__ order) {
+  __shared__ IntraLdsT<LEAN> L;
   __shared__ IntraSched Q;
   __shared__ IntraScratch W[WAVES];
   const int slot = blockIdx.x / 3, comp = blockIdx.x % 3, ctu = ldg(order + blockIdx.y);
@@ -798,6 +944,9 @@ __global__ void __launch_bounds__(64 * WAVES) k_intra(const PicDev* __restrict__
   const int first = b.first_ctu[slot], last = first + b.num_ctus[slot] - 1;
   if (!P.has_intra_dir || ctu < first || ctu > last || !ldg(P.ctu_intra + ctu) || (comp && (P.mono || P.fmt == 2))) return;      // (4:2:2 chroma: k_intra_chroma_422)
   if (ctu == P.debug_skip_ctu) return;                         // (test hook: its neighbours run into the bounded wait)
+#if defined(INTRA_EXP) && (INTRA_EXP & 16)    // experiment (no chroma): the luma wavefront alone
+  if (comp) return;
+#endif
   uint32_t* done = P.intra_done + (size_t)comp * P.num_ctus;
   const int cx = ctu % P.ctus_w, cy = ctu / P.ctus_w;
 #ifdef INTRA_TIMING
@@ -824,10 +973,14 @@ __global__ void __launch_bounds__(64 * WAVES) k_intra(const PicDev* __restrict__
   };
   // the residual of this CTU does not depend on anybody: on its way into LDS while the neighbours finish (all threads of the workgroup
   // stage; the barrier in front of the TU loop orders it).  Tiles of TUs that are not coded hold stale data and are never read.
+  // A CTU with few intra CUs (scattered ones in a P picture) does not stage at all: 16 KB of samples and residual per CTU and component
+  // for a handful of TUs was most of what such a picture's intra CUs cost.  Its TUs take their reference samples and residual from the
+  // picture (intra_tu), one round trip each on a chain of a few TUs.
+  const bool sparse = LEAN || (int)ldg(P.ctu_intra + ctu) * 64 <= INTRA_SPARSE_MAX * (P.parts >> 2);
   const int wv = threadIdx.x >> 6;
   {
-  {
-    const int cs = comp ? P.csx : 0;
+  if (!sparse) {
+    const int cs = (comp && P.csx) ? 1 : 0;
     const int tpr = ((1 << P.log2ctu) >> cs) >> 3, rtw = (P.grid_w / 2) >> cs;           // tiles per CTU row / per picture row
     const int tx0 = cx * tpr, ty0 = cy * tpr;
     const int16_t* src = P.resid[comp];
@@ -836,8 +989,14 @@ __global__ void __launch_bounds__(64 * WAVES) k_intra(const PicDev* __restrict__
       *reinterpret_cast<u32x4*>(&L.res[tile * 64 + v * 8]) = ldg4(src + ((size_t)(ty0 + tile / tpr) * rtw + tx0 + tile % tpr) * 64 + v * 8);
     }
   }
-  intra_stage(P, comp, ctu, L);
+  intra_stage(P, comp, ctu, L, !sparse);
   }
+#ifdef INTRA_TIMING
+  if (threadIdx.x == 0) Q.t_a = wall_clock64();
+#endif
+#if defined(INTRA_STOP) && INTRA_STOP == 1      // experiment (no reconstruction): the time of the launch up to here
+  if (pw > 0) return;
+#endif
   unsigned my_l, my_r, my_t, my_b;
   border_mask(ctu, my_l, my_r, my_t, my_b);
   Neighbours nbs;
@@ -862,17 +1021,23 @@ __global__ void __launch_bounds__(64 * WAVES) k_intra(const PicDev* __restrict__
   // at its next sync) instead of hanging the device.
   poll_neighbours(P, nbs, P.pw);
   wave_lds_sync();
-  intra_ctu(P, comp, ctu, L, Q, W[wv], nbs);
+#if defined(INTRA_STOP) && INTRA_STOP == 2
+  if (pw > 0) return;
+#endif
+#ifdef INTRA_TIMING
+  if (threadIdx.x == 0) Q.t_b = wall_clock64();
+#endif
+  intra_ctu(P, comp, ctu, sparse, L, Q, W[wv], nbs);
   __syncthreads();                                           // every wave's stores are acknowledged (intra_ctu ends with the wait)
 #ifdef INTRA_TIMING
   if (threadIdx.x == 0 && comp == 0 && slot == 0 && (cy == 10 || cy == 11) && cx >= 20 && cx < 32)
-    printf("TM cy %d cx %d start %llu first %llu last %llu end %llu ntu %u tu %llu claim %llu post %llu idle %llu nidle %u\n", cy, cx, tk0, Q.t_first, Q.t_last,
-           wall_clock64(), Q.n_run, Q.t_tu, Q.t_claim, Q.t_post, Q.t_idle, Q.n_idle);
+    printf("TM cy %d cx %d start %llu first %llu last %llu end %llu ntu %u tu %llu claim %llu post %llu idle %llu nidle %u stage %llu nbrs %llu list %llu\n", cy, cx, tk0, Q.t_first, Q.t_last,
+           wall_clock64(), Q.n_run, Q.t_tu, Q.t_claim, Q.t_post, Q.t_idle, Q.n_idle, Q.t_a - tk0, Q.t_b - Q.t_a, Q.t_c - Q.t_b);
 #endif
-  if (wv == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    publish_progress(done, ctu, 0xffffffffu);
-  }
+  // (No release fence in front of the last word: every store to the picture is a write-through atomic store that has been acknowledged by now --
+  // intra_ctu ends with the wait.  An agent-scope release fence writes the L2 back: one per workgroup, ~98 000 of them in sixteen 2160p P
+  // pictures with scattered intra CUs, was HALF of this kernel's time there -- 0.65 of 1.33 ms, found by cutting the kernel short phase by phase.)
+  if (wv == 0) publish_progress(done, ctu, 0xffffffffu);
 }
 
 // ---- 4:2:2 chroma.  A chroma block of a transform unit is two SQUARES of half the unit's width, one above the other, the
@@ -1030,7 +1195,7 @@ void launch_intra_chroma_422(const PicDev* pics, const Batch& b, hipStream_t s) 
   hipLaunchKernelGGL(k_intra_chroma_422, dim3((unsigned)b.n * 2), dim3(64), 0, s, pics, b);
 }
 
-void launch_intra(const PicDev* pics, const Batch& b, const int32_t* order, int num_ctus, hipStream_t s) {
+void launch_intra(const PicDev* pics, const Batch& b, const int32_t* order, int num_ctus, bool lean, hipStream_t s) {
   // measured on 2160p I pictures: one picture 17.9 / 11.6 / 9.7 ms with 1 / 2 / 4 waves per CTU, sixteen at once 19.4 / 13.5 / 17.7;
   // with the residual from k_itx (140 instead of 212 VGPRs: three waves per SIMD) 8.7 ms (4 or 6 waves), sixteen 11.4 / 10.8 / 11.7 (2 / 3 / 4);
   // after the trims of the TU chain: 7.78 / 7.41 / 7.27 / 7.15 ms with 3 / 4 / 6 / 8 waves, sixteen 9.93 / 9.66 / 10.7 (2 / 3 / 4)
@@ -1038,8 +1203,16 @@ void launch_intra(const PicDev* pics, const Batch& b, const int32_t* order, int 
 #define INTRA_WAVES_ONE 8
 #define INTRA_WAVES_MANY 3
 #endif
-  if (b.n >= 4) hipLaunchKernelGGL(k_intra<INTRA_WAVES_MANY>, dim3((unsigned)b.n * 3, (unsigned)num_ctus), dim3(64 * INTRA_WAVES_MANY), 0, s, pics, b, order);
-  else hipLaunchKernelGGL(k_intra<INTRA_WAVES_ONE>, dim3((unsigned)b.n * 3, (unsigned)num_ctus), dim3(64 * INTRA_WAVES_ONE), 0, s, pics, b, order);
+  // Many pictures without I slices (P / B pictures with scattered intra CUs): independent CTUs in plenty, each with a handful of TUs.  What counts
+  // is how many of them a CU holds at a time: one wave per CTU and no staging (LEAN), a third of the LDS and of the wave slots of the general kernel
+  // -- 2160p x 16 with 5 % intra CUs: 1.39 ms with three waves and staged dense CTUs, 0.xx ms this way.
+#ifndef INTRA_WAVES_LEAN
+#define INTRA_WAVES_LEAN 1
+#endif
+  const dim3 grid((unsigned)b.n * 3, (unsigned)num_ctus);
+  if (b.n >= 4 && lean) hipLaunchKernelGGL((k_intra<INTRA_WAVES_LEAN, true>), grid, dim3(64 * INTRA_WAVES_LEAN), 0, s, pics, b, order);
+  else if (b.n >= 4) hipLaunchKernelGGL((k_intra<INTRA_WAVES_MANY, false>), grid, dim3(64 * INTRA_WAVES_MANY), 0, s, pics, b, order);
+  else hipLaunchKernelGGL((k_intra<INTRA_WAVES_ONE, false>), grid, dim3(64 * INTRA_WAVES_ONE), 0, s, pics, b, order);
 }
 
 }  // namespace hmgpu

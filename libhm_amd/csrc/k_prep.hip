@@ -364,7 +364,14 @@ __global__ void __launch_bounds__(256) k_prep(const PicDev* __restrict__ pics, B
     if (parts > 0) return;
 #endif
     if (q.valid) atomicAdd(&lds_stat[q.intra ? 0 : 1], 4u);
-    if (q.valid && q.intra) stg(P.ctu_intra + q.ctu, (uint8_t)1);        // same value from every writer
+    {
+      // how many of the CTU's 8x8 areas are intra (k_intra: a CTU with few of them does not stage its samples).  The areas of a CTU are
+      // parts / 4 = 64, 16 or 4 consecutive lanes of one wave
+      const int qpc = parts >> 2, ln = threadIdx.x & 63, seg = ln & ~(qpc - 1);
+      const unsigned long long m = __builtin_amdgcn_ballot_w64(q.valid && q.intra);
+      const unsigned long long sm = qpc >= 64 ? m : (m >> seg) & ((1ull << qpc) - 1ull);
+      if (ln == seg && sm) stg(P.ctu_intra + q.ctu, (uint8_t)__popcll(sm));
+    }
     // ---- which transform units originate in this 8x8 area.  The TUs of intra CUs are listed too (not those of PCM CUs): their residual
     // does not depend on the neighbours, k_itx computes it ahead of k_intra, which walks the TUs in dependency order and only adds it.
     // cbf bit d of a partition = cbf of its ancestor TU node at transform depth d (TComDataCU.h:310); HM descends only
