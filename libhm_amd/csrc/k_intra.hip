@@ -1205,11 +1205,14 @@ void launch_intra(const PicDev* pics, const Batch& b, const int32_t* order, int 
 #endif
   // Many pictures without I slices (P / B pictures with scattered intra CUs): independent CTUs in plenty, each with a handful of TUs.  What counts
   // is how many of them a CU holds at a time: one wave per CTU and no staging (LEAN), a third of the LDS and of the wave slots of the general kernel
-  // -- 2160p x 16 with 5 % intra CUs: 1.39 ms with three waves and staged dense CTUs, 0.xx ms this way.
+  // -- 2160p x 16 with 5 / 10 / 25 % intra CUs: see DESIGN.md 4.12 for the two kernels side by side.
 #ifndef INTRA_WAVES_LEAN
 #define INTRA_WAVES_LEAN 1
 #endif
   const dim3 grid((unsigned)b.n * 3, (unsigned)num_ctus);
+#ifdef INTRA_NO_LEAN                     // experiment: the general kernel for every call
+  lean = false;
+#endif
   if (b.n >= 4 && lean) hipLaunchKernelGGL((k_intra<INTRA_WAVES_LEAN, true>), grid, dim3(64 * INTRA_WAVES_LEAN), 0, s, pics, b, order);
   else if (b.n >= 4) hipLaunchKernelGGL((k_intra<INTRA_WAVES_MANY, false>), grid, dim3(64 * INTRA_WAVES_MANY), 0, s, pics, b, order);
   else hipLaunchKernelGGL((k_intra<INTRA_WAVES_ONE, false>), grid, dim3(64 * INTRA_WAVES_ONE), 0, s, pics, b, order);

@@ -344,6 +344,60 @@ def test_pictures_batch_entry_matches_oracle(oracle, width, height, bd):
             ctx.decompress_pictures([(hs[0], [pics[0].slice], pics[0].meta, pics[0].coeffs), (hs[1], [qsl], q.meta, q.coeffs)])
 
 
+@pytest.mark.parametrize("width,height,bd,cip,one_i_picture", [(832, 480, 10, 0, False), (832, 480, 8, 1, False), (1920, 1080, 10, 0, True),
+                                                             (200, 136, 8, 0, False)])
+def test_scattered_intra_cus_in_batches(oracle, width, height, bd, cip, one_i_picture):
+    """P pictures with scattered intra CUs, five per call: the calls k_intra<1, LEAN> serves (no I slice, less than half of the partitions
+    intra: one wave per CTU, reference samples and residual straight from the picture) -- and, with one all-intra I picture among
+    them, the general kernel, whose CTUs with few intra areas take the same unstaged path beside staged dense ones.  3 % .. 45 %
+    intra CUs, all TU sizes, multi-slice pictures, constrained intra prediction (availability with holes), partial CTUs."""
+    import libhm_amd
+    fr = [0.03, 0.1, 0.25, 0.45, 0.08]
+    n = len(fr)
+    pics = []
+    for i in range(n):
+        probs = [(0.1, 0.3, 0.3, 0.2, 0.1), (0, 0, 0.3, 0.7, 0), (0.3, 0.3, 0.2, 0.1, 0.1), (0, 0.2, 0.4, 0.4, 0), (0, 0, 0, 1, 0)][i]
+        if width % 16 or height % 16:
+            probs = (0, 0, 0, 1, 0)
+        pics.append(synth.make_picture(width, height, bd, seed=0x5CA7 + 7 * i + cip, intra_frac=fr[i], mode_probs=probs, tr_split_prob=0.3 + 0.15 * i,
+                                       cbf_prob=0.6, ref_handles=([0], [0]), num_slices=(3 if i == 2 else 1)))
+    if one_i_picture:
+        pics[3] = synth.make_picture(width, height, bd, seed=0x5CA7 + 99, intra_frac=1.0, cbf_prob=0.6, ref_handles=([0], [0]))
+        for sl in pics[3].slices:
+            sl.slice_type = abi.I_SLICE
+    for p in pics:
+        for sl in p.slices:
+            sl.constrained_intra_pred = cip
+    ref0 = synth.noise_planes(width, height, bd, 51)
+    cur = synth.blocky_planes(width, height, bd, 53)
+    want_rec, want_fin = [], []
+    for p in pics:
+        rec = [a.copy() for a in cur]
+        oracle.decompress_ctus(p.seq, p.slices, p.meta, p.coeffs, rec, [ref0])
+        want_rec.append([a.copy() for a in rec])
+        oracle.loop_filter_pic(p.seq, p.slices, p.meta, p.pp, rec, 3)
+        prm = oracle.sao_reconstruct_params(p.seq, p.pp, p.meta, p.sao_raw)
+        want_fin.append(oracle.sao_process(p.seq, p.slices, p.pp, p.meta, prm, rec))
+    with libhm_amd.Context(abi.make_seq(width, height, bd, bd, log2_ctu=6, max_pictures=1 + n)) as ctx:
+        h0 = ctx.acquire()
+        ctx.upload(h0, ref0)
+        hs = [ctx.acquire() for _ in range(n)]
+        for rnd in range(2):                                         # second round: compact levels
+            for h in hs:
+                ctx.upload(h, cur)
+            ctx.decompress_pictures([(hs[i], pics[i].slices, pics[i].meta, pics[i].coeffs if rnd == 0 else ctx.pack_levels(pics[i].meta, pics[i].coeffs))
+                                     for i in range(n)])
+            for i in range(n):
+                got = ctx.download(hs[i])
+                for c in range(3):
+                    assert np.array_equal(got[c], want_rec[i][c]), "round %d reconstruction of picture %d comp %d" % (rnd, i, c)
+            ctx.filter_pictures([(hs[i], pics[i].pp, abi.sao_array_from_raw(pics[i].sao_raw)) for i in range(n)])
+            for i in range(n):
+                got = ctx.download(hs[i])
+                for c in range(3):
+                    assert np.array_equal(got[c], want_fin[i][c]), "round %d picture %d comp %d" % (rnd, i, c)
+
+
 @pytest.mark.parametrize("across", [0, 1])
 def test_multi_slice_picture_matches_oracle(oracle, across):
     """five slices starting at arbitrary CTUs (own QP / deblocking offsets), one hmgpu_decompress_slice call per slice: slice
