@@ -65,6 +65,14 @@ libHMDec_error libHMDEC_clear_internal_info(libHMDec_context* decCtx);        /*
 
 /* ---------------------------------------------------------------------------------------------- this library's own additions */
 void hmdec_set_device(libHMDec_context* ctx, int device_ordinal);             /* GPU to decode on (default 0); before the first NAL unit */
+/* Several device contexts, one per entry (GPU ordinals; the same ordinal twice: two contexts on one GPU).  The pictures libHM would
+ * reconstruct one after the other and that do not predict from each other -- the B pictures of one temporal level, TDecTop.cpp:672 /
+ * TDecGop.cpp:105 per picture -- are placed round-robin on the contexts; a reference picture is copied once to each context that
+ * predicts from it (hmgpu_picture_transfer: over xGMI between GPUs), reference picture sets and lists (TComSlice.cpp:318-376), hash
+ * checks and the output order (TDecTop.cpp:192-213) are as with one.  Before the first NAL unit.  hmdec_transfer_bytes: bytes copied. */
+void hmdec_set_devices(libHMDec_context* ctx, const int* device_ordinals, int n);
+int hmdec_num_devices(libHMDec_context* ctx);
+unsigned long long hmdec_transfer_bytes(libHMDec_context* ctx);
 /* parser threads (1..16, default 1): slice data of several pictures is parsed concurrently (frame-parallel, a picture at most one
  * CTB row behind the picture it takes temporal motion vectors from); pictures come out in the same order, later.  Before the first NAL unit. */
 void hmdec_set_threads(libHMDec_context* ctx, int n);

@@ -309,6 +309,10 @@ void         hmgpu_staging_free(hmgpu_ctx* ctx, hmgpu_staging* staging);
 /* blocks until the copies of the last hmgpu_decompress_pictures call that read the block have been made: from then on a parser may
  * write the next picture into it (the kernels read the device copies).  A block no call has read yet returns at once. */
 hmgpu_status hmgpu_staging_wait(hmgpu_ctx* ctx, hmgpu_staging* staging);
+/* A caller that drives several contexts (one per GPU, pictures of one temporal level placed on different ones: hmgpu_picture_transfer)
+ * parses into ONE set of blocks and decides late where a picture is decoded: after hmgpu_staging_share, `other` -- a context with equal
+ * hmgpu_seq_params on any device -- takes the block's arrays in the same few DMAs as `owner`, which still owns and frees the block. */
+hmgpu_status hmgpu_staging_share(hmgpu_ctx* owner, hmgpu_staging* staging, hmgpu_ctx* other);
 /* (the block also holds the three ctu_level_start arrays: coeffs->ctu_level_start[] of hmgpu_staging_alloc points at them; a caller
  * that fills the block with HM's dense layout sets the three pointers to NULL in the struct it passes to the calls) */
 

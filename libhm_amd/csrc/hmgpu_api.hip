@@ -60,7 +60,10 @@ struct hmgpu_staging {
   char* host = nullptr;
   size_t meta_bytes = 0, coef_bytes = 0, start_bytes = 0;   // metadata block | dense-capacity levels | [3][num_ctus + 1] CTU starts
   size_t grp[5] = {0, 0, 0, 0, 0};                         // carve_meta: where the optional groups of the metadata block start
-  uint64_t copy_seq = 0;                                   // the staging pass (hmgpu_decompress_pictures) that last read the block
+  uint64_t copy_seq = 0;                                   // the staging pass (hmgpu_decompress_pictures) that last read the block ...
+  hmgpu_ctx* reader = nullptr;                             // ... and the context it ran on (the owner, or one the block is shared with)
+  hmgpu_ctx* owner = nullptr;
+  std::vector<hmgpu_ctx*> sharers;                         // hmgpu_staging_share: contexts that take the block's arrays in one DMA too
   hmgpu_ctu_meta m;
   hmgpu_coeffs co;
 };
@@ -77,6 +80,7 @@ struct hmgpu_ctx {
   hipEvent_t copy_ev[8] = {}, use_ev[8] = {};
   uint64_t copy_seq = 0, use_seq = 0;
   std::vector<hmgpu_staging*> stagings;
+  std::vector<hmgpu_staging*> shared_stagings;   // blocks of other contexts (hmgpu_staging_share): recognised, not owned
   hipEvent_t dl_ev[32] = {};           // hmgpu_picture_download_begin tickets: ticket t completes with dl_ev[t % 32]
   std::atomic<uint64_t> dl_seq{0};
   // hmgpu_picture_hash_begin: MD5 chains of finished pictures over packed copies in a ring of slots; launched in batches (one lane per
@@ -647,7 +651,15 @@ void hmgpu_destroy(hmgpu_ctx* c) {
   if (c->stream2) hipStreamDestroy(c->stream2);
   if (c->copy_stream) { hipStreamSynchronize(c->copy_stream); hipStreamDestroy(c->copy_stream); }
   for (int k = 0; k < 8; k++) { if (c->copy_ev[k]) hipEventDestroy(c->copy_ev[k]); if (c->use_ev[k]) hipEventDestroy(c->use_ev[k]); }
-  for (hmgpu_staging* st : c->stagings) { if (st->host) hipHostFree(st->host); delete st; }
+  for (hmgpu_staging* st : c->shared_stagings) {
+    st->sharers.erase(std::remove(st->sharers.begin(), st->sharers.end(), c), st->sharers.end());
+    if (st->reader == c) { st->reader = nullptr; st->copy_seq = 0; }      // (the copy stream was drained above)
+  }
+  for (hmgpu_staging* st : c->stagings) {
+    for (hmgpu_ctx* o : st->sharers) o->shared_stagings.erase(std::remove(o->shared_stagings.begin(), o->shared_stagings.end(), st), o->shared_stagings.end());
+    if (st->host) hipHostFree(st->host);
+    delete st;
+  }
   for (int k = 0; k < 32; k++) if (c->dl_ev[k]) hipEventDestroy(c->dl_ev[k]);
   if (c->dl_fault) (void)hipHostFree(c->dl_fault);
   for (int k = 0; k < hmgpu_ctx::kHashStreams; k++) if (c->hash_stream[k]) { (void)hipStreamSynchronize(c->hash_stream[k]); (void)hipStreamDestroy(c->hash_stream[k]); }
@@ -1104,7 +1116,8 @@ static bool stg_starts_contiguous(const hmgpu_coeffs* co, int num_ctus) {
 
 // a staging block whose arrays the caller handed over for a whole picture: its metadata is ONE copy, its levels another
 static const hmgpu_staging* staging_of(const hmgpu_ctx* c, const hmgpu_ctu_meta* m, const hmgpu_coeffs* co) {
-  for (const hmgpu_staging* st : c->stagings) {
+  for (size_t i = 0; i < c->stagings.size() + c->shared_stagings.size(); i++) {
+    const hmgpu_staging* st = i < c->stagings.size() ? c->stagings[i] : c->shared_stagings[i - c->stagings.size()];
     const hmgpu_ctu_meta& h = st->m;
     if (m->depth != h.depth) continue;
     // the required arrays are the block's; the optional ones are the block's or left out (NULL: that group does not travel)
@@ -1396,7 +1409,9 @@ hmgpu_status hmgpu_staging_alloc(hmgpu_ctx* c, hmgpu_staging** out, hmgpu_ctu_me
   for (int k = 0; k < 3; k++) st->coef_bytes += align_up(c->coef_elems[k] * sizeof(int16_t), 256);
   st->start_bytes = align_up((size_t)3 * (c->num_ctus + 1) * sizeof(uint32_t), 256);
   const size_t total = st->meta_bytes + st->coef_bytes + st->start_bytes;
-  if (hipHostMalloc((void**)&st->host, total, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); delete st; return HMGPU_ENOMEM; }
+  // (portable: every device of the process may copy from the block -- hmgpu_staging_share)
+  if (hipHostMalloc((void**)&st->host, total, hipHostMallocPortable) != hipSuccess) { (void)hipGetLastError(); delete st; return HMGPU_ENOMEM; }
+  st->owner = c;
   memset(st->host, 0, total);
   { Carver m(st->host); carve_meta(m, lay, np, c->num_ctus); }
   hmgpu_ctu_meta& h = st->m;
@@ -1421,8 +1436,23 @@ hmgpu_status hmgpu_staging_alloc(hmgpu_ctx* c, hmgpu_staging** out, hmgpu_ctu_me
 hmgpu_status hmgpu_staging_wait(hmgpu_ctx* c, hmgpu_staging* st) {
   if (!c || !st) return HMGPU_EINVAL;
   if (st->copy_seq == 0) return HMGPU_OK;
-  hipSetDevice(c->device);
-  if (hipEventSynchronize(c->copy_ev[st->copy_seq % 8]) != hipSuccess) return HMGPU_EDEVICE;
+  hmgpu_ctx* r = st->reader ? st->reader : c;              // the context whose copy stream read the block last
+  hipSetDevice(r->device);
+  if (hipEventSynchronize(r->copy_ev[st->copy_seq % 8]) != hipSuccess) return HMGPU_EDEVICE;
+  return HMGPU_OK;
+}
+
+// A decoder that places pictures on several contexts parses into ONE set of blocks and decides late which context decodes a picture:
+// `other` -- a context of the same geometry, on any device -- recognises the block's arrays from now on as `owner` does.
+hmgpu_status hmgpu_staging_share(hmgpu_ctx* owner, hmgpu_staging* st, hmgpu_ctx* other) {
+  if (!owner || !st || !other || st->owner != owner) return HMGPU_EINVAL;
+  if (other == owner || std::find(st->sharers.begin(), st->sharers.end(), other) != st->sharers.end()) return HMGPU_OK;
+  const hmgpu_seq_params &a = owner->seq, &b = other->seq;
+  if (a.width != b.width || a.height != b.height || a.log2_ctu_size != b.log2_ctu_size || a.chroma_format != b.chroma_format ||
+      owner->num_ctus != other->num_ctus || owner->parts != other->parts) return HMGPU_EINVAL;
+  for (int k = 0; k < 3; k++) if (owner->coef_elems[k] != other->coef_elems[k]) return HMGPU_EINVAL;
+  st->sharers.push_back(other);
+  other->shared_stagings.push_back(st);
   return HMGPU_OK;
 }
 
@@ -1430,6 +1460,8 @@ void hmgpu_staging_free(hmgpu_ctx* c, hmgpu_staging* st) {
   if (!c || !st) return;
   hipSetDevice(c->device);
   if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
+  if (st->reader && st->reader != c && st->reader->copy_stream) { hipSetDevice(st->reader->device); (void)hipStreamSynchronize(st->reader->copy_stream); }
+  for (hmgpu_ctx* o : st->sharers) o->shared_stagings.erase(std::remove(o->shared_stagings.begin(), o->shared_stagings.end(), st), o->shared_stagings.end());
   c->stagings.erase(std::remove(c->stagings.begin(), c->stagings.end(), st), c->stagings.end());
   if (st->host) (void)hipHostFree(st->host);
   delete st;
@@ -1486,7 +1518,7 @@ hmgpu_status hmgpu_decompress_pictures(hmgpu_ctx* c, int32_t n, const hmgpu_pict
     if (st != HMGPU_OK) return st;
     c->copy_seq++;
     for (int i = 0; i < n; i++)
-      if (const hmgpu_staging* sb = staging_of(c, jobs[i].meta, jobs[i].coeffs)) const_cast<hmgpu_staging*>(sb)->copy_seq = c->copy_seq;
+      if (const hmgpu_staging* sb = staging_of(c, jobs[i].meta, jobs[i].coeffs)) { const_cast<hmgpu_staging*>(sb)->copy_seq = c->copy_seq; const_cast<hmgpu_staging*>(sb)->reader = c; }
     HIP_TRY(c, hipEventRecord(c->copy_ev[c->copy_seq % 8], c->copy_stream));
     HIP_TRY(c, hipStreamWaitEvent(c->stream, c->copy_ev[c->copy_seq % 8], 0));
   }

@@ -57,16 +57,33 @@ Decoder::~Decoder() {
     for (std::thread& t : workers_) t.join();
   }
   if (gpu_ && getenv("HMDEC_STATS")) {          // tuning aid: device time per kernel class over the life of the decoder
-    hmgpu_stats st;
-    if (hmgpu_get_stats(gpu_, &st, 0) == HMGPU_OK)
-      for (int k = 0; k < HMGPU_NUM_KERNELS; k++)
-        if (st.kernel_launches[k]) fprintf(stderr, "hmdec: %-14s %8.3f ms in %llu launches\n", hmgpu_kernel_name(k), st.kernel_ms[k], (unsigned long long)st.kernel_launches[k]);
+    for (size_t d = 0; d < gpus_.size(); d++) {
+      hmgpu_stats st;
+      if (hmgpu_get_stats(gpus_[d], &st, 0) == HMGPU_OK)
+        for (int k = 0; k < HMGPU_NUM_KERNELS; k++)
+          if (st.kernel_launches[k]) fprintf(stderr, "hmdec[%zu]: %-14s %8.3f ms in %llu launches\n", d, hmgpu_kernel_name(k), st.kernel_ms[k], (unsigned long long)st.kernel_launches[k]);
+    }
+    if (gpus_.size() > 1) fprintf(stderr, "hmdec: %llu bytes of reference pictures copied between the contexts\n", (unsigned long long)transfer_bytes());
   }
   poll_device_hashes(true);
   batch_.clear();
-  pool_.clear();                            // (the pictures' staging blocks belong to the context)
+  pool_.clear();                            // (the pictures' staging blocks belong to the first context)
   retired_.clear();
-  if (gpu_) hmgpu_destroy(gpu_);
+  for (size_t d = gpus_.size(); d-- > 0;) hmgpu_destroy(gpus_[d]);
+}
+
+uint64_t Decoder::transfer_bytes() const {
+  uint64_t n = transfer_bytes_closed_;
+  for (hmgpu_ctx* g : gpus_) n += hmgpu_transfer_bytes(g);
+  return n;
+}
+
+void Decoder::sync_all() {
+  for (hmgpu_ctx* g : gpus_) {
+    const hmgpu_status st = hmgpu_sync(g);
+    if (st != HMGPU_OK) throw std::runtime_error(std::string("hmgpu_sync: ") + hmgpu_status_string(st));   // e.g. an intra wavefront that gave up
+  }
+  synced_seq_ = submitted_seq_;
 }
 
 // ------------------------------------------------------------------------------------------------ NAL level
@@ -224,7 +241,10 @@ void Decoder::activate(const SliceHeader& sh) {
   scan_.clear();
   scan_idx_ = 0;
   last_decoded_ = nullptr;
-  if (gpu_) { hmgpu_destroy(gpu_); gpu_ = nullptr; }
+  transfer_bytes_closed_ = transfer_bytes();
+  for (size_t d = gpus_.size(); d-- > 0;) hmgpu_destroy(gpus_[d]);
+  gpus_.clear();
+  gpu_ = nullptr;
   zscan_.init(sps_->log2_ctb);
   memset(&seq_, 0, sizeof(seq_));
   seq_.width = sps_->width;
@@ -240,9 +260,14 @@ void Decoder::activate(const SliceHeader& sh) {
   seq_.pcm_bit_depth_luma = sps_->pcm_bit_depth_luma;
   seq_.pcm_bit_depth_chroma = sps_->pcm_bit_depth_chroma;
   if (!parse_only_) {
-    const hmgpu_status st = hmgpu_create(&seq_, device_, &gpu_);
-    if (st != HMGPU_OK) throw std::runtime_error(std::string("hmgpu_create: ") + hmgpu_status_string(st));
-    if (getenv("HMDEC_STATS")) hmgpu_set_profiling(gpu_, 1);
+    for (int ordinal : devices_) {
+      hmgpu_ctx* g = nullptr;
+      const hmgpu_status st = hmgpu_create(&seq_, ordinal, &g);
+      if (st != HMGPU_OK) throw std::runtime_error(std::string("hmgpu_create: ") + hmgpu_status_string(st));
+      gpus_.push_back(g);
+      if (getenv("HMDEC_STATS")) hmgpu_set_profiling(g, 1);
+    }
+    gpu_ = gpus_[0];
   }
 }
 
@@ -273,12 +298,10 @@ PicData* Decoder::acquire_buffer() {
       flush_batch();                                      // (nothing that names the buffer may still be waiting to be submitted)
       if (gpu_ && p->submit_seq > synced_seq_) {          // the copies out of the arrays of the picture that lived here may still be under way
         if (p->stg && !p->has_pcm) {                         // (PCM samples travel from arrays of their own)
-          const hmgpu_status st = hmgpu_staging_wait(gpu_, p->stg);   // the copies only: the kernels read the device's arrays
+          const hmgpu_status st = hmgpu_staging_wait(gpu_, p->stg);   // the copies only (of whichever context read the block): the kernels read the device's arrays
           if (st != HMGPU_OK) throw std::runtime_error(std::string("hmgpu_staging_wait: ") + hmgpu_status_string(st));
         } else {
-          const hmgpu_status st = hmgpu_sync(gpu_);
-          synced_seq_ = submitted_seq_;
-          if (st != HMGPU_OK) throw std::runtime_error(std::string("hmgpu_sync: ") + hmgpu_status_string(st));   // e.g. an intra wavefront that gave up
+          sync_all();
         }
       }
       return p.get();
@@ -290,9 +313,18 @@ PicData* Decoder::acquire_buffer() {
   p->allocate(*sps_, &zscan_, gpu_);
   if (gpu_) for (int c = 0; c < 3; c++) p->plane[c].resize((size_t)(p->width >> (c ? p->csx : 0)) * (p->height >> (c ? p->csy : 0)));
   host_alloc_use_pinned(false);
-  if (gpu_) {
-    const hmgpu_status st = hmgpu_picture_acquire(gpu_, &p->handle);
+  for (size_t d = 0; d < gpus_.size(); d++) {
+    // the same buffer in every context: acquired in the same order everywhere, so the handles -- what ref_pic[][] of the slice parameters
+    // names -- are the same numbers
+    hmgpu_pic h = HMGPU_NO_PIC;
+    const hmgpu_status st = hmgpu_picture_acquire(gpus_[d], &h);
     if (st != HMGPU_OK) throw std::runtime_error(std::string("hmgpu_picture_acquire: ") + hmgpu_status_string(st));
+    if (d == 0) p->handle = h;
+    else if (h != p->handle) throw std::runtime_error("hmdec: the device contexts do not hand out the same picture handles");
+    if (d > 0 && p->stg) {
+      const hmgpu_status ss = hmgpu_staging_share(gpu_, p->stg, gpus_[d]);
+      if (ss != HMGPU_OK) throw std::runtime_error(std::string("hmgpu_staging_share: ") + hmgpu_status_string(ss));
+    }
   }
   return p;
 }
@@ -847,11 +879,46 @@ void Decoder::flush_batch() {
   }
   std::vector<PicData*> pics;
   pics.swap(batch_);
-  hmgpu_status st = hmgpu_decompress_pictures(gpu_, (int32_t)n, jobs.data());
-  if (st != HMGPU_OK) throw std::runtime_error(std::string("hmgpu_decompress_pictures: ") + hmgpu_status_string(st));
-  if (resync) (void)hmgpu_sync(gpu_);                      // (the dense stand-in of a damaged picture is not page-locked staging: let its copies finish)
-  st = hmgpu_filter_pictures(gpu_, (int32_t)n, fjobs.data());
-  if (st != HMGPU_OK) throw std::runtime_error(std::string("hmgpu_filter_pictures: ") + hmgpu_status_string(st));
+  // placement: the pictures of the batch round-robin over the contexts (a batch of one stays where its first reference lives: a chain of
+  // P pictures does not hop); every reference picture a context has not seen yet is copied there once, behind its reconstruction
+  const size_t nd = gpus_.size();
+  std::vector<int> where(n, 0);
+  if (nd > 1) {
+    for (size_t i = 0; i < n; i++) where[i] = (int)((rr_ + i) % nd);
+    static const bool hop = getenv("HMDEC_PLACE_ROUND_ROBIN") != nullptr && getenv("HMDEC_PLACE_ROUND_ROBIN")[0] == '1';   // (tests: every picture moves on)
+    if (n == 1 && !hop) {
+      const PicData* r = nullptr;
+      for (auto& sl : pics[0]->slices) for (int l = 0; l < 2 && !r; l++) for (int k = 0; k < 16 && !r; k++) r = sl->ref_pics[l][k];
+      if (r) where[0] = r->home;
+    } else {
+      rr_ += n;
+    }
+  }
+  for (size_t d = 0; d < nd; d++) {
+    std::vector<hmgpu_picture_job> dj;
+    std::vector<hmgpu_filter_job> df;
+    for (size_t i = 0; i < n; i++) {
+      if (where[i] != (int)d) continue;
+      for (auto& sl : pics[i]->slices)
+        for (int l = 0; l < 2; l++)
+          for (int k = 0; k < 16; k++) {
+            PicData* r = sl->ref_pics[l][k];
+            if (!r || ((r->present >> d) & 1u)) continue;
+            const hmgpu_status ts = hmgpu_picture_transfer(gpus_[r->home], r->handle, gpus_[d], r->handle);
+            if (ts != HMGPU_OK) throw std::runtime_error(std::string("hmgpu_picture_transfer: ") + hmgpu_status_string(ts));
+            r->present |= 1u << d;
+          }
+      dj.push_back(jobs[i]);
+      df.push_back(fjobs[i]);
+    }
+    if (dj.empty()) continue;
+    hmgpu_status st = hmgpu_decompress_pictures(gpus_[d], (int32_t)dj.size(), dj.data());
+    if (st != HMGPU_OK) throw std::runtime_error(std::string("hmgpu_decompress_pictures: ") + hmgpu_status_string(st));
+    if (resync) (void)hmgpu_sync(gpus_[d]);                  // (the dense stand-in of a damaged picture is not page-locked staging: let its copies finish)
+    st = hmgpu_filter_pictures(gpus_[d], (int32_t)df.size(), df.data());
+    if (st != HMGPU_OK) throw std::runtime_error(std::string("hmgpu_filter_pictures: ") + hmgpu_status_string(st));
+  }
+  for (size_t i = 0; i < n; i++) { pics[i]->home = where[i]; pics[i]->present = 1u << where[i]; }
   ++submitted_seq_;
   batches_submitted_++;
   for (PicData* p : pics) p->submit_seq = submitted_seq_;
@@ -863,7 +930,7 @@ bool Decoder::fetch_planes(PicData* pic) {
   if (pic->planes_valid) return true;
   flush_batch();
   if (const uint64_t t = pic->dl_ticket.load()) {        // begun for the hash check: wait for it instead of copying again
-    if (hmgpu_download_wait(gpu_, t) != HMGPU_OK) return false;
+    if (hmgpu_download_wait(ctx_of(pic), t) != HMGPU_OK) return false;
     pic->planes_valid = true;
     return true;
   }
@@ -873,8 +940,8 @@ bool Decoder::fetch_planes(PicData* pic) {
   int16_t* planes[3] = {pic->plane[0].data(), pic->plane[1].data(), pic->plane[2].data()};
   const int32_t strides[3] = {pic->width, pic->width >> pic->csx, pic->width >> pic->csx};
   const uint64_t seq = submitted_seq_;
-  if (hmgpu_picture_download(gpu_, pic->handle, planes, strides) != HMGPU_OK) return false;
-  synced_seq_ = seq;                         // a download returns after everything enqueued before it
+  if (hmgpu_picture_download(ctx_of(pic), pic->handle, planes, strides) != HMGPU_OK) return false;
+  if (gpus_.size() == 1) synced_seq_ = seq;  // a download returns after everything enqueued before it (on that context)
   pic->planes_valid = true;
   return true;
 }
@@ -910,7 +977,7 @@ void Decoder::hash_main() {
       hash_busy_++;
     }
     bool landed = true;
-    if (const uint64_t t = j.pic->dl_ticket.load()) landed = hmgpu_download_wait(gpu_, t) == HMGPU_OK;
+    if (const uint64_t t = j.pic->dl_ticket.load()) landed = hmgpu_download_wait(ctx_of(j.pic), t) == HMGPU_OK;
     if (!landed || !md5_plane_matches(j.pic, j.comp, j.bd, j.want)) {
       if (!j.pic->hash_mismatch.exchange(true)) {
         hash_mismatches_++;
@@ -932,7 +999,7 @@ void Decoder::poll_device_hashes(bool block) {
   while (gpu_ && !dev_hashes_.empty()) {
     uint8_t got[3][16];
     int32_t len = 0, ready = 0;
-    if (hmgpu_hash_wait(gpu_, dev_hashes_.front().ticket, block ? 1 : 0, got, &len, &ready) != HMGPU_OK) { ready = 1; len = 0; }
+    if (hmgpu_hash_wait(dev_hashes_.front().ctx, dev_hashes_.front().ticket, block ? 1 : 0, got, &len, &ready) != HMGPU_OK) { ready = 1; len = 0; }
     if (!ready) return;
     const DevHash& h = dev_hashes_.front();
     if (len != 16 || memcmp(got, h.want, 16 * h.ncomp) != 0) {
@@ -965,7 +1032,8 @@ void Decoder::check_hash(PicData* pic) {
     h.poc = pic->poc;
     h.ncomp = pic->num_comps;
     memcpy(h.want, pic->sei_hash, sizeof(h.want));
-    if (hmgpu_picture_hash_begin(gpu_, pic->handle, 1, &h.ticket) != HMGPU_OK) return;
+    h.ctx = ctx_of(pic);
+    if (hmgpu_picture_hash_begin(h.ctx, pic->handle, 1, &h.ticket) != HMGPU_OK) return;
     dev_hashes_.push_back(h);
     poll_device_hashes(false);
     return;
@@ -982,7 +1050,7 @@ void Decoder::check_hash(PicData* pic) {
         int16_t* planes[3] = {pic->plane[0].data(), pic->plane[1].data(), pic->plane[2].data()};
         const int32_t strides[3] = {pic->width, pic->width >> pic->csx, pic->width >> pic->csx};
         uint64_t t = 0;
-        if (hmgpu_picture_download_begin(gpu_, pic->handle, planes, strides, &t) != HMGPU_OK) return;
+        if (hmgpu_picture_download_begin(ctx_of(pic), pic->handle, planes, strides, &t) != HMGPU_OK) return;
         pic->dl_ticket.store(t);
       }
       pic->users.fetch_add(pic->num_comps);
@@ -1009,7 +1077,7 @@ void Decoder::check_hash(PicData* pic) {
     return;
   } else {
     int32_t n = 0;
-    if (hmgpu_picture_hash(gpu_, pic->handle, pic->sei_hash_method, got, &n) != HMGPU_OK) return;
+    if (hmgpu_picture_hash(ctx_of(pic), pic->handle, pic->sei_hash_method, got, &n) != HMGPU_OK) return;
     len = n;
   }
   bool ok = true;

@@ -26,7 +26,13 @@ class Decoder {
   // configuration (before the first NAL unit)
   void set_parse_only(bool v) { parse_only_ = v; }        // no device: metadata only (host-side tests)
   void set_check_hash(bool v) { check_hash_ = v; }
-  void set_device(int ordinal) { device_ = ordinal; }
+  void set_device(int ordinal) { device_ = ordinal; devices_.assign(1, ordinal); }
+  // Several device contexts (one per GPU; the same ordinal twice gives two contexts on one GPU): the pictures retired together -- the B
+  // pictures of one temporal level, TDecTop.cpp:672 per picture -- are placed round-robin on them, each reference picture is copied once to
+  // every context that predicts from it (hmgpu_picture_transfer), the output order is HM's as ever.
+  void set_devices(const int* ordinals, int n) { devices_.assign(ordinals, ordinals + (n > 0 ? n : 0)); if (devices_.empty()) devices_.assign(1, device_); device_ = devices_[0]; }
+  int num_devices() const { return (int)devices_.size(); }
+  uint64_t transfer_bytes() const;                        // bytes of reference pictures copied between the contexts so far
   // Parser threads (frame-parallel parsing): 1 = everything on the caller's thread (default).  With n > 1 the slice data of up to n
   // pictures is parsed concurrently, a picture running at most one CTB row behind the picture it takes temporal motion vectors
   // from; pictures are handed to the device, checked and put out in decoding order all the same, only later.
@@ -81,7 +87,13 @@ class Decoder {
   std::shared_ptr<Sps> sps_;
   std::shared_ptr<Pps> pps_;
   ZScan zscan_;
-  hmgpu_ctx* gpu_ = nullptr;
+  hmgpu_ctx* gpu_ = nullptr;                               // the first context (owner of the staging blocks); null: parse only
+  std::vector<hmgpu_ctx*> gpus_;                           // all of them (set_devices), gpus_[0] == gpu_
+  std::vector<int> devices_{0};
+  hmgpu_ctx* ctx_of(const PicData* p) const { return gpus_.empty() ? gpu_ : gpus_[p->home]; }
+  void sync_all();
+  uint64_t rr_ = 0;                                        // round-robin position of the next batch
+  uint64_t transfer_bytes_closed_ = 0;                     // ... of the contexts of earlier sequences
   hmgpu_seq_params seq_{};
   std::vector<std::unique_ptr<PicData>> pool_;            // DPB + free buffers
   std::vector<std::unique_ptr<PicData>> retired_;         // pictures of the previous sequence the application may still hold
@@ -119,7 +131,7 @@ class Decoder {
   void drain_hash_jobs();
   static bool md5_plane_matches(const PicData* pic, int comp, int bd, const uint8_t want[16]);
   uint64_t submitted_seq_ = 0, synced_seq_ = 0;            // device submissions / the last one known to have completed
-  struct DevHash { uint64_t ticket; int poc; int ncomp; uint8_t want[3][16]; };
+  struct DevHash { uint64_t ticket; int poc; int ncomp; uint8_t want[3][16]; hmgpu_ctx* ctx; };
   std::deque<DevHash> dev_hashes_;                         // MD5 chains under way on the device (hmgpu_picture_hash_begin)
   bool device_md5_ = !(getenv("HMDEC_DEVICE_MD5") != nullptr && getenv("HMDEC_DEVICE_MD5")[0] == '0');   // default on
   std::vector<PicData*> batch_;                            // pictures retired and not yet submitted: mutually independent

@@ -290,6 +290,9 @@ libHMDec_error libHMDEC_clear_internal_info(libHMDec_context* ctx) {
 
 // ------------------------------------------------------------------------------------------------ this library's own additions
 void hmdec_set_device(libHMDec_context* ctx, int ordinal) { if (ctx) static_cast<Wrapper*>(ctx)->dec.set_device(ordinal); }
+void hmdec_set_devices(libHMDec_context* ctx, const int* ordinals, int n) { if (ctx && ordinals && n > 0 && n <= 32) static_cast<Wrapper*>(ctx)->dec.set_devices(ordinals, n); }
+int hmdec_num_devices(libHMDec_context* ctx) { return ctx ? static_cast<Wrapper*>(ctx)->dec.num_devices() : -1; }
+unsigned long long hmdec_transfer_bytes(libHMDec_context* ctx) { return ctx ? (unsigned long long)static_cast<Wrapper*>(ctx)->dec.transfer_bytes() : 0ull; }
 void hmdec_set_threads(libHMDec_context* ctx, int n) { if (ctx) static_cast<Wrapper*>(ctx)->dec.set_threads(n); }
 void hmdec_set_parse_only(libHMDec_context* ctx, int on) { if (ctx) static_cast<Wrapper*>(ctx)->dec.set_parse_only(on != 0); }
 int hmdec_hash_mismatches(libHMDec_context* ctx) { return ctx ? static_cast<Wrapper*>(ctx)->dec.hash_mismatches() : -1; }

@@ -128,7 +128,9 @@ struct PicData {
   int num_comps = 3;                           // 1: monochrome (chroma_format_idc 0)
   int chroma_format = 1;                       // chroma_format_idc of the active SPS
   int range_ext_flags = 0;                     // HMGPU_REXT_* of the active SPS
-  hmgpu_pic handle = HMGPU_NO_PIC;
+  hmgpu_pic handle = HMGPU_NO_PIC;   // the same handle in every device context of the decoder
+  int home = 0;                      // the context that decoded the picture (Decoder::gpus_) ...
+  uint32_t present = 0;              // ... and the contexts that hold its finished samples (bit k: gpus_[k])
   uint64_t submit_seq = 0;           // device submission that last read these arrays
   // output side
   bool planes_valid = false;

@@ -38,6 +38,10 @@ def lib():
         L.libHMDEC_get_chroma_format.argtypes = [C.c_void_p]
         L.libHMDEC_get_internal_bit_depth.argtypes = [C.c_int]
         L.hmdec_set_device.argtypes = [C.c_void_p, C.c_int]
+        L.hmdec_set_devices.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.c_int]
+        L.hmdec_num_devices.argtypes = [C.c_void_p]
+        L.hmdec_transfer_bytes.argtypes = [C.c_void_p]
+        L.hmdec_transfer_bytes.restype = C.c_ulonglong
         L.hmdec_set_parse_only.argtypes = [C.c_void_p, C.c_int]
         L.hmdec_set_threads.argtypes = [C.c_void_p, C.c_int]
         L.hmdec_hash_mismatches.argtypes = [C.c_void_p]
@@ -173,12 +177,15 @@ class Picture:
 
 
 class Decoder:
-    def __init__(self, parse_only=False, device=0, check_hash=True, max_temporal_layer=-1, threads=1, device_md5=None):
+    def __init__(self, parse_only=False, device=0, check_hash=True, max_temporal_layer=-1, threads=1, device_md5=None, devices=None):
+        """devices: GPU ordinals of several device contexts (hmdec_set_devices; the same ordinal twice = two contexts on one GPU)"""
         self.ctx = lib().libHMDec_new_decoder()
         if not self.ctx:
             raise MemoryError("libHMDec_new_decoder")
         lib().hmdec_set_parse_only(self.ctx, 1 if parse_only else 0)
         lib().hmdec_set_device(self.ctx, device)
+        if devices:
+            lib().hmdec_set_devices(self.ctx, (C.c_int * len(devices))(*devices), len(devices))
         lib().hmdec_set_threads(self.ctx, threads)
         lib().libHMDec_set_SEI_Check(self.ctx, check_hash)
         lib().libHMDec_set_max_temporal_layer(self.ctx, max_temporal_layer)
@@ -232,6 +239,14 @@ class Decoder:
     @property
     def device_batches(self):
         return lib().hmdec_device_batches(self.ctx)
+
+    @property
+    def num_devices(self):
+        return lib().hmdec_num_devices(self.ctx)
+
+    @property
+    def transfer_bytes(self):
+        return int(lib().hmdec_transfer_bytes(self.ctx))
 
     def decode_stream(self, stream, on_decoded=None, on_output=None):
         """libHM's documented loop (libHMDecoder.h:36-77) over an Annex B stream"""

@@ -227,3 +227,44 @@ def test_md5_sei_checked_on_the_device(stream, pictures, threads):
     with hmdec.Decoder(threads=threads, device_md5=True) as d:
         d.decode_stream(b"".join(b"\x00\x00\x00\x01" + n for n in bad))
         assert d.hash_mismatches == n_sei
+
+
+@pytest.mark.parametrize("contexts,threads,device_md5", [(2, 1, True), (2, 4, False), (3, 3, True)])
+def test_pictures_placed_on_several_device_contexts(contexts, threads, device_md5, monkeypatch):
+    """hmdec_set_devices: the B pictures of one temporal level go round-robin to several device contexts (here all on GPU 0 -- the trick of
+    test_picture_transfer_between_contexts; on a node they are one per GPU), every reference picture is copied once to each context
+    that predicts from it, and the pictures, their order and the hash SEI checks are what one context gives (TDecTop.cpp:192-213,672;
+    TComSlice.cpp:318-376)"""
+    import os
+    # (pictures that retire alone stay with their first reference; the test makes them move on as well, so that references travel whatever
+    # the timing of the parser threads)
+    monkeypatch.setenv("HMDEC_PLACE_ROUND_ROBIN", "1")
+    name = "ra_main10_208x120"
+    z = gu.load("stream_" + name)
+    want = {p.poc: p for p in gu.stream_pictures(name)}
+    out = []
+    with hmdec.Decoder(threads=threads, devices=[0] * contexts, device_md5=device_md5) as d:
+        assert d.num_devices == contexts
+        def on_output(p):
+            out.append(p.poc)
+            for c in range(3):
+                assert np.array_equal(p.plane(c), want[p.poc].fin[c]), "POC %d component %d" % (p.poc, c)
+        d.decode_stream(z["bitstream"], on_output=on_output)
+        assert d.pictures_decoded == len(want)
+        assert d.hash_mismatches == 0
+        moved, batches = d.transfer_bytes, d.device_batches
+        assert 0 < batches <= len(want)
+    assert out == sorted(want)
+    assert moved > 0
+    # the full-size random-access clip: hash SEIs green on every picture, same number of pictures, output order kept
+    data = open(os.path.join(gu.GOLD, "bench_ra_main10_1920x1080.bin"), "rb").read()
+    out = []
+    with hmdec.Decoder(threads=threads, devices=[0] * contexts, device_md5=device_md5) as d:
+        d.decode_stream(data, on_output=lambda p: out.append(p.poc))
+        assert d.pictures_decoded == 9
+        assert d.hash_mismatches == 0
+        moved = d.transfer_bytes
+    with hmdec.Decoder(threads=threads, device_md5=device_md5) as d:      # one context: nothing travels
+        d.decode_stream(data)
+        assert d.hash_mismatches == 0 and d.transfer_bytes == 0
+    assert out == sorted(out) and len(out) == 9 and moved > 0
