@@ -120,7 +120,9 @@ typedef struct hmgpu_slice_params {
   int32_t wp_log2_denom[2];             /* luma, chroma */
   int16_t wp_weight[2][HMGPU_MAX_REF][3];
   int16_t wp_offset[2][HMGPU_MAX_REF][3];
-  const hmgpu_scaling_lists* scaling_lists;   /* SPS scaling_list_enabled_flag: the lists in force, else NULL (flat, m = 16) */
+  const hmgpu_scaling_lists* scaling_lists;   /* SPS scaling_list_enabled_flag: the lists in force, else NULL (flat, m = 16).  All slices of a
+                                               * picture name one PPS (7.4.7.1), i.e. the same lists: the device keeps ONE table per picture,
+                                               * written by every slice call */
 } hmgpu_slice_params;
 
 /* The picture-persistent TComDataCU arrays of TComPicSym (TComPicSym.cpp:93-114).  Every array covers the WHOLE

@@ -398,6 +398,60 @@ def test_scattered_intra_cus_in_batches(oracle, width, height, bd, cip, one_i_pi
                     assert np.array_equal(got[c], want_fin[i][c]), "round %d picture %d comp %d" % (rnd, i, c)
 
 
+@pytest.mark.parametrize("width,height,bd,slices", [(1920, 1080, 10, 1), (1920, 1080, 8, 1), (832, 480, 10, 4)])
+def test_custom_scaling_lists_on_every_list_id(oracle, width, height, bd, slices):
+    """scaling lists other than HM's defaults on every list id -- intra and inter, luma / Cb / Cr, 4x4 .. 32x32 with their DC entries -- on a
+    picture with intra and inter CUs and every TU size: de-quantisation with m_dequantCoef (TComTrQuant.cpp:1203-1313, setScalingListDec /
+    processScalingListDec :1920-1959) through k_itx, for the inter residual and for the residual k_intra adds; one picture in four slices
+    (all slices of a picture name the same PPS, hence the same lists).  (The HM-made scaling-list streams are 208x120.)"""
+    import ctypes
+    import libhm_amd
+    p = synth.make_picture(width, height, bd, seed=0x5CA1 + bd + slices, intra_frac=0.4, cbf_prob=0.85, tr_split_prob=0.5, sao=False,
+                           mode_probs=(0.15, 0.25, 0.3, 0.2, 0.1), ref_handles=([0], [0]), num_slices=slices)
+    rng = np.random.RandomState(0x11575 + bd)
+    keep = []
+    for k in range(1):
+        lists = abi.ScalingLists()
+        for sz in range(4):
+            for l in range(6):
+                lists.dc[sz][l] = int(rng.randint(1, 256)) if sz >= 2 else 16
+                n = 16 if sz == 0 else 64
+                # a ramp as encoders send it, a flat one and a wild one, list by list
+                kind = (sz + l + k) % 3
+                for i in range(64):
+                    v = 16
+                    if i < n:
+                        v = int(rng.randint(1, 256)) if kind == 0 else (min(255, 8 + 3 * i + l) if kind == 1 else 16 + 8 * l)
+                    lists.coef[sz][l][i] = v
+        keep.append(lists)
+    for sl in p.slices:
+        sl.scaling_lists = ctypes.pointer(keep[0])
+    ref0 = synth.noise_planes(width, height, bd, 61)
+    cur = synth.blocky_planes(width, height, bd, 63)
+    want = [a.copy() for a in cur]
+    oracle.decompress_ctus(p.seq, p.slices, p.meta, p.coeffs, want, [ref0])
+    # (the lists matter: the same picture with HM's flat default differs)
+    flat = [a.copy() for a in cur]
+    plain = [abi.clone_slice(sl) for sl in p.slices]
+    for sl in plain:
+        sl.scaling_lists = None
+    oracle.decompress_ctus(p.seq, plain, p.meta, p.coeffs, flat, [ref0])
+    assert any(not np.array_equal(flat[c], want[c]) for c in range(3))
+    with libhm_amd.Context(p.seq) as ctx:
+        h0, hc = ctx.acquire(), ctx.acquire()
+        ctx.upload(h0, ref0)
+        ctx.upload(hc, cur)
+        ctx.decompress_pictures([(hc, p.slices, p.meta, p.coeffs)])
+        got = ctx.download(hc)
+        for c in range(3):
+            assert np.array_equal(got[c], want[c]), "reconstruction comp %d" % c
+        ctx.upload(hc, cur)
+        ctx.decompress_pictures([(hc, p.slices, p.meta, ctx.pack_levels(p.meta, p.coeffs))])
+        got = ctx.download(hc)
+        for c in range(3):
+            assert np.array_equal(got[c], want[c]), "compact levels, comp %d" % c
+
+
 @pytest.mark.parametrize("across", [0, 1])
 def test_multi_slice_picture_matches_oracle(oracle, across):
     """five slices starting at arbitrary CTUs (own QP / deblocking offsets), one hmgpu_decompress_slice call per slice: slice
