@@ -62,8 +62,8 @@ typedef int32_t hmgpu_pic;       /* handle of a device-resident picture (TComPic
  * g_uiMaxCUDepth ...).  Fixed for the life of a context. */
 typedef struct hmgpu_seq_params {
   int32_t width, height;          /* SPS pic_{width,height}_in_luma_samples (multiple of the 8x8 minimum CU) */
-  int32_t bit_depth_luma;         /* g_bitDepth[CHANNEL_TYPE_LUMA]   (8..10) */
-  int32_t bit_depth_chroma;       /* g_bitDepth[CHANNEL_TYPE_CHROMA] (8..10) */
+  int32_t bit_depth_luma;         /* g_bitDepth[CHANNEL_TYPE_LUMA]   (8..12; without extended_precision_processing) */
+  int32_t bit_depth_chroma;       /* g_bitDepth[CHANNEL_TYPE_CHROMA] (8..12) */
   int32_t chroma_format;          /* chroma_format_idc: 1 (4:2:0), 2 (4:2:2), 3 (4:4:4), or 0 (4:0:0, monochrome: the chroma arrays hold no coded
                                      blocks, the chroma planes are allocated like those of 4:2:0 and left alone; picture hashes: the first
                                      digest).  Chroma planes, level arrays and PCM buffers have (width >> sx) x (height >> sy) samples per

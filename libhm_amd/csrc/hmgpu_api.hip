@@ -566,7 +566,7 @@ hmgpu_status hmgpu_create(const hmgpu_seq_params* seq, int device_ordinal, hmgpu
   if (seq->max_pictures < 1 || seq->max_pictures > kMaxPics) return HMGPU_EINVAL;
   if (seq->chroma_format < 0 || seq->chroma_format > 3) return HMGPU_EINVAL;              // 0: monochrome -- the chroma planes exist and are left alone
   if (seq->range_ext_flags & ~(HMGPU_REXT_ROTATION | HMGPU_REXT_IMPLICIT_RDPCM | HMGPU_REXT_EXPLICIT_RDPCM | HMGPU_REXT_INTRA_SMOOTHING_DISABLED)) return HMGPU_EUNSUPPORTED;
-  if (seq->bit_depth_luma < 8 || seq->bit_depth_luma > 10 || seq->bit_depth_chroma < 8 || seq->bit_depth_chroma > 10) return HMGPU_EUNSUPPORTED;
+  if (seq->bit_depth_luma < 8 || seq->bit_depth_luma > 12 || seq->bit_depth_chroma < 8 || seq->bit_depth_chroma > 12) return HMGPU_EUNSUPPORTED;
   hmgpu_ctx* c = new (std::nothrow) hmgpu_ctx();
   if (!c) return HMGPU_ENOMEM;
   c->seq = *seq;
@@ -1704,7 +1704,7 @@ hmgpu_status hmgpu_get_stats(hmgpu_ctx* c, hmgpu_stats* out, int32_t reset) {
 hmgpu_status hmgpu_inverse_transform_batch(hmgpu_ctx* c, int32_t log2_size, int32_t bit_depth, int32_t n, const int16_t* levels,
                                            const int8_t* qp_per, const int8_t* qp_rem, const uint8_t* flags, int16_t* resid) {
   if (!c || log2_size < 2 || log2_size > 5 || n < 1 || !levels || !qp_per || !qp_rem || !flags || !resid) return HMGPU_EINVAL;
-  if (bit_depth < 8 || bit_depth > 10) return HMGPU_EUNSUPPORTED;
+  if (bit_depth < 8 || bit_depth > 12) return HMGPU_EUNSUPPORTED;
   hipSetDevice(c->device);
   const size_t elems = (size_t)n << (2 * log2_size);
   int16_t *d_lev = nullptr, *d_res = nullptr; int8_t *d_per = nullptr, *d_rem = nullptr; uint8_t* d_fl = nullptr;
@@ -1730,7 +1730,7 @@ hmgpu_status hmgpu_inverse_transform_batch(hmgpu_ctx* c, int32_t log2_size, int3
 hmgpu_status hmgpu_mc_batch(hmgpu_ctx* c, int32_t is_chroma, int32_t bit_depth, const int16_t* ref_plane, int32_t ref_stride,
                             int32_t ref_w, int32_t ref_h, int32_t n, const int32_t* blocks, int32_t bi, int16_t* dst) {
   if (!c || !ref_plane || !blocks || !dst || n < 1 || ref_w < 1 || ref_h < 1 || ref_stride < ref_w) return HMGPU_EINVAL;
-  if (bit_depth < 8 || bit_depth > 10) return HMGPU_EUNSUPPORTED;
+  if (bit_depth < 8 || bit_depth > 12) return HMGPU_EUNSUPPORTED;
   hipSetDevice(c->device);
   std::vector<int32_t> off(n);
   size_t total = 0;

@@ -557,7 +557,7 @@ __global__ void __launch_bounds__(256, (WP || BI) ? 1 : MC_LB_LUMA) k_mc_luma(co
 // no pairing of neighbouring samples, no parity of the window start.  16 bits are enough because every chroma tap is even: with
 // S = sum of (c_k / 2) x_k, HM's first-stage value (sum of c_k x_k - (8192 << s)) >> s, s = bit depth - 8 (filter<4, false, true, false>,
 // TComInterpolationFilter.cpp:195-212) is ((S - (4096 << s)) << 1) >> s, and S - (4096 << s) lies in [-21499, 21467] at 10 bits, [-5371,
-// 5339] at 8 (wrapping on the way is harmless, the end value fits).  Bit depths above 10 would need the 32-bit form.
+// 5339] at 8 (wrapping on the way is harmless, the end value fits).  Bit depths above 10 take the 32-bit form (h_item_chroma).
 struct alignas(16) HTapsChroma { uint32_t e[9][4]; };
 constexpr HTapsChroma make_htaps_chroma() {
   constexpr int c[9][4] = {{0, 64, 0, 0}, {-2, 58, 10, -2}, {-4, 54, 16, -2}, {-6, 46, 28, -4}, {-4, 36, 36, -4}, {-4, 28, 46, -6}, {-2, 16, 54, -4}, {-2, 10, 58, -2},
@@ -589,6 +589,32 @@ __device__ inline uint32_t pk_shl(uint32_t v, uint32_t sh2) {
 __device__ inline void h_item_chroma(const u32x4 (&r)[4], const uint32_t* __restrict__ tap, int sh1, uint32_t* __restrict__ out) {
   const u32x4 t = *reinterpret_cast<const u32x4*>(tap);
   const uint32_t tc[4] = {t.x, t.y, t.z, t.w};
+  if (sh1 > 2) {
+    // bit depths above 10 (12: S - (4096 << 4) needs 18 bits): the 32-bit form, one v_dot2 per tap and component -- (c, 0) picks Cb out of a
+    // pair, (0, c) Cr; the taps are the table's halves doubled
+    const int seed = -(8192 << sh1);
+    uint32_t bcb[4], bcr[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) { bcb[k] = (tc[k] << 1) & 0xffffu; bcr[k] = (tc[k] & 0xffff0000u) << 1; }
+    uint32_t hb[2][4], hr[2][4];
+#pragma unroll
+    for (int row = 0; row < 2; row++) {
+      const uint32_t d[8] = {r[2 * row].x, r[2 * row].y, r[2 * row].z, r[2 * row].w, r[2 * row + 1].x, r[2 * row + 1].y, r[2 * row + 1].z, r[2 * row + 1].w};
+#pragma unroll
+      for (int x = 0; x < 4; x++) {
+        int vb = seed, vr = seed;
+#pragma unroll
+        for (int k = 0; k < 4; k++) { vb = dot2(d[x + k], bcb[k], vb); vr = dot2(d[x + k], bcr[k], vr); }
+        hb[row][x] = (uint32_t)(vb >> sh1); hr[row][x] = (uint32_t)(vr >> sh1);
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < 2; c++) {
+      *reinterpret_cast<u32x2*>(out + c * 32) = u32x2{__builtin_amdgcn_perm(hb[1][2 * c], hb[0][2 * c], 0x05040100u), __builtin_amdgcn_perm(hb[1][2 * c + 1], hb[0][2 * c + 1], 0x05040100u)};
+      *reinterpret_cast<u32x2*>(out + 64 + c * 32) = u32x2{__builtin_amdgcn_perm(hr[1][2 * c], hr[0][2 * c], 0x05040100u), __builtin_amdgcn_perm(hr[1][2 * c + 1], hr[0][2 * c + 1], 0x05040100u)};
+    }
+    return;
+  }
   const uint32_t init = (uint32_t)((-(4096 << sh1)) & 0xffff) * 0x10001u;
   uint32_t h[2][4];
 #pragma unroll

@@ -250,7 +250,7 @@ std::shared_ptr<Sps> parse_sps(BitReader& br) {
   }
   s.bit_depth_luma = 8 + br.ue();
   s.bit_depth_chroma = 8 + br.ue();
-  if (s.bit_depth_luma > 10 || s.bit_depth_chroma > 10) throw Unsupported("bit depths above 10 are outside the device path");
+  if (s.bit_depth_luma > 12 || s.bit_depth_chroma > 12) throw Unsupported("bit depths above 12 are outside the device path");
   s.log2_max_poc_lsb = 4 + br.ue();
   if (s.log2_max_poc_lsb > 16) throw ParseError("log2_max_pic_order_cnt_lsb_minus4 out of range");
   const bool sub_layer_ordering = br.flag();

@@ -157,6 +157,15 @@ def split_planes(fr, w, h, csx, csy):
     return fr[:w * h].reshape(h, w), fr[w * h:w * h + cw * ch].reshape(ch, cw), fr[w * h + cw * ch:w * h + 2 * cw * ch].reshape(ch, cw)
 
 
+# bit depth 12 in 4:2:0: interpolation head room 2 (TComInterpolationFilter.cpp:195-212), transformShift = 15 - 12 - log2(N)
+# negative for 32x32 blocks (TComTrQuant.cpp:1203-1313), QP range up to 51 + 24
+CF420 = ["--InputChromaFormat=420", "--ChromaFormatIDC=420", "--CrossComponentPrediction=0", "--ExtendedPrecision=0"]
+STREAMS.update({
+    "ldb_main12_208x120": ("encoder_lowdelay_main_rext.cfg", 208, 120, 3, 12, 12, 26, CF420),
+    "intra_main12_208x120": ("encoder_intra_main_rext.cfg", 208, 120, 1, 12, 12, 22, CF420),
+})
+
+
 def encode(name, tmp):
     cfg, w, h, frames, ibd, bd, qp, extra = STREAMS[name]
     yuv = os.path.join(tmp, name + ".yuv")
@@ -364,6 +373,18 @@ LITE.update({
     "intra_422_qp12_main10_208x120": ("encoder_intra_main_rext.cfg", 208, 120, 1, 10, 10, 12, CF422),
     "ldb_422_ctu32_main8_208x120": ("encoder_lowdelay_main_rext.cfg", 208, 120, 3, 8, 8, 30, CF422 + ["--MaxCUWidth=32", "--MaxCUHeight=32", "--MaxPartitionDepth=3"]),
 })
+
+
+LITE.update({
+    # 12 bits with what moves with the bit depth: transform skip up to 32x32 (negative transform shift: a left shift, TComTrQuant.cpp:1920-1959),
+    # explicit weighted prediction (shift 14 - 12), scaling lists, PCM at a smaller bit depth, a low QP (large levels) and a 10-bit chroma
+    "ldb_ts32_main12_208x120": ("encoder_lowdelay_main_rext.cfg", 208, 120, 3, 12, 12, 24, CF420 + ["--TransformSkipLog2MaxSize=5"]),
+    "ldb_wp_main12_208x120": ("encoder_lowdelay_main_rext.cfg", 208, 120, 3, 12, 12, 28, CF420 + ["--WeightedPredP=1", "--WeightedPredB=1"]),
+    "ldb_sl_main12_208x120": ("encoder_lowdelay_main_rext.cfg", 208, 120, 3, 12, 12, 27, CF420 + ["--ScalingList=2", "--ScalingListFile=@SLFILE@"]),
+    "intra_qp4_main12_208x120": ("encoder_intra_main_rext.cfg", 208, 120, 1, 12, 12, 4, CF420),
+    "ldb_bd12_10_208x120": ("encoder_lowdelay_main_rext.cfg", 208, 120, 3, 12, 12, 28, CF420 + ["--InternalBitDepthC=10"]),
+})
+LITE_BD12 = ["ldb_ts32_main12_208x120", "ldb_wp_main12_208x120", "ldb_sl_main12_208x120", "intra_qp4_main12_208x120", "ldb_bd12_10_208x120"]
 
 
 def make_lite(names=None):

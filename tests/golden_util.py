@@ -30,6 +30,11 @@ LITE = ["ldp_slices_main8_208x120", "ldp_depslices_main10_208x120", "ldp_wpp_mai
 LITE_CF = ["ldb_444_main10_208x120", "ldb_444_lossless_main8_208x120", "intra_444_ts32_nosmooth_main8_208x120", "ldb_444_ccp_bd10_8_208x120",
            "ldb_444_ctu16_main8_208x120", "ldb_422_lossless_main8_208x120", "ldb_422_wp_main10_208x120", "ldb_422_wpp_depslices_main8_416x240",
            "intra_422_qp12_main10_208x120", "ldb_422_ctu32_main8_208x120"]
+# bit depth 12, 4:2:0 (oracle/make_golden.py: CF420 streams)
+STREAMS_BD12 = ["ldb_main12_208x120", "intra_main12_208x120"]
+LITE_BD12 = ["ldb_ts32_main12_208x120", "ldb_wp_main12_208x120", "ldb_sl_main12_208x120", "intra_qp4_main12_208x120", "ldb_bd12_10_208x120"]
+STREAMS_EXT = STREAMS_CF + STREAMS_BD12          # beyond Main / Main10: other chroma formats, 12 bits
+LITE_EXT = LITE_CF + LITE_BD12
 # HM-encoded streams rewritten at the bit level (oracle/make_surgery.py) for syntax HM's encoder never writes; expected pictures = HM's own
 # DECODER on the rewritten stream: pps_scaling_list_data; long-term reference pictures + ref_pic_list_modification
 SURGERY = ["surgery_ppssl_main8_208x120", "surgery_ltr_rplm_main10_208x120"]

@@ -85,7 +85,7 @@ def test_internals_describe_the_picture():
 
 
 # 4:2:2 / 4:4:4 variants on the device; the metadata fixtures' streams too (expected: HM's decoder output)
-LITE_444 = gu.LITE_CF + ["stream:" + n for n in gu.STREAMS_CF]
+LITE_444 = gu.LITE_EXT + ["stream:" + n for n in gu.STREAMS_EXT]
 
 
 @pytest.mark.parametrize("threads", [1, 3])

@@ -59,7 +59,8 @@ def test_explicit_weighted_prediction_matches_oracle(oracle, bi):
 @pytest.mark.parametrize("width,height,bd,bi,intra", [(3840, 2160, 10, False, 0.1), (3840, 2160, 10, True, 0.0),
                                                       (3840, 2160, 10, True, 0.25),      # the slowest filter configuration: bi-pred + Bs 2 edges
                                                       (1920, 1080, 10, False, 0.05), (416, 240, 8, True, 0.1),
-                                                      (1920, 1080, 10, False, 1.0), (832, 480, 8, False, 0.5)])
+                                                      (1920, 1080, 10, False, 1.0), (832, 480, 8, False, 0.5),
+                                                      (1920, 1080, 12, True, 0.1), (832, 480, 12, False, 0.3)])      # 12 bits: head room 2, 32-bit chroma H pass
 def test_synthetic_picture_matches_oracle(oracle, width, height, bd, bi, intra):
     import libhm_amd
     p = synth.make_picture(width, height, bd, seed=width + bd + int(bi), bi=bi, intra_frac=intra, ref_handles=([0], [1]))

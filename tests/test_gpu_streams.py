@@ -24,7 +24,7 @@ def _run_stream(name, check):
 
 
 # 4:4:4 (with cross-component prediction) and 4:2:2 on the device
-STREAMS_444 = gu.STREAMS_CF
+STREAMS_444 = gu.STREAMS_EXT
 
 
 @pytest.mark.parametrize("name", gu.STREAMS + STREAMS_444)

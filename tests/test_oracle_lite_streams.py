@@ -36,7 +36,7 @@ def _parsed_pictures(stream):
     return pics
 
 
-@pytest.mark.parametrize("name", gu.LITE + gu.LITE_CF + gu.SURGERY)
+@pytest.mark.parametrize("name", gu.LITE + gu.LITE_EXT + gu.SURGERY)
 def test_oracle_reconstructs_the_encoders_pictures(oracle, name):
     z = gu.load("lite_" + name)
     pics = _parsed_pictures(z["bitstream"])

@@ -6,7 +6,7 @@ import pytest
 from tests import golden_util as gu
 
 
-@pytest.mark.parametrize("name", gu.STREAMS + gu.STREAMS_CF)
+@pytest.mark.parametrize("name", gu.STREAMS + gu.STREAMS_EXT)
 def test_reconstruction_matches_hm(oracle, name):
     """every sample of every picture -- inter CUs (MC + residual) and intra CUs (reference samples, smoothing, planar / DC /
     angular prediction, residual, in decoding order) -- recomputed from the parsed data alone"""
@@ -45,7 +45,7 @@ def _inside(p):
     return ok
 
 
-@pytest.mark.parametrize("name", gu.STREAMS + gu.STREAMS_CF)
+@pytest.mark.parametrize("name", gu.STREAMS + gu.STREAMS_EXT)
 def test_deblocking_matches_hm(oracle, name):
     changed = 0
     for p in gu.stream_pictures(name):
@@ -60,7 +60,7 @@ def test_deblocking_matches_hm(oracle, name):
         assert changed == 0
 
 
-@pytest.mark.parametrize("name", gu.STREAMS + gu.STREAMS_CF)
+@pytest.mark.parametrize("name", gu.STREAMS + gu.STREAMS_EXT)
 def test_sao_matches_hm(oracle, name):
     any_sao = False
     for p in gu.stream_pictures(name):
@@ -78,7 +78,7 @@ def test_sao_matches_hm(oracle, name):
     assert any_sao or "lossless" in name            # (lossless CUs get their reconstruction back after SAO: nothing may change)
 
 
-@pytest.mark.parametrize("name", gu.STREAMS + gu.STREAMS_CF)
+@pytest.mark.parametrize("name", gu.STREAMS + gu.STREAMS_EXT)
 def test_picture_hashes_match_hm(name):
     """the oracle's CRC / checksum restatement (TComPicYuvMD5.cpp:87-181) against the values HM computed for its own
     output pictures -- the pin for the device hashes of the GPU suite"""

@@ -36,7 +36,7 @@ def _decode(name, **kw):
 
 
 @pytest.mark.parametrize("threads", [1, 4])
-@pytest.mark.parametrize("name", gu.STREAMS + gu.STREAMS_CF)
+@pytest.mark.parametrize("name", gu.STREAMS + gu.STREAMS_EXT)
 def test_parser_reproduces_hm_metadata(name, threads):
     z, got, outputs = _decode(name, threads=threads)
     pics = gu.stream_pictures(name)
@@ -69,7 +69,7 @@ def test_parser_reproduces_hm_metadata(name, threads):
                 assert np.array_equal(g["arrays"]["pcm%d" % c][mask], z[k + "pcm%d" % c].reshape(-1)[mask])
 
 
-@pytest.mark.parametrize("name", gu.STREAMS + gu.STREAMS_CF)
+@pytest.mark.parametrize("name", gu.STREAMS + gu.STREAMS_EXT)
 def test_parser_reproduces_hm_sao_and_slice_constants(name):
     z, got, outputs = _decode(name)
     pics = gu.stream_pictures(name)
