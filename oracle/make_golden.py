@@ -383,8 +383,12 @@ LITE.update({
     "ldb_sl_main12_208x120": ("encoder_lowdelay_main_rext.cfg", 208, 120, 3, 12, 12, 27, CF420 + ["--ScalingList=2", "--ScalingListFile=@SLFILE@"]),
     "intra_qp4_main12_208x120": ("encoder_intra_main_rext.cfg", 208, 120, 1, 12, 12, 4, CF420),
     "ldb_bd12_10_208x120": ("encoder_lowdelay_main_rext.cfg", 208, 120, 3, 12, 12, 28, CF420 + ["--InternalBitDepthC=10"]),
+    # 12 bits at the other chroma formats (4:4:4 with cross-component prediction)
+    "ldb_444_ccp_main12_208x120": ("encoder_lowdelay_main_rext.cfg", 208, 120, 3, 12, 12, 27, CF444 + ["--ExtendedPrecision=0"]),
+    "ldb_422_main12_208x120": ("encoder_lowdelay_main_rext.cfg", 208, 120, 3, 12, 12, 28, CF422 + ["--ExtendedPrecision=0"]),
 })
-LITE_BD12 = ["ldb_ts32_main12_208x120", "ldb_wp_main12_208x120", "ldb_sl_main12_208x120", "intra_qp4_main12_208x120", "ldb_bd12_10_208x120"]
+LITE_BD12 = ["ldb_ts32_main12_208x120", "ldb_wp_main12_208x120", "ldb_sl_main12_208x120", "intra_qp4_main12_208x120", "ldb_bd12_10_208x120",
+             "ldb_444_ccp_main12_208x120", "ldb_422_main12_208x120"]
 
 
 def make_lite(names=None):

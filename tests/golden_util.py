@@ -32,7 +32,8 @@ LITE_CF = ["ldb_444_main10_208x120", "ldb_444_lossless_main8_208x120", "intra_44
            "intra_422_qp12_main10_208x120", "ldb_422_ctu32_main8_208x120"]
 # bit depth 12, 4:2:0 (oracle/make_golden.py: CF420 streams)
 STREAMS_BD12 = ["ldb_main12_208x120", "intra_main12_208x120"]
-LITE_BD12 = ["ldb_ts32_main12_208x120", "ldb_wp_main12_208x120", "ldb_sl_main12_208x120", "intra_qp4_main12_208x120", "ldb_bd12_10_208x120"]
+LITE_BD12 = ["ldb_ts32_main12_208x120", "ldb_wp_main12_208x120", "ldb_sl_main12_208x120", "intra_qp4_main12_208x120", "ldb_bd12_10_208x120",
+             "ldb_444_ccp_main12_208x120", "ldb_422_main12_208x120"]
 STREAMS_EXT = STREAMS_CF + STREAMS_BD12          # beyond Main / Main10: other chroma formats, 12 bits
 LITE_EXT = LITE_CF + LITE_BD12
 # HM-encoded streams rewritten at the bit level (oracle/make_surgery.py) for syntax HM's encoder never writes; expected pictures = HM's own
