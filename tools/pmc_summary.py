@@ -15,7 +15,7 @@ from pmc_summary_digest import csrc_digest
 
 BENCH_NAME = {"k_itx": "itx", "k_mc_luma<false, false>": "mc_luma", "k_mc_chroma<false, false>": "mc_chroma", "k_mc_luma<false, false, true>": "mc_luma",
               "k_mc_chroma<false, false, true>": "mc_chroma", "k_mc_luma<false, false, false>": "mc_luma", "k_mc_chroma<false, false, false>": "mc_chroma", "k_deblock<0>": "deblock_ver",
-              "k_deblock<1>": "deblock_hor", "k_sao": "sao", "k_prep": "prep", "k_extend": "extend_border",
+              "k_deblock<1>": "deblock_hor", "k_sao": "sao", "k_prep": "prep", "k_prep<1>": "prep", "k_extend": "extend_border",
               "k_filter_fused<false>": "filter_fused", "k_intra": "intra"}
 args = sys.argv[1:]
 json_out = None
