@@ -416,6 +416,7 @@ def host_inclusive(ctx, metas, pics, refs_of, nb, w, h, args):
     t0 = time.perf_counter()
     for k in range(n):
         step(k)
+    t_issue = time.perf_counter() - t0                        # the host's share: the calls return once everything is enqueued
     ctx.sync()
     dt = time.perf_counter() - t0
     a0 = stg[0].arrays
@@ -430,7 +431,7 @@ def host_inclusive(ctx, metas, pics, refs_of, nb, w, h, args):
     return {"host_inclusive_Mpixels_s": round(n * nb * w * h / dt / 1e6, 1),
             "host_inclusive": {"ms_per_step": round(dt / n * 1e3, 3), "steps": n, "staged_bytes_per_picture": int(staged),
                                "staged_bytes_per_picture_dense_levels": int(dense),
-                               "PCIe_GBps": round(n * nb * staged / dt / 1e9, 1),
+                               "PCIe_GBps": round(n * nb * staged / dt / 1e9, 1), "host_issue_ms_per_step": round(t_issue / n * 1e3, 3),
                                "what": "hmgpu_decompress_pictures + hmgpu_filter_pictures per step, inputs copied from page-locked staging "
                                        "blocks every step (the metadata a P picture without intra CUs needs in one DMA, compact levels -- coded TUs only -- in "
                                        "three, on a copy stream; two sets of device pictures: "

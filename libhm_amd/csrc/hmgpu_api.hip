@@ -7,6 +7,7 @@
 #include "hmgpu_dev.h"
 
 #include <algorithm>
+#include <chrono>
 #include <atomic>
 #include <cstdio>
 #include <cstring>
@@ -77,10 +78,29 @@ struct hmgpu_ctx {
   // kernels of this one run.  Two rings of events order it against the compute stream: copy_ev (inputs of a batch have arrived) and
   // use_ev (the kernels that read a picture's inputs have finished: its device arrays may be overwritten)
   hipStream_t copy_stream = nullptr;
+  // ... and every second picture of a call on a second one: one stream's copies run on one DMA engine (~40 GB/s from page-locked memory on
+  // this host), two reach 50-57 (tools/dbg/pcie.py).  The second lane joins the first before copy_ev is recorded (copy_join).
+  hipStream_t copy_stream2 = nullptr;
+  hipEvent_t copy_join = nullptr;
   hipEvent_t copy_ev[8] = {}, use_ev[8] = {};
   uint64_t copy_seq = 0, use_seq = 0;
   std::vector<hmgpu_staging*> stagings;
   std::vector<hmgpu_staging*> shared_stagings;   // blocks of other contexts (hmgpu_staging_share): recognised, not owned
+  // Small host structures (descriptors, slice table entries, resolved SAO parameters) travel through a ring of page-locked memory: an
+  // asynchronous copy from pageable memory makes the runtime stage the bytes itself, 20-100 us of the calling thread per copy (the resolved
+  // SAO parameters of a picture: 0.18 ms; sixteen pictures per call spent 7 of their 7.7 ms on the host that way, round 4).  Eight segments; a
+  // segment is reused when the events recorded at its close -- one per stream that may carry its copies -- have passed.
+  static constexpr int kBounceSegs = 8;
+  static constexpr size_t kBounceSeg = 1u << 20;
+  char* bounce = nullptr;
+  int bounce_seg = 0;
+  size_t bounce_off = 0;
+  hipEvent_t bounce_ev[kBounceSegs][3] = {};
+  bool bounce_used[kBounceSegs] = {};
+  // HMGPU_HOST_TIMING=1: wall time the calling thread spends inside the batch entry points, by part (printed by hmgpu_destroy)
+  bool host_timing = false;
+  double host_s[6] = {0, 0, 0, 0, 0, 0};
+  uint64_t host_calls = 0;
   hipEvent_t dl_ev[32] = {};           // hmgpu_picture_download_begin tickets: ticket t completes with dl_ev[t % 32]
   std::atomic<uint64_t> dl_seq{0};
   // hmgpu_picture_hash_begin: MD5 chains of finished pictures over packed copies in a ring of slots; launched in batches (one lane per
@@ -130,6 +150,12 @@ struct hmgpu_ctx {
 
 namespace {
 
+struct HostTimer {                      // adds the time between construction and destruction to one slot (when timing is on)
+  hmgpu_ctx* c; int slot; std::chrono::steady_clock::time_point t0;
+  HostTimer(hmgpu_ctx* c_, int slot_) : c(c_), slot(slot_) { if (c->host_timing) t0 = std::chrono::steady_clock::now(); }
+  ~HostTimer() { if (c->host_timing) c->host_s[slot] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); }
+};
+
 #define HIP_TRY(ctx, expr)                                   \
   do {                                                       \
     hipError_t e__ = (expr);                                 \
@@ -138,6 +164,25 @@ namespace {
       return HMGPU_EDEVICE;                                  \
     }                                                        \
   } while (0)
+
+// host -> device copy of a small structure on stream hs: through the context's page-locked ring (hmgpu_ctx::bounce) when it fits
+static hipError_t h2d_small(hmgpu_ctx* c, void* dst, const void* src, size_t bytes, hipStream_t hs) {
+  const size_t need = (bytes + 63) & ~(size_t)63;
+  if (!c->bounce || need > hmgpu_ctx::kBounceSeg) return hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, hs);
+  if (c->bounce_off + need > hmgpu_ctx::kBounceSeg) {
+    hipStream_t streams[3] = {c->stream, c->copy_stream, c->copy_stream2};
+    for (int k = 0; k < 3; k++) (void)hipEventRecord(c->bounce_ev[c->bounce_seg][k], streams[k]);
+    c->bounce_used[c->bounce_seg] = true;
+    c->bounce_seg = (c->bounce_seg + 1) % hmgpu_ctx::kBounceSegs;
+    c->bounce_off = 0;
+    if (c->bounce_used[c->bounce_seg]) for (int k = 0; k < 3; k++) (void)hipEventSynchronize(c->bounce_ev[c->bounce_seg][k]);
+  }
+  char* at = c->bounce + (size_t)c->bounce_seg * hmgpu_ctx::kBounceSeg + c->bounce_off;
+  memcpy(at, src, bytes);
+  c->bounce_off += need;
+  return hipMemcpyAsync(dst, at, bytes, hipMemcpyHostToDevice, hs);
+}
+
 
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 // one set of planes of a picture: luma, then the plane that holds Cb and Cr
@@ -327,13 +372,13 @@ void free_picture(Picture& p) {
 }
 
 hmgpu_status push_picdev(hmgpu_ctx* c, int pic) {
-  HIP_TRY(c, hipMemcpyAsync(c->d_pics + pic, &c->pics[pic].dev, sizeof(PicDev), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, h2d_small(c, c->d_pics + pic, &c->pics[pic].dev, sizeof(PicDev), c->stream));
   return HMGPU_OK;
 }
 hmgpu_status push_final(hmgpu_ctx* c, int pic) {
   Picture& p = c->pics[pic];
   for (int k = 0; k < 3; k++) c->h_finals[pic].p[k] = p.sao_applied ? p.dev.sao[k] : p.dev.rec[k];
-  HIP_TRY(c, hipMemcpyAsync(c->d_finals + pic, &c->h_finals[pic], sizeof(PlaneSet), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, h2d_small(c, c->d_finals + pic, &c->h_finals[pic], sizeof(PlaneSet), c->stream));
   return HMGPU_OK;
 }
 
@@ -531,7 +576,7 @@ hmgpu_status stage_sao(hmgpu_ctx* c, Picture& p, const hmgpu_pic_params* pp, con
     }
   }
   p.sao_any = any;
-  HIP_TRY(c, hipMemcpyAsync(p.dev.saoprm, dev.data(), dev.size() * sizeof(SaoDev), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, h2d_small(c, p.dev.saoprm, dev.data(), dev.size() * sizeof(SaoDev), c->stream));
   return HMGPU_OK;
 }
 
@@ -571,10 +616,16 @@ hmgpu_status hmgpu_create(const hmgpu_seq_params* seq, int device_ordinal, hmgpu
   if (!c) return HMGPU_ENOMEM;
   c->seq = *seq;
   c->device = device_ordinal;
+  c->host_timing = getenv("HMGPU_HOST_TIMING") != nullptr;
   hipError_t e = hipSetDevice(device_ordinal);
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking);
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->copy_stream2, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&c->copy_join, hipEventDisableTiming);
+  if (e == hipSuccess) e = hipHostMalloc((void**)&c->bounce, hmgpu_ctx::kBounceSegs * hmgpu_ctx::kBounceSeg, hipHostMallocDefault);
+  for (int g = 0; g < hmgpu_ctx::kBounceSegs && e == hipSuccess; g++)
+    for (int k = 0; k < 3 && e == hipSuccess; k++) e = hipEventCreateWithFlags(&c->bounce_ev[g][k], hipEventDisableTiming);
   for (int k = 0; k < 8 && e == hipSuccess; k++) e = hipEventCreateWithFlags(&c->copy_ev[k], hipEventDisableTiming);
   for (int k = 0; k < 8 && e == hipSuccess; k++) e = hipEventCreateWithFlags(&c->use_ev[k], hipEventDisableTiming);
   for (int k = 0; k < 32 && e == hipSuccess; k++) e = hipEventCreateWithFlags(&c->dl_ev[k], hipEventDisableTiming | hipEventBlockingSync);   // (waited for by helper threads: sleep, do not spin)
@@ -641,6 +692,10 @@ void hmgpu_destroy(hmgpu_ctx* c) {
   if (c->stream) hipStreamSynchronize(c->stream);
   prof_drain(c);
   for (EventPair& ep : c->free_events) { hipEventDestroy(ep.a); hipEventDestroy(ep.b); }
+  if (c->host_timing && c->host_calls)
+    fprintf(stderr, "hmgpu host time per hmgpu_decompress_pictures + hmgpu_filter_pictures (%llu calls): validate %.3f ms, slices %.3f, stage_inputs %.3f, recon launches %.3f, sao staging %.3f, filter launches %.3f\n",
+            (unsigned long long)c->host_calls, 1e3 * c->host_s[0] / c->host_calls, 1e3 * c->host_s[1] / c->host_calls, 1e3 * c->host_s[2] / c->host_calls,
+            1e3 * c->host_s[3] / c->host_calls, 1e3 * c->host_s[4] / c->host_calls, 1e3 * c->host_s[5] / c->host_calls);
   for (Picture& p : c->pics) free_picture(p);
   if (c->d_pics) hipFree(c->d_pics);
   if (c->d_finals) hipFree(c->d_finals);
@@ -649,7 +704,11 @@ void hmgpu_destroy(hmgpu_ctx* c) {
   if (c->d_ctu_order) hipFree(c->d_ctu_order);
   if (c->stream) hipStreamDestroy(c->stream);
   if (c->stream2) hipStreamDestroy(c->stream2);
+  if (c->copy_stream2) { hipStreamSynchronize(c->copy_stream2); hipStreamDestroy(c->copy_stream2); }
   if (c->copy_stream) { hipStreamSynchronize(c->copy_stream); hipStreamDestroy(c->copy_stream); }
+  if (c->copy_join) hipEventDestroy(c->copy_join);
+  for (int g = 0; g < hmgpu_ctx::kBounceSegs; g++) for (int k = 0; k < 3; k++) if (c->bounce_ev[g][k]) hipEventDestroy(c->bounce_ev[g][k]);
+  if (c->bounce) (void)hipHostFree(c->bounce);
   for (int k = 0; k < 8; k++) { if (c->copy_ev[k]) hipEventDestroy(c->copy_ev[k]); if (c->use_ev[k]) hipEventDestroy(c->use_ev[k]); }
   for (hmgpu_staging* st : c->shared_stagings) {
     st->sharers.erase(std::remove(st->sharers.begin(), st->sharers.end(), c), st->sharers.end());
@@ -1103,10 +1162,10 @@ static hmgpu_status register_slice(hmgpu_ctx* c, hmgpu_pic cur, int32_t slice_id
             t[y * n + x] = (uint8_t)v;
           }
       }
-    HIP_TRY(c, hipMemcpyAsync(p.sl_table, p.sl_host.data(), p.sl_host.size(), hipMemcpyHostToDevice, hs));
+    HIP_TRY(c, h2d_small(c, p.sl_table, p.sl_host.data(), p.sl_host.size(), hs));
     p.dev.sl_m = p.sl_table;
   }
-  HIP_TRY(c, hipMemcpyAsync((void*)(p.dev.slices + slice_idx), &p.slices[slice_idx], sizeof(SliceDev), hipMemcpyHostToDevice, hs));
+  HIP_TRY(c, h2d_small(c, (void*)(p.dev.slices + slice_idx), &p.slices[slice_idx], sizeof(SliceDev), hs));
   return HMGPU_OK;
 }
 
@@ -1214,8 +1273,8 @@ static hmgpu_status stage_inputs(hmgpu_ctx* c, hmgpu_pic cur, int32_t slice_idx,
       p.h_tile_idx.resize(c->num_ctus);
       for (int i = 0; i < num_ctus; i++) p.h_slice_idx[first_ctu + i] = m->slice_idx ? m->slice_idx[first_ctu + i] : (uint16_t)slice_idx;
       for (int i = 0; i < num_ctus; i++) p.h_tile_idx[first_ctu + i] = m->tile_idx ? m->tile_idx[first_ctu + i] : (uint16_t)0;
-      HIP_TRY(c, hipMemcpyAsync((void*)(p.dev.slice_idx + first_ctu), p.h_slice_idx.data() + first_ctu, (size_t)num_ctus * 2, hipMemcpyHostToDevice, hs));
-      HIP_TRY(c, hipMemcpyAsync((void*)(p.dev.tile_idx + first_ctu), p.h_tile_idx.data() + first_ctu, (size_t)num_ctus * 2, hipMemcpyHostToDevice, hs));
+      HIP_TRY(c, h2d_small(c, (void*)(p.dev.slice_idx + first_ctu), p.h_slice_idx.data() + first_ctu, (size_t)num_ctus * 2, hs));
+      HIP_TRY(c, h2d_small(c, (void*)(p.dev.tile_idx + first_ctu), p.h_tile_idx.data() + first_ctu, (size_t)num_ctus * 2, hs));
     }
     for (int k = 0; k < 3 && !compact; k++) {
       const size_t per = (size_t)(c->ctu * c->ctu) >> (k ? c->csx + c->csy : 0);
@@ -1251,35 +1310,44 @@ static hmgpu_status stage_inputs(hmgpu_ctx* c, hmgpu_pic cur, int32_t slice_idx,
       p.dev.pcm_shift[1] = p.dev.pcm_shift[2] = c->seq.bit_depth_chroma - c->seq.pcm_bit_depth_chroma;
     }
     if (any_bypass || (any_pcm && c->seq.pcm_loop_filter_disable)) p.dev.any_nofilt = 1;
-    HIP_TRY(c, hipMemcpyAsync(c->d_pics + cur, &p.dev, sizeof(PicDev), hipMemcpyHostToDevice, hs));
+    HIP_TRY(c, h2d_small(c, c->d_pics + cur, &p.dev, sizeof(PicDev), hs));
   }
   // a range decoded again (picture buffer reused without release/acquire) replaces the earlier record
   p.calls.erase(std::remove_if(p.calls.begin(), p.calls.end(), [&](const SliceCall& o) {
                   return o.first_ctu < first_ctu + num_ctus && first_ctu < o.first_ctu + o.num_ctus; }), p.calls.end());
-  // the caller's arrays are at hand: whether the range holds intra CUs at all decides if the intra kernel is launched
-  const bool has_intra = p.dev.has_intra_dir && memchr(m->pred_mode + po, HMGPU_MODE_INTRA, pn) != nullptr;
-  // PUs that cut an 8x8 luma tile: 2NxN / Nx2N (/ NxN) parts of 8x8 CUs, the 4- and 12-sample parts of AMP in 16x16 CUs
-  bool cells = false;
+  // The caller's arrays are at hand: ONE pass over three of them (branch-free, so that the compiler vectorises it: ~1.5 MB per 2160p picture)
+  // says whether the range holds intra CUs at all and how many (which intra kernel, if any: launch_intra) and whether it holds PUs that cut
+  // an 8x8 luma tile -- 2NxN / Nx2N (/ NxN) parts of 8x8 CUs, the 4- and 12-sample parts of AMP in 16x16 CUs -- (the cells kernels).
+  // (Round 4: the search for such PUs was a loop with an early exit over every 8x8 area; on pictures without them it walked all of them,
+  // 0.2 ms of the calling thread per 2160p picture; this pass takes ~0.05.)
+  size_t n_intra = 0;
+  unsigned cells_u = 0;
   {
-    const int d8 = c->seq.log2_ctu_size - 3;
-    const int8_t* ps = m->part_size + po;
-    const uint8_t* dp = m->depth + po;
-    const int8_t* pm = m->pred_mode + po;
-    unsigned other = 0;                                       // (a loop the compiler vectorises: most pictures stop here)
-    for (size_t i = 0; i < pn; i++) other |= (unsigned)(ps[i] != HMGPU_SIZE_2Nx2N && ps[i] != HMGPU_SIZE_NONE);
-    for (size_t i = 0; other && i < pn && !cells; i += 4)     // 8x8 is the minimum CU size: four consecutive partitions share these fields
-      cells = ps[i] != HMGPU_SIZE_2Nx2N && ps[i] != HMGPU_SIZE_NONE && pm[i] != HMGPU_MODE_INTRA &&
-              (dp[i] >= d8 || (dp[i] == d8 - 1 && ps[i] >= HMGPU_SIZE_2NxnU));
+    // (byte lanes throughout -- 16 or 32 partitions per vector instruction --: the counts of a chunk of 192 stay below 256)
+    const uint8_t d8 = (uint8_t)(c->seq.log2_ctu_size - 3), d8m = (uint8_t)(d8 - 1);
+    const int8_t* __restrict ps = m->part_size + po;
+    const uint8_t* __restrict dp = m->depth + po;
+    const int8_t* __restrict pm = m->pred_mode + po;
+    for (size_t base = 0; base < pn; base += 192) {
+      const size_t n = std::min<size_t>(192, pn - base);
+      uint8_t cnt = 0, cel = 0;
+      for (size_t i = 0; i < n; i++) {
+        const uint8_t ptn = (uint8_t)ps[base + i], d = dp[base + i];
+        const uint8_t intra = (uint8_t)(pm[base + i] == HMGPU_MODE_INTRA);
+        const uint8_t part = (uint8_t)((ptn != HMGPU_SIZE_2Nx2N) & (ptn != HMGPU_SIZE_NONE));
+        const uint8_t small = (uint8_t)((d >= d8) | ((d == d8m) & (ptn >= HMGPU_SIZE_2NxnU)));
+        cnt = (uint8_t)(cnt + intra);
+        cel = (uint8_t)(cel | (part & (intra ^ 1) & small));
+      }
+      n_intra += cnt; cells_u |= cel;
+    }
   }
+  const bool has_intra = p.dev.has_intra_dir && n_intra != 0;
+  const bool cells = cells_u != 0;
   bool any_b = false, any_i = false;
   for (int si : slices) { any_b |= p.slices[si].slice_type == HMGPU_B_SLICE; any_i |= p.slices[si].slice_type == HMGPU_I_SLICE; }
-  // which intra kernel (launch_intra): I slices, or a range at least half intra, take the one that stages whole CTUs
-  if (has_intra && !any_i) {
-    const int8_t* pm = m->pred_mode + po;
-    size_t n_intra = 0;
-    for (size_t i = 0; i < pn; i++) n_intra += (size_t)(pm[i] == HMGPU_MODE_INTRA);
-    any_i = 2 * n_intra >= pn;
-  }
+  // I slices, or a range at least half intra, take the intra kernel that stages whole CTUs
+  if (has_intra && !any_i) any_i = 2 * n_intra >= pn;
   SliceCall call = {first_ctu, num_ctus, slice_idx, has_intra, any_wp, cells, any_b, any_i};
   p.calls.push_back(call);
   p.extended = false;
@@ -1468,15 +1536,17 @@ void hmgpu_staging_free(hmgpu_ctx* c, hmgpu_staging* st) {
 }
 
 // the copy stream may overwrite a picture's input arrays once the kernels that last read them have finished
-static void wait_for_last_use(hmgpu_ctx* c, const Picture& p) {
+static void wait_for_last_use(hmgpu_ctx* c, const Picture& p, hipStream_t hs) {
   if (!p.last_use) return;
   // (events older than the ring are gone: the newest one was recorded later and is a safe stand-in)
   const uint64_t seq = c->use_seq - p.last_use < 8 ? p.last_use : c->use_seq;
-  (void)hipStreamWaitEvent(c->copy_stream, c->use_ev[seq % 8], 0);
+  (void)hipStreamWaitEvent(hs, c->use_ev[seq % 8], 0);
 }
 
 hmgpu_status hmgpu_decompress_pictures(hmgpu_ctx* c, int32_t n, const hmgpu_picture_job* jobs) {
   if (!c || !jobs || n < 1 || n > kMaxBatch) return HMGPU_EINVAL;
+  c->host_calls++;
+  { HostTimer tv(c, 0);
   for (int i = 0; i < n; i++) {
     const hmgpu_picture_job& j = jobs[i];
     if (!valid_pic(c, j.pic) || !j.slices || j.num_slices < 1 || j.num_slices > HMGPU_MAX_SLICES || !meta_complete(j.meta, j.coeffs)) return HMGPU_EINVAL;
@@ -1489,6 +1559,7 @@ hmgpu_status hmgpu_decompress_pictures(hmgpu_ctx* c, int32_t n, const hmgpu_pict
         for (int r = 0; r < j.slices[s2]->num_ref_idx[l] && r < HMGPU_MAX_REF; r++)
           for (int k = 0; k < n; k++) if (j.slices[s2]->ref_pic[l][r] == jobs[k].pic) return HMGPU_EINVAL;
   }
+  }
   hipSetDevice(c->device);
   Batch b; memset(&b, 0, sizeof(b));
   b.n = n;
@@ -1500,20 +1571,28 @@ hmgpu_status hmgpu_decompress_pictures(hmgpu_ctx* c, int32_t n, const hmgpu_pict
     for (int i = 0; i < n && st == HMGPU_OK; i++) {
       const hmgpu_picture_job& j = jobs[i];
       Picture& p = c->pics[j.pic];
-      wait_for_last_use(c, p);
+      const hipStream_t hs = (i & 1) ? c->copy_stream2 : c->copy_stream;       // two copy lanes: two DMA engines
+      wait_for_last_use(c, p, hs);
       if (p.sao_applied) { p.sao_applied = false; p.dev.sao_applied = 0; for (int k = 0; k < 3; k++) c->h_finals[j.pic].p[k] = p.dev.rec[k];
-                           HIP_TRY(c, hipMemcpyAsync(c->d_finals + j.pic, &c->h_finals[j.pic], sizeof(PlaneSet), hipMemcpyHostToDevice, c->copy_stream)); }
+                           HIP_TRY(c, h2d_small(c, c->d_finals + j.pic, &c->h_finals[j.pic], sizeof(PlaneSet), hs)); }
       bool wp = false;
+      { HostTimer ts(c, 1);
       for (int k = 0; k < j.num_slices && st == HMGPU_OK; k++) {
-        st = register_slice(c, j.pic, k, j.slices[k], c->copy_stream);
+        st = register_slice(c, j.pic, k, j.slices[k], hs);
         all[i].push_back(k);
         wp |= j.slices[k] && j.slices[k]->weighted_pred != 0;
       }
+      }
       SliceCall call;
-      if (st == HMGPU_OK) st = stage_inputs(c, j.pic, 0, all[i], wp, j.meta, j.coeffs, 0, c->num_ctus, c->copy_stream, &call);
+      HostTimer ti(c, 2);
+      if (st == HMGPU_OK) st = stage_inputs(c, j.pic, 0, all[i], wp, j.meta, j.coeffs, 0, c->num_ctus, hs, &call);
       if (st != HMGPU_OK) break;
       b.pic[i] = j.pic; b.first_ctu[i] = 0; b.num_ctus[i] = c->num_ctus;
       any_intra |= call.intra; any_wp |= call.wp; any_cells |= call.cells; any_bi |= call.bi; any_islice |= call.islice;
+    }
+    if (n > 1) {                        // (also after an error: whatever the second lane was given is ordered in front of the next event of the first)
+      (void)hipEventRecord(c->copy_join, c->copy_stream2);
+      (void)hipStreamWaitEvent(c->copy_stream, c->copy_join, 0);
     }
     if (st != HMGPU_OK) return st;
     c->copy_seq++;
@@ -1522,6 +1601,7 @@ hmgpu_status hmgpu_decompress_pictures(hmgpu_ctx* c, int32_t n, const hmgpu_pict
     HIP_TRY(c, hipEventRecord(c->copy_ev[c->copy_seq % 8], c->copy_stream));
     HIP_TRY(c, hipStreamWaitEvent(c->stream, c->copy_ev[c->copy_seq % 8], 0));
   }
+  HostTimer tr(c, 3);
   for (int i = 0; i < n && st == HMGPU_OK; i++) st = extend_refs_of(c, jobs[i].pic, all[i]);
   if (st == HMGPU_OK) st = run_recon(c, b, any_intra, any_wp, any_cells, any_bi, any_islice);
   mark_use(c, b);
@@ -1538,6 +1618,7 @@ hmgpu_status hmgpu_filter_pictures(hmgpu_ctx* c, int32_t n, const hmgpu_filter_j
   hipSetDevice(c->device);
   Batch b; memset(&b, 0, sizeof(b));
   b.n = n;
+  { HostTimer tsao(c, 4);
   for (int i = 0; i < n; i++) {
     Picture& p = c->pics[jobs[i].pic];
     p.sao_any = false;
@@ -1551,6 +1632,8 @@ hmgpu_status hmgpu_filter_pictures(hmgpu_ctx* c, int32_t n, const hmgpu_filter_j
     p.filter_ready = true;
     b.pic[i] = jobs[i].pic; b.first_ctu[i] = 0; b.num_ctus[i] = c->num_ctus;
   }
+  }
+  HostTimer tf(c, 5);
   hmgpu_status st = run_filter(c, b, 7);
   if (st != HMGPU_OK) return st;
   for (int i = 0; i < n && st == HMGPU_OK; i++) {
