@@ -21,6 +21,7 @@
 #include "hmgpu_dev.h"
 #include "itx_core.h"       // packed 16-bit helpers, wave_lds_sync
 #include <algorithm>
+#include <type_traits>
 
 namespace hmgpu {
 
@@ -464,12 +465,36 @@ __device__ __attribute__((always_inline)) inline void intra_stage(const PicDev& 
 // four in the list: one wave runs them one after the other (they are a dependent chain anyway) without going back to the list in between --,
 // 3: the other three (list entries for their availability masks only, never pending)
 struct TuRun { uint8_t z, z_cu, log2n, kind; };
-struct IntraSched {
+// PACKED: the per-entry words squeezed (the LEAN kernel: LDS decides how many of its workgroups a CU holds); the general kernel keeps them
+// plain -- unpacking them in the ready-scan cost an I picture 3 %
+template <bool PACKED>
+struct IntraSchedT {
   TuRun tu[256];
-  uint32_t need_col[256];        // bit y: unit (x4 - 1, y) of the column left of the TU must be final (the left CTU's last column when x4 = 0)
-  uint32_t clampi[256];          // the run of available units as line indices: first sample | last sample << 16 (0xffffffff: not one run, the general substitution applies)
-  uint64_t avail[256];           // bit u: reference unit u of the TU (intra_tu's numbering) is available (6.4.1 + constrained intra prediction)
-  uint64_t need_row[256];        // bit c + 1: unit (c, y4 - 1), c = -1 .. 31, of the row above the TU (the row of the CTUs above when y4 = 0)
+  // per list entry; packed (round 4: 4.5 instead of 7 KB -- the LEAN kernel's workgroups are 9.5 KB, 16 of them per CU) as follows:
+  //   col    bits 0-15: bit y = unit (x4 - 1, y) of the column left of the TU must be final (the left CTU's last column when x4 = 0);
+  //          bit 16 / 17: bit 32 of the row mask / of the availability mask
+  //   row    bit c + 1: unit (c, y4 - 1), c = -1 .. 31, of the row above the TU (the row of the CTUs above when y4 = 0), bits 0-31
+  //   avl    bit u: reference unit u of the TU (intra_tu's numbering) is available (6.4.1 + constrained intra prediction), bits 0-31
+  //   clamp  the run of available units as line indices (at most 128): first sample | last sample << 8 (0xffff: not one run)
+  // (plain: col = the 16 bits, row / avl 64 bits, clamp = first | last << 16, 0xffffffff: not one run)
+  using Wide = std::conditional_t<PACKED, uint32_t, uint64_t>;
+  using Clamp = std::conditional_t<PACKED, uint16_t, uint32_t>;
+  uint32_t e_col[256];
+  Wide e_row[256], e_avl[256];
+  Clamp e_clamp[256];
+  __device__ void put(int i, uint32_t nc, uint64_t nr, uint64_t am, uint32_t cl) {
+    if constexpr (PACKED) {
+      e_col[i] = (nc & 0xffffu) | ((uint32_t)(nr >> 32) & 1u) << 16 | ((uint32_t)(am >> 32) & 1u) << 17;
+      e_row[i] = (uint32_t)nr; e_avl[i] = (uint32_t)am;
+      e_clamp[i] = cl == 0xffffffffu ? (uint16_t)0xffffu : (uint16_t)((cl & 0xffu) | ((cl >> 16) << 8));
+    } else { e_col[i] = nc; e_row[i] = nr; e_avl[i] = am; e_clamp[i] = cl; }
+  }
+  __device__ uint32_t need_col(int i) const { if constexpr (PACKED) return e_col[i] & 0xffffu; else return e_col[i]; }
+  __device__ uint64_t need_row(int i) const { if constexpr (PACKED) return (uint64_t)e_row[i] | ((uint64_t)((e_col[i] >> 16) & 1u) << 32); else return e_row[i]; }
+  __device__ uint64_t avail(int i) const { if constexpr (PACKED) return (uint64_t)e_avl[i] | ((uint64_t)((e_col[i] >> 17) & 1u) << 32); else return e_avl[i]; }
+  __device__ uint32_t clampi(int i) const {
+    if constexpr (PACKED) { const uint32_t v = e_clamp[i]; return v == 0xffffu ? 0xffffffffu : (v & 0xffu) | ((v >> 8) << 16); } else return e_clamp[i];
+  }
   uint32_t done_r[16], done_c[16];   // final units per row (bit x) / per column (bit y); set with LDS atomics by the wave that finished a TU
   uint32_t got[3];                   // border units of the neighbouring CTUs whose samples are in LDS (L.pix columns 0, 1 / L.top): column | row lo | row hi
   uint32_t pend[8];                  // list entries nobody has taken yet (bit i & 31 of pend[i >> 5]); a wave takes one with an atomic AND
@@ -521,7 +546,7 @@ __device__ __attribute__((always_inline)) inline void poll_neighbours(const PicD
 // (the masks of what has been fetched are shared by the waves of the workgroup: a wave with nothing to run fetches what has become final
 // next door, so that the TUs along the CTU's left and top border find their reference samples in LDS)
 // org: the CTU's first sample of this component in the picture, pitch: the plane's
-template <class IntraLds>
+template <class IntraLds, class IntraSched>
 __device__ __attribute__((always_inline)) inline void fetch_border(const int16_t* org, int pitch, int comp, int cs, uint32_t need_col, uint64_t need_row, IntraSched& Q, IntraLds& L) {
   const int lane = threadIdx.x & 63, us = 4 >> cs;
   const uint32_t mc = need_col & ~Q.got[0];
@@ -559,7 +584,7 @@ __device__ __attribute__((always_inline)) inline void fetch_border(const int16_t
 // that is ready and that nobody has taken (an atomic AND on the pending mask), runs it and marks its units final (atomic ORs).  TUs that
 // do not depend on each other -- the next ones along an anti-diagonal of the CTU -- run side by side; the CTU's samples, the done masks
 // and the list are shared in LDS, the reference line / transform scratch of a TU in flight is the wave's own (IntraScratch).
-template <class IntraLds>
+template <class IntraLds, class IntraSched>
 __device__ __attribute__((always_inline)) inline void intra_ctu(const PicDev& P, int comp, int ctu, bool sparse_ctu, IntraLds& L, IntraSched& Q, IntraScratch& W, Neighbours& nb) {
   const bool sparse = IntraLds::lean || sparse_ctu;
   const int parts = P.parts, pw = P.pw;
@@ -710,7 +735,7 @@ __device__ __attribute__((always_inline)) inline void intra_ctu(const PicDev& P,
           cl = (uint32_t)lo | ((uint32_t)hi << 16);
         }
       }
-      if (lane == 0) { Q.need_col[i] = nc; Q.need_row[i] = nr; Q.avail[i] = am; Q.clampi[i] = cl; }
+      if (lane == 0) Q.put(i, nc, nr, am, cl);
     }
   } else
   for (int i = lane; i < n_tus; i += 64) {
@@ -729,7 +754,6 @@ __device__ __attribute__((always_inline)) inline void intra_ctu(const PicDev& P,
       if (y4 == 0) { for (int c = x4 - 1; c < x4 + 2 * Un; c++) nr |= 1ull << (c + 1); }
       else for (int c = x4; c < min(pw, x4 + 2 * Un); c++) if (z_of(c, y4 - 1) < e.z) nr |= 1ull << (c + 1);
     }
-    Q.need_col[i] = nc; Q.need_row[i] = nr;
     // availability of the TU's reference units (intra_tu: 2U units of the left column bottom-up, the corner, 2U units of the row above)
     uint64_t am = 0;
     if (e.kind != 1) {
@@ -746,7 +770,6 @@ __device__ __attribute__((always_inline)) inline void intra_ctu(const PicDev& P,
 #endif
       }
     }
-    Q.avail[i] = am;
     // fillReferenceSamples pads unavailable samples from the nearest available one before them (the first available one for those in front):
     // when the available units are one run -- missing below-left and / or above-right units, the usual case -- that is a clamp of the index
     uint32_t cl = 0xffffffffu;
@@ -759,7 +782,7 @@ __device__ __attribute__((always_inline)) inline void intra_ctu(const PicDev& P,
         cl = (uint32_t)lo | ((uint32_t)hi << 16);
       }
     }
-    Q.clampi[i] = cl;
+    Q.put(i, nc, nr, am, cl);
   }
   wave_lds_sync();
 #if defined(INTRA_STOP) && INTRA_STOP == 5
@@ -809,7 +832,7 @@ __device__ __attribute__((always_inline)) inline void intra_ctu(const PicDev& P,
         const int x4 = zscan_x(e.z), y4 = zscan_y(e.z);
         const uint32_t have_c = x4 == 0 ? nb.ext_col : Q.done_c[x4 - 1];
         const uint64_t have_r = y4 == 0 ? nb.ext_row : ((uint64_t)Q.done_r[y4 - 1] << 1) | 1ull;
-        ready = (Q.need_col[c] & ~have_c) == 0 && (Q.need_row[c] & ~have_r) == 0;
+        ready = (Q.need_col(c) & ~have_c) == 0 && (Q.need_row(c) & ~have_r) == 0;
       }
       any_pending |= __builtin_amdgcn_ballot_w64(pending) != 0;
       const unsigned long long m = __builtin_amdgcn_ballot_w64(ready);
@@ -880,9 +903,9 @@ __device__ __attribute__((always_inline)) inline void intra_ctu(const PicDev& P,
         if (comp && mode == 36) mode = uni(L.m_dirl[h_fmt == 3 ? zs : z]);
         t.mode = mode;
         {
-          const uint64_t a = Q.avail[idx];
+          const uint64_t a = Q.avail(idx);
           t.am = (unsigned long long)(uint32_t)uni((int)(uint32_t)a) | ((unsigned long long)(uint32_t)uni((int)(uint32_t)(a >> 32)) << 32);
-          const uint32_t cl = (uint32_t)uni((int)Q.clampi[idx]);
+          const uint32_t cl = (uint32_t)uni((int)Q.clampi(idx));
           t.sub_lo = cl == 0xffffffffu ? -1 : (int)(cl & 0xffff); t.sub_hi = (int)(cl >> 16);
         }
         // (4:4:4: the tiles hold zeros where nothing is coded and the cross-component term where only that is: always added)
@@ -891,7 +914,7 @@ __device__ __attribute__((always_inline)) inline void intra_ctu(const PicDev& P,
         intra_tu_any(P, t, L, W);
       };
       if (!sparse && (x4 == 0 || y4 == 0))                      // (a TU inside the CTU reads nothing from next door; a group: what an 8x8 TU would read)
-        fetch_border(org, h_pitch, comp, cs, x4 == 0 ? Q.need_col[i] : 0u, y4 == 0 ? Q.need_row[i] : 0ull, Q, L);
+        fetch_border(org, h_pitch, comp, cs, x4 == 0 ? Q.need_col(i) : 0u, y4 == 0 ? Q.need_row(i) : 0ull, Q, L);
 #ifdef INTRA_TIMING
       if (lane == 0) { atomicMin(&Q.t_first, wall_clock64()); atomicAdd(&Q.n_run, 1u); }
 #endif
@@ -937,7 +960,11 @@ __device__ __attribute__((always_inline)) inline void intra_ctu(const PicDev& P,
 template <int WAVES, bool LEAN>          // waves per CTU and component: they run the CTU's ready TUs side by side (intra_ctu)
 __global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(LEAN ? INTRA_LEAN_OCC : 1))) k_intra(const PicDev* __restrict__ pics, Batch b, const int32_t* __restrict__ order) {
   __shared__ IntraLdsT<LEAN> L;
-  __shared__ IntraSched Q;
+#ifdef INTRA_LDS_PAD                     // experiment: fewer workgroups per CU
+  __shared__ uint32_t lds_pad[INTRA_LDS_PAD / 4];
+  if (blockIdx.x == 0xffffffffu) lds_pad[threadIdx.x] = 1;
+#endif
+  __shared__ IntraSchedT<LEAN> Q;
   __shared__ IntraScratch W[WAVES];
   const int slot = blockIdx.x / 3, comp = blockIdx.x % 3, ctu = ldg(order + blockIdx.y);
   const PicDev& P = pics[b.pic[slot]];
