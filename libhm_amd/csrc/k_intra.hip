@@ -89,7 +89,7 @@ struct IntraLdsT {
   // for every coded TU before this kernel starts --, as PicDev::resid lays it out (8x8 tiles of 128 bytes, rows in resid_slot order,
   // tile (tx, ty) of the CTU at index ty * tiles per CTU row + tx), staged while the block still waits for its neighbours
   __attribute__((aligned(16))) int16_t res[LEAN ? 8 : 64 * 64];
-  __attribute__((aligned(4))) uint8_t m_depth[256], m_part[256], m_pred[256], m_tr[256], m_qp[256], m_cbf[256], m_ts[256], m_dir[256], m_dirl[256], m_byp[256], m_pcm[256];
+  __attribute__((aligned(4))) uint8_t m_depth[256], m_part[256], m_pred[256], m_tr[256], m_cbf[256], m_dir[256], m_dirl[256], m_byp[256], m_pcm[256];
 };
 
 struct TuCtx {
@@ -418,10 +418,10 @@ __device__ __attribute__((always_inline)) inline void intra_stage(const PicDev& 
   if (threadIdx.x < 64 && 4 * lane < parts) {
     const size_t o = base + 4 * lane;
     auto dw = [&](const void* p) { return ldg(reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint8_t*>(p) + o)); };
-    const uint32_t a0 = dw(P.depth), a1 = dw(P.part_size), a2 = dw(P.pred_mode), a3 = dw(P.tr_idx), a4 = dw(P.qp), a5 = dw(P.cbf[comp]),
-                   a6 = dw(P.tskip[comp]), a7 = dw(P.intra_dir[comp ? 1 : 0]), a8 = dw(P.intra_dir[0]), a9 = dw(P.bypass), a10 = dw(P.ipcm);
+    const uint32_t a0 = dw(P.depth), a1 = dw(P.part_size), a2 = dw(P.pred_mode), a3 = dw(P.tr_idx), a5 = dw(P.cbf[comp]),
+                   a7 = dw(P.intra_dir[comp ? 1 : 0]), a8 = dw(P.intra_dir[0]), a9 = dw(P.bypass), a10 = dw(P.ipcm);
     auto put = [&](uint8_t* d, uint32_t v) { *reinterpret_cast<uint32_t*>(d + 4 * lane) = v; };
-    put(L.m_depth, a0); put(L.m_part, a1); put(L.m_pred, a2); put(L.m_tr, a3); put(L.m_qp, a4); put(L.m_cbf, a5); put(L.m_ts, a6);
+    put(L.m_depth, a0); put(L.m_part, a1); put(L.m_pred, a2); put(L.m_tr, a3); put(L.m_cbf, a5);
     put(L.m_dir, a7); put(L.m_dirl, a8); put(L.m_byp, a9); put(L.m_pcm, a10);
   }
   if (pix) {
