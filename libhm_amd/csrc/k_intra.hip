@@ -882,7 +882,7 @@ __device__ __attribute__((always_inline)) inline void intra_ctu(const PicDev& P,
         for (int x = 0; x < n_cu; x += 2) {
           const uint32_t v = ldg(reinterpret_cast<const uint32_t*>(src + x));
           const uint32_t o = ((v & 0xffffu) << P.pcm_shift[comp]) | ((v >> 16) << (16 + P.pcm_shift[comp]));
-          lrow[x / 2] = o;
+          if (!sparse) lrow[x / 2] = o;                       // (no copy of the CTU in LDS otherwise -- the LEAN kernel has none at all)
           if (comp == 0) st_coh(row + x / 2, o); else st_coh_c2(prow + kCStep * x, o);
         }
       }

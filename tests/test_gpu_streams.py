@@ -104,3 +104,41 @@ def test_device_hash_and_packed_output_match_hm(name):
             with pytest.raises(libhm_amd.HmgpuError):
                 ctx.download_packed(h, 1, (1, 0, 0, 0))              # odd window with subsampled chroma
     _run_stream(name, check)
+
+
+@pytest.mark.parametrize("name", ["ldp_pcm_main8_208x120", "ldp_cip_main10_208x120", "ldp_lossless_main10_208x120", "ldp_tiles_main10_832x128",
+                                  "ldp_sl_main10_208x120", "ra_main10_208x120", "ldb_444_ccp_main8_208x120", "ldb_422_main10_208x120", "ldb_main12_208x120"])
+def test_inter_pictures_with_intra_cus_in_batches_of_five(name):
+    """the P / B pictures of HM's streams -- intra CUs (PCM, lossless, constrained intra prediction, scaling lists, tiles, other chroma formats, 12 bits)
+    scattered among inter CUs -- reconstructed FIVE per call: the calls k_intra<1, LEAN> serves (no I slice, mostly inter; one wave per CTU,
+    nothing staged in LDS), against HM's reconstruction before the loop filters"""
+    import copy
+    import libhm_amd
+    pics = gu.stream_pictures(name)
+    seq = copy.copy(pics[0].seq) if False else type(pics[0].seq).from_buffer_copy(pics[0].seq)
+    seq.max_pictures = pics[0].seq.max_pictures + 4
+    n_batched = 0
+    with libhm_amd.Context(seq) as ctx:
+        handles = [ctx.acquire() for _ in pics]
+        assert handles == [p.index for p in pics]
+        extra = [ctx.acquire() for _ in range(4)]
+        for p in pics:
+            h = p.index
+            junk = [np.full_like(a, 55) for a in p.pre]
+            ctx.upload(h, junk)
+            if all(int(sl.slice_type) != abi.I_SLICE for sl in p.slices):
+                for e in extra:
+                    ctx.upload(e, junk)
+                ctx.decompress_pictures([(t, p.slices, p.meta, p.coeffs) for t in [h] + extra])
+                for t in [h] + extra:
+                    rec = ctx.download(t)
+                    for c in range(3):
+                        assert np.array_equal(rec[c], p.pre[c]), "%s pic %d comp %d (device picture %d)" % (name, p.index, c, t)
+                n_batched += 1
+            else:
+                ctx.decompress_pictures([(h, p.slices, p.meta, p.coeffs)])
+            ctx.filter_picture(h, p.pp, p.sao_raw)
+            fin = ctx.download(h)
+            for c in range(3):
+                assert np.array_equal(fin[c], p.fin[c]), "%s pic %d comp %d: final" % (name, p.index, c)
+    assert n_batched >= 1
