@@ -15,7 +15,10 @@ names = ["stream_ldp_main8_416x240", "stream_ra_main10_208x120", "lite_ldp_wpp_d
          "lite_ldp_slices_main8_208x120", "lite_ldp_dqp_main10_208x120", "lite_ldp_wpp_main10_416x240",
          "lite_ldb_rext420_main8_208x120", "lite_ldb_rext420_lossless_main8_208x120", "lite_ldb_rext420_ts32_nosmooth_main8_208x120",
          "lite_intra_rext420_lossless_main8_208x120", "lite_ldb_rext420_wp_hp_main10_208x120", "lite_ldb_mono_rext_main8_208x120",
-         "lite_intra_mono_main8_208x120"]
+         "lite_intra_mono_main8_208x120",
+         # round 4: other chroma formats, 12 bits (k_cfmt, k_intra_chroma_422, the unstaged intra paths)
+         "stream_ldb_444_ccp_main8_208x120", "stream_ldb_422_main10_208x120", "stream_intra_422_main8_208x120", "lite_ldb_444_main10_208x120",
+         "lite_ldb_422_wpp_depslices_main8_416x240", "stream_ldb_main12_208x120", "lite_ldb_444_ccp_main12_208x120", "lite_ldb_ts32_main12_208x120"]
 with tempfile.TemporaryDirectory() as tmp:
     exe = os.path.join(tmp, "client")
     subprocess.check_call(["g++", "-std=c++17", "-O1", "-o", exe, os.path.join(ROOT, "tests", "client", "libhm_client.cpp"), "-I" + os.path.join(ROOT, "include"),
