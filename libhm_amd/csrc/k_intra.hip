@@ -74,8 +74,19 @@ struct IntraScratch {                    // what ONE TU in flight needs: one per
   int line[4 * 32 + 4];                  // reference line: [0,2N) left column bottom-up, [2N] corner, (2N,4N] row above
   int filt[4 * 32 + 4];                  // the same after smoothing
   int proj[3 * 32 + 4];                  // angular modes: main reference incl. the projected side samples, index k + 32
+#ifdef INTRA_TIMING2                 // diagnostic build: shader-clock cycles per phase of the TU path, summed per wave (printed by k_intra)
+  unsigned tm[16];
+#endif
 };
 // LEAN: the kernel for calls whose CTUs are ALL taken as sparse (k_intra): no copy of the samples and of the residual at all
+#ifdef INTRA_TIMING2
+#define TK_START() long long tk0 = clock64()
+#define TK(k) { const long long tkc = clock64(); if ((threadIdx.x & 63) == 0) W.tm[k] += (unsigned)(tkc - tk0); tk0 = tkc; }
+#else
+#define TK_START()
+#define TK(k)
+#endif
+
 template <bool LEAN>
 struct IntraLdsT {
   static constexpr bool lean = LEAN;
@@ -150,6 +161,7 @@ __device__ __attribute__((always_inline)) inline void intra_tu(const PicDev& P, 
 
   const int n = lane & (N - 1);
   const bool active = lane < N;
+  TK_START();
 
   // the residual of row n: from the CTU's staged tiles (D.); a sparse CTU has none: from the picture's tiles, on its way while the
   // reference line is built (k_itx computed it in an earlier launch; RExt rotation / RDPCM included)
@@ -212,6 +224,7 @@ __device__ __attribute__((always_inline)) inline void intra_tu(const PicDev& P, 
     W.line[i] = v;
   }
   wave_lds_sync();
+  TK(0)
 
   // ---- B. smoothing (filteringIntraReferenceSamples + initAdiPatternChType); most TUs are not smoothed (chroma, 4x4, DC,
   // the modes near horizontal / vertical) and predict straight from line[]: one LDS round trip less on the serial chain
@@ -248,6 +261,7 @@ __device__ __attribute__((always_inline)) inline void intra_tu(const PicDev& P, 
     }
     wave_lds_sync();
   }
+  TK(1)
 
   // ---- C. prediction of row n by lane n
 #if defined(INTRA_EXP) && (INTRA_EXP & 2)
@@ -357,6 +371,7 @@ __device__ __attribute__((always_inline)) inline void intra_tu(const PicDev& P, 
     }
   }
 
+  TK(2)
   // ---- D. residual of row n: from the CTU's staged tiles
 #if defined(INTRA_EXP) && (INTRA_EXP & 1)      // experiment: no residual (wrong samples)
   if (false) {
@@ -373,6 +388,7 @@ __device__ __attribute__((always_inline)) inline void intra_tu(const PicDev& P, 
     }
   }
 
+  TK(3)
   // ---- E. reconstruction of row n: into the LDS copy (what later TUs of this CTU predict from) and, two samples per
   // coherent dword store, into the picture (what other CTUs and the loop filters read; nobody here waits for it)
   if (active) {
@@ -394,6 +410,7 @@ __device__ __attribute__((always_inline)) inline void intra_tu(const PicDev& P, 
   // (sparse CTU: whoever predicts from this TU next -- this wave or another -- loads its samples from the picture: acknowledged first)
   if (sparse) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   wave_lds_sync();
+  TK(4)
 }
 
 template <class IntraLds>
@@ -482,14 +499,16 @@ struct IntraSchedT {
   uint32_t e_col[256];
   Wide e_row[256], e_avl[256];
   Clamp e_clamp[256];
-  __device__ void put(int i, uint32_t nc, uint64_t nr, uint64_t am, uint32_t cl) {
+  // bits 24-31 of col (both forms): what the TU chain wants to know about the TU besides its place -- prediction mode (6 bits, DM_CHROMA resolved),
+  // coded flag, lossless flag -- looked up once, when the list is built, instead of byte by byte out of the CTU's arrays on the chain
+  __device__ void put(int i, uint32_t nc, uint64_t nr, uint64_t am, uint32_t cl, uint32_t desc) {
     if constexpr (PACKED) {
-      e_col[i] = (nc & 0xffffu) | ((uint32_t)(nr >> 32) & 1u) << 16 | ((uint32_t)(am >> 32) & 1u) << 17;
+      e_col[i] = (nc & 0xffffu) | ((uint32_t)(nr >> 32) & 1u) << 16 | ((uint32_t)(am >> 32) & 1u) << 17 | desc << 24;
       e_row[i] = (uint32_t)nr; e_avl[i] = (uint32_t)am;
       e_clamp[i] = cl == 0xffffffffu ? (uint16_t)0xffffu : (uint16_t)((cl & 0xffu) | ((cl >> 16) << 8));
-    } else { e_col[i] = nc; e_row[i] = nr; e_avl[i] = am; e_clamp[i] = cl; }
+    } else { e_col[i] = (nc & 0xffffu) | desc << 24; e_row[i] = nr; e_avl[i] = am; e_clamp[i] = cl; }
   }
-  __device__ uint32_t need_col(int i) const { if constexpr (PACKED) return e_col[i] & 0xffffu; else return e_col[i]; }
+  __device__ uint32_t need_col(int i) const { return e_col[i] & 0xffffu; }
   __device__ uint64_t need_row(int i) const { if constexpr (PACKED) return (uint64_t)e_row[i] | ((uint64_t)((e_col[i] >> 16) & 1u) << 32); else return e_row[i]; }
   __device__ uint64_t avail(int i) const { if constexpr (PACKED) return (uint64_t)e_avl[i] | ((uint64_t)((e_col[i] >> 17) & 1u) << 32); else return e_avl[i]; }
   __device__ uint32_t clampi(int i) const {
@@ -627,6 +646,17 @@ __device__ __attribute__((always_inline)) inline void intra_ctu(const PicDev& P,
 #if defined(INTRA_STOP) && INTRA_STOP == 6
   if (IntraLds::lean && pw > 0 && nb_same >= 0 && h_plane != nullptr && h_resid != nullptr) return;
 #endif
+  // mode | coded << 6 | lossless << 7 of the TU of list entry e (IntraSched::put)
+  auto tu_desc = [&](const TuRun& e) -> uint32_t {
+    if (e.kind == 1) return 0u;
+    const int zs = e.z, tr = L.m_tr[zs];
+    int mode = L.m_dir[zs];
+    // DM_CHROMA_IDX (TDecCu.cpp:523-524, getChromasCorrespondingPULumaIdx): the luma mode of the CU's first partition; 4:4:4: of the block's own partition
+    if (comp && mode == 36) mode = L.m_dirl[h_fmt == 3 ? zs : e.z_cu];
+    // (4:4:4: the tiles hold zeros where nothing is coded and the cross-component term where only that is: always added)
+    const uint32_t cbf = (comp && h_fmt != 1) ? 1u : (uint32_t)((L.m_cbf[zs] >> tr) & 1);
+    return (uint32_t)(mode & 63) | cbf << 6 | (L.m_byp[zs] ? 1u << 7 : 0u);
+  };
   if (wv == 0) {
   // ---- 1. the list, in raster order of the TU origins (= the priority they run in), one lane per 8x8 AREA of the CTU (a coding unit is at
   // least that large: prediction mode, transform depth and PCM flag are the same in the area's four partitions).  An area starts a TU of
@@ -735,7 +765,7 @@ __device__ __attribute__((always_inline)) inline void intra_ctu(const PicDev& P,
           cl = (uint32_t)lo | ((uint32_t)hi << 16);
         }
       }
-      if (lane == 0) Q.put(i, nc, nr, am, cl);
+      if (lane == 0) Q.put(i, nc, nr, am, cl, tu_desc(e));
     }
   } else
   for (int i = lane; i < n_tus; i += 64) {
@@ -782,7 +812,7 @@ __device__ __attribute__((always_inline)) inline void intra_ctu(const PicDev& P,
         cl = (uint32_t)lo | ((uint32_t)hi << 16);
       }
     }
-    Q.put(i, nc, nr, am, cl);
+    Q.put(i, nc, nr, am, cl, tu_desc(e));
   }
   wave_lds_sync();
 #if defined(INTRA_STOP) && INTRA_STOP == 5
@@ -816,6 +846,7 @@ __device__ __attribute__((always_inline)) inline void intra_ctu(const PicDev& P,
 #endif
   if (!sparse && wv == (int)(blockDim.x >> 6) - 1) fetch_border(org, h_pitch, comp, cs, nb.ext_col, nb.ext_row, Q, L);   // what is final next door already
   for (;;) {
+    TK_START();
     // the scheduler words in LDS (pend, done_c, done_r, got) are updated by the other waves with atomics: read them afresh in every round
     asm volatile("" ::: "memory");
     // the first list entry that is pending and ready (the list is in priority order); the pending masks may be stale by the time the
@@ -855,6 +886,7 @@ __device__ __attribute__((always_inline)) inline void intra_ctu(const PicDev& P,
       TM_ADD(t_idle)
       continue;
     }
+    TK(5)
     // claim it
     uint32_t old = 0;
     if (lane == 0) {
@@ -863,6 +895,7 @@ __device__ __attribute__((always_inline)) inline void intra_ctu(const PicDev& P,
     }
     old = (uint32_t)__builtin_amdgcn_readfirstlane((int)old);
     if (!((old >> (i & 31)) & 1)) continue;                  // another wave was faster
+    TK(6)
     // everything about the TU is the same in all lanes, but it comes out of LDS into vector registers: moved to scalar ones, what is derived
     // from it (coordinates, the mode's angle, branch conditions) runs on the scalar unit beside the lanes' own work
     auto uni = [](int v) { return __builtin_amdgcn_readfirstlane(v); };
@@ -889,7 +922,6 @@ __device__ __attribute__((always_inline)) inline void intra_ctu(const PicDev& P,
     } else {
       // one TU of the list: entry idx (its availability), first partition zs, origin unit (xs, ys) of the CTU
       auto run_tu = [&](int idx, int zs, int xs, int ys) {
-        const int tr = uni(L.m_tr[zs]);
         TuCtx t;
         t.comp = comp; t.ctu = ctu; t.z_tu = zs; t.cip = cip; t.slice = slice; t.tile = tile; t.nb_same = nb_same;
         t.cx0 = ctu_x >> cs; t.cy0 = ctu_y >> cs;
@@ -897,21 +929,21 @@ __device__ __attribute__((always_inline)) inline void intra_ctu(const PicDev& P,
         t.log2n = e.log2n;
         t.plane = h_plane; t.pitch = h_pitch; t.bd = h_bd; t.log2ctu = h_log2ctu; t.rext = h_rext; t.strong = h_strong; t.cs = cs; t.fmt = h_fmt;
         t.sparse = sparse; t.resid = h_resid; t.rtw = h_rtw;
-        int mode = uni(L.m_dir[zs]);
-        // DM_CHROMA_IDX (TDecCu.cpp:523-524, getChromasCorrespondingPULumaIdx): the luma mode of the CU's first partition (z: the CU's
-        // origin); 4:4:4: of the block's own partition
-        if (comp && mode == 36) mode = uni(L.m_dirl[h_fmt == 3 ? zs : z]);
-        t.mode = mode;
+        const uint32_t colw = (uint32_t)uni((int)Q.e_col[idx]);      // (with the TU's descriptor in bits 24-31: IntraSched::put)
+        t.mode = (int)((colw >> 24) & 63u);
         {
           const uint64_t a = Q.avail(idx);
           t.am = (unsigned long long)(uint32_t)uni((int)(uint32_t)a) | ((unsigned long long)(uint32_t)uni((int)(uint32_t)(a >> 32)) << 32);
           const uint32_t cl = (uint32_t)uni((int)Q.clampi(idx));
           t.sub_lo = cl == 0xffffffffu ? -1 : (int)(cl & 0xffff); t.sub_hi = (int)(cl >> 16);
         }
-        // (4:4:4: the tiles hold zeros where nothing is coded and the cross-component term where only that is: always added)
-        t.cbf = (comp && h_fmt != 1) ? 1 : (uni(L.m_cbf[zs]) >> tr) & 1;
-        t.bypass = uni(L.m_byp[zs]);
+        t.cbf = (int)((colw >> 30) & 1u);
+        t.bypass = (int)(colw >> 31);
+        TK(7)
         intra_tu_any(P, t, L, W);
+#ifdef INTRA_TIMING2
+        tk0 = clock64();
+#endif
       };
       if (!sparse && (x4 == 0 || y4 == 0))                      // (a TU inside the CTU reads nothing from next door; a group: what an 8x8 TU would read)
         fetch_border(org, h_pitch, comp, cs, x4 == 0 ? Q.need_col(i) : 0u, y4 == 0 ? Q.need_row(i) : 0ull, Q, L);
@@ -932,6 +964,7 @@ __device__ __attribute__((always_inline)) inline void intra_ctu(const PicDev& P,
     }
     if (sparse) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (sparse CTU: the samples are in the picture, where the CTU's other TUs read them)
     wave_lds_sync();                                         // the TU's samples are in the CTU copy before its units count as final
+    TK(8)
     mark_done(x4, y4, U);
     if (lane == 0) atomicSub(&Q.running, 1);
     if (x4 + U == pw || y4 + U == pw) {
@@ -944,6 +977,10 @@ __device__ __attribute__((always_inline)) inline void intra_ctu(const PicDev& P,
     if (lane == 0) atomicMax(&Q.t_last, wall_clock64());
 #endif
     TM_ADD(t_post)
+    TK(9)
+#ifdef INTRA_TIMING2
+    if (lane == 0) W.tm[15] += 1u;
+#endif
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
@@ -1054,12 +1091,24 @@ __global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu
 #ifdef INTRA_TIMING
   if (threadIdx.x == 0) Q.t_b = wall_clock64();
 #endif
+#ifdef INTRA_TIMING2
+  if ((threadIdx.x & 63) < 16) W[wv].tm[threadIdx.x & 63] = 0;
+  wave_lds_sync();
+#endif
   intra_ctu(P, comp, ctu, sparse, L, Q, W[wv], nbs);
   __syncthreads();                                           // every wave's stores are acknowledged (intra_ctu ends with the wait)
 #ifdef INTRA_TIMING
   if (threadIdx.x == 0 && comp == 0 && slot == 0 && (cy == 10 || cy == 11) && cx >= 20 && cx < 32)
     printf("TM cy %d cx %d start %llu first %llu last %llu end %llu ntu %u tu %llu claim %llu post %llu idle %llu nidle %u stage %llu nbrs %llu list %llu\n", cy, cx, tk0, Q.t_first, Q.t_last,
            wall_clock64(), Q.n_run, Q.t_tu, Q.t_claim, Q.t_post, Q.t_idle, Q.n_idle, Q.t_a - tk0, Q.t_b - Q.t_a, Q.t_c - Q.t_b);
+#endif
+#ifdef INTRA_TIMING2
+  if (threadIdx.x == 0 && comp == 0 && slot == 0 && (cy == 10 || cy == 11) && cx >= 20 && cx < 32) {
+    unsigned sum[16];
+    for (int k = 0; k < 16; k++) { sum[k] = 0; for (int w = 0; w < WAVES; w++) sum[k] += W[w].tm[k]; }
+    printf("TK cy %d cx %d tus %u line %u filt %u pred %u resid %u store %u scan %u claim %u setup %u sync %u post %u\n", cy, cx, sum[15], sum[0], sum[1], sum[2], sum[3], sum[4],
+           sum[5], sum[6], sum[7], sum[8], sum[9]);
+  }
 #endif
   // (No release fence in front of the last word: every store to the picture is a write-through atomic store that has been acknowledged by now --
   // intra_ctu ends with the wait.  An agent-scope release fence writes the L2 back: one per workgroup, ~98 000 of them in sixteen 2160p P
