@@ -518,7 +518,7 @@ struct IntraSchedT {
   uint32_t got[3];                   // border units of the neighbouring CTUs whose samples are in LDS (L.pix columns 0, 1 / L.top): column | row lo | row hi
   uint32_t pend[8];                  // list entries nobody has taken yet (bit i & 31 of pend[i >> 5]); a wave takes one with an atomic AND
   uint8_t member[64][4];             // list entries of the four 4x4 luma TUs of every 8x8 area (kinds 2 and 3), by z >> 2 and z & 3
-  int32_t n_tus, running;            // list length; waves inside a TU right now
+  int32_t n_tus;                     // list length
 #ifdef INTRA_TIMING                  // diagnostic build: where the time of a CTU goes (printed by k_intra for one CTU row)
   unsigned long long t_tu, t_claim, t_post, t_idle, t_first, t_last, t_a, t_b, t_c;
   uint32_t n_run, n_idle;
@@ -820,7 +820,7 @@ __device__ __attribute__((always_inline)) inline void intra_ctu(const PicDev& P,
 #endif
     // ---- 3. what is final before anything ran (the neighbours may pass inter areas at once), the pending mask
     if (lane < 8) Q.pend[lane] = n_tus >= 32 * (lane + 1) ? 0xffffffffu : (n_tus > 32 * lane ? (1u << (n_tus - 32 * lane)) - 1u : 0u);
-    if (lane == 0) { Q.n_tus = n_tus; Q.running = 0; }
+    if (lane == 0) Q.n_tus = n_tus;
     if (lane < 3) Q.got[lane] = 0;
     wave_lds_sync();
     for (int i = lane; i < n_tus; i += 64) if (Q.tu[i].kind == 3) atomicAnd(&Q.pend[i >> 5], ~(1u << (i & 31)));     // run by their group's first TU
@@ -853,6 +853,11 @@ __device__ __attribute__((always_inline)) inline void intra_ctu(const PicDev& P,
     // entry is claimed: the atomic AND decides
     int i = -1;
     bool any_pending = false;
+    // (what the lane read about its entry stays in its registers: the winner's words are fetched from the winning LANE -- v_readlane -- instead of
+    // from LDS a second time)
+    uint32_t sc_e = 0, sc_col = 0;
+    uint64_t sc_row = 0;
+    int sc_lane = 0;
     for (int wbase = 0; wbase < n_tus && i < 0; wbase += 64) {
       const int c = wbase + lane;
       const uint32_t pm = Q.pend[c >> 5];
@@ -863,11 +868,12 @@ __device__ __attribute__((always_inline)) inline void intra_ctu(const PicDev& P,
         const int x4 = zscan_x(e.z), y4 = zscan_y(e.z);
         const uint32_t have_c = x4 == 0 ? nb.ext_col : Q.done_c[x4 - 1];
         const uint64_t have_r = y4 == 0 ? nb.ext_row : ((uint64_t)Q.done_r[y4 - 1] << 1) | 1ull;
-        ready = (Q.need_col(c) & ~have_c) == 0 && (Q.need_row(c) & ~have_r) == 0;
+        sc_e = __builtin_bit_cast(uint32_t, e); sc_col = Q.e_col[c]; sc_row = Q.need_row(c);
+        ready = ((sc_col & 0xffffu) & ~have_c) == 0 && (sc_row & ~have_r) == 0;
       }
       any_pending |= __builtin_amdgcn_ballot_w64(pending) != 0;
       const unsigned long long m = __builtin_amdgcn_ballot_w64(ready);
-      if (m) i = wbase + (int)__builtin_ctzll(m);
+      if (m) { sc_lane = (int)__builtin_ctzll(m); i = wbase + sc_lane; }
     }
     if (i < 0) {
       if (!any_pending) break;                               // every TU is taken: the waves that hold one finish it
@@ -878,7 +884,9 @@ __device__ __attribute__((always_inline)) inline void intra_ctu(const PicDev& P,
 #ifdef INTRA_TIMING
       if (lane == 0) atomicAdd(&Q.n_idle, 1u);
 #endif
-      if (__hip_atomic_load(&Q.running, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0 || (spins & 15) == 0) {
+      // (every fourth round; a count of the waves inside a TU used to decide between every round and every sixteenth -- two LDS atomics per
+      // TU on the chain for a distinction the picture does not feel: 2.6 % of an I picture)
+      if ((spins & 3) == 0) {
         if (spins > (1u << 22)) { if (lane == 0) atomicOr(P.fault, 1u); nb.broken = true; }
         poll_neighbours(P, nb, pw);
         if (!sparse) fetch_border(org, h_pitch, comp, cs, nb.ext_col, nb.ext_row, Q, L);   // whatever has become final next door
@@ -891,7 +899,6 @@ __device__ __attribute__((always_inline)) inline void intra_ctu(const PicDev& P,
     uint32_t old = 0;
     if (lane == 0) {
       old = atomicAnd(&Q.pend[i >> 5], ~(1u << (i & 31)));
-      if ((old >> (i & 31)) & 1) atomicAdd(&Q.running, 1);
     }
     old = (uint32_t)__builtin_amdgcn_readfirstlane((int)old);
     if (!((old >> (i & 31)) & 1)) continue;                  // another wave was faster
@@ -899,7 +906,10 @@ __device__ __attribute__((always_inline)) inline void intra_ctu(const PicDev& P,
     // everything about the TU is the same in all lanes, but it comes out of LDS into vector registers: moved to scalar ones, what is derived
     // from it (coordinates, the mode's angle, branch conditions) runs on the scalar unit beside the lanes' own work
     auto uni = [](int v) { return __builtin_amdgcn_readfirstlane(v); };
-    const TuRun e = __builtin_bit_cast(TuRun, (uint32_t)uni((int)__builtin_bit_cast(uint32_t, Q.tu[i])));
+    const TuRun e = __builtin_bit_cast(TuRun, (uint32_t)__builtin_amdgcn_readlane((int)sc_e, sc_lane));
+    const uint32_t e_colw = (uint32_t)__builtin_amdgcn_readlane((int)sc_col, sc_lane);
+    const uint64_t e_roww = (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)sc_row, sc_lane) |
+                            ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(sc_row >> 32), sc_lane) << 32);
     int x4, y4, U;
     footprint(e, x4, y4, U);
     const int z = e.z_cu, zc = e.z;
@@ -921,7 +931,7 @@ __device__ __attribute__((always_inline)) inline void intra_ctu(const PicDev& P,
       }
     } else {
       // one TU of the list: entry idx (its availability), first partition zs, origin unit (xs, ys) of the CTU
-      auto run_tu = [&](int idx, int zs, int xs, int ys) {
+      auto run_tu = [&](int idx, int zs, int xs, int ys, uint32_t colw) {
         TuCtx t;
         t.comp = comp; t.ctu = ctu; t.z_tu = zs; t.cip = cip; t.slice = slice; t.tile = tile; t.nb_same = nb_same;
         t.cx0 = ctu_x >> cs; t.cy0 = ctu_y >> cs;
@@ -929,8 +939,7 @@ __device__ __attribute__((always_inline)) inline void intra_ctu(const PicDev& P,
         t.log2n = e.log2n;
         t.plane = h_plane; t.pitch = h_pitch; t.bd = h_bd; t.log2ctu = h_log2ctu; t.rext = h_rext; t.strong = h_strong; t.cs = cs; t.fmt = h_fmt;
         t.sparse = sparse; t.resid = h_resid; t.rtw = h_rtw;
-        const uint32_t colw = (uint32_t)uni((int)Q.e_col[idx]);      // (with the TU's descriptor in bits 24-31: IntraSched::put)
-        t.mode = (int)((colw >> 24) & 63u);
+        t.mode = (int)((colw >> 24) & 63u);                          // (the TU's descriptor in bits 24-31 of its column word: IntraSched::put)
         {
           const uint64_t a = Q.avail(idx);
           t.am = (unsigned long long)(uint32_t)uni((int)(uint32_t)a) | ((unsigned long long)(uint32_t)uni((int)(uint32_t)(a >> 32)) << 32);
@@ -946,7 +955,7 @@ __device__ __attribute__((always_inline)) inline void intra_ctu(const PicDev& P,
 #endif
       };
       if (!sparse && (x4 == 0 || y4 == 0))                      // (a TU inside the CTU reads nothing from next door; a group: what an 8x8 TU would read)
-        fetch_border(org, h_pitch, comp, cs, x4 == 0 ? Q.need_col(i) : 0u, y4 == 0 ? Q.need_row(i) : 0ull, Q, L);
+        fetch_border(org, h_pitch, comp, cs, x4 == 0 ? (e_colw & 0xffffu) : 0u, y4 == 0 ? e_roww : 0ull, Q, L);
 #ifdef INTRA_TIMING
       if (lane == 0) { atomicMin(&Q.t_first, wall_clock64()); atomicAdd(&Q.n_run, 1u); }
 #endif
@@ -957,7 +966,11 @@ __device__ __attribute__((always_inline)) inline void intra_ctu(const PicDev& P,
         // below and below-left -- waits for the fourth TU too.  (One call site: the TU code is the bulk of this kernel's 47 KB.)
         const int last = e.kind == 2 ? 3 : 0;
         const uint32_t mem = e.kind == 2 ? (uint32_t)uni((int)*reinterpret_cast<const uint32_t*>(Q.member[zc >> 2])) : (uint32_t)i;
-        for (int j = 0; j <= last; j++) run_tu((int)((mem >> (8 * j)) & 0xff), zc + j, x4 + (j & 1), y4 + (j >> 1));
+        for (int j = 0; j <= last; j++) {
+          const int idx = (int)((mem >> (8 * j)) & 0xff);
+          // (a group's other three TUs: their own entries' words)
+          run_tu(idx, zc + j, x4 + (j & 1), y4 + (j >> 1), j == 0 ? e_colw : (uint32_t)uni((int)Q.e_col[idx]));
+        }
         if (last) U = 2;                                     // the common exit publishes the 2 x 2 units of the area
       }
       TM_ADD(t_tu)
@@ -966,7 +979,6 @@ __device__ __attribute__((always_inline)) inline void intra_ctu(const PicDev& P,
     wave_lds_sync();                                         // the TU's samples are in the CTU copy before its units count as final
     TK(8)
     mark_done(x4, y4, U);
-    if (lane == 0) atomicSub(&Q.running, 1);
     if (x4 + U == pw || y4 + U == pw) {
       // the neighbours are shown THIS TU's border units, once its stores are acknowledged
       const uint32_t bits = (x4 + U == pw ? ((1u << U) - 1u) << y4 : 0u) | (y4 + U == pw ? (((1u << U) - 1u) << x4) << 16 : 0u);
