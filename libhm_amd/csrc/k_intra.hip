@@ -838,6 +838,13 @@ __device__ __attribute__((always_inline)) inline void intra_ctu(const PicDev& P,
 #endif
   const int n_tus = Q.n_tus;
   uint32_t spins = 0;
+  // A list of up to 64 entries is one scan round, lane c = entry c: what does not change while the CTU runs -- the entry, its column and row
+  // words -- is read ONCE and stays in the lane's registers; a round then reads the pending word and the two done masks only.
+  // (not in the three-wave kernel of batches: sixteen I pictures were 2.5 % slower with it -- idle waves that scan faster -- where one picture gained 2.7 %)
+  const bool cached = n_tus <= 64 && (IntraLds::lean || blockDim.x > 192);
+  uint32_t my_e = 0, my_col = 0;
+  uint64_t my_row = 0;
+  if (cached && lane < n_tus) { my_e = __builtin_bit_cast(uint32_t, Q.tu[lane]); my_col = Q.e_col[lane]; my_row = Q.need_row(lane); }
 #ifdef INTRA_TIMING
   unsigned long long tm0 = wall_clock64();
 #define TM_ADD(field) { const unsigned long long tm1 = wall_clock64(); if (lane == 0) atomicAdd(&Q.field, tm1 - tm0); tm0 = tm1; }
@@ -864,11 +871,12 @@ __device__ __attribute__((always_inline)) inline void intra_ctu(const PicDev& P,
       const bool pending = c < n_tus && ((pm >> (c & 31)) & 1);
       bool ready = false;
       if (pending) {
-        const TuRun e = Q.tu[c];
+        if (cached) { sc_e = my_e; sc_col = my_col; sc_row = my_row; }
+        else { sc_e = __builtin_bit_cast(uint32_t, Q.tu[c]); sc_col = Q.e_col[c]; sc_row = Q.need_row(c); }
+        const TuRun e = __builtin_bit_cast(TuRun, sc_e);
         const int x4 = zscan_x(e.z), y4 = zscan_y(e.z);
         const uint32_t have_c = x4 == 0 ? nb.ext_col : Q.done_c[x4 - 1];
         const uint64_t have_r = y4 == 0 ? nb.ext_row : ((uint64_t)Q.done_r[y4 - 1] << 1) | 1ull;
-        sc_e = __builtin_bit_cast(uint32_t, e); sc_col = Q.e_col[c]; sc_row = Q.need_row(c);
         ready = ((sc_col & 0xffffu) & ~have_c) == 0 && (sc_row & ~have_r) == 0;
       }
       any_pending |= __builtin_amdgcn_ballot_w64(pending) != 0;
