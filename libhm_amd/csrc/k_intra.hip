@@ -304,8 +304,10 @@ __device__ __attribute__((always_inline)) inline void intra_tu(const PicDev& P, 
     const bool ver = t.mode >= 18;
     const int am_ = ver ? t.mode - 26 : -(t.mode - 10);
     const int aa = abs(am_);
-    const int ang_abs = aa == 0 ? 0 : aa == 1 ? 2 : aa == 2 ? 5 : aa == 3 ? 9 : aa == 4 ? 13 : aa == 5 ? 17 : aa == 6 ? 21 : aa == 7 ? 26 : 32;
-    const int inv = aa == 0 ? 0 : aa == 1 ? 4096 : aa == 2 ? 1638 : aa == 3 ? 910 : aa == 4 ? 630 : aa == 5 ? 482 : aa == 6 ? 390 : aa == 7 ? 315 : 256;
+    // intraPredAngle {0, 2, 5, 9, 13, 17, 21, 26, 32} and its inverse {-, 4096, 1638, 910, 630, 482, 390, 315, 256} (TComPrediction.cpp:276-277) out of
+    // packed constants: the chains of conditionals the tables were written as before compiled into ~20 scalar branches on the TU chain
+    const int ang_abs = aa >= 8 ? 32 : (int)((0x1a15110d09050200ull >> (8 * aa)) & 0xffu);
+    const int inv = aa >= 8 ? 256 : (int)(((aa & 4) ? 0x013b018601e20276ull : 0x038e066610000000ull) >> (16 * (aa & 3)) & 0xffffu);
     const int ang = am_ < 0 ? -ang_abs : ang_abs;
     const int sgn = ver ? 1 : -1;                           // MAIN(i) = f[corner + sgn*i], SIDE(i) = f[corner - sgn*i]
     if (ang == 0) {
@@ -1213,8 +1215,10 @@ __device__ void intra_square_422(const PicDev& P, int comp, int ctu, int zb, int
   } else {
     const bool ver = mode >= 18;
     const int am_ = ver ? mode - 26 : -(mode - 10), aa = abs(am_);
-    const int ang_abs = aa == 0 ? 0 : aa == 1 ? 2 : aa == 2 ? 5 : aa == 3 ? 9 : aa == 4 ? 13 : aa == 5 ? 17 : aa == 6 ? 21 : aa == 7 ? 26 : 32;
-    const int inv = aa == 0 ? 0 : aa == 1 ? 4096 : aa == 2 ? 1638 : aa == 3 ? 910 : aa == 4 ? 630 : aa == 5 ? 482 : aa == 6 ? 390 : aa == 7 ? 315 : 256;
+    // intraPredAngle {0, 2, 5, 9, 13, 17, 21, 26, 32} and its inverse {-, 4096, 1638, 910, 630, 482, 390, 315, 256} (TComPrediction.cpp:276-277) out of
+    // packed constants: the chains of conditionals the tables were written as before compiled into ~20 scalar branches on the TU chain
+    const int ang_abs = aa >= 8 ? 32 : (int)((0x1a15110d09050200ull >> (8 * aa)) & 0xffu);
+    const int inv = aa >= 8 ? 256 : (int)(((aa & 4) ? 0x013b018601e20276ull : 0x038e066610000000ull) >> (16 * (aa & 3)) & 0xffffu);
     const int ang = am_ < 0 ? -ang_abs : ang_abs, sgn = ver ? 1 : -1;        // MAIN(i) = line[corner + sgn * i], SIDE(i) = line[corner - sgn * i]
     // main reference with its extension to negative indices: proj[k + 32], k in [-n, 2n]
     for (int k = lane - n; k <= 2 * n; k += 64) {
