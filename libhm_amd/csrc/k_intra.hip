@@ -219,7 +219,8 @@ __device__ __attribute__((always_inline)) inline void intra_tu(const PicDev& P, 
     if (ref_src(i, sx, sy)) {
       // position of the source sample relative to the CTU: row -1 lives in top[], everything else in pix[]
       sx -= t.cx0; sy -= t.cy0;
-      v = sy < 0 ? L.top[sx + 2] : L.pix[sy][sx + 2];
+      const int16_t* at = sy < 0 ? &L.top[sx + 2] : &L.pix[sy][sx + 2];       // (one load, its address selected)
+      v = *at;
     }
     W.line[i] = v;
   }
@@ -349,10 +350,10 @@ __device__ __attribute__((always_inline)) inline void intra_tu(const PicDev& P, 
     } else {
       // main reference with its extension: proj[k + 32], k in [-N, N]; main = row above for vertical modes, left column otherwise
       for (int k = lane - N; k <= N; k += 64) {
-        int v = 0;
-        if (k >= 0) v = f[corner + sgn * k];
-        else if (k > ((N * ang) >> 5)) v = f[corner - sgn * ((128 + __mul24(-k, inv)) >> 8)];
-        W.proj[k + 32] = v;
+        // (one load whatever the side: the index chosen by arithmetic, not by a branch around two loads)
+        const int off = k >= 0 ? k : -((128 + __mul24(-k, inv)) >> 8);
+        const int v = f[corner + sgn * off];
+        W.proj[k + 32] = (k >= 0 || k > ((N * ang) >> 5)) ? v : 0;
       }
       wave_lds_sync();
       const int* r = W.proj + 32;
@@ -400,13 +401,20 @@ __device__ __attribute__((always_inline)) inline void intra_tu(const PicDev& P, 
     const uint32_t maxv2 = (uint32_t)maxv * 0x10001u;
     // (a TU's rows start at multiples of four samples of planes whose pitch is a multiple of 64: 8-byte stores; chroma: sample by sample, the
     // other component's workgroup owns the other half of every dword)
+    uint32_t v[N / 2];
 #pragma unroll
-    for (int x = 0; x < N; x += 4) {
-      const uint32_t v0 = pk_clip_u(pk_add_sat(cvt_pk_sat(p[x], p[x + 1]), res[x / 2]), maxv2);
-      const uint32_t v1 = pk_clip_u(pk_add_sat(cvt_pk_sat(p[x + 2], p[x + 3]), res[x / 2 + 1]), maxv2);
-      if (!sparse) { lrow[x / 2] = v0; lrow[x / 2 + 1] = v1; }
-      if (comp == 0) st_coh2(row + x / 2, v0, v1);
-      else { st_coh_c2(prow + kCStep * x, v0); st_coh_c2(prow + kCStep * (x + 2), v1); }
+    for (int x = 0; x < N; x += 2) v[x / 2] = pk_clip_u(pk_add_sat(cvt_pk_sat(p[x], p[x + 1]), res[x / 2]), maxv2);
+    // (the three uniform conditions once per row, not once per four samples)
+    if (!sparse) {
+#pragma unroll
+      for (int x = 0; x < N / 2; x++) lrow[x] = v[x];
+    }
+    if (comp == 0) {
+#pragma unroll
+      for (int x = 0; x < N / 2; x += 2) st_coh2(row + x, v[x], v[x + 1]);
+    } else {
+#pragma unroll
+      for (int x = 0; x < N / 2; x++) st_coh_c2(prow + kCStep * 2 * x, v[x]);
     }
   }
   // (sparse CTU: whoever predicts from this TU next -- this wave or another -- loads its samples from the picture: acknowledged first)
