@@ -673,7 +673,7 @@ __device__ __attribute__((always_inline)) inline void intra_ctu(const PicDev& P,
   // 8x8 or more when its z index is aligned to the TU's size, or holds the four 4x4 luma TUs of an 8x8 CU (kinds 2, 3, 3, 3 -- with
   // subsampled chroma their one 4x4 chroma TU).  Areas that are not reconstructed here (inter CUs, outside the picture) are final from the
   // start.  (Round 4: this walk was lane-parallel over the 256 4x4 units, four rounds of two passes -- 3-4 of a sparse CTU's ~15 us.)
-  int n_tus = 0;
+  int n_tus = 0, n_sched = 0;
   {
     const int paw = pw >> 1, log2paw = P.log2ctu - 3, areas = paw * paw;       // areas per CTU row (8, 4, 2)
     const int pic_w = P.width, pic_h = P.height;
@@ -721,15 +721,19 @@ __device__ __attribute__((always_inline)) inline void intra_ctu(const PicDev& P,
       Q.done_r[lane] = twice((uint32_t)(m0 >> sh) & ((1u << paw) - 1u));
       Q.done_c[lane] = twice((uint32_t)(m1 >> sh) & ((1u << paw) - 1u));
     }
+    // What waves can take -- TUs of 8x8 and more, PCM CUs, the heads of the 4x4 groups: at most one per area, 64 -- comes first, in raster order; the
+    // groups' other three entries (never pending: list entries for their availability words only) behind them.  A scan is ONE round of 64 lanes whatever
+    // the CTU holds.
     const unsigned long long c1 = __builtin_amdgcn_ballot_w64(cnt == 1), c4 = __builtin_amdgcn_ballot_w64(cnt == 4);
     const unsigned long long below = (1ull << lane) - 1ull;
-    const int off = __popcll(c1 & below) + 4 * __popcll(c4 & below);
-    if (cnt) Q.tu[off] = e;
+    n_sched = __popcll(c1 | c4);
+    if (cnt) Q.tu[__popcll((c1 | c4) & below)] = e;
     if (cnt == 4) {
+      const int off = n_sched + 3 * __popcll(c4 & below);
 #pragma unroll
-      for (int j = 1; j < 4; j++) Q.tu[off + j] = TuRun{(uint8_t)(e.z + j), e.z_cu, 2, 3};
+      for (int j = 1; j < 4; j++) Q.tu[off + j - 1] = TuRun{(uint8_t)(e.z + j), e.z_cu, 2, 3};
     }
-    n_tus = __popcll(c1) + 4 * __popcll(c4);
+    n_tus = n_sched + 3 * __popcll(c4);
   }
   wave_lds_sync();
 #if defined(INTRA_STOP) && INTRA_STOP == 4     // (LEAN kernel only: one wave, nobody is left at the barrier)
@@ -829,11 +833,9 @@ __device__ __attribute__((always_inline)) inline void intra_ctu(const PicDev& P,
   if (IntraLds::lean && pw > 0) return;
 #endif
     // ---- 3. what is final before anything ran (the neighbours may pass inter areas at once), the pending mask
-    if (lane < 8) Q.pend[lane] = n_tus >= 32 * (lane + 1) ? 0xffffffffu : (n_tus > 32 * lane ? (1u << (n_tus - 32 * lane)) - 1u : 0u);
-    if (lane == 0) Q.n_tus = n_tus;
+    if (lane < 8) Q.pend[lane] = n_sched >= 32 * (lane + 1) ? 0xffffffffu : (n_sched > 32 * lane ? (1u << (n_sched - 32 * lane)) - 1u : 0u);
+    if (lane == 0) Q.n_tus = n_sched;                          // (what the scans look at: the entries behind are reached through Q.member only)
     if (lane < 3) Q.got[lane] = 0;
-    wave_lds_sync();
-    for (int i = lane; i < n_tus; i += 64) if (Q.tu[i].kind == 3) atomicAnd(&Q.pend[i >> 5], ~(1u << (i & 31)));     // run by their group's first TU
     wave_lds_sync();
     const uint32_t word0 = Q.done_c[pw - 1] | (Q.done_r[pw - 1] << 16);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
