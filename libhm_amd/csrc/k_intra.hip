@@ -642,9 +642,12 @@ __device__ __attribute__((always_inline)) inline void intra_ctu(const PicDev& P,
   const int16_t* const org = comp == 0 ? h_plane + (ptrdiff_t)ctu_y * h_pitch + ctu_x : P.rec[1] + (ptrdiff_t)(ctu_y >> cs) * h_pitch + kCStep * (ctu_x >> cs);
   const int wv = threadIdx.x >> 6;
   auto mark_done = [&](int x4, int y4, int U) {           // units [x4, x4 + U) x [y4, y4 + U) are final
-    // (lanes 0-15 the rows, 16-31 the columns: done_c follows done_r in the scheduler's words, one atomic under one condition)
-    const int k = lane & 15, lo = lane < 16 ? y4 : x4, sh = lane < 16 ? x4 : y4;
-    if (lane < 32 && k >= lo && k < lo + U) atomicOr(&Q.done_r[lane], ((1u << U) - 1u) << sh);
+    if (lane < 16) {
+      if (lane >= y4 && lane < y4 + U) atomicOr(&Q.done_r[lane], ((1u << U) - 1u) << x4);
+    } else if (lane < 32) {
+      const int c = lane - 16;
+      if (c >= x4 && c < x4 + U) atomicOr(&Q.done_c[c], ((1u << U) - 1u) << y4);
+    }
   };
   auto footprint = [&](const TuRun& e, int& x4, int& y4, int& U) {     // in 4x4 luma units of the CTU
     x4 = zscan_x(e.z); y4 = zscan_y(e.z);
@@ -884,9 +887,8 @@ __device__ __attribute__((always_inline)) inline void intra_ctu(const PicDev& P,
         else { sc_e = __builtin_bit_cast(uint32_t, Q.tu[c]); sc_col = Q.e_col[c]; sc_row = Q.need_row(c); }
         const TuRun e = __builtin_bit_cast(TuRun, sc_e);
         const int x4 = zscan_x(e.z), y4 = zscan_y(e.z);
-        const uint32_t dc = Q.done_c[max(x4 - 1, 0)], dr = Q.done_r[max(y4 - 1, 0)];      // (both loads always: no branch around either)
-        const uint32_t have_c = x4 == 0 ? nb.ext_col : dc;
-        const uint64_t have_r = y4 == 0 ? nb.ext_row : ((uint64_t)dr << 1) | 1ull;
+        const uint32_t have_c = x4 == 0 ? nb.ext_col : Q.done_c[x4 - 1];
+        const uint64_t have_r = y4 == 0 ? nb.ext_row : ((uint64_t)Q.done_r[y4 - 1] << 1) | 1ull;
         ready = ((sc_col & 0xffffu) & ~have_c) == 0 && (sc_row & ~have_r) == 0;
       }
       any_pending |= __builtin_amdgcn_ballot_w64(pending) != 0;
