@@ -66,6 +66,9 @@ __device__ inline int ld_sample(const int16_t* p) {
 #ifndef INTRA_LEAN_OCC
 #define INTRA_LEAN_OCC 4                 // waves per SIMD the LEAN kernel is compiled for (128 VGPRs; it would take 130)
 #endif
+#ifndef INTRA_MANY_OCC
+#define INTRA_MANY_OCC 4                 // ... and the three-wave kernel of batches (128 VGPRs and 44 bytes of scratch instead of 147: a fifth workgroup per CU,
+#endif                                   // sixteen I pictures 7.38 -> 6.82 ms; the eight-wave kernel of single pictures is latency, not residency: left alone)
 #ifndef INTRA_SPARSE_MAX
 #define INTRA_SPARSE_MAX 16              // in 64ths of a CTU's 8x8 areas: at most this share intra -> the CTU is not staged (k_intra)
 #endif
@@ -1027,7 +1030,7 @@ __device__ __attribute__((always_inline)) inline void intra_ctu(const PicDev& P,
 // before it (no deadlock however few blocks are resident), and the blocks resident at any time are the wavefront itself.
 // LEAN: every CTU on the unstaged path (below), in a third of the LDS: the variant for calls without I slices
 template <int WAVES, bool LEAN>          // waves per CTU and component: they run the CTU's ready TUs side by side (intra_ctu)
-__global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(LEAN ? INTRA_LEAN_OCC : 1))) k_intra(const PicDev* __restrict__ pics, Batch b, const int32_t* __restrict__ order) {
+__global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(LEAN ? INTRA_LEAN_OCC : (WAVES <= 4 ? INTRA_MANY_OCC : 1)))) k_intra(const PicDev* __restrict__ pics, Batch b, const int32_t* __restrict__ order) {
   __shared__ IntraLdsT<LEAN> L;
 #ifdef INTRA_LDS_PAD                     // experiment: fewer workgroups per CU
   __shared__ uint32_t lds_pad[INTRA_LDS_PAD / 4];
